@@ -1,0 +1,100 @@
+"""Deterministic synthetic weights / inputs for tests and benchmarks (numpy PCG64).
+
+There is no network and no ``pretrained/*.pth`` in the image, so every measurement runs on
+random-init weights of the reference architecture.  Both sides of every parity test (the
+reference model in the dev container, the oracle, the HIP path) load the SAME arrays produced
+here, keyed by the reference ``state_dict`` names relative to ``diffusion.model.``
+(dumped from the built reference model).
+"""
+import numpy as np
+
+F32 = np.float32
+
+INNER = 128
+HEADS = 8
+D_HEAD = 16
+N_CLASS = 4
+ZDIM = 256
+CTX_DIM = ZDIM + 6 + N_CLASS + 256  # 522: [part_code | mean | var | eye | t_embed]
+IN_CH = 3 + 6 + N_CLASS             # 13:  [x_t | anchors | variances | onehot(seg)]
+FF_INNER = 4 * INNER                # 512 (GEGLU projects to 2*512)
+
+
+def denoiser_param_shapes(depth=5):
+    """(name, shape) in reference ``state_dict`` order (TransformerNet, attention.py:318-383)."""
+    s = [
+        ("pre_norm.weight", (INNER,)), ("pre_norm.bias", (INNER,)),
+        ("post_norm.weight", (INNER,)), ("post_norm.bias", (INNER,)),
+        ("proj_in.weight", (INNER, IN_CH)), ("proj_in.bias", (INNER,)),
+        ("time_embed.net.0.proj.weight", (2048, 256)), ("time_embed.net.0.proj.bias", (2048,)),
+        ("time_embed.net.2.weight", (256, 1024)), ("time_embed.net.2.bias", (256,)),
+    ]
+    for i in range(depth):
+        p = f"transformer_blocks.{i}."
+        s += [
+            (p + "ff.net.0.proj.weight", (2 * FF_INNER, INNER)), (p + "ff.net.0.proj.bias", (2 * FF_INNER,)),
+            (p + "ff.net.2.weight", (INNER, FF_INNER)), (p + "ff.net.2.bias", (INNER,)),
+            (p + "attn2.to_q.weight", (INNER, INNER)),
+            (p + "attn2.to_k.weight", (INNER, CTX_DIM)),
+            (p + "attn2.to_v.weight", (INNER, CTX_DIM)),
+            (p + "attn2.to_out.0.weight", (INNER, INNER)), (p + "attn2.to_out.0.bias", (INNER,)),
+            (p + "norm2.weight", (INNER,)), (p + "norm2.bias", (INNER,)),
+            (p + "norm3.weight", (INNER,)), (p + "norm3.bias", (INNER,)),
+        ]
+    s += [("proj_out.weight", (3, INNER)), ("proj_out.bias", (3,))]
+    return s
+
+
+def make_denoiser_weights(seed=0, depth=5):
+    """PyTorch-default-like scale: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for Linear weight and
+    bias; LayerNorm weight 1 + U(-.1,.1), bias U(-.1,.1) so the affine terms are exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = {}
+    fan = {}
+    for name, shape in denoiser_param_shapes(depth):
+        if "norm" in name:
+            u = rng.uniform(-0.1, 0.1, size=shape)
+            W[name] = (u + (1.0 if name.endswith("weight") else 0.0)).astype(F32)
+        elif name.endswith("weight"):
+            bound = 1.0 / np.sqrt(shape[1])
+            fan[name[:-len("weight")]] = bound
+            W[name] = rng.uniform(-bound, bound, size=shape).astype(F32)
+        else:
+            bound = fan[name[:-len("bias")]]
+            W[name] = rng.uniform(-bound, bound, size=shape).astype(F32)
+    return W
+
+
+def chair_part_distribution():
+    """Presence patterns of the 4 chair parts (back, seat, leg, arm): synthetic stand-in for
+    ``shapenet_chair_part_distribution`` (datasets/dataset_utils.py:170-179); the data set is
+    not in the image, so these are the plausible patterns with fixed weights."""
+    pats = np.array([[1, 1, 1, 1], [1, 1, 1, 0], [0, 1, 1, 0], [1, 1, 0, 0], [0, 1, 1, 1]], dtype=F32)
+    prob = np.array([0.45, 0.40, 0.05, 0.05, 0.05])
+    return pats, prob
+
+
+def make_latents(B, seed=1, all_valid=False):
+    """Synthetic per-shape latents with the shapes/scales ``PartEncoder.sample_latents``
+    (part_encoders.py:1052-1110) hands to ``decode``: part_code (B,256,4), mean (B,3,4),
+    logvar (B,3,4), valid_id (B,4)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    part_code = rng.standard_normal((B, ZDIM, N_CLASS)).astype(F32)
+    mean = (0.3 * rng.standard_normal((B, 3, N_CLASS))).astype(F32)
+    logvar = (-3.0 + 0.5 * rng.standard_normal((B, 3, N_CLASS))).astype(F32)
+    if all_valid:
+        valid = np.ones((B, N_CLASS), dtype=F32)
+    else:
+        pats, prob = chair_part_distribution()
+        valid = pats[rng.choice(len(pats), size=B, p=prob)]
+    return part_code, mean, logvar, valid
+
+
+def make_seg_mask(valid, npoints):
+    """part_encoders.py:1105-1106: npoints//n_class consecutive points per part; points of an
+    absent part are re-labelled to the first valid part."""
+    valid = np.asarray(valid, dtype=F32)
+    B, J = valid.shape
+    ids = np.arange(J, dtype=F32)[None] * valid + np.argmax(valid, axis=1)[:, None].astype(F32) * (1 - valid)
+    seg = np.repeat(ids.astype(np.int32)[:, :, None], npoints // J, axis=2).reshape(B, -1)
+    return np.ascontiguousarray(seg)

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE's own Python model on CPU (dev container only).
+
+    python tests/golden/make_golden.py          # writes tests/golden/*.npz
+
+The reference (/root/reference) is imported through tools/ref_import.py (six stub modules,
+SURVEY.md §8c).  Weights are NOT stored: both sides regenerate them with
+difffacto_amd.synth.make_denoiser_weights(seed) and the reference loads them through
+``load_state_dict``.  Fixtures hold inputs and the reference's outputs only (data, no code).
+
+What is pinned
+--------------
+denoiser_eps_*.npz   TransformerNet.forward (attention.py:385) at chosen t
+chain_T10_*.npz      AnchoredDiffusion.p_sample_loop_progressive (anchored_diffusion.py:528) for
+                     T=10 with explicit noise (torch.randn / randn_like patched to replay the
+                     recorded arrays, in the reference's own draw order), every step's sample,
+                     and AnchorDiffAE.decode's dict (anchor_gen.py:145)
+tables_T{10,100,1000}.npz  the schedule tables as the reference casts them to fp32
+pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
+                     (models/encoders/pointnet2_utils.py:84-104,41-57)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_import  # noqa: E402
+from difffacto_amd import synth  # noqa: E402
+
+F32 = np.float32
+
+
+def load_denoiser_weights(model, W):
+    sd = {k: torch.from_numpy(v.copy()) for k, v in W.items()}
+    missing, unexpected = model.diffusion.model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def make_case(B, N, seed, all_valid):
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=seed, all_valid=all_valid)
+    seg = synth.make_seg_mask(valid, N)
+    return part_code, mean, logvar, valid, seg
+
+
+def to_ref_inputs(part_code, mean, logvar, valid, seg):
+    pc, m, lv, va = map(torch.from_numpy, (part_code, mean, logvar, valid))
+    sg = torch.from_numpy(seg)
+    from pointnet2_ops.pointnet2_utils import gather_operation
+    anchors = gather_operation(m.contiguous(), sg)             # (B,3,N)  part_encoders.py:423
+    logvar_pp = gather_operation(lv.contiguous(), sg)
+    variance = torch.exp(logvar_pp)                            # anchor_gen.py:1044
+    ctx = [pc, torch.cat([m, torch.exp(lv)], dim=1)]           # part_encoders.py:1317-1326 (log_scale_var = 0)
+    return anchors, variance, ctx, va, sg
+
+
+def gen_eps(model, tag, B, N, seed, all_valid, ts):
+    case = make_case(B, N, seed, all_valid)
+    anchors, variance, ctx, va, sg = to_ref_inputs(*case)
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    x = (np.sqrt(variance.numpy()) * rng.standard_normal((B, 3, N)).astype(F32) + anchors.numpy()).astype(F32)
+    out = {}
+    with torch.no_grad():
+        for t in ts:
+            tt = torch.tensor([t] * B)
+            eps = model.diffusion.model(torch.from_numpy(x), tt, ctx, anchors=anchors.transpose(1, 2),
+                                        variances=variance.transpose(1, 2), valid_id=va, anchor_assignment=sg)
+            out[f"eps_t{t}"] = eps.numpy().astype(F32)
+    np.savez_compressed(os.path.join(HERE, f"denoiser_eps_{tag}.npz"), x=x, part_code=case[0], mean=case[1],
+                        logvar=case[2], valid=case[3], seg=case[4], ts=np.array(ts), weight_seed=np.array(0), **out)
+    print("wrote denoiser_eps_" + tag, {k: float(np.abs(v).max()) for k, v in out.items()})
+
+
+def gen_chain(model, tag, B, N, seed, all_valid, T):
+    assert model.diffusion.num_timesteps == T
+    case = make_case(B, N, seed, all_valid)
+    anchors, variance, ctx, va, sg = to_ref_inputs(*case)
+    rng = np.random.Generator(np.random.PCG64(seed + 200))
+    x_T_noise = rng.standard_normal((B, 3, N)).astype(F32)
+    step_noise = rng.standard_normal((T, B, 3, N)).astype(F32)
+    queue = [torch.from_numpy(step_noise[i]) for i in range(T)]
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def fake_randn(*shape, **kw):   # anchored_diffusion.py:564
+        assert tuple(shape) == (B, 3, N)
+        return torch.from_numpy(x_T_noise)
+
+    def fake_randn_like(x):         # anchored_diffusion.py:476 (drawn every step incl. t=0)
+        return queue.pop(0)
+
+    samples = {}
+    try:
+        torch.randn, torch.randn_like = fake_randn, fake_randn_like
+        with torch.no_grad():
+            for t, out in model.diffusion.p_sample_loop_progressive(
+                    [B, 3, N], anchors=anchors, variance=variance, ctx=ctx, noise=None,
+                    anchor_assignment=sg.to(torch.int32), valid_id=va, device="cpu"):
+                samples[t] = out["sample"].numpy().astype(F32)
+        assert not queue
+        # decode dict through the network-level entry point (anchor_gen.py:145-169)
+        queue = [torch.from_numpy(step_noise[i]) for i in range(T)]
+        model.ret_traj, model.ret_interval = True, 5
+        with torch.no_grad():
+            dec = model.decode(anchors, ctx=ctx, variance=variance, anchor_assignments=sg.to(torch.int32),
+                               valid_id=va, device="cpu")
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    traj = np.stack([samples[t] for t in range(T, -1, -1)])   # index 0 = x_T, index T = x_0
+    dec_np = {f"decode_{k}": v.numpy().astype(F32) for k, v in dec.items()}
+    np.savez_compressed(os.path.join(HERE, f"chain_T{T}_{tag}.npz"), part_code=case[0], mean=case[1], logvar=case[2],
+                        valid=case[3], seg=case[4], x_T_noise=x_T_noise, step_noise=step_noise, traj=traj,
+                        ret_interval=np.array(5), weight_seed=np.array(0), **dec_np)
+    print(f"wrote chain_T{T}_{tag}", traj.shape, float(np.abs(traj[-1]).max()), sorted(dec_np))
+
+
+def gen_tables():
+    from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
+    from difffacto.utils.registry import DIFFUSIONS
+    names = ["sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+             "posterior_mean_coef1", "posterior_mean_coef2", "posterior_mean_coef3",
+             "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"]
+    for T in (10, 100, 1000):
+        model, _ = ref_import.build_reference_model(num_timesteps=T)
+        d = model.diffusion
+        t = torch.arange(T)
+        out = {n: extract_into_tensor(getattr(d, n), t, (T,)).numpy().astype(F32) for n in names}
+        np.savez_compressed(os.path.join(HERE, f"tables_T{T}.npz"), **out)
+        print("wrote tables", T)
+
+
+def gen_pn2_torch():
+    """Reference pure-torch PointNet++ helpers as a semantic cross-check for ball query/grouping."""
+    ref_import.import_reference()
+    from difffacto.models.encoders.pointnet2_utils import query_ball_point, index_points
+    rng = np.random.Generator(np.random.PCG64(7))
+    B, N, M, ns, r = 2, 256, 32, 16, 0.35
+    xyz = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    new_xyz = xyz[:, rng.permutation(N)[:M]].copy()
+    idx = query_ball_point(r, ns, torch.from_numpy(xyz), torch.from_numpy(new_xyz))
+    grouped = index_points(torch.from_numpy(xyz), idx)
+    np.savez_compressed(os.path.join(HERE, "pn2_torch_ballquery.npz"), xyz=xyz, new_xyz=new_xyz, radius=np.array(r, F32),
+                        nsample=np.array(ns), idx=idx.numpy().astype(np.int64), grouped=grouped.numpy().astype(F32))
+    print("wrote pn2_torch_ballquery")
+
+
+def main():
+    torch.manual_seed(0)
+    W = synth.make_denoiser_weights(seed=0)
+    model, _ = ref_import.build_reference_model(num_timesteps=10)
+    load_denoiser_weights(model, W)
+    if "--only-pn2" in sys.argv:
+        gen_pn2_torch()
+        return
+    gen_eps(model, "B2_N128_mixed", B=2, N=128, seed=11, all_valid=False, ts=[0, 3, 9])
+    gen_eps(model, "B2_N128_allvalid", B=2, N=128, seed=12, all_valid=True, ts=[5])
+    gen_eps(model, "B1_N2048", B=1, N=2048, seed=13, all_valid=True, ts=[7])
+    gen_chain(model, "B2_N128_mixed", B=2, N=128, seed=21, all_valid=False, T=10)
+    gen_chain(model, "B3_N64_allvalid", B=3, N=64, seed=22, all_valid=True, T=10)
+    gen_tables()
+    gen_pn2_torch()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Pin the numpy oracle against golden vectors produced by the reference's own Python model
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from difffacto_amd import synth
+from oracle import denoiser as dn
+from oracle import diffusion as df
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL_EPS = 2e-5     # fp32 restatement vs reference, |eps| ~ 1
+TOL_CHAIN = 1e-4   # BASELINE.md config 1 gate for the restatement
+
+
+def _ctx(g):
+    return [g["part_code"], np.concatenate([g["mean"], np.exp(g["logvar"])], axis=1).astype(np.float32)]
+
+
+def _per_point(g):
+    return df.gather_params(g["seg"], g["mean"], np.exp(g["logvar"]).astype(np.float32))
+
+
+@pytest.fixture(scope="module")
+def W():
+    return synth.make_denoiser_weights(seed=0)
+
+
+@pytest.mark.parametrize("tag", ["B2_N128_mixed", "B2_N128_allvalid", "B1_N2048"])
+def test_denoiser_eps_matches_reference(W, tag):
+    g = np.load(os.path.join(GOLDEN, f"denoiser_eps_{tag}.npz"))
+    anchors, variance = _per_point(g)
+    B = g["x"].shape[0]
+    for t in g["ts"]:
+        eps = dn.transformer_net_forward(W, g["x"], np.full((B,), t), _ctx(g), anchors.transpose(0, 2, 1),
+                                         variance.transpose(0, 2, 1), g["valid"], g["seg"])
+        ref = g[f"eps_t{int(t)}"]
+        assert eps.shape == ref.shape
+        assert np.abs(eps - ref).max() < TOL_EPS, (tag, t, np.abs(eps - ref).max())
+
+
+@pytest.mark.parametrize("T", [10, 100, 1000])
+def test_tables_match_reference(T):
+    g = np.load(os.path.join(GOLDEN, f"tables_T{T}.npz"))
+    tb = df.Tables(T)
+    for name in g.files:
+        mine = getattr(tb, name).astype(np.float32)
+        assert np.array_equal(mine, g[name]), name
+
+
+@pytest.mark.parametrize("tag", ["B2_N128_mixed", "B3_N64_allvalid"])
+def test_chain_matches_reference(W, tag):
+    g = np.load(os.path.join(GOLDEN, f"chain_T10_{tag}.npz"))
+    T = 10
+    tb = df.Tables(T)
+    anchors, variance = _per_point(g)
+    traj = []
+    for t, out in df.p_sample_loop_progressive(tb, W, anchors, _ctx(g), variance, g["seg"], g["valid"],
+                                               g["x_T_noise"], g["step_noise"]):
+        traj.append(out["sample"])
+    traj = np.stack(traj)
+    assert traj.shape == g["traj"].shape
+    err = np.abs(traj - g["traj"]).reshape(T + 1, -1).max(axis=1)
+    assert err.max() < TOL_CHAIN, err
+    dec = df.decode(tb, W, anchors, _ctx(g), variance, g["seg"], g["valid"], g["x_T_noise"], g["step_noise"],
+                    ret_traj=True, ret_interval=int(g["ret_interval"]))
+    keys = sorted(k for k in g.files if k.startswith("decode_"))
+    assert sorted("decode_" + str(k) for k in dec) == keys
+    for k, v in dec.items():
+        assert np.abs(v - g["decode_" + str(k)]).max() < TOL_CHAIN
+
+
+def test_seg_mask_relabels_absent_part():
+    valid = np.array([[0, 1, 1, 0], [1, 1, 1, 1]], dtype=np.float32)
+    seg = synth.make_seg_mask(valid, 16)
+    assert seg.shape == (2, 16)
+    assert seg[0].tolist() == [1] * 4 + [1] * 4 + [2] * 4 + [1] * 4
+    assert seg[1].tolist() == [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4
