@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: generated shapes/sec for gen_chair (2048 pts x 4 parts, 1000-step DDPM).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch: per-batch shape-context preparation +
+the full T-step reverse chain (persistent kernel, in-kernel Philox noise) for B shapes per GPU,
+plus — for N>1 — the gather of the generated clouds to rank 0.  Latents are synthetic and already
+resident in HBM when the timed region starts.  Weak scaling: B shapes per GPU, independent shapes,
+no per-step collective; the frozen weights are broadcast from rank 0 once (RCCL), outside the timed
+region (reported as weights_bcast_ms).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from difffacto_amd import synth  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
+
+
+def flops_per_step(N, depth=5):
+    """Algorithmic matmul FLOPs of one denoiser evaluation for one shape."""
+    per_point = 13 * 128 + depth * (128 * 128 + 128 * 128 + 128 * 1024 + 512 * 128 + 2 * 8 * 4 * 16) + 128 * 3
+    return 2 * (N * per_point + depth * 2 * 4 * 522 * 128 + 256 * 2048 + 1024 * 256)
+
+
+def cpu_baseline(W, N, budget_s=20.0):
+    """The numpy oracle (validated against the reference model, tests/test_oracle_golden.py) timed on
+    this box's host cores on a bounded sample: B shapes x Tc steps of the same workload; the chain is
+    strictly sequential in t, so shapes/s at T=1000 is extrapolated linearly from s/step/shape."""
+    from oracle import diffusion as odf
+    B, Tc = 4, 5
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=7)
+    var = np.exp(logvar).astype(np.float32)
+    seg = synth.make_seg_mask(valid, N)
+    anchors, variance = odf.gather_params(seg, mean, var)
+    ctx = [part_code, np.concatenate([mean, var], 1)]
+    tb = odf.Tables(1000)
+    rng = np.random.default_rng(0)
+    x = (np.sqrt(variance) * rng.standard_normal((B, 3, N)).astype(np.float32) + anchors).astype(np.float32)
+    z = rng.standard_normal((B, 3, N)).astype(np.float32)
+    odf.p_sample(tb, W, x, 999, anchors, ctx, variance, seg, valid, z)   # warm-up (BLAS threads, page-in)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for i in range(Tc):
+            x = odf.p_sample(tb, W, x, 999 - i, anchors, ctx, variance, seg, valid, z)["sample"]
+        n += Tc
+        if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
+            break
+    dt = time.perf_counter() - t0
+    s_per_step_shape = dt / (n * B)
+    return {"value": 1.0 / (s_per_step_shape * 1000), "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy fp32 oracle, B={B} shapes x {n} p_sample steps at N={N} ({dt:.1f}s), "
+                      f"{s_per_step_shape * 1e3:.1f} ms/step/shape extrapolated to T=1000",
+            "ms_per_step_per_shape": s_per_step_shape * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="shapes per GPU (shipped val batch_size=128)")
+    ap.add_argument("--npoints", type=int, default=2048)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1:
+        import torch.distributed as dist
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from difffacto_amd.engine import DenoiserEngine
+    from difffacto_amd.parallel import broadcast_params, gather_clouds
+
+    B, N, T = args.batch, args.npoints, args.timesteps
+    names = [n for n, _ in synth.denoiser_param_shapes()]
+    if rank == 0:
+        Wnp = synth.make_denoiser_weights(seed=0)
+        params = {k: torch.from_numpy(Wnp[k]).to(dev) for k in names}
+    else:
+        Wnp = None
+        params = {k: torch.empty(s, dtype=torch.float32, device=dev) for k, s in synth.denoiser_param_shapes()}
+    bcast_ms = 0.0
+    if dist is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        broadcast_params(params, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    eng = DenoiserEngine(params, num_timesteps=T, precision=args.precision, device=dev)
+
+    # per-rank synthetic latents, resident in HBM (shape ids are global so results do not depend on world size)
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=1000 + rank)
+    seg = torch.from_numpy(synth.make_seg_mask(valid, N)).to(dev)
+    part_code, mean, var, valid = (torch.from_numpy(a).to(dev) for a in
+                                   (part_code, mean, np.exp(logvar).astype(np.float32), valid))
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def one_step(i, timed):
+        ctx = eng.prepare_shapes(part_code, mean, var, valid)
+        if timed:
+            ev[i][0].record()
+        pred, _ = eng.sample_chain(ctx, seg, seed=(rank << 32) + i)
+        if timed:
+            ev[i][1].record()
+        if dist is not None:
+            pred = gather_clouds(pred, dst=0)
+        return pred
+
+    for i in range(args.warmup):
+        one_step(i, False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = one_step(i, True)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        assert out is not None and torch.isfinite(out).all()
+        total_shapes = B * world * args.steps
+        value = total_shapes / dt
+        F = flops_per_step(N) * T * B                      # algorithmic FLOPs per launch (one rank)
+        achieved = F / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        res = {
+            "metric": "generated shapes/sec (2048 pts, 1000-step DDPM)",
+            "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"gen_chair decode: {B} shapes/GPU x {N} pts x 4 parts, T={T} DDPM steps, "
+                                   f"random-init denoiser (depth 5, inner 128), in-kernel Philox noise",
+                       "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
+                       "weights_bcast_ms": bcast_ms},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": "k_denoise (persistent T-step chain)", "kernel_ms": kern_ms,
+                         "flops_per_launch": F},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(Wnp, N)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

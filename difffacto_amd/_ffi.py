@@ -1,0 +1,109 @@
+"""ctypes binding of libdfx.so (the C-ABI declared in include/dfx.h).
+
+Thin by design: pointers are ``tensor.data_ptr()``, the stream is torch's current HIP stream, a
+non-zero return code becomes ``RuntimeError`` (the reference's pybind layer raises RuntimeError
+through AT_ASSERT, pointnet2_ops/_ext-src/include/utils.h:5-25).
+
+There is NO fallback: if the HIP library is missing or does not load, importing a kernel entry
+point raises ``DfxLibraryError``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfx.so")
+
+DFX_PREC_F32 = 0
+DFX_PREC_BF16 = 1
+DFX_MAX_DEPTH = 8
+
+
+class DfxLibraryError(RuntimeError):
+    pass
+
+
+c_fp = ctypes.c_void_p  # device pointers travel as integers
+
+
+class BlockWeights(ctypes.Structure):
+    _fields_ = [(n, c_fp) for n in (
+        "norm2_w", "norm2_b", "to_q", "to_k", "to_v", "to_out_w", "to_out_b",
+        "norm3_w", "norm3_b", "ff0_w", "ff0_b", "ff2_w", "ff2_b")]
+
+
+class DenoiserWeights(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_int)] + [(n, c_fp) for n in (
+        "proj_in_w", "proj_in_b", "pre_norm_w", "pre_norm_b", "post_norm_w", "post_norm_b",
+        "proj_out_w", "proj_out_b", "te0_w", "te0_b", "te2_w", "te2_b")] + [("blk", BlockWeights * DFX_MAX_DEPTH)]
+
+
+# name -> (restype, argtypes); every symbol include/dfx.h declares
+_I, _F, _P, _U64, _SZ, _D = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_double
+SIGNATURES = {
+    "dfx_version": (_I, []),
+    "dfx_last_error": (ctypes.c_char_p, []),
+    "dfx_gather_points_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfx_gather_points_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfx_furthest_point_sampling_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "dfx_fps_max_resident": (_I, []),
+    "dfx_ball_query_f32": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "dfx_group_points_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfx_group_points_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfx_three_nn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfx_three_interpolate_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfx_three_interpolate_grad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfx_denoiser_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(DenoiserWeights), _I, _D, _D, _I, _P]),
+    "dfx_denoiser_destroy": (None, [_P]),
+    "dfx_denoiser_num_timesteps": (_I, [_P]),
+    "dfx_denoiser_precision": (_I, [_P]),
+    "dfx_denoiser_get_tables": (_I, [_P, _P]),
+    "dfx_shape_ctx_bytes": (_SZ, [_P, _I]),
+    "dfx_shape_ctx_prepare": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "dfx_denoise_eps": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "dfx_p_sample": (_I, [_P, _P, _P, _P, _I, _P, _U64, _P, _P, _I, _I, _P]),
+    "dfx_chain_num_snapshots": (_I, [_I, _I]),
+    "dfx_sample_chain": (_I, [_P, _P, _P, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
+    "dfx_set_event_timing": (None, [_I]),
+    "dfx_last_kernel_ms": (_F, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdfx.so once.  Raises DfxLibraryError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfxLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m difffacto_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise DfxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise DfxLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dfx_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """data_ptr of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

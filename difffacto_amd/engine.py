@@ -1,0 +1,195 @@
+"""Host-side driver of libdfx's denoiser: owns the opaque ``dfx_denoiser`` handle and the per-batch
+shape context.  PyTorch is used for device memory and the stream only.
+
+    eng = DenoiserEngine(params, num_timesteps=1000, precision="bf16")
+    ctx = eng.prepare_shapes(part_code, mean, var, valid)       # once per batch of shapes
+    pred, traj = eng.sample_chain(ctx, seg, ret_interval=10)    # the whole reverse chain, one launch
+
+``params`` maps the reference ``state_dict`` names relative to ``diffusion.model.``
+ to fp32 CUDA tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+PRECISIONS = {"f32": _ffi.DFX_PREC_F32, "fp32": _ffi.DFX_PREC_F32, "bf16": _ffi.DFX_PREC_BF16}
+
+TABLE_NAMES = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+               "posterior_mean_coef2", "posterior_mean_coef3", "posterior_variance", "sqrt_alphas_cumprod",
+               "sqrt_one_minus_alphas_cumprod")
+
+_BLOCK_FIELDS = {
+    "norm2_w": "norm2.weight", "norm2_b": "norm2.bias", "to_q": "attn2.to_q.weight", "to_k": "attn2.to_k.weight",
+    "to_v": "attn2.to_v.weight", "to_out_w": "attn2.to_out.0.weight", "to_out_b": "attn2.to_out.0.bias",
+    "norm3_w": "norm3.weight", "norm3_b": "norm3.bias", "ff0_w": "ff.net.0.proj.weight",
+    "ff0_b": "ff.net.0.proj.bias", "ff2_w": "ff.net.2.weight", "ff2_b": "ff.net.2.bias",
+}
+_TOP_FIELDS = {
+    "proj_in_w": "proj_in.weight", "proj_in_b": "proj_in.bias", "pre_norm_w": "pre_norm.weight",
+    "pre_norm_b": "pre_norm.bias", "post_norm_w": "post_norm.weight", "post_norm_b": "post_norm.bias",
+    "proj_out_w": "proj_out.weight", "proj_out_b": "proj_out.bias", "te0_w": "time_embed.net.0.proj.weight",
+    "te0_b": "time_embed.net.0.proj.bias", "te2_w": "time_embed.net.2.weight", "te2_b": "time_embed.net.2.bias",
+}
+
+EXPECTED_SHAPES = {
+    "proj_in.weight": (128, 13), "proj_in.bias": (128,), "proj_out.weight": (3, 128), "proj_out.bias": (3,),
+    "time_embed.net.0.proj.weight": (2048, 256), "time_embed.net.2.weight": (256, 1024),
+    "attn2.to_q.weight": (128, 128), "attn2.to_k.weight": (128, 522), "attn2.to_v.weight": (128, 522),
+    "attn2.to_out.0.weight": (128, 128), "ff.net.0.proj.weight": (1024, 128), "ff.net.2.weight": (128, 512),
+}
+
+
+def _dev_f32(t, name, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+    for suffix, shape in EXPECTED_SHAPES.items():
+        if name.endswith(suffix) and tuple(t.shape) != shape:
+            raise RuntimeError(f"{name}: expected shape {shape}, got {tuple(t.shape)} "
+                               "(libdfx is specialised for the shipped gen_* denoiser)")
+    return t
+
+
+class ShapeContext:
+    """Per-batch static operands living in one device buffer (dfx_shape_ctx_prepare)."""
+
+    def __init__(self, buf, B):
+        self.buf = buf
+        self.B = B
+
+
+class DenoiserEngine:
+    def __init__(self, params, num_timesteps, beta_1=1e-4, beta_T=0.02, precision="bf16", device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DenoiserEngine needs a HIP device (there is no CPU path)")
+        self.device = torch.device(device if device is not None else "cuda")
+        self.precision = precision
+        prec = PRECISIONS[precision]
+        depth = 0
+        while f"transformer_blocks.{depth}.norm2.weight" in params:
+            depth += 1
+        if not 1 <= depth <= _ffi.DFX_MAX_DEPTH:
+            raise RuntimeError(f"unsupported depth {depth}")
+        self.depth = depth
+        self.num_timesteps = int(num_timesteps)
+        keep = []
+        w = _ffi.DenoiserWeights()
+        w.depth = depth
+        for field, key in _TOP_FIELDS.items():
+            t = _dev_f32(params[key], key, self.device)
+            keep.append(t)
+            setattr(w, field, t.data_ptr())
+        for b in range(depth):
+            for field, key in _BLOCK_FIELDS.items():
+                full = f"transformer_blocks.{b}.{key}"
+                t = _dev_f32(params[full], full, self.device)
+                keep.append(t)
+                setattr(w.blk[b], field, t.data_ptr())
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_denoiser_create(ctypes.byref(handle), ctypes.byref(w), self.num_timesteps,
+                                               float(beta_1), float(beta_T), prec, _ffi.current_stream())
+        _ffi.check(rc, "dfx_denoiser_create")
+        del keep  # create() synchronised the stream: parameters are no longer referenced
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().dfx_denoiser_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def tables(self):
+        """The fp32 schedule tables the kernels use, dict name -> (T,) numpy."""
+        out = np.empty((8, self.num_timesteps), dtype=np.float32)
+        _ffi.check(_ffi.lib().dfx_denoiser_get_tables(self._h, out.ctypes.data_as(ctypes.c_void_p)), "get_tables")
+        return dict(zip(TABLE_NAMES, out))
+
+    def prepare_shapes(self, part_code, mean, var, valid):
+        """part_code (B,256,4), mean (B,3,4), var (B,3,4) [= exp(logvar)], valid (B,4) -> ShapeContext."""
+        f = lambda t: t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        part_code, mean, var, valid = f(part_code), f(mean), f(var), f(valid)
+        B = part_code.shape[0]
+        if tuple(part_code.shape) != (B, 256, 4) or tuple(mean.shape) != (B, 3, 4) or tuple(var.shape) != (B, 3, 4) \
+                or tuple(valid.shape) != (B, 4):
+            raise RuntimeError("prepare_shapes: expected part_code (B,256,4), mean/var (B,3,4), valid (B,4)")
+        nbytes = _ffi.lib().dfx_shape_ctx_bytes(self._h, B)
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_shape_ctx_prepare(self._h, _ffi.ptr(part_code), _ffi.ptr(mean), _ffi.ptr(var),
+                                                 _ffi.ptr(valid), _ffi.ptr(buf), B, _ffi.current_stream())
+        _ffi.check(rc, "dfx_shape_ctx_prepare")
+        return ShapeContext(buf, B)
+
+    @staticmethod
+    def _seg(seg, device):
+        seg = seg.detach().to(device=device, dtype=torch.int32).contiguous()
+        return seg
+
+    def eps(self, ctx, x, seg, t):
+        """TransformerNet.forward: x (B,3,N), seg (B,N) -> eps (B,3,N)."""
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        seg = self._seg(seg, self.device)
+        B, _, N = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_denoise_eps(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t),
+                                           _ffi.ptr(out), B, N, _ffi.current_stream())
+        _ffi.check(rc, "dfx_denoise_eps")
+        return out
+
+    def p_sample(self, ctx, x, seg, t, noise=None, seed=0, want_xstart=False):
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        seg = self._seg(seg, self.device)
+        B, _, N = x.shape
+        if noise is not None:
+            noise = noise.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            assert noise.shape == x.shape
+        out = torch.empty_like(x)
+        xs = torch.empty_like(x) if want_xstart else None
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_p_sample(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t),
+                                        _ffi.ptr(noise), int(seed), _ffi.ptr(out), _ffi.ptr(xs), B, N,
+                                        _ffi.current_stream())
+        _ffi.check(rc, "dfx_p_sample")
+        return (out, xs) if want_xstart else out
+
+    def sample_chain(self, ctx, seg, x_T_noise=None, step_noise=None, seed=0, ret_interval=None):
+        """Whole reverse chain in one launch.  Returns (pred (B,N,3), traj or None) where traj is
+        (n_keep,B,N,3) with snapshot k <-> t = (T // ret_interval - k) * ret_interval."""
+        seg = self._seg(seg, self.device)
+        B, N = seg.shape
+        T = self.num_timesteps
+        f = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        x_T_noise, step_noise = f(x_T_noise), f(step_noise)
+        if x_T_noise is not None:
+            assert tuple(x_T_noise.shape) == (B, 3, N)
+        if step_noise is not None:
+            assert tuple(step_noise.shape) == (T, B, 3, N)
+        pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
+        traj = None
+        ri = 0
+        if ret_interval:
+            ri = int(ret_interval)
+            nk = _ffi.lib().dfx_chain_num_snapshots(T, ri)
+            traj = torch.empty(nk, B, N, 3, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_sample_chain(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), _ffi.ptr(x_T_noise),
+                                            _ffi.ptr(step_noise), int(seed), ri, _ffi.ptr(traj), _ffi.ptr(pred), B, N,
+                                            _ffi.current_stream())
+        _ffi.check(rc, "dfx_sample_chain")
+        return pred, traj
+
+    def snapshot_times(self, ret_interval):
+        T = self.num_timesteps
+        nk = T // ret_interval
+        return [(nk - k) * ret_interval for k in range(nk)]

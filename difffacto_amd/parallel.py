@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing for sampling: one process per GPU, independent shapes sharded over ranks.
+
+The path shards naturally: shapes are independent, so the ONLY communication is
+  (1) one broadcast of the frozen parameter blob from rank 0 (RCCL over xGMI; flat 1->N), and
+  (2) one gather of the generated clouds (B_r, N, 3) to rank 0 at the end.
+Nothing per diffusion step.  The reference's own multi-GPU mode is nn.DataParallel / DDP with NCCL
+(python/difffacto/runner/runner.py:61-73, utils/dist_utils.py:9-62) and has no sampling collective.
+Works with the "nccl" (= RCCL) backend on GPUs and with "gloo" on CPU tensors (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous block partition of `total` shapes: rank r gets [lo, hi).  Sizes differ by <= 1."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_params(params, src=0):
+    """One collective for the whole frozen parameter set: pack -> broadcast -> unpack in place.
+    `params` is an ordered dict name -> tensor, same shapes on every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return params
+    names = list(params)
+    flat = torch.cat([params[k].reshape(-1).to(torch.float32) for k in names])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for k in names:
+        n = params[k].numel()
+        params[k].copy_(flat[off:off + n].view_as(params[k]))
+        off += n
+    return params
+
+
+def gather_clouds(pred, dst=0):
+    """Gather per-rank generated clouds (B_r, N, 3) to `dst`; returns the concatenation on dst
+    (rank order) and None elsewhere.  Ragged B_r is allowed (sizes exchanged first)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return pred
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=pred.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([pred.shape[0]], dtype=torch.int64, device=pred.device))
+    sizes = [int(s.item()) for s in sizes]
+    bmax = max(sizes)
+    pad = pred
+    if pred.shape[0] < bmax:
+        pad = torch.cat([pred, pred.new_zeros((bmax - pred.shape[0],) + tuple(pred.shape[1:]))])
+    pad = pad.contiguous()
+    if rank == dst:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, gather_list=bufs, dst=dst)
+        return torch.cat([b[:n] for b, n in zip(bufs, sizes)])
+    dist.gather(pad, gather_list=None, dst=dst)
+    return None

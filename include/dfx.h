@@ -1,0 +1,190 @@
+/* libdfx — MI355X-native (gfx950) kernels for DiffFacto's reverse-diffusion sampling hot path.
+ *
+ * C-ABI drop-in boundary.  Plain pointers and sizes only; every pointer is a
+ * DEVICE pointer unless stated otherwise; every launch goes on the caller's HIP stream
+ * (`stream` is a hipStream_t passed as void*; NULL = the default stream), no hidden syncs.
+ * Inputs are borrowed, outputs are caller-allocated and fully written by the call (no
+ * dependence on pre-zeroed outputs unless stated).  Return value: 0 = DFX_OK, negative =
+ * error (never exit(), unlike the reference's CUDA_CHECK_ERRORS,
+ * pointnet2_ops_lib/pointnet2_ops/_ext-src/include/cuda_utils.h:30-39); dfx_last_error() gives the
+ * message for the calling thread.  Single caller thread per device.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repo root; SRC = pointnet2_ops_lib/pointnet2_ops/_ext-src/src).
+ */
+#ifndef DFX_H
+#define DFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFX_OK 0
+#define DFX_ERR_INVALID_ARG (-1)
+#define DFX_ERR_HIP (-2)
+#define DFX_ERR_UNSUPPORTED (-3)
+#define DFX_ERR_ALLOC (-4)
+
+#define DFX_MAX_DEPTH 8
+
+/* arithmetic of the dense contraction (LayerNorm, softmax, GELU, posterior are fp32 in both) */
+#define DFX_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32, the parity gate            */
+#define DFX_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate       */
+
+typedef void *dfx_stream_t;
+
+int dfx_version(void);
+const char *dfx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * pointnet2_ops primitives — replace the pybind module `pointnet2_ops._ext`
+ * (SRC/bindings.cpp:6-19); fp32 + int32, contiguous.
+ * ------------------------------------------------------------------------------------------ */
+
+/* _ext.gather_points  (SRC/sampling.cpp:15-38 -> SRC/sampling_gpu.cu:8-30)
+ * out[b,c,j] = points[b,c,idx[b,j]];  points (B,C,N), idx (B,M) -> out (B,C,M) */
+int dfx_gather_points_f32(const float *points, const int32_t *idx, float *out, int B, int C, int N, int M,
+                          dfx_stream_t stream);
+
+/* _ext.gather_points_grad  (SRC/sampling.cpp:40-64 -> SRC/sampling_gpu.cu:34-57)
+ * grad_points (B,C,N) is ZEROED by the call, then scatter-added from grad_out (B,C,M). */
+int dfx_gather_points_grad_f32(const float *grad_out, const int32_t *idx, float *grad_points, int B, int C, int N,
+                               int M, dfx_stream_t stream);
+
+/* _ext.furthest_point_sampling  (SRC/sampling.cpp:66-87 -> SRC/sampling_gpu.cu:69-229)
+ * xyz (B,N,3) -> idx (B,M).  Starts at index 0, skips points with |p|^2 <= 1e-3, reproduces the
+ * reference block-reduction tie rule for opt_n_threads(N) threads.  `tmp` (B,N) floats is scratch
+ * (the reference's `temp`, filled with 1e10 by the call); may be NULL when N <= dfx_fps_max_resident(). */
+int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, int B, int N, int M,
+                                    dfx_stream_t stream);
+int dfx_fps_max_resident(void);
+
+/* _ext.ball_query  (SRC/ball_query.cpp:8-32 -> SRC/ball_query_gpu.cu:9-54)
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample): first `nsample` indices k (ascending) with
+ * d2 < radius^2; first hit pre-fills all slots; no hit -> zeros.  Argument order is the C++ op's. */
+int dfx_ball_query_f32(const float *new_xyz, const float *xyz, int32_t *idx, int B, int N, int M, float radius,
+                       int nsample, dfx_stream_t stream);
+
+/* _ext.group_points  (SRC/group_points.cpp:12-36 -> SRC/group_points_gpu.cu:8-39)
+ * out[b,c,j,k] = points[b,c,idx[b,j,k]];  points (B,C,N), idx (B,npoints,nsample). */
+int dfx_group_points_f32(const float *points, const int32_t *idx, float *out, int B, int C, int N, int npoints,
+                         int nsample, dfx_stream_t stream);
+
+/* _ext.group_points_grad  (SRC/group_points.cpp:38-62 -> SRC/group_points_gpu.cu:43-75); zeroes grad_points. */
+int dfx_group_points_grad_f32(const float *grad_out, const int32_t *idx, float *grad_points, int B, int C, int N,
+                              int npoints, int nsample, dfx_stream_t stream);
+
+/* _ext.three_nn  (SRC/interpolate.cpp:14-40 -> SRC/interpolate_gpu.cu:9-68)
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) SQUARED distances, idx (B,n,3). */
+int dfx_three_nn_f32(const float *unknown, const float *known, float *dist2, int32_t *idx, int B, int n, int m,
+                     dfx_stream_t stream);
+
+/* _ext.three_interpolate (SRC/interpolate.cpp:42-70 -> SRC/interpolate_gpu.cu:72-111)
+ * points (B,c,m), idx (B,n,3), weight (B,n,3) -> out (B,c,n). */
+int dfx_three_interpolate_f32(const float *points, const int32_t *idx, const float *weight, float *out, int B,
+                              int c, int m, int n, dfx_stream_t stream);
+
+/* _ext.three_interpolate_grad (SRC/interpolate.cpp:72-99 -> SRC/interpolate_gpu.cu:116-154); zeroes grad_points (B,c,m). */
+int dfx_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, const float *weight,
+                                   float *grad_points, int B, int c, int n, int m, dfx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cross-diffusion denoiser + anchored DDPM reverse process.
+ * Replaces, for the shipped gen_* configs (inner 128 = 8 heads x 16, n_class 4, ctx 522,
+ * GEGLU FF 128 -> 2*512 -> 128, single cross-attention per block):
+ *   TransformerNet.forward        python/difffacto/models/diffusions/nets/attention.py:385-440
+ *   AnchoredDiffusion.p_mean_variance / p_sample / p_sample_loop_progressive
+ *                                 python/difffacto/models/diffusions/anchored_diffusion.py:227-395,450-484,528-588
+ *   gather_operation of the per-part params (part_encoders.py:417-428) — folded in: the kernels
+ *   index the (B,3,4) part params by `seg` instead of materialising (B,3,N) tensors.
+ * ------------------------------------------------------------------------------------------ */
+
+/* fp32 device pointers to the reference parameters (torch Linear layout: weight (out,in)),
+ * named by their state_dict keys relative to `diffusion.model.`. */
+typedef struct dfx_block_weights {
+  const float *norm2_w, *norm2_b;   /* transformer_blocks.i.norm2.{weight,bias}      (128)     */
+  const float *to_q;                /* ...attn2.to_q.weight                          (128,128) */
+  const float *to_k, *to_v;         /* ...attn2.to_{k,v}.weight                      (128,522) */
+  const float *to_out_w, *to_out_b; /* ...attn2.to_out.0.{weight,bias}               (128,128),(128) */
+  const float *norm3_w, *norm3_b;   /* ...norm3.{weight,bias}                        (128)     */
+  const float *ff0_w, *ff0_b;       /* ...ff.net.0.proj.{weight,bias}                (1024,128),(1024) */
+  const float *ff2_w, *ff2_b;       /* ...ff.net.2.{weight,bias}                     (128,512),(128) */
+} dfx_block_weights;
+
+typedef struct dfx_denoiser_weights {
+  int depth;                          /* number of transformer blocks (<= DFX_MAX_DEPTH)  */
+  const float *proj_in_w, *proj_in_b; /* proj_in.{weight,bias}            (128,13),(128)  */
+  const float *pre_norm_w, *pre_norm_b;
+  const float *post_norm_w, *post_norm_b;
+  const float *proj_out_w, *proj_out_b; /* proj_out.{weight,bias}         (3,128),(3)     */
+  const float *te0_w, *te0_b;           /* time_embed.net.0.proj.{weight,bias} (2048,256),(2048) */
+  const float *te2_w, *te2_b;           /* time_embed.net.2.{weight,bias}      (256,1024),(256)  */
+  dfx_block_weights blk[DFX_MAX_DEPTH];
+} dfx_denoiser_weights;
+
+typedef struct dfx_denoiser dfx_denoiser; /* opaque; owns repacked weights + per-t tables on the device */
+
+/* Build the frozen denoiser for one diffusion schedule (AnchoredDiffusion.__init__,
+ * anchored_diffusion.py:62-112, mode='linear'): repacks weights into MFMA fragment order for
+ * `precision`, tabulates the time-embedding MLP and the per-t attention/posterior constants for
+ * t = 0..num_timesteps-1.  The source parameters are only read during this call (stream-ordered:
+ * keep them alive until the stream has passed it). */
+int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int num_timesteps, double beta_1,
+                        double beta_T, int precision, dfx_stream_t stream);
+void dfx_denoiser_destroy(dfx_denoiser *d);
+int dfx_denoiser_num_timesteps(const dfx_denoiser *d);
+int dfx_denoiser_precision(const dfx_denoiser *d);
+
+/* Copies the 8 fp32 schedule tables the kernels use to HOST memory, each `num_timesteps` long, in the
+ * order: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, _coef2, _coef3,
+ * posterior_variance, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod  (out: host float[8*T]). */
+int dfx_denoiser_get_tables(const dfx_denoiser *d, float *host_out);
+
+/* Per-batch static context (once per batch of shapes, before the T-loop): the 4 part tokens'
+ * K/V projections folded with to_q / to_out and the per-part proj_in constants.
+ *   part_code (B,256,4)  mean (B,3,4)  var (B,3,4) = exp(logvar)   [ctx list of prepare_ctx,
+ *   part_encoders.py:1317-1326]   valid (B,4) floats (mask of attention.py:192-197)
+ * `ctx_out` is a caller-allocated device buffer of dfx_shape_ctx_bytes(d, B) bytes. */
+size_t dfx_shape_ctx_bytes(const dfx_denoiser *d, int B);
+int dfx_shape_ctx_prepare(const dfx_denoiser *d, const float *part_code, const float *mean, const float *var,
+                          const float *valid, void *ctx_out, int B, dfx_stream_t stream);
+
+/* One TransformerNet.forward: eps (B,3,N) = eps_theta(x (B,3,N), t) with anchors/variances/one-hot
+ * taken from the shape context through seg (B,N) int32 in [0,4).  N % 32 == 0.  `t` is the same for
+ * the whole batch (anchored_diffusion.py:576). */
+int dfx_denoise_eps(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t,
+                    float *eps, int B, int N, dfx_stream_t stream);
+
+/* One p_sample (anchored_diffusion.py:450-484): x_prev = mean + 1[t!=0] sqrt(var) z.
+ * noise (B,3,N) = the z of :476, or NULL -> in-kernel Philox4x32-10 normals keyed by
+ * (seed, global point id, t).  x_prev may alias x.  pred_xstart (B,3,N) is optional (NULL to skip):
+ * the x_0 prediction p_sample returns next to the sample (:484). */
+int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t,
+                 const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                 dfx_stream_t stream);
+
+/* The whole reverse chain in ONE persistent launch (p_sample_loop_progressive :528-588 driven by
+ * AnchorDiffAE.decode, python/difffacto/models/networks/anchor_gen.py:145-169): x_t stays in registers
+ * for all T steps.
+ *   x_T_noise  (B,3,N) the randn of :564, or NULL -> Philox
+ *   step_noise (T,B,3,N), step_noise[i] = z of the i-th executed step (t = T-1-i), or NULL -> Philox
+ *   pred       (B,N,3)  final cloud, already transposed like decode's 'pred'
+ *   traj       NULL, or (n_keep,B,N,3) snapshots for t = T, then every t>0 with t % ret_interval == 0 in
+ *              descending order (decode's ret_traj entries); n_keep = dfx_chain_num_snapshots(T, ret_interval). */
+int dfx_chain_num_snapshots(int num_timesteps, int ret_interval);
+int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const float *x_T_noise,
+                     const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
+                     int N, dfx_stream_t stream);
+
+/* Name + average duration bookkeeping for bench.py: duration in ms of the last dfx_sample_chain /
+ * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */
+void dfx_set_event_timing(int enable);
+float dfx_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_H */

@@ -1,0 +1,126 @@
+"""ctypes wrapper around the C oracle of the pointnet2_ops kernels (ORACLE — test only).
+
+Allocation / fill conventions follow the reference's C++ wrappers:
+  gather / group / interpolate outputs  torch::zeros      (sampling.cpp:25-27, group_points.cpp, interpolate.cpp)
+  FPS scratch                           full(1e10)        (sampling.cpp:74-76)
+  ball_query idx                        zeros             (ball_query.cpp:19-21)
+The python-level ``three_nn`` returns sqrt(dist2) (pointnet2_utils.py:124-125).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle_pn2.so")
+_lib = None
+
+_F = np.float32
+_I = np.int32
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "pointnet2.c")):
+            build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+def opt_n_threads(n):
+    return lib().oracle_opt_n_threads(int(n))
+
+
+def gather_points(points, idx):
+    points, idx = _c(points, _F), _c(idx, _I)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = np.zeros((B, C, M), _F)
+    lib().oracle_gather_points(B, C, N, M, _p(points), _p(idx), _p(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, N):
+    grad_out, idx = _c(grad_out, _F), _c(idx, _I)
+    B, C, M = grad_out.shape
+    out = np.zeros((B, C, N), _F)
+    lib().oracle_gather_points_grad(B, C, N, M, _p(grad_out), _p(idx), _p(out))
+    return out
+
+
+def furthest_point_sampling(xyz, npoint):
+    xyz = _c(xyz, _F)
+    B, N, _ = xyz.shape
+    tmp = np.full((B, N), 1e10, _F)
+    out = np.zeros((B, npoint), _I)
+    lib().oracle_furthest_point_sampling(B, N, int(npoint), _p(xyz), _p(tmp), _p(out))
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """python-level argument order (pointnet2_utils.py:265)."""
+    xyz, new_xyz = _c(xyz, _F), _c(new_xyz, _F)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), _I)
+    lib().oracle_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), _p(new_xyz), _p(xyz), _p(idx))
+    return idx
+
+
+def group_points(points, idx):
+    points, idx = _c(points, _F), _c(idx, _I)
+    B, C, N = points.shape
+    _, NP, NS = idx.shape
+    out = np.zeros((B, C, NP, NS), _F)
+    lib().oracle_group_points(B, C, N, NP, NS, _p(points), _p(idx), _p(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, N):
+    grad_out, idx = _c(grad_out, _F), _c(idx, _I)
+    B, C, NP, NS = grad_out.shape
+    out = np.zeros((B, C, N), _F)
+    lib().oracle_group_points_grad(B, C, N, NP, NS, _p(grad_out), _p(idx), _p(out))
+    return out
+
+
+def three_nn(unknown, known):
+    unknown, known = _c(unknown, _F), _c(known, _F)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.zeros((B, n, 3), _F)
+    idx = np.zeros((B, n, 3), _I)
+    lib().oracle_three_nn(B, n, m, _p(unknown), _p(known), _p(d2), _p(idx))
+    return np.sqrt(d2), idx
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _c(points, _F), _c(idx, _I), _c(weight, _F)
+    B, C, m = points.shape
+    n = idx.shape[1]
+    out = np.zeros((B, C, n), _F)
+    lib().oracle_three_interpolate(B, C, m, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, idx, weight = _c(grad_out, _F), _c(idx, _I), _c(weight, _F)
+    B, C, n = grad_out.shape
+    out = np.zeros((B, C, m), _F)
+    lib().oracle_three_interpolate_grad(B, C, n, m, _p(grad_out), _p(idx), _p(weight), _p(out))
+    return out

@@ -1,0 +1,82 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol
+include/dfx.h declares; host-side modules keep the reference's names and state_dict layout.
+No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from difffacto_amd import build
+    return build.build(verbose=False)
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    names = _declared_symbols()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"libdfx.so does not export {n}"
+
+
+def test_ffi_signatures_cover_header(built_lib):
+    from difffacto_amd import _ffi
+    assert sorted(_ffi.SIGNATURES) == _declared_symbols()
+    L = _ffi.lib()
+    assert L.dfx_version() >= 100
+    assert L.dfx_chain_num_snapshots(100, 10) == 10
+    assert L.dfx_chain_num_snapshots(10, 3) == 3
+    assert L.dfx_fps_max_resident() >= 8192
+
+
+def test_error_codes_without_gpu(built_lib):
+    """Argument validation happens before any HIP call, so it is testable on CPU."""
+    from difffacto_amd import _ffi
+    L = _ffi.lib()
+    rc = L.dfx_gather_points_f32(None, None, None, -1, 1, 1, 1, None)
+    assert rc == -1 and b"negative" in L.dfx_last_error()
+    assert L.dfx_gather_points_f32(None, None, None, 0, 3, 5, 0, None) == 0          # empty input is a no-op
+    assert L.dfx_furthest_point_sampling_f32(None, None, None, 0, 0, 0, None) == 0
+    assert L.dfx_denoise_eps(None, None, None, None, 0, None, 1, 32, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from difffacto_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_ffi.DfxLibraryError):
+        _ffi.lib()
+
+
+def test_pointnet2_api_surface():
+    from difffacto_amd.pointnet2_ops import pointnet2_utils as pu, pointnet2_modules as pm
+    for name in ["furthest_point_sample", "gather_operation", "three_nn", "three_interpolate",
+                 "grouping_operation", "ball_query", "QueryAndGroup", "GroupAll"]:
+        assert hasattr(pu, name)
+    sa = pm.PointnetSAModule(npoint=512, radius=0.2, nsample=64, mlp=[4, 64, 64, 128], use_xyz=True)
+    keys = list(sa.state_dict().keys())
+    assert keys[0] == "mlps.0.0.weight" and sa.state_dict()["mlps.0.0.weight"].shape == (64, 7, 1, 1)
+    msg = pm.PointnetSAModuleMSG(npoint=128, radii=[0.1, 0.2], nsamples=[16, 32], mlps=[[3, 8], [3, 16]])
+    assert len(msg.groupers) == 2
+    fp = pm.PointnetFPModule(mlp=[16, 8])
+    assert "mlp.0.weight" in fp.state_dict()
+
+
+def test_cpu_tensors_rejected_like_reference():
+    import torch
+    from difffacto_amd.pointnet2_ops import pointnet2_utils as pu
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        pu.gather_operation(torch.zeros(1, 3, 4), torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        pu.furthest_point_sample(torch.zeros(1, 8, 3), 4)

@@ -1,0 +1,121 @@
+"""CPU: the C oracle of the pointnet2_ops kernels against hand-checked known answers, numpy
+restatements, and the golden vectors from the reference's pure-torch PointNet++ helpers."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pointnet2 as opn
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_ball_query_matches_reference_torch_helper():
+    g = np.load(os.path.join(GOLDEN, "pn2_torch_ballquery.npz"))
+    idx = opn.ball_query(float(g["radius"]), int(g["nsample"]), g["xyz"], g["new_xyz"])
+    assert np.array_equal(idx.astype(np.int64), g["idx"])
+    grouped = opn.group_points(np.ascontiguousarray(g["xyz"].transpose(0, 2, 1)), idx)   # (B,3,M,ns)
+    assert np.array_equal(grouped.transpose(0, 2, 3, 1), g["grouped"])
+
+
+def test_ball_query_known_answer():
+    xyz = np.array([[[0, 0, 0], [1, 0, 0], [0.1, 0, 0], [0.2, 0, 0], [5, 5, 5]]], np.float32)
+    q = np.array([[[0, 0, 0], [9, 9, 9], [1, 0, 0]]], np.float32)
+    idx = opn.ball_query(0.25, 4, xyz, q)
+    assert idx[0, 0].tolist() == [0, 2, 3, 0]      # first hit pads
+    assert idx[0, 1].tolist() == [0, 0, 0, 0]      # no hit -> zeros
+    assert idx[0, 2].tolist() == [1, 1, 1, 1]
+    idx = opn.ball_query(0.25, 2, xyz, q)          # truncation keeps ascending first hits
+    assert idx[0, 0].tolist() == [0, 2]
+    xyz2 = np.array([[[0, 0, 0], [0.5, 0, 0]]], np.float32)   # strict '<' on d2 == r^2
+    assert opn.ball_query(0.5, 2, xyz2, xyz2[:, :1])[0, 0].tolist() == [0, 0]
+
+
+def _fps_naive(xyz, m):
+    """Plain numpy FPS with 'first maximum' ties; equals the reference only when there are no ties."""
+    n = xyz.shape[0]
+    tmp = np.full(n, 1e10, np.float32)
+    live = (xyz.astype(np.float32) ** 2).sum(1) > 1e-3
+    out = [0]
+    for _ in range(1, m):
+        d = ((xyz - xyz[out[-1]]) ** 2).sum(1).astype(np.float32)
+        tmp = np.where(live, np.minimum(tmp, d), tmp)
+        cand = np.where(live, tmp, -1)
+        out.append(int(np.argmax(cand)))
+    return out
+
+
+def test_fps_generic_and_origin_skip():
+    rng = np.random.default_rng(3)
+    xyz = rng.standard_normal((2, 700, 3)).astype(np.float32)
+    xyz[0, 5] = 0.0          # |p|^2 <= 1e-3 -> never selected (except as the forced start index 0)
+    xyz[0, 9] = [0.02, 0.01, 0.0]
+    idx = opn.furthest_point_sampling(xyz, 64)
+    assert idx.shape == (2, 64) and idx[:, 0].tolist() == [0, 0]
+    assert 5 not in idx[0].tolist() and 9 not in idx[0].tolist()
+    for b in range(2):
+        assert len(set(idx[b].tolist())) == 64
+        # no ties in random data -> must agree with the naive arg-max order in distance terms
+        naive = _fps_naive(xyz[b], 64)
+        assert idx[b].tolist() == naive
+
+
+def test_fps_tie_rule_block_reduction():
+    # 4 corners of a square: after 0 the opposite corner 3 wins; then corners 1 and 2 tie exactly.
+    # opt_n_threads(4) = 4: the tree first folds slot 2 into slot 0 and slot 3 into slot 1 (stride 2), then
+    # compares slot 0 (now k=2) with slot 1 (k=1) and keeps slot 0 on the tie -> index 2, not 1.
+    sq = np.array([[[1, 1, 0], [1, -1, 0], [-1, 1, 0], [-1, -1, 0]]], np.float32)
+    assert opn.furthest_point_sampling(sq, 3)[0].tolist() == [0, 3, 2]
+    # duplicates: with bs = 512 a tie between k=1 (slot 1) and k=2 (slot 2) goes to k=2, because the tree
+    # (stride 256..1) compares slot 0<-1 LAST: bit-reversed slot order decides, not the index.
+    n = 600
+    pts = np.zeros((1, n, 3), np.float32)
+    pts[0, :, 0] = 1.0                      # everyone sits at (1,0,0) ...
+    pts[0, 1] = pts[0, 2] = [-3.0, 0, 0]    # ... except two duplicates far away
+    assert opn.opt_n_threads(n) == 512
+    assert opn.furthest_point_sampling(pts, 2)[0].tolist() == [0, 2]
+    # same cloud, third pick: every remaining point has distance 0 -> all-zero tie -> slot 0 -> index 0
+    assert opn.furthest_point_sampling(pts, 3)[0].tolist() == [0, 2, 0]
+
+
+def test_fps_all_points_skipped():
+    z = np.zeros((1, 40, 3), np.float32)
+    assert opn.furthest_point_sampling(z, 5)[0].tolist() == [0, 0, 0, 0, 0]
+
+
+def test_gather_group_interpolate_against_numpy():
+    rng = np.random.default_rng(0)
+    B, C, N, M = 3, 5, 37, 11
+    pts = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, M)).astype(np.int32)
+    out = opn.gather_points(pts, idx)
+    ref = np.take_along_axis(pts, np.broadcast_to(idx[:, None, :].astype(np.int64), (B, C, M)), axis=2)
+    assert np.array_equal(out, ref)
+    g = rng.standard_normal((B, C, M)).astype(np.float32)
+    gp = opn.gather_points_grad(g, idx, N)
+    ref = np.zeros((B, C, N), np.float32)
+    for b in range(B):
+        for j in range(M):
+            ref[b, :, idx[b, j]] += g[b, :, j]
+    assert np.allclose(gp, ref, atol=1e-6)
+    gi = rng.integers(0, N, size=(B, 4, 6)).astype(np.int32)
+    grp = opn.group_points(pts, gi)
+    assert np.array_equal(grp, pts[np.arange(B)[:, None, None, None], np.arange(C)[None, :, None, None], gi[:, None]])
+    unknown = rng.standard_normal((B, 9, 3)).astype(np.float32)
+    known = rng.standard_normal((B, 20, 3)).astype(np.float32)
+    dist, nn = opn.three_nn(unknown, known)
+    d2 = ((unknown[:, :, None] - known[:, None]) ** 2).sum(-1)
+    assert np.array_equal(nn, np.argsort(d2, axis=-1, kind="stable")[..., :3].astype(np.int32))
+    assert np.allclose(dist, np.sqrt(np.sort(d2, axis=-1)[..., :3]), atol=1e-6)
+    w = rng.random((B, 9, 3)).astype(np.float32)
+    feats = rng.standard_normal((B, C, 20)).astype(np.float32)
+    it = opn.three_interpolate(feats, nn, w)
+    ref = sum(np.take_along_axis(feats, np.broadcast_to(nn[:, None, :, k].astype(np.int64), (B, C, 9)), 2) * w[:, None, :, k]
+              for k in range(3))
+    assert np.allclose(it, ref, atol=1e-6)
+
+
+def test_empty_inputs():
+    assert opn.gather_points(np.zeros((0, 3, 4), np.float32), np.zeros((0, 2), np.int32)).shape == (0, 3, 2)
+    assert opn.ball_query(0.1, 4, np.zeros((1, 0, 3), np.float32), np.zeros((1, 2, 3), np.float32)).tolist() == [[[0] * 4] * 2]
+    assert opn.furthest_point_sampling(np.ones((1, 5, 3), np.float32), 0).shape == (1, 0)
