@@ -48,13 +48,26 @@ __host__ __device__ inline int cvec_index(int ch) {  // channel -> position in c
   return hf * 64 + c * 16 + r;
 }
 
-// Per-block packed weights (device pointers into one allocation).
+// Streaming records.  Everything the hot kernel reads per stage is laid out as whole 1 KiB pieces
+// so that a stage is copied HBM/L2 -> LDS by a fixed number of 1 KiB LDS-DMA instructions.
+//   FF chunk record (per block, per hidden chunk u): 12 weight tiles
+//        tiles 0..7  = W1 rows {a: 32u.., g: 512+32u..} x k-tiles c  (index part*4 + c), norm3 affine folded in
+//        tiles 8..11 = W2 rows 32ct.. x hidden k-tile u              (index 8 + ct)
+//   block-constant record (per block): b1' [u][part][hf][16] fp32 (4 KiB) | b2 cvec (512 B) | pad (512 B)
+//   c_t rows (per block): [T] x 1 KiB, first 512 B = cvec of to_out(W_v[:,266:] t_embed(t)) + to_out.bias
+//   attention record (per shape, per block): 4 A_s tiles (k-tile c) | 4 M_s tiles (row-tile ct) |
+//        1 KiB: sbias [hf][16] fp32 (beta2 . A_s rows) + pad
+constexpr int CHUNK_TILES = 12;
+__host__ __device__ constexpr int chunk_bytes(int prec) { return CHUNK_TILES * tile_bytes(prec); }
+constexpr int BCONST_BYTES = 5 * 1024;
+constexpr int BCONST_B2_OFF = 1024;   // float offset of b2 inside the block-constant record
+constexpr int CT_ROW = 256;           // floats per c_t row (1 KiB)
+__host__ __device__ constexpr int asms_bytes(int prec) { return 8 * tile_bytes(prec) + 1024; }
+
 struct BlockPack {
-  const uint4 *w1;      // [FF_CHUNKS][2 (a,g)][4 (c)] tiles, LN3 affine folded in
-  const float *b1;      // [FF_CHUNKS][2][hf][16]  (b1 + W1 beta3), C-layout per chunk
-  const uint4 *w2;      // [FF_CHUNKS][4 (ct)] tiles
-  const float *b2;      // cvec
-  const float *ct;      // [T][128] cvec: to_out(W_v[:,266:] t_embed(t)) + to_out.bias
+  const uint4 *chunks;   // [FF_CHUNKS] chunk records
+  const float *bconst;   // block-constant record
+  const float *ct;       // [T][CT_ROW]
 };
 
 struct DenoiserDev {
@@ -71,8 +84,7 @@ struct DenoiserDev {
 struct ShapeCtxView {
   float *part;    // [B][32]: mean[3][4], var[3][4], valid[4], pad
   float *cpart;   // [B][4][128] cvec: proj_in of [anchors|variances|onehot] + bias, per part
-  float *sbias;   // [B][depth][32]  C-layout [hf][16]: beta2 . A_s rows
-  uint4 *as_ms;   // [B][depth][8 tiles]: 4 A_s tiles (k-tile c) then 4 M_s tiles (row-tile ct)
+  uint4 *as_ms;   // [B][depth] attention records (asms_bytes each)
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -84,10 +96,8 @@ inline size_t shape_ctx_view(ShapeCtxView *v, void *base, int B, int depth, int 
   off += align256(sizeof(float) * 32 * (size_t)B);
   if (v) v->cpart = reinterpret_cast<float *>(p + off);
   off += align256(sizeof(float) * 4 * 128 * (size_t)B);
-  if (v) v->sbias = reinterpret_cast<float *>(p + off);
-  off += align256(sizeof(float) * 32 * (size_t)B * depth);
   if (v) v->as_ms = reinterpret_cast<uint4 *>(p + off);
-  off += align256((size_t)tile_bytes(prec) * 8 * (size_t)B * depth);
+  off += align256((size_t)asms_bytes(prec) * (size_t)B * depth);
   return off;
 }
 

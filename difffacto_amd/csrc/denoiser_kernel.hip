@@ -31,7 +31,6 @@ struct KParams {
   DenoiserDev d;
   const float *part;     // shape ctx regions
   const float *cpart;
-  const float *sbias;
   const uint4 *as_ms;
   const float *x_in;     // (B,3,N)        eps / p_sample
   const int32_t *seg;    // (B,N)
@@ -171,41 +170,164 @@ __device__ __forceinline__ void philox_normal3(unsigned long long seed, unsigned
 }
 
 // ----------------------------------------------------------------------------------------------
-template <int PREC, int NW>
-__global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
-  constexpr int TU = tile_units(PREC);         // 16-byte units per 32x32 weight tile
-  constexpr int TSTRIDE = TU * 64;             // uint4 elements per tile
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hf = lane >> 5, pj = lane & 31;
-  const long long g0 = ((long long)blockIdx.x * NW + wave) * 32;
-  if (g0 >= (long long)p.B * p.N) return;
-  const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));
-  const int n = (int)(g0 - (long long)s * p.N) + pj;
-  const unsigned long long gid = (unsigned long long)g0 + pj;
-  const int depth = p.d.depth;
+// Building blocks shared by the direct (v0) and the LDS-pipelined kernels.  Pointers may be global
+// or LDS: after inlining the compiler infers the address space from the call site.
 
-  // ---- per-point constants through seg (replaces gather_operation, part_encoders.py:417-428) ----
+// proj_in (13 -> 128) + pre_norm.  x-columns on the VALU; the 10 per-part-constant inputs
+// (anchors | variances | onehot, attention.py:398-408) are pre-folded into cpart[seg].
+__device__ __forceinline__ void proj_in_prenorm(v16f (&h)[4], const float (&x)[3], const float *cpart,
+                                                const float4 *winx, const float2 *pregb) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float4 cp = *reinterpret_cast<const float4 *>(cpart + c * 16 + r4 * 4);
+      const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 w = winx[c * 16 + r4 * 4 + e];
+        h[c][r4 * 4 + e] = fmaf(w.z, x[2], fmaf(w.y, x[1], fmaf(w.x, x[0], cpv[e])));
+      }
+    }
+  float mean, rstd;
+  ln_stats(h, mean, rstd);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 gb = pregb[c * 16 + r];
+      h[c][r] = fmaf((h[c][r] - mean) * rstd, gb.x, gb.y);  // affine kept: h is the residual stream
+    }
+}
+
+__device__ __forceinline__ void load16(v16f &v, const float *src) {
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const float4 t4 = *reinterpret_cast<const float4 *>(src + r4 * 4);
+    v[r4 * 4 + 0] = t4.x; v[r4 * 4 + 1] = t4.y; v[r4 * 4 + 2] = t4.z; v[r4 * 4 + 3] = t4.w;
+  }
+}
+
+// Cross attention to the 4 part tokens (attention.py:179-204 with q/k/v folded away, see denoiser_setup.hip):
+//   sim = A_s LN2(h) + sbias;  P = softmax over the 4 keys of each head (masked);  h += M_s P + c_t
+// `rec` = this lane's view of the attention record (tiles 0..3 = A_s, 4..7 = M_s).
+template <int PREC>
+__device__ __forceinline__ void attention(v16f (&h)[4], const uint4 *rec, const float *sbias, const float *ct,
+                                          unsigned vmask) {
+  constexpr int TSTRIDE = tile_units(PREC) * 64;
+  Act<PREC> xn[4];
+  ln_to_act<PREC>(h, xn);
+  v16f sim;
+  load16(sim, sbias);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mma_tile<PREC>(sim, rec + c * TSTRIDE, xn[c]);
+  // registers 4g..4g+3 = keys 0..3 of head 2g+hf
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // :195-197
+    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[j] = __expf(sj[j] - m);
+      sum += e[j];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
+  }
+  Act<PREC> pa;
+  pa.set(sim);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], rec + (4 + t) * TSTRIDE, pa);
+  add_cvec(h, ct);
+}
+
+// GELU for the bf16 path: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), coefficients fitted to the exact erf
+// form on [-8, 8] (max abs error 2.5e-5, an order of magnitude below the bf16 rounding of the hidden
+// activation it feeds).  10 VALU ops incl. v_exp_f32 + v_rcp_f32.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  // -log2(e) * (1.59501577 + 0.0740112920 x^2 - 7.03033575e-4 x^4)
+  const float u = fmaf(fmaf(1.01426306e-3f, x2, -0.106775722f), x2, -2.30112134f);
+  const float e = __builtin_amdgcn_exp2f(xc * u);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int PREC>
+__device__ __forceinline__ float gelu_for(float x) {
+  return PREC == DFX_PREC_BF16 ? gelu_fast(x) : gelu_erf(x);
+}
+
+// One hidden chunk (32 units) of the GEGLU feed-forward (attention.py:50-57,77-94):
+//   a = W1a xn + b1a; g = W1g xn + b1g; hid = a * gelu(g); h += W2[:, chunk] hid.  Hidden stays in registers.
+template <int PREC>
+__device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4], const uint4 *ck, const float *b1) {
+  constexpr int TSTRIDE = tile_units(PREC) * 64;
+  v16f a, g;
+  load16(a, b1);
+  load16(g, b1 + 32);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mma_tile<PREC>(a, ck + (0 + c) * TSTRIDE, xn[c]);
+    mma_tile<PREC>(g, ck + (4 + c) * TSTRIDE, xn[c]);
+  }
+  v16f hid;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hid[r] = a[r] * gelu_for<PREC>(g[r]);
+  Act<PREC> ha;
+  ha.set(hid);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], ck + (8 + t) * TSTRIDE, ha);
+}
+
+// post_norm (affine folded into W_out) + proj_out (128 -> 3) on the VALU.
+__device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout, const float (&bout)[4],
+                                         float (&eps)[3]) {
+  float mean, rstd;
+  ln_stats(h, mean, rstd);
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w = wout[c * 16 + r];
+      const float v = (h[c][r] - mean) * rstd;
+      e0 = fmaf(w.x, v, e0);
+      e1 = fmaf(w.y, v, e1);
+      e2 = fmaf(w.z, v, e2);
+    }
+  eps[0] = e0 + xhalf(e0) + bout[0];
+  eps[1] = e1 + xhalf(e1) + bout[1];
+  eps[2] = e2 + xhalf(e2) + bout[2];
+}
+
+// Per-point state that lives in registers for the whole chain.
+struct PointState {
+  float x[3], anc[3], var[3], L[3];
+  int s, n, sg;
+  unsigned long long gid;
+};
+
+__device__ __forceinline__ void point_init(const KParams &p, PointState &ps, int s, int n, unsigned long long gid,
+                                           unsigned &vmask) {
+  ps.s = s; ps.n = n; ps.gid = gid;
   const float *part = p.part + (size_t)s * 32;
-  const int sg = p.seg[(size_t)s * p.N + n];
-  float anc[3], var[3], L[3];
+  ps.sg = p.seg[(size_t)s * p.N + n];  // replaces gather_operation (part_encoders.py:417-428)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    anc[i] = part[i * 4 + sg];
-    var[i] = part[12 + i * 4 + sg];
-    L[i] = sqrtf(var[i]);  // anchored_diffusion.py:306 / :562
+    ps.anc[i] = part[i * 4 + ps.sg];
+    ps.var[i] = part[12 + i * 4 + ps.sg];
+    ps.L[i] = sqrtf(ps.var[i]);  // anchored_diffusion.py:306 / :562
   }
-  unsigned vmask = 0;
+  vmask = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) vmask |= (part[24 + j] != 0.f ? 1u : 0u) << j;  // mask.to(bool), attention.py:196
   vmask = __builtin_amdgcn_readfirstlane(vmask);
-
-  const float *cpart = p.cpart + ((size_t)s * NCLS + sg) * INNER + hf * 64;
-  const uint4 *asms_s = p.as_ms + (size_t)s * depth * 8 * TSTRIDE + lane;
-  const float *sbias_s = p.sbias + (size_t)s * depth * 32 + hf * 16;
-
-  // ---- x_t ----
-  float x[3];
+  const int hf = (threadIdx.x >> 5) & 1;
   if (p.mode == MODE_CHAIN) {
     float z[3];
     if (p.xT_noise) {
@@ -215,185 +337,287 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
       philox_normal3(p.seed, gid, (unsigned)p.d.T, 1u, z);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) x[i] = L[i] * z[i] + anc[i];  // anchored_diffusion.py:563-564
+    for (int i = 0; i < 3; ++i) ps.x[i] = ps.L[i] * z[i] + ps.anc[i];  // anchored_diffusion.py:563-564
     if (p.traj && p.d.T % p.ret_interval == 0 && hf == 0) {
-      float *o = p.traj + ((size_t)s * p.N + n) * 3;  // snapshot index 0 <-> t = T
-      o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+      float *o = p.traj + ((size_t)s * p.N + n) * 3;  // snapshot 0 <-> t = T
+      o[0] = ps.x[0]; o[1] = ps.x[1]; o[2] = ps.x[2];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) x[i] = p.x_in[((size_t)s * 3 + i) * p.N + n];
+    for (int i = 0; i < 3; ++i) ps.x[i] = p.x_in[((size_t)s * 3 + i) * p.N + n];
   }
+}
+
+// What happens to eps after the network: store it (MODE_EPS), or the anchored posterior update
+// (anchored_diffusion.py:306-319,365-367,378-380,401-409,175-213,476-483; reference op order, no contraction)
+// plus the bookkeeping of AnchorDiffAE.decode (anchor_gen.py:160-167).  Returns true when the kernel is done.
+__device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, const float (&eps)[3], int step, int t) {
+  const int hf = (threadIdx.x >> 5) & 1;
+  const int s = ps.s, n = ps.n;
+  if (p.mode == MODE_EPS) {
+    if (hf == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) p.out[((size_t)s * 3 + i) * p.N + n] = eps[i];
+    }
+    return true;
+  }
+  float z[3];
+  if (p.noise) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
+  } else {
+    philox_normal3(p.seed, ps.gid, (unsigned)t, 0u, z);
+  }
+  {
+#pragma clang fp contract(off)
+    const float *tb = p.d.tab + (size_t)t * 8;
+    const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
+    const float nz = t != 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float x0 = sra * (ps.x[i] - ps.anc[i]) + ps.anc[i] - srm1 * ps.L[i] * eps[i];
+      if (p.xstart && hf == 0) p.xstart[((size_t)s * 3 + i) * p.N + n] = x0;
+      const float mu = c1 * x0 + c2 * ps.x[i] + c3 * ps.anc[i];
+      const float mv = pv * ps.var[i];
+      ps.x[i] = mu + nz * sqrtf(mv) * z[i];
+    }
+  }
+  if (p.mode == MODE_PSAMPLE) {
+    if (hf == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) p.out[((size_t)s * 3 + i) * p.N + n] = ps.x[i];
+    }
+    return true;
+  }
+  if (hf == 0) {
+    if (t == 0) {
+      float *o = p.out + ((size_t)s * p.N + n) * 3;
+      o[0] = ps.x[0]; o[1] = ps.x[1]; o[2] = ps.x[2];
+    } else if (p.traj && t % p.ret_interval == 0) {
+      const int k = p.d.T / p.ret_interval - t / p.ret_interval;
+      float *o = p.traj + (((size_t)k * p.B + s) * p.N + n) * 3;
+      o[0] = ps.x[0]; o[1] = ps.x[1]; o[2] = ps.x[2];
+    }
+  }
+  return false;
+}
+
+// ----------------------------------------------------------------------------------------------
+// v0 "direct" kernel: every operand comes straight from global memory (L2-resident).  Any N % 32 == 0,
+// both precisions.  It is the general fallback and the exact-fp32 parity path.
+template <int PREC, int NW>
+__global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
+  constexpr int TSTRIDE = tile_units(PREC) * 64;  // uint4 elements per 32x32 weight tile
+  constexpr int AREC = asms_bytes(PREC) / 16;     // uint4 per attention record
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const long long g0 = ((long long)blockIdx.x * NW + wave) * 32;
+  if (g0 >= (long long)p.B * p.N) return;
+  const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));
+  const int n = (int)(g0 - (long long)s * p.N) + pj;
+  const int depth = p.d.depth;
+  PointState ps;
+  unsigned vmask;
+  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
+  const float *cpart = p.cpart + ((size_t)s * NCLS + ps.sg) * INNER + hf * 64;
+  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
 
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = p.t0 - step;
     v16f h[4];
-    // ---- proj_in (13 -> 128): x-columns on the VALU, the 10 per-part-constant inputs pre-folded ----
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 cp = *reinterpret_cast<const float4 *>(cpart + c * 16 + r4 * 4);
-        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float4 w = p.d.win_x[hf * 64 + c * 16 + r4 * 4 + e];
-          h[c][r4 * 4 + e] = fmaf(w.z, x[2], fmaf(w.y, x[1], fmaf(w.x, x[0], cpv[e])));
-        }
-      }
-    // ---- pre_norm (affine kept: h is the residual stream) ----
-    {
-      float mean, rstd;
-      ln_stats(h, mean, rstd);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float2 gb = p.d.pre_gb[hf * 64 + c * 16 + r];
-          h[c][r] = fmaf((h[c][r] - mean) * rstd, gb.x, gb.y);
-        }
-    }
-    // ---- transformer blocks (attention.py:296-306) ----
+    proj_in_prenorm(h, ps.x, cpart, p.d.win_x + hf * 64, p.d.pre_gb + hf * 64);
     for (int b = 0; b < depth; ++b) {
       const BlockPack &bp = p.d.blk[b];
+      const uint4 *rec = asms_s + (size_t)b * AREC;
+      attention<PREC>(h, rec, reinterpret_cast<const float *>(rec - lane + 8 * TSTRIDE) + hf * 16,
+                      bp.ct + (size_t)t * CT_ROW + hf * 64, vmask);
       Act<PREC> xn[4];
-      // -- cross attention to the 4 part tokens --
       ln_to_act<PREC>(h, xn);
-      const uint4 *as = asms_s + (size_t)b * 8 * TSTRIDE;
-      v16f sim;
-      {
-        const float *sb = sbias_s + b * 32;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const float4 t4 = *reinterpret_cast<const float4 *>(sb + r4 * 4);
-          sim[r4 * 4 + 0] = t4.x; sim[r4 * 4 + 1] = t4.y; sim[r4 * 4 + 2] = t4.z; sim[r4 * 4 + 3] = t4.w;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) mma_tile<PREC>(sim, as + c * TSTRIDE, xn[c]);
-      // softmax over the 4 keys of each head: registers 4g..4g+3 = keys 0..3 of head 2g+hf
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float sj[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // :195-197
-        const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
-        float e[4], sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          e[j] = __expf(sj[j] - m);
-          sum += e[j];
-        }
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
-      }
-      {
-        Act<PREC> pa;
-        pa.set(sim);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) mma_tile<PREC>(h[ct], as + (4 + ct) * TSTRIDE, pa);
-      }
-      add_cvec(h, bp.ct + (size_t)t * INNER + hf * 64);
-      // -- GEGLU feed-forward, 16 hidden chunks of 32 units; hidden never leaves registers --
-      ln_to_act<PREC>(h, xn);
-      const uint4 *w1 = bp.w1 + lane;
-      const uint4 *w2 = bp.w2 + lane;
-      const float *b1 = bp.b1 + hf * 16;
 #pragma unroll 1
-      for (int u = 0; u < FF_CHUNKS; ++u) {
-        v16f a, g;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const float4 ta = *reinterpret_cast<const float4 *>(b1 + (u * 2 + 0) * 32 + r4 * 4);
-          const float4 tg = *reinterpret_cast<const float4 *>(b1 + (u * 2 + 1) * 32 + r4 * 4);
-          a[r4 * 4 + 0] = ta.x; a[r4 * 4 + 1] = ta.y; a[r4 * 4 + 2] = ta.z; a[r4 * 4 + 3] = ta.w;
-          g[r4 * 4 + 0] = tg.x; g[r4 * 4 + 1] = tg.y; g[r4 * 4 + 2] = tg.z; g[r4 * 4 + 3] = tg.w;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          mma_tile<PREC>(a, w1 + ((u * 2 + 0) * 4 + c) * TSTRIDE, xn[c]);
-          mma_tile<PREC>(g, w1 + ((u * 2 + 1) * 4 + c) * TSTRIDE, xn[c]);
-        }
-        v16f hid;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = a[r] * gelu_erf(g[r]);
-        Act<PREC> ha;
-        ha.set(hid);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) mma_tile<PREC>(h[ct], w2 + (u * 4 + ct) * TSTRIDE, ha);
-      }
-      add_cvec(h, bp.b2 + hf * 64);
+      for (int u = 0; u < FF_CHUNKS; ++u)
+        ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
+      add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
     }
-    // ---- post_norm (affine folded) + proj_out (128 -> 3) on the VALU ----
     float eps[3];
-    {
-      float mean, rstd;
-      ln_stats(h, mean, rstd);
-      float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float4 w = p.d.wout[hf * 64 + c * 16 + r];
-          const float v = (h[c][r] - mean) * rstd;
-          e0 = fmaf(w.x, v, e0);
-          e1 = fmaf(w.y, v, e1);
-          e2 = fmaf(w.z, v, e2);
-        }
-      eps[0] = e0 + xhalf(e0) + p.d.bout[0];
-      eps[1] = e1 + xhalf(e1) + p.d.bout[1];
-      eps[2] = e2 + xhalf(e2) + p.d.bout[2];
-    }
-    if (p.mode == MODE_EPS) {
-      if (hf == 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) p.out[((size_t)s * 3 + i) * p.N + n] = eps[i];
-      }
-      return;
-    }
-    // ---- posterior (anchored_diffusion.py:306-319,365-367,378-380,401-409,175-213,476-483), reference op order ----
-    float z[3];
-    if (p.noise) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
-    } else {
-      philox_normal3(p.seed, gid, (unsigned)t, 0u, z);
-    }
-    {
-#pragma clang fp contract(off)
-      const float *tb = p.d.tab + (size_t)t * 8;
-      const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
-      const float nz = t != 0 ? 1.0f : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float x0 = sra * (x[i] - anc[i]) + anc[i] - srm1 * L[i] * eps[i];
-        if (p.xstart && hf == 0) p.xstart[((size_t)s * 3 + i) * p.N + n] = x0;
-        const float mu = c1 * x0 + c2 * x[i] + c3 * anc[i];
-        const float mv = pv * var[i];
-        x[i] = mu + nz * sqrtf(mv) * z[i];
-      }
-    }
-    if (p.mode == MODE_PSAMPLE) {
-      if (hf == 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) p.out[((size_t)s * 3 + i) * p.N + n] = x[i];
-      }
-      return;
-    }
-    // ---- chain bookkeeping of AnchorDiffAE.decode (anchor_gen.py:160-167) ----
-    if (hf == 0) {
-      if (t == 0) {
-        float *o = p.out + ((size_t)s * p.N + n) * 3;
-        o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
-      } else if (p.traj && t % p.ret_interval == 0) {
-        const int k = p.d.T / p.ret_interval - t / p.ret_interval;
-        float *o = p.traj + (((size_t)k * p.B + s) * p.N + n) * 3;
-        o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
-      }
+    post_eps(h, p.d.wout + hf * 64, p.d.bout, eps);
+    if (step_epilogue(p, ps, eps, step, t)) return;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LDS-pipelined kernel (bf16, N % 256 == 0): 8 wavefronts = 256 points of ONE shape per workgroup.
+// All weights stream L2 -> LDS through a 3-slot ring of 24 KiB stages filled by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wavefront-instruction, 3 per wave per stage), two stages ahead
+// of the compute, with ONE workgroup barrier per stage and a counted s_waitcnt vmcnt (never 0 in
+// steady state).  Stage sequence per transformer block: [attention record] then 16 x [FF chunk record].
+// The DMA is issued from inline asm so that hipcc does not serialise the ring behind vmcnt(0) waits
+// (it cannot prove the ds_reads do not alias an in-flight LDS-DMA); the data hazards are handled here:
+//   RAW: issuing wave's vmcnt(CALLS) + s_barrier before any wave reads the slot;
+//   WAR: a slot is refilled only after the barrier that every wave reaches after its last read of it.
+constexpr int PIPE_NW = 8;
+constexpr int SLOT_BYTES = 24 * 1024;
+constexpr int NSLOT = 3;
+constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per stage
+constexpr int STAGES_PER_BLOCK = 1 + FF_CHUNKS;
+// LDS map (bytes)
+constexpr int L_RING = 0;
+constexpr int L_BCONST = L_RING + NSLOT * SLOT_BYTES;  // 2 x block-constant record (b1', b2)
+constexpr int L_WINX = L_BCONST + 2 * BCONST_BYTES;    // float4[128]
+constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
+constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
+constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
+constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs
+constexpr int L_TOTAL = L_DUMMY + 1024;
+static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
+
+extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
+
+// one 1 KiB LDS-DMA: lane l copies 16 B from gbase + voff(l) to LDS byte address lds_addr + 16 l
+__device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");  // m0 is reserved: hipcc re-materialises it before each of its own uses
+}
+
+struct Cursor {
+  int step, b, k, seq;  // k: 0 = attention record, 1..16 = FF chunk k-1; seq = running block number
+};
+
+__device__ __forceinline__ void cursor_next(Cursor &c, int depth) {
+  if (++c.k == STAGES_PER_BLOCK) {
+    c.k = 0;
+    ++c.seq;
+    if (++c.b == depth) {
+      c.b = 0;
+      ++c.step;
     }
   }
 }
+
+__device__ __forceinline__ void issue_stage(const KParams &p, const Cursor &c, int slot, int wave, unsigned voff,
+                                            unsigned lds0, int s) {
+  const unsigned ring = lds0 + L_RING + slot * SLOT_BYTES;
+  const bool valid = c.step < p.nsteps;
+  const BlockPack &bp = p.d.blk[valid ? c.b : 0];
+#pragma unroll
+  for (int j = 0; j < CALLS; ++j) {
+    const int q = wave * CALLS + j;  // 1 KiB piece of this stage
+    const char *src = reinterpret_cast<const char *>(bp.bconst);
+    unsigned dst = lds0 + L_DUMMY;
+    if (valid) {
+      if (c.k > 0) {
+        src = reinterpret_cast<const char *>(bp.chunks) + (size_t)(c.k - 1) * SLOT_BYTES + q * 1024;
+        dst = ring + q * 1024;
+      } else if (q < 17) {
+        src = reinterpret_cast<const char *>(p.as_ms) + ((size_t)s * p.d.depth + c.b) * asms_bytes(DFX_PREC_BF16) + q * 1024;
+        dst = ring + q * 1024;
+      } else if (q < 22) {
+        src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
+        dst = lds0 + L_BCONST + (c.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
+      } else if (q == 22) {
+        src = reinterpret_cast<const char *>(bp.ct + (size_t)(p.t0 - c.step) * CT_ROW);
+        dst = ring + 17 * 1024;
+      }
+    }
+    dma1k(src, voff, dst);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams p) {
+  constexpr int PREC = DFX_PREC_BF16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const long long g0 = ((long long)blockIdx.x * PIPE_NW + wave) * 32;
+  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * PIPE_NW * 32) / p.N));  // one shape per WG
+  const int n = (int)(g0 - (long long)s * p.N) + pj;
+  const int depth = p.d.depth;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
+
+  // ---- prologue DMA: stages 0 and 1 in flight while the per-point state is set up ----
+  Cursor pf{0, 0, 0, 0};
+  issue_stage(p, pf, 0, wave, voff, lds0, s);
+  cursor_next(pf, depth);
+  issue_stage(p, pf, 1, wave, voff, lds0, s);
+  cursor_next(pf, depth);
+
+  // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
+  {
+    float4 *winx = reinterpret_cast<float4 *>(pipe_smem + L_WINX);
+    float2 *pregb = reinterpret_cast<float2 *>(pipe_smem + L_PREGB);
+    float4 *wout = reinterpret_cast<float4 *>(pipe_smem + L_WOUT);
+    float *cp = reinterpret_cast<float *>(pipe_smem + L_CPART);
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+      winx[tid] = p.d.win_x[tid];
+      pregb[tid] = p.d.pre_gb[tid];
+      wout[tid] = p.d.wout[tid];
+    }
+    cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+  }
+  PointState ps;
+  unsigned vmask;
+  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
+  __syncthreads();
+
+  const float *cpart = reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64;
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
+
+  int cur = 0;  // ring slot of the stage being computed
+  int seq = 0;  // running block number (parity selects the block-constant buffer)
+  // top of every stage: my DMA pieces of this stage have landed (the next stage's CALLS may still fly),
+  // everyone's have after the barrier, and everyone is done with the slot that is refilled next.
+#define DFX_STAGE_BEGIN()                                         \
+  do {                                                            \
+    wait_vmcnt<CALLS>();                                          \
+    __builtin_amdgcn_s_barrier();                                 \
+    issue_stage(p, pf, cur == 0 ? 2 : cur - 1, wave, voff, lds0, s); \
+    cursor_next(pf, depth);                                       \
+  } while (0)
+
+  for (int step = 0; step < p.nsteps; ++step) {
+    const int t = p.t0 - step;
+    v16f h[4];
+    proj_in_prenorm(h, ps.x, cpart, winx, pregb);
+    for (int b = 0; b < depth; ++b, ++seq) {
+      const float *bconst = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
+      DFX_STAGE_BEGIN();
+      {
+        const unsigned char *slot = pipe_smem + L_RING + cur * SLOT_BYTES;
+        attention<PREC>(h, reinterpret_cast<const uint4 *>(slot) + lane,
+                        reinterpret_cast<const float *>(slot + 16 * 1024) + hf * 16,
+                        reinterpret_cast<const float *>(slot + 17 * 1024) + hf * 64, vmask);
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+      Act<PREC> xn[4];
+      ln_to_act<PREC>(h, xn);
+#pragma unroll 1
+      for (int u = 0; u < FF_CHUNKS; ++u) {
+        DFX_STAGE_BEGIN();
+        ff_chunk<PREC>(h, xn, reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane,
+                       bconst + u * 64 + hf * 16);
+        cur = cur == 2 ? 0 : cur + 1;
+      }
+      add_cvec(h, bconst + BCONST_B2_OFF + hf * 64);
+    }
+    float eps[3];
+    post_eps(h, wout, p.d.bout, eps);
+    if (step_epilogue(p, ps, eps, step, t)) break;
+  }
+#undef DFX_STAGE_BEGIN
+  wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
+}
+
+bool g_force_direct = false;
 
 int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t st) {
   ShapeCtxView v;
@@ -401,15 +625,24 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   p.d = d->dev;
   p.part = v.part;
   p.cpart = v.cpart;
-  p.sbias = v.sbias;
   p.as_ms = v.as_ms;
   constexpr int NW = 4;
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
+  const bool pipe = d->dev.prec == DFX_PREC_BF16 && p.N % (PIPE_NW * 32) == 0 && !g_force_direct;
+  if (pipe) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+      attr_set = true;
+    }
+  }
   EventTimer tm;
   tm.begin(st);
-  if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
+  if (pipe) k_denoise_pipe<<<(int)(waves / PIPE_NW), PIPE_NW * 64, L_TOTAL, st>>>(p);
+  else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");
   tm.end();
@@ -453,6 +686,8 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
   p.B = B; p.N = N; p.t0 = t; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_PSAMPLE;
   return launch(d, shape_ctx, p, as_stream(stream));
 }
+
+void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
 
 int dfx_chain_num_snapshots(int num_timesteps, int ret_interval) {
   if (num_timesteps <= 0 || ret_interval <= 0) return 0;

@@ -52,11 +52,11 @@ __global__ void k_geglu(const float *__restrict__ in, float *__restrict__ out, i
 
 // rows of Y (M x 128, natural channel order) -> cvec order, optional bias add
 __global__ void k_to_cvec(const float *__restrict__ Y, const float *__restrict__ bias, float *__restrict__ out,
-                          int M) {
+                          int M, int out_stride) {
   const long long i = blockIdx.x * 256LL + threadIdx.x;
   if (i >= (long long)M * 128) return;
   const int m = (int)(i >> 7), ch = (int)(i & 127);
-  out[(size_t)m * 128 + cvec_index(ch)] = Y[i] + (bias ? bias[ch] : 0.f);
+  out[(size_t)m * out_stride + cvec_index(ch)] = Y[i] + (bias ? bias[ch] : 0.f);
 }
 
 template <int PREC>
@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_store(void *dst, long long gi, float v) {
   else reinterpret_cast<float *>(dst)[gi] = v;
 }
 
-// W1 (1024 x 128) with norm3.weight folded in -> [chunk u][part][c] tiles
+// W1 (1024 x 128) with norm3.weight folded in -> tiles part*4+c of chunk record u
 template <int PREC>
 __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict__ g3, void *__restrict__ dst) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
@@ -88,7 +88,8 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   tile_decode<PREC>((int)(gi & 1023), i, kk);
   const int c = tile & 3, part = (tile >> 2) & 1, u = tile >> 3;
   const int row = part * FF_HID + 32 * u + i, col = 32 * c + kk;
-  tile_store<PREC>(dst, gi, W1[(size_t)row * INNER + col] * g3[col]);
+  const long long di = ((long long)(u * CHUNK_TILES + part * 4 + c) << 10) + (gi & 1023);
+  tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col]);
 }
 
 // b1' = b1 + W1 beta3, stored [u][part][hf][16]
@@ -103,7 +104,7 @@ __global__ void k_pack_b1(const float *__restrict__ W1, const float *__restrict_
   dst[gi] = b1[row] + acc;
 }
 
-// W2 (128 x 512) -> [chunk u][ct] tiles
+// W2 (128 x 512) -> tiles 8+ct of chunk record u
 template <int PREC>
 __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
@@ -112,7 +113,8 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   int i, kk;
   tile_decode<PREC>((int)(gi & 1023), i, kk);
   const int ct = tile & 3, u = tile >> 2;
-  tile_store<PREC>(dst, gi, W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk]);
+  const long long di = ((long long)(u * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
+  tile_store<PREC>(dst, di, W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk]);
 }
 
 // proj_in x-columns, pre_norm affine, post_norm-folded proj_out, all in cvec order
@@ -170,7 +172,9 @@ __global__ void __launch_bounds__(256) k_shape_ctx(const float *__restrict__ par
   __syncthreads();
   const float scale = 0.25f;  // dim_head ** -0.5 (attention.py:167)
   const size_t sb = (size_t)s * depth + b;
-  void *tiles = reinterpret_cast<char *>(out.as_ms) + sb * 8 * tile_bytes(PREC);
+  char *rec = reinterpret_cast<char *>(out.as_ms) + sb * asms_bytes(PREC);
+  void *tiles = rec;
+  float *sbias = reinterpret_cast<float *>(rec + 8 * tile_bytes(PREC));
   for (int gi = tid; gi < 8 * 1024; gi += 256) {
     const int tile = gi >> 10;
     int i, kk;
@@ -190,7 +194,9 @@ __global__ void __launch_bounds__(256) k_shape_ctx(const float *__restrict__ par
     const int hf = tid >> 4, r = tid & 15, R = rho(r, hf), head = R >> 2, j = R & 3;
     float acc = 0.f;
     for (int d = 0; d < DHEAD; ++d) acc = fmaf(s_wqb[head * DHEAD + d], s_k[j][head * DHEAD + d], acc);
-    out.sbias[sb * 32 + tid] = acc * scale;
+    sbias[tid] = acc * scale;
+  } else if (tid < 256) {
+    sbias[tid] = 0.f;  // pad of the 1 KiB piece
   }
   if (b == 0) {
     if (tid < 32) {
@@ -290,7 +296,6 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   hipStream_t st = as_stream(stream);
   dfx_denoiser *d = new (std::nothrow) dfx_denoiser();
   if (!d) return set_error(DFX_ERR_ALLOC, "denoiser_create: host allocation failed");
-  const int tb = tile_bytes(precision);
 
   // two passes over the same carving code: measure, then place
   struct Carve {
@@ -300,8 +305,8 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     float *win, *bin;
     const float **wptrs;
     struct {
-      uint4 *w1, *w2;
-      float *b1, *b2, *ct, *wq, *wk, *wv, *wo, *g2, *be2;
+      uint4 *chunks;
+      float *bconst, *ct, *wq, *wk, *wv, *wo, *g2, *be2;
     } blk[DFX_MAX_DEPTH];
   } cv;
   auto carve = [&](char *base) {
@@ -320,11 +325,9 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     cv.bin = bp.take<float>(INNER);
     cv.wptrs = bp.take<const float *>(DFX_MAX_DEPTH * 6);
     for (int b = 0; b < depth; ++b) {
-      cv.blk[b].w1 = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_CHUNKS * 2 * 4 * tb));
-      cv.blk[b].w2 = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_CHUNKS * 4 * tb));
-      cv.blk[b].b1 = bp.take<float>(FF_CHUNKS * 2 * 32);
-      cv.blk[b].b2 = bp.take<float>(INNER);
-      cv.blk[b].ct = bp.take<float>((size_t)T * INNER);
+      cv.blk[b].chunks = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_CHUNKS * chunk_bytes(precision)));
+      cv.blk[b].bconst = bp.take<float>(BCONST_BYTES / 4);
+      cv.blk[b].ct = bp.take<float>((size_t)(T + 1) * CT_ROW);
       cv.blk[b].wq = bp.take<float>(INNER * INNER);
       cv.blk[b].wk = bp.take<float>(INNER * CTX_DIM);
       cv.blk[b].wv = bp.take<float>(INNER * CTX_DIM);
@@ -434,21 +437,23 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     k_linear<<<nblk((long long)T * INNER), 256, 0, st>>>(cv.vt, INNER, k.to_out_w, INNER, 0, nullptr, cv.y, T, INNER,
                                                        INNER);
     TRY_LAUNCH("ct");
-    k_to_cvec<<<nblk((long long)T * INNER), 256, 0, st>>>(cv.y, k.to_out_b, c.ct, T);
+    TRY_HIP(hipMemsetAsync(c.ct, 0, sizeof(float) * (size_t)(T + 1) * CT_ROW, st));
+    TRY_HIP(hipMemsetAsync(c.bconst, 0, BCONST_BYTES, st));
+    k_to_cvec<<<nblk((long long)T * INNER), 256, 0, st>>>(cv.y, k.to_out_b, c.ct, T, CT_ROW);
     TRY_LAUNCH("ct_cvec");
-    k_to_cvec<<<1, 256, 0, st>>>(k.ff2_b, nullptr, c.b2, 1);
+    k_to_cvec<<<1, 256, 0, st>>>(k.ff2_b, nullptr, c.bconst + BCONST_B2_OFF, 1, INNER);
     TRY_LAUNCH("b2_cvec");
-    k_pack_b1<<<nblk(FF_CHUNKS * 2 * 32), 256, 0, st>>>(k.ff0_w, k.ff0_b, k.norm3_b, c.b1);
+    k_pack_b1<<<nblk(FF_CHUNKS * 2 * 32), 256, 0, st>>>(k.ff0_w, k.ff0_b, k.norm3_b, c.bconst);
     TRY_LAUNCH("pack_b1");
     if (precision == DFX_PREC_BF16) {
-      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.w1);
-      k_pack_w2<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.w2);
+      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);
+      k_pack_w2<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     } else {
-      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.w1);
-      k_pack_w2<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.w2);
+      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);
+      k_pack_w2<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     }
     TRY_LAUNCH("pack_w1w2");
-    d->dev.blk[b] = BlockPack{c.w1, c.b1, c.w2, c.b2, c.ct};
+    d->dev.blk[b] = BlockPack{c.chunks, c.bconst, c.ct};
     d->wq[b] = c.wq; d->wk[b] = c.wk; d->wv[b] = c.wv; d->wo[b] = c.wo; d->g2[b] = c.g2; d->be2[b] = c.be2;
     wptrs[(size_t)b * 6 + 0] = c.wq; wptrs[(size_t)b * 6 + 1] = c.wk; wptrs[(size_t)b * 6 + 2] = c.wv;
     wptrs[(size_t)b * 6 + 3] = c.wo; wptrs[(size_t)b * 6 + 4] = c.g2; wptrs[(size_t)b * 6 + 5] = c.be2;

@@ -179,6 +179,9 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
                      const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
                      int N, dfx_stream_t stream);
 
+/* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
+void dfx_debug_force_direct(int on);
+
 /* Name + average duration bookkeeping for bench.py: duration in ms of the last dfx_sample_chain /
  * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */
 void dfx_set_event_timing(int enable);
