@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0, help="timing ablations (invalid results)")
+    ap.add_argument("--force-direct", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +98,9 @@ def main():
     from difffacto_amd.parallel import broadcast_params, gather_clouds
 
     B, N, T = args.batch, args.npoints, args.timesteps
+    from difffacto_amd import _ffi
+    _ffi.lib().dfx_debug_flags(args.debug_flags)
+    _ffi.lib().dfx_debug_force_direct(int(args.force_direct))
     names = [n for n, _ in synth.denoiser_param_shapes()]
     if rank == 0:
         Wnp = synth.make_denoiser_weights(seed=0)
@@ -154,7 +159,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
-        assert out is not None and torch.isfinite(out).all()
+        assert out is not None and (args.debug_flags or torch.isfinite(out).all())
         total_shapes = B * world * args.steps
         value = total_shapes / dt
         F = flops_per_step(N) * T * B                      # algorithmic FLOPs per launch (one rank)

@@ -41,6 +41,7 @@ struct KParams {
   float *xstart;         // p_sample: optional pred_xstart (B,3,N)
   unsigned long long seed;
   int B, N, t0, nsteps, ret_interval, mode;
+  int debug;  // timing ablations only (dfx_debug_flags): 2 = no DMA, 4 = no GELU, 8 = no stage barrier
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -284,6 +285,99 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
   for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], ck + (8 + t) * TSTRIDE, ha);
 }
 
+// ---- half-phases of the LDS-pipelined bf16 kernel --------------------------------------------------------
+// Every stage is split into an MFMA-heavy half (P1) and a VALU-heavy half (P2); the two wavefronts that share
+// a SIMD run these halves out of phase (see k_denoise_pipe), so the matrix pipe and the VALU overlap.
+// A-fragment units are fetched in batches of eight ds_read_b128 that run one batch AHEAD of the MFMAs that
+// consume them (two 32-VGPR register sets) instead of read-wait-MFMA pairs.
+__device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
+
+// FF P1: a = W1a xn + b1a, g = W1g xn + b1g  (16 MFMAs)
+__device__ __forceinline__ void ff_p1(v16f &a, v16f &g, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *ck,
+                                      const float *b1) {
+  uint4 A0[8], A1[8];
+  // batch 0: W1 tiles (a,c0) (g,c0) (a,c1) (g,c1); unit order a.q0 a.q1 g.q0 g.q1
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A0[i] = ck[((i >> 2) + (i & 2 ? 4 : 0)) * 128 + (i & 1) * 64];
+  load16(a, b1);
+  load16(g, b1 + 32);
+  // batch 1: W1 tiles (a,c2) (g,c2) (a,c3) (g,c3)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A1[i] = ck[(2 + (i >> 2) + (i & 2 ? 4 : 0)) * 128 + (i & 1) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v16f &acc = (i & 2) ? g : a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 2].f[i & 1], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v16f &acc = (i & 2) ? g : a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[2 + (i >> 2)].f[i & 1], acc, 0, 0, 0);
+  }
+}
+
+// FF P2: hid = a * gelu(g) (VALU) ; h += W2[:, chunk] hid  (8 MFMAs).  The W2 reads are issued before the GELU.
+__device__ __forceinline__ void ff_p2(v16f (&h)[4], const v16f &a, const v16f &g, const uint4 *ck, bool no_gelu) {
+  uint4 A0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A0[i] = ck[(8 + (i >> 1)) * 128 + (i & 1) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+  v16f hid;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hid[r] = a[r] * (no_gelu ? g[r] : gelu_fast(g[r]));
+  Act<DFX_PREC_BF16> ha;
+  ha.set(hid);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), ha.f[i & 1], h[i >> 1], 0, 0, 0);
+}
+
+// attention P1: P = softmax_keys(A_s LN2(h) + sbias)   (8 MFMAs + LN + softmax)
+__device__ __forceinline__ void attn_p1(const v16f (&h)[4], Act<DFX_PREC_BF16> &pa, const uint4 *rec, const float *sbias,
+                                        unsigned vmask) {
+  uint4 A0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A0[i] = rec[(i >> 1) * 128 + (i & 1) * 64];
+  v16f sim;
+  load16(sim, sbias);
+  Act<DFX_PREC_BF16> xn[4];
+  ln_to_act<DFX_PREC_BF16>(h, xn);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // attention.py:195-197
+    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[j] = __expf(sj[j] - m);
+      sum += e[j];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
+  }
+  pa.set(sim);
+}
+
+// attention P2: h += M_s P + c_t ; xn = LN3(h) for the feed-forward  (8 MFMAs + LN)
+__device__ __forceinline__ void attn_p2(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, Act<DFX_PREC_BF16> (&xn)[4],
+                                        const uint4 *rec, const float *ct) {
+  uint4 A0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A0[i] = rec[(4 + (i >> 1)) * 128 + (i & 1) * 64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+  add_cvec(h, ct);
+  ln_to_act<DFX_PREC_BF16>(h, xn);
+}
+
 // post_norm (affine folded into W_out) + proj_out (128 -> 3) on the VALU.
 __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout, const float (&bout)[4],
                                          float (&eps)[3]) {
@@ -457,7 +551,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 //   WAR: a slot is refilled only after the barrier that every wave reaches after its last read of it.
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
-constexpr int NSLOT = 3;
+constexpr int NSLOT = 4;
 constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per stage
 constexpr int STAGES_PER_BLOCK = 1 + FF_CHUNKS;
 // LDS map (bytes)
@@ -540,12 +634,18 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
+  // Ping-pong groups: waves w and w+4 share a SIMD.  Group A (waves 0-3) runs one half-phase AHEAD of group B
+  // (waves 4-7): while an A wave is in the MFMA-heavy half of a stage its SIMD partner is in the VALU-heavy half
+  // of the previous one.  There is one workgroup barrier per half-phase; B passes one extra barrier up front
+  // and A one extra at the end, so both groups execute the same number of barriers.
+  const bool grpA = wave < PIPE_NW / 2;
 
   // ---- prologue DMA: stages 0 and 1 in flight while the per-point state is set up ----
   Cursor pf{0, 0, 0, 0};
-  issue_stage(p, pf, 0, wave, voff, lds0, s);
+  int pfslot = 0;
+  issue_stage(p, pf, pfslot++, wave, voff, lds0, s);
   cursor_next(pf, depth);
-  issue_stage(p, pf, 1, wave, voff, lds0, s);
+  issue_stage(p, pf, pfslot++, wave, voff, lds0, s);
   cursor_next(pf, depth);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
@@ -572,40 +672,54 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-  int cur = 0;  // ring slot of the stage being computed
-  int seq = 0;  // running block number (parity selects the block-constant buffer)
-  // top of every stage: my DMA pieces of this stage have landed (the next stage's CALLS may still fly),
-  // everyone's have after the barrier, and everyone is done with the slot that is refilled next.
-#define DFX_STAGE_BEGIN()                                         \
-  do {                                                            \
-    wait_vmcnt<CALLS>();                                          \
-    __builtin_amdgcn_s_barrier();                                 \
-    issue_stage(p, pf, cur == 0 ? 2 : cur - 1, wave, voff, lds0, s); \
-    cursor_next(pf, depth);                                       \
+  // Half-phase boundary.  The ring is managed at every SECOND global barrier; `mine` tells whether that is this
+  // boundary for this wave's group (A: before P1, B: before P2).  Management = my LDS-DMA pieces of the stage
+  // that group A reads next have landed (the following stage's CALLS pieces may still be in flight) -> barrier
+  // -> refill the slot whose last reader (group B, P2 of stage s-2) finished before this barrier.
+  //   RAW: issuing wave's vmcnt(CALLS) + this barrier precede every read of the slot (A reads first).
+  //   WAR: stage s+2 overwrites the slot of stage s-2 (4 slots); B's last read of s-2 is two barriers back.
+#define DFX_SYNC(mine)                                                \
+  do {                                                                \
+    if (mine) wait_vmcnt<CALLS>();                                    \
+    if (!(p.debug & 8)) __builtin_amdgcn_s_barrier();                 \
+    if (mine) {                                                       \
+      if (!(p.debug & 2)) issue_stage(p, pf, pfslot, wave, voff, lds0, s); \
+      cursor_next(pf, depth);                                         \
+      pfslot = (pfslot + 1) & (NSLOT - 1);                            \
+    }                                                                 \
   } while (0)
 
+  if (!grpA) DFX_SYNC(true);  // B's extra barrier: it is the management barrier of stage 0
+
+  int cur = 0;  // ring slot of the stage being computed
+  int seq = 0;  // running block number (parity selects the block-constant buffer)
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = p.t0 - step;
     v16f h[4];
     proj_in_prenorm(h, ps.x, cpart, winx, pregb);
     for (int b = 0; b < depth; ++b, ++seq) {
       const float *bconst = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
-      DFX_STAGE_BEGIN();
+      Act<PREC> xn[4];
       {
         const unsigned char *slot = pipe_smem + L_RING + cur * SLOT_BYTES;
-        attention<PREC>(h, reinterpret_cast<const uint4 *>(slot) + lane,
-                        reinterpret_cast<const float *>(slot + 16 * 1024) + hf * 16,
-                        reinterpret_cast<const float *>(slot + 17 * 1024) + hf * 64, vmask);
+        Act<PREC> pa;
+        DFX_SYNC(grpA);
+        attn_p1(h, pa, reinterpret_cast<const uint4 *>(slot) + lane,
+                reinterpret_cast<const float *>(slot + 16 * 1024) + hf * 16, vmask);
+        DFX_SYNC(!grpA);
+        attn_p2(h, pa, xn, reinterpret_cast<const uint4 *>(slot) + lane,
+                reinterpret_cast<const float *>(slot + 17 * 1024) + hf * 64);
       }
-      cur = cur == 2 ? 0 : cur + 1;
-      Act<PREC> xn[4];
-      ln_to_act<PREC>(h, xn);
+      cur = (cur + 1) & (NSLOT - 1);
 #pragma unroll 1
       for (int u = 0; u < FF_CHUNKS; ++u) {
-        DFX_STAGE_BEGIN();
-        ff_chunk<PREC>(h, xn, reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane,
-                       bconst + u * 64 + hf * 16);
-        cur = cur == 2 ? 0 : cur + 1;
+        const uint4 *ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane;
+        v16f a, g;
+        DFX_SYNC(grpA);
+        ff_p1(a, g, xn, ck, bconst + u * 64 + hf * 16);
+        DFX_SYNC(!grpA);
+        ff_p2(h, a, g, ck, (p.debug & 4) != 0);
+        cur = (cur + 1) & (NSLOT - 1);
       }
       add_cvec(h, bconst + BCONST_B2_OFF + hf * 64);
     }
@@ -613,11 +727,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     post_eps(h, wout, p.d.bout, eps);
     if (step_epilogue(p, ps, eps, step, t)) break;
   }
-#undef DFX_STAGE_BEGIN
+  if (grpA && !(p.debug & 8)) __builtin_amdgcn_s_barrier();  // A's extra barrier (B's last management barrier)
+#undef DFX_SYNC
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
 bool g_force_direct = false;
+int g_debug = 0;
 
 int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t st) {
   ShapeCtxView v;
@@ -626,6 +742,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   p.part = v.part;
   p.cpart = v.cpart;
   p.as_ms = v.as_ms;
+  p.debug = g_debug;
   constexpr int NW = 4;
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
@@ -688,6 +805,7 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
+void dfx_debug_flags(int flags) { g_debug = flags; }
 
 int dfx_chain_num_snapshots(int num_timesteps, int ret_interval) {
   if (num_timesteps <= 0 || ret_interval <= 0) return 0;

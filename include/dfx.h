@@ -181,6 +181,8 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
 
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
+/* Timing ablations (results become WRONG): 2 = skip LDS-DMA, 4 = skip GELU, 8 = skip stage barriers. */
+void dfx_debug_flags(int flags);
 
 /* Name + average duration bookkeeping for bench.py: duration in ms of the last dfx_sample_chain /
  * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */
