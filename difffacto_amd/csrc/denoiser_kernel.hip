@@ -266,7 +266,8 @@ __device__ __forceinline__ float gelu_for(float x) {
 // One hidden chunk (32 units) of the GEGLU feed-forward (attention.py:50-57,77-94):
 //   a = W1a xn + b1a; g = W1g xn + b1g; hid = a * gelu(g); h += W2[:, chunk] hid.  Hidden stays in registers.
 template <int PREC>
-__device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4], const uint4 *ck, const float *b1) {
+__device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4], const uint4 *ck, const uint4 *ck2,
+                                         const float *b1) {
   constexpr int TSTRIDE = tile_units(PREC) * 64;
   v16f a, g;
   load16(a, b1);
@@ -282,100 +283,113 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
   Act<PREC> ha;
   ha.set(hid);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], ck + (8 + t) * TSTRIDE, ha);
+  for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], ck2 + (8 + t) * TSTRIDE, ha);
 }
 
-// ---- half-phases of the LDS-pipelined bf16 kernel --------------------------------------------------------
-// Every stage is split into an MFMA-heavy half (P1) and a VALU-heavy half (P2); the two wavefronts that share
-// a SIMD run these halves out of phase (see k_denoise_pipe), so the matrix pipe and the VALU overlap.
-// A-fragment units are fetched in batches of eight ds_read_b128 that run one batch AHEAD of the MFMAs that
-// consume them (two 32-VGPR register sets) instead of read-wait-MFMA pairs.
+// ---- building blocks of the LDS-pipelined bf16 kernel ---------------------------------------------------
 __device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
 
-// FF P1: a = W1a xn + b1a, g = W1g xn + b1g  (16 MFMAs)
-__device__ __forceinline__ void ff_p1(v16f &a, v16f &g, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *ck,
-                                      const float *b1) {
-  uint4 A0[8], A1[8];
-  // batch 0: W1 tiles (a,c0) (g,c0) (a,c1) (g,c1); unit order a.q0 a.q1 g.q0 g.q1
+// One iteration j of the SOFTWARE-PIPELINED feed-forward over PT point tiles (32 points each).  The three
+// sub-steps touch disjoint registers, so their MFMA and VALU instructions interleave freely in one stream:
+//   S3: h       += W2[:, chunk j-2] hid_old           (8 MFMAs / tile, tiles 8..11 of the stage record)
+//   S1: ag_cur   = b1[j] + W1[chunk j] xn             (16 MFMAs / tile, tiles 0..7)
+//   S2: hid_new  = bf16(a_prev * gelu(g_prev))         (VALU, chunk j-1)
+// Every A-fragment unit is read from LDS once and used for all PT point tiles.
+template <int PT, bool S1, bool S2, bool S3>
+__device__ __forceinline__ void ff_iter(v16f (&h)[PT][4], const Act<DFX_PREC_BF16> (&xn)[PT][4], v16f (&ag_cur)[PT][2],
+                                        const v16f (&ag_prev)[PT][2], Act<DFX_PREC_BF16> (&hid_new)[PT],
+                                        const Act<DFX_PREC_BF16> (&hid_old)[PT], const uint4 *ck, const float *b1,
+                                        bool no_gelu) {
+  if (S3) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) A0[i] = ck[((i >> 2) + (i & 2 ? 4 : 0)) * 128 + (i & 1) * 64];
-  load16(a, b1);
-  load16(g, b1 + 32);
-  // batch 1: W1 tiles (a,c2) (g,c2) (a,c3) (g,c3)
+    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) A1[i] = ck[(2 + (i >> 2) + (i & 2 ? 4 : 0)) * 128 + (i & 1) * 64];
-  __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < 2; ++q) {
+        const v8bf w = as_bf(ck[(8 + ct) * 128 + q * 64]);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v16f &acc = (i & 2) ? g : a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 2].f[i & 1], acc, 0, 0, 0);
+        for (int pt = 0; pt < PT; ++pt)
+          h[pt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, hid_old[pt].f[q], h[pt][ct], 0, 0, 0);
+      }
   }
+  if (S1) {
+    v16f ba, bg;
+    load16(ba, b1);
+    load16(bg, b1 + 32);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v16f &acc = (i & 2) ? g : a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[2 + (i >> 2)].f[i & 1], acc, 0, 0, 0);
+    for (int pt = 0; pt < PT; ++pt) {
+      ag_cur[pt][0] = ba;
+      ag_cur[pt][1] = bg;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          const v8bf w = as_bf(ck[(part * 4 + c) * 128 + q * 64]);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt)
+            ag_cur[pt][part] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xn[pt][c].f[q], ag_cur[pt][part], 0, 0, 0);
+        }
+  }
+  if (S2) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      v16f hid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        hid[r] = ag_prev[pt][0][r] * (no_gelu ? ag_prev[pt][1][r] : gelu_fast(ag_prev[pt][1][r]));
+      hid_new[pt].set(hid);
+    }
   }
 }
 
-// FF P2: hid = a * gelu(g) (VALU) ; h += W2[:, chunk] hid  (8 MFMAs).  The W2 reads are issued before the GELU.
-__device__ __forceinline__ void ff_p2(v16f (&h)[4], const v16f &a, const v16f &g, const uint4 *ck, bool no_gelu) {
-  uint4 A0[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) A0[i] = ck[(8 + (i >> 1)) * 128 + (i & 1) * 64];
-  __builtin_amdgcn_sched_barrier(0);
-  v16f hid;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) hid[r] = a[r] * (no_gelu ? g[r] : gelu_fast(g[r]));
-  Act<DFX_PREC_BF16> ha;
-  ha.set(hid);
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), ha.f[i & 1], h[i >> 1], 0, 0, 0);
-}
-
-// attention P1: P = softmax_keys(A_s LN2(h) + sbias)   (8 MFMAs + LN + softmax)
-__device__ __forceinline__ void attn_p1(const v16f (&h)[4], Act<DFX_PREC_BF16> &pa, const uint4 *rec, const float *sbias,
-                                        unsigned vmask) {
+// attention for PT point tiles: P = softmax_keys(A_s LN2(h) + sbias); h += M_s P + c_t; xn = LN3(h).
+template <int PT>
+__device__ __forceinline__ void attention_pipe(v16f (&h)[PT][4], Act<DFX_PREC_BF16> (&xn)[PT][4], const uint4 *rec,
+                                               const float *sbias, const float *ct, unsigned vmask) {
   uint4 A0[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) A0[i] = rec[(i >> 1) * 128 + (i & 1) * 64];
-  v16f sim;
-  load16(sim, sbias);
-  Act<DFX_PREC_BF16> xn[4];
-  ln_to_act<DFX_PREC_BF16>(h, xn);
+  v16f sb;
+  load16(sb, sbias);
+  Act<DFX_PREC_BF16> pa[PT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+  for (int pt = 0; pt < PT; ++pt) {
+    ln_to_act<DFX_PREC_BF16>(h[pt], xn[pt]);
+    v16f sim = sb;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float sj[4];
+    for (int i = 0; i < 8; ++i)
+      sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[pt][i >> 1].f[i & 1], sim, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // attention.py:195-197
-    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
-    float e[4], sum = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      float sj[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      e[j] = __expf(sj[j] - m);
-      sum += e[j];
+      for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // attention.py:195-197
+      const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+      float e[4], sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        e[j] = __expf(sj[j] - m);
+        sum += e[j];
+      }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
     }
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
+    pa[pt].set(sim);
   }
-  pa.set(sim);
-}
-
-// attention P2: h += M_s P + c_t ; xn = LN3(h) for the feed-forward  (8 MFMAs + LN)
-__device__ __forceinline__ void attn_p2(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, Act<DFX_PREC_BF16> (&xn)[4],
-                                        const uint4 *rec, const float *ct) {
-  uint4 A0[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) A0[i] = rec[(4 + (i >> 1)) * 128 + (i & 1) * 64];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
-  add_cvec(h, ct);
-  ln_to_act<DFX_PREC_BF16>(h, xn);
+  for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      h[pt][i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa[pt].f[i & 1], h[pt][i >> 1], 0, 0, 0);
+    add_cvec(h[pt], ct);
+    ln_to_act<DFX_PREC_BF16>(h[pt], xn[pt]);
+  }
 }
 
 // post_norm (affine folded into W_out) + proj_out (128 -> 3) on the VALU.
@@ -530,7 +544,8 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
       ln_to_act<PREC>(h, xn);
 #pragma unroll 1
       for (int u = 0; u < FF_CHUNKS; ++u)
-        ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
+        ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane,
+                       bp.chunks + (size_t)(u + 2) * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
       add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
     }
     float eps[3];
@@ -540,20 +555,19 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// LDS-pipelined kernel (bf16, N % 256 == 0): 8 wavefronts = 256 points of ONE shape per workgroup.
-// All weights stream L2 -> LDS through a 3-slot ring of 24 KiB stages filled by LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wavefront-instruction, 3 per wave per stage), two stages ahead
-// of the compute, with ONE workgroup barrier per stage and a counted s_waitcnt vmcnt (never 0 in
-// steady state).  Stage sequence per transformer block: [attention record] then 16 x [FF chunk record].
-// The DMA is issued from inline asm so that hipcc does not serialise the ring behind vmcnt(0) waits
-// (it cannot prove the ds_reads do not alias an in-flight LDS-DMA); the data hazards are handled here:
+// LDS-pipelined kernel (bf16, N % 256 == 0): one workgroup = 256 points of ONE shape = 256/(32 PT) wavefronts,
+// each owning PT point tiles.  All weights stream L2 -> LDS through a ring of 24 KiB stages filled by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wavefront-instruction, CALLS per wave per stage), two stages ahead of the
+// compute, with ONE workgroup barrier per stage and a counted s_waitcnt vmcnt (never 0 in steady state).
+// Stage sequence per transformer block: [attention record] then 18 x [FF stage record]; the FF records are
+// skewed (W1 of chunk j with W2 of chunk j-2) so that one stage = one iteration of the software pipeline.
+// The DMA is issued from inline asm so that hipcc does not serialise the ring behind vmcnt(0) waits (it cannot
+// prove the ds_reads do not alias an in-flight LDS-DMA); the data hazards are handled here:
 //   RAW: issuing wave's vmcnt(CALLS) + s_barrier before any wave reads the slot;
 //   WAR: a slot is refilled only after the barrier that every wave reaches after its last read of it.
-constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
-constexpr int NSLOT = 4;
-constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per stage
-constexpr int STAGES_PER_BLOCK = 1 + FF_CHUNKS;
+constexpr int NSLOT = 3;
+constexpr int STAGES_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
 constexpr int L_BCONST = L_RING + NSLOT * SLOT_BYTES;  // 2 x block-constant record (b1', b2)
@@ -574,7 +588,7 @@ __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned
 }
 
 struct Cursor {
-  int step, b, k, seq;  // k: 0 = attention record, 1..16 = FF chunk k-1; seq = running block number
+  int step, b, k, seq;  // k: 0 = attention record, 1..18 = FF stage record k-1; seq = running block number
 };
 
 __device__ __forceinline__ void cursor_next(Cursor &c, int depth) {
@@ -588,6 +602,7 @@ __device__ __forceinline__ void cursor_next(Cursor &c, int depth) {
   }
 }
 
+template <int CALLS>
 __device__ __forceinline__ void issue_stage(const KParams &p, const Cursor &c, int slot, int wave, unsigned voff,
                                             unsigned lds0, int s) {
   const unsigned ring = lds0 + L_RING + slot * SLOT_BYTES;
@@ -622,30 +637,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams p) {
+template <int PT>
+__global__ void __launch_bounds__(256 / PT * 2, PT == 1 ? 2 : 1) k_denoise_pipe(const KParams p) {
   constexpr int PREC = DFX_PREC_BF16;
+  constexpr int NW = 8 / PT;                        // wavefronts per workgroup (256 points)
+  constexpr int CALLS = SLOT_BYTES / 1024 / NW;     // LDS-DMA instructions per wave per stage
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
-  const long long g0 = ((long long)blockIdx.x * PIPE_NW + wave) * 32;
-  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * PIPE_NW * 32) / p.N));  // one shape per WG
-  const int n = (int)(g0 - (long long)s * p.N) + pj;
+  const long long g0 = ((long long)blockIdx.x * NW + wave) * 32 * PT;
+  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * 256) / p.N));  // one shape per WG
+  const int n0 = (int)(g0 - (long long)s * p.N) + pj;
   const int depth = p.d.depth;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
-  // Ping-pong groups: waves w and w+4 share a SIMD.  Group A (waves 0-3) runs one half-phase AHEAD of group B
-  // (waves 4-7): while an A wave is in the MFMA-heavy half of a stage its SIMD partner is in the VALU-heavy half
-  // of the previous one.  There is one workgroup barrier per half-phase; B passes one extra barrier up front
-  // and A one extra at the end, so both groups execute the same number of barriers.
-  const bool grpA = wave < PIPE_NW / 2;
 
   // ---- prologue DMA: stages 0 and 1 in flight while the per-point state is set up ----
   Cursor pf{0, 0, 0, 0};
-  int pfslot = 0;
-  issue_stage(p, pf, pfslot++, wave, voff, lds0, s);
+  issue_stage<CALLS>(p, pf, 0, wave, voff, lds0, s);
   cursor_next(pf, depth);
-  issue_stage(p, pf, pfslot++, wave, voff, lds0, s);
+  issue_stage<CALLS>(p, pf, 1, wave, voff, lds0, s);
   cursor_next(pf, depth);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
@@ -654,86 +666,88 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     float2 *pregb = reinterpret_cast<float2 *>(pipe_smem + L_PREGB);
     float4 *wout = reinterpret_cast<float4 *>(pipe_smem + L_WOUT);
     float *cp = reinterpret_cast<float *>(pipe_smem + L_CPART);
-    const int tid = threadIdx.x;
-    if (tid < 128) {
-      winx[tid] = p.d.win_x[tid];
-      pregb[tid] = p.d.pre_gb[tid];
-      wout[tid] = p.d.wout[tid];
+    for (int i = threadIdx.x; i < 128; i += NW * 64) {
+      winx[i] = p.d.win_x[i];
+      pregb[i] = p.d.pre_gb[i];
+      wout[i] = p.d.wout[i];
     }
-    cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+    for (int i = threadIdx.x; i < NCLS * INNER; i += NW * 64) cp[i] = p.cpart[(size_t)s * NCLS * INNER + i];
   }
-  PointState ps;
-  unsigned vmask;
-  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
+  PointState ps[PT];
+  unsigned vmask = 0;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) point_init(p, ps[pt], s, n0 + 32 * pt, (unsigned long long)g0 + 32 * pt + pj, vmask);
   __syncthreads();
 
-  const float *cpart = reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64;
+  const float *cpart0 = reinterpret_cast<const float *>(pipe_smem + L_CPART) + hf * 64;
   const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-  // Half-phase boundary.  The ring is managed at every SECOND global barrier; `mine` tells whether that is this
-  // boundary for this wave's group (A: before P1, B: before P2).  Management = my LDS-DMA pieces of the stage
-  // that group A reads next have landed (the following stage's CALLS pieces may still be in flight) -> barrier
-  // -> refill the slot whose last reader (group B, P2 of stage s-2) finished before this barrier.
-  //   RAW: issuing wave's vmcnt(CALLS) + this barrier precede every read of the slot (A reads first).
-  //   WAR: stage s+2 overwrites the slot of stage s-2 (4 slots); B's last read of s-2 is two barriers back.
-#define DFX_SYNC(mine)                                                \
-  do {                                                                \
-    if (mine) wait_vmcnt<CALLS>();                                    \
-    if (!(p.debug & 8)) __builtin_amdgcn_s_barrier();                 \
-    if (mine) {                                                       \
-      if (!(p.debug & 2)) issue_stage(p, pf, pfslot, wave, voff, lds0, s); \
-      cursor_next(pf, depth);                                         \
-      pfslot = (pfslot + 1) & (NSLOT - 1);                            \
-    }                                                                 \
-  } while (0)
-
-  if (!grpA) DFX_SYNC(true);  // B's extra barrier: it is the management barrier of stage 0
-
   int cur = 0;  // ring slot of the stage being computed
   int seq = 0;  // running block number (parity selects the block-constant buffer)
+  // top of every stage: my DMA pieces of this stage have landed (the next stage's CALLS may still fly),
+  // everyone's have after the barrier, and everyone is done with the slot that is refilled next.
+#define DFX_STAGE_BEGIN()                                                                   \
+  do {                                                                                      \
+    wait_vmcnt<CALLS>();                                                                    \
+    if (!(p.debug & 8)) __builtin_amdgcn_s_barrier();                                       \
+    if (!(p.debug & 2)) issue_stage<CALLS>(p, pf, cur == 0 ? 2 : cur - 1, wave, voff, lds0, s); \
+    cursor_next(pf, depth);                                                                 \
+    ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane;     \
+    cur = cur == 2 ? 0 : cur + 1;                                                           \
+  } while (0)
+
+  const bool ng = (p.debug & 4) != 0;
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = p.t0 - step;
-    v16f h[4];
-    proj_in_prenorm(h, ps.x, cpart, winx, pregb);
+    v16f h[PT][4];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) proj_in_prenorm(h[pt], ps[pt].x, cpart0 + ps[pt].sg * INNER, winx, pregb);
     for (int b = 0; b < depth; ++b, ++seq) {
-      const float *bconst = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
-      Act<PREC> xn[4];
-      {
-        const unsigned char *slot = pipe_smem + L_RING + cur * SLOT_BYTES;
-        Act<PREC> pa;
-        DFX_SYNC(grpA);
-        attn_p1(h, pa, reinterpret_cast<const uint4 *>(slot) + lane,
-                reinterpret_cast<const float *>(slot + 16 * 1024) + hf * 16, vmask);
-        DFX_SYNC(!grpA);
-        attn_p2(h, pa, xn, reinterpret_cast<const uint4 *>(slot) + lane,
-                reinterpret_cast<const float *>(slot + 17 * 1024) + hf * 64);
-      }
-      cur = (cur + 1) & (NSLOT - 1);
+      const float *b1 = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES) + hf * 16;
+      const uint4 *ck;
+      Act<PREC> xn[PT][4];
+      DFX_STAGE_BEGIN();
+      attention_pipe<PT>(h, xn, ck, reinterpret_cast<const float *>(ck - lane + 1024) + hf * 16,
+                         reinterpret_cast<const float *>(ck - lane + 1088) + hf * 64, vmask);
+      // software-pipelined feed-forward: 18 iterations; registers rotate by parity (static indexing)
+      v16f ag[2][PT][2];
+      Act<PREC> hid[2][PT];
+      DFX_STAGE_BEGIN();
+      ff_iter<PT, true, false, false>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1 + 0 * 64, ng);
+      DFX_STAGE_BEGIN();
+      ff_iter<PT, true, true, false>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1 + 1 * 64, ng);
 #pragma unroll 1
-      for (int u = 0; u < FF_CHUNKS; ++u) {
-        const uint4 *ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane;
-        v16f a, g;
-        DFX_SYNC(grpA);
-        ff_p1(a, g, xn, ck, bconst + u * 64 + hf * 16);
-        DFX_SYNC(!grpA);
-        ff_p2(h, a, g, ck, (p.debug & 4) != 0);
-        cur = (cur + 1) & (NSLOT - 1);
+      for (int u = 2; u < FF_CHUNKS; u += 2) {
+        DFX_STAGE_BEGIN();
+        ff_iter<PT, true, true, true>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1 + u * 64, ng);
+        DFX_STAGE_BEGIN();
+        ff_iter<PT, true, true, true>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1 + (u + 1) * 64, ng);
       }
-      add_cvec(h, bconst + BCONST_B2_OFF + hf * 64);
+      DFX_STAGE_BEGIN();
+      ff_iter<PT, false, true, true>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1, ng);
+      DFX_STAGE_BEGIN();
+      ff_iter<PT, false, false, true>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1, ng);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) add_cvec(h[pt], b1 - hf * 16 + BCONST_B2_OFF + hf * 64);
     }
-    float eps[3];
-    post_eps(h, wout, p.d.bout, eps);
-    if (step_epilogue(p, ps, eps, step, t)) break;
+    bool done = false;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      float eps[3];
+      post_eps(h[pt], wout, p.d.bout, eps);
+      done = step_epilogue(p, ps[pt], eps, step, t);
+    }
+    if (done) break;
   }
-  if (grpA && !(p.debug & 8)) __builtin_amdgcn_s_barrier();  // A's extra barrier (B's last management barrier)
-#undef DFX_SYNC
+#undef DFX_STAGE_BEGIN
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
 bool g_force_direct = false;
 int g_debug = 0;
+int g_pipe_pt = 1;  // point tiles per wavefront in the pipelined kernel (debug flag 16 selects 2)
 
 int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t st) {
   ShapeCtxView v;
@@ -747,18 +761,21 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
-  const bool pipe = d->dev.prec == DFX_PREC_BF16 && p.N % (PIPE_NW * 32) == 0 && !g_force_direct;
+  const bool pipe = d->dev.prec == DFX_PREC_BF16 && p.N % 256 == 0 && !g_force_direct;
   if (pipe) {
     static bool attr_set = false;
     if (!attr_set) {
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe),
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
       attr_set = true;
     }
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe) k_denoise_pipe<<<(int)(waves / PIPE_NW), PIPE_NW * 64, L_TOTAL, st>>>(p);
+  if (pipe && g_pipe_pt == 2) k_denoise_pipe<2><<<(int)(waves / 8), 256, L_TOTAL, st>>>(p);
+  else if (pipe) k_denoise_pipe<1><<<(int)(waves / 8), 512, L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");
@@ -805,7 +822,10 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_flags(int flags) { g_debug = flags; }
+void dfx_debug_flags(int flags) {
+  g_debug = flags & ~16;
+  g_pipe_pt = (flags & 16) ? 2 : 1;
+}
 
 int dfx_chain_num_snapshots(int num_timesteps, int ret_interval) {
   if (num_timesteps <= 0 || ret_interval <= 0) return 0;

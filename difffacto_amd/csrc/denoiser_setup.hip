@@ -104,7 +104,7 @@ __global__ void k_pack_b1(const float *__restrict__ W1, const float *__restrict_
   dst[gi] = b1[row] + acc;
 }
 
-// W2 (128 x 512) -> tiles 8+ct of chunk record u
+// W2 (128 x 512) -> tiles 8+ct of stage record u+2 (software-pipeline skew, see denoiser_internal.h)
 template <int PREC>
 __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
@@ -113,7 +113,7 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   int i, kk;
   tile_decode<PREC>((int)(gi & 1023), i, kk);
   const int ct = tile & 3, u = tile >> 2;
-  const long long di = ((long long)(u * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
+  const long long di = ((long long)((u + 2) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
   tile_store<PREC>(dst, di, W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk]);
 }
 
@@ -325,7 +325,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     cv.bin = bp.take<float>(INNER);
     cv.wptrs = bp.take<const float *>(DFX_MAX_DEPTH * 6);
     for (int b = 0; b < depth; ++b) {
-      cv.blk[b].chunks = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_CHUNKS * chunk_bytes(precision)));
+      cv.blk[b].chunks = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_STAGES * chunk_bytes(precision)));
       cv.blk[b].bconst = bp.take<float>(BCONST_BYTES / 4);
       cv.blk[b].ct = bp.take<float>((size_t)(T + 1) * CT_ROW);
       cv.blk[b].wq = bp.take<float>(INNER * INNER);
@@ -439,6 +439,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     TRY_LAUNCH("ct");
     TRY_HIP(hipMemsetAsync(c.ct, 0, sizeof(float) * (size_t)(T + 1) * CT_ROW, st));
     TRY_HIP(hipMemsetAsync(c.bconst, 0, BCONST_BYTES, st));
+    TRY_HIP(hipMemsetAsync(c.chunks, 0, (size_t)FF_STAGES * chunk_bytes(precision), st));
     k_to_cvec<<<nblk((long long)T * INNER), 256, 0, st>>>(cv.y, k.to_out_b, c.ct, T, CT_ROW);
     TRY_LAUNCH("ct_cvec");
     k_to_cvec<<<1, 256, 0, st>>>(k.ff2_b, nullptr, c.bconst + BCONST_B2_OFF, 1, INNER);
