@@ -65,6 +65,7 @@ SIGNATURES = {
     "dfx_sample_chain": (_I, [_P, _P, _P, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
     "dfx_debug_flags": (None, [_I]),
+    "dfx_debug_trace": (None, [_P, _I]),
     "dfx_set_event_timing": (None, [_I]),
     "dfx_last_kernel_ms": (_F, []),
 }

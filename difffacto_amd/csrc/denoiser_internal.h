@@ -50,17 +50,18 @@ __host__ __device__ inline int cvec_index(int ch) {  // channel -> position in c
 
 // Streaming records.  Everything the hot kernel reads per stage is laid out as whole 1 KiB pieces
 // so that a stage is copied HBM/L2 -> LDS by a fixed number of 1 KiB LDS-DMA instructions.
-//   FF stage record j = 0..17 (per block): 12 weight tiles, laid out for a SOFTWARE-PIPELINED feed-forward
-//   (iteration j runs GEMM1 of hidden chunk j, the GELU of chunk j-1 and GEMM2 of chunk j-2):
+//   FF stage record j = 0..16 (per block): 12 weight tiles, skewed by FF_SKEW = 1 chunk so that ONE record feeds
+//   one uninterrupted MFMA burst (GEMM2 of hidden chunk j-1 followed by GEMM1 of chunk j):
 //        tiles 0..7  = W1 rows {a: 32j.., g: 512+32j..} x k-tiles c  (index part*4 + c), norm3 affine folded in
-//                      (zero for j >= 16)
-//        tiles 8..11 = W2 rows 32ct.. x hidden k-tile (j-2)          (index 8 + ct; zero for j < 2)
+//                      (zero for j = 16)
+//        tiles 8..11 = W2 rows 32ct.. x hidden k-tile (j-1)          (index 8 + ct; zero for j = 0)
 //   block-constant record (per block): b1' [u][part][hf][16] fp32 (4 KiB) | b2 cvec (512 B) | pad (512 B)
 //   c_t rows (per block): [T] x 1 KiB, first 512 B = cvec of to_out(W_v[:,266:] t_embed(t)) + to_out.bias
 //   attention record (per shape, per block): 4 A_s tiles (k-tile c) | 4 M_s tiles (row-tile ct) |
 //        1 KiB: sbias [hf][16] fp32 (beta2 . A_s rows) + pad
 constexpr int CHUNK_TILES = 12;
-constexpr int FF_STAGES = FF_CHUNKS + 2;  // software-pipeline prologue/epilogue records
+constexpr int FF_SKEW = 1;
+constexpr int FF_STAGES = FF_CHUNKS + FF_SKEW;
 __host__ __device__ constexpr int chunk_bytes(int prec) { return CHUNK_TILES * tile_bytes(prec); }
 constexpr int BCONST_BYTES = 5 * 1024;
 constexpr int BCONST_B2_OFF = 1024;   // float offset of b2 inside the block-constant record

@@ -41,7 +41,9 @@ struct KParams {
   float *xstart;         // p_sample: optional pred_xstart (B,3,N)
   unsigned long long seed;
   int B, N, t0, nsteps, ret_interval, mode;
-  int debug;  // timing ablations only (dfx_debug_flags): 2 = no DMA, 4 = no GELU, 8 = no stage barrier
+  unsigned long long *trace;  // debug: s_memtime stamps of waves 0 and 4 of workgroup 0 at every slot boundary
+  int trace_cap;
+  int debug;  // reserved (dfx_debug_flags)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -246,15 +248,16 @@ __device__ __forceinline__ void attention(v16f (&h)[4], const uint4 *rec, const 
   add_cvec(h, ct);
 }
 
-// GELU for the bf16 path: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), coefficients fitted to the exact erf
-// form on [-8, 8] (max abs error 2.5e-5, an order of magnitude below the bf16 rounding of the hidden
-// activation it feeds).  10 VALU ops incl. v_exp_f32 + v_rcp_f32.
+// GELU for the bf16 path: x * sigmoid(x (c1 + c3 x^2)) with (c1, c3) = (1.60031416, 0.06940179) fitted to the
+// exact erf form (max abs error 2.7e-4 over all x, below the bf16 rounding of the hidden activation it
+// feeds; the standard tanh constants give 4.7e-4).  The argument is monotone in x, so no clamp is needed:
+// +-inf / huge inputs give sigmoid = 1 / 0 exactly.  6 plain VALU + v_exp_f32 + v_rcp_f32 per element.
+__device__ __forceinline__ float gelu_sigmoid_arg(float x) {
+  const float x2 = x * x;
+  return x * fmaf(-0.100125614f, x2, -2.30876530f);  // -log2(e) * x (c1 + c3 x^2)
+}
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-  const float x2 = xc * xc;
-  // -log2(e) * (1.59501577 + 0.0740112920 x^2 - 7.03033575e-4 x^4)
-  const float u = fmaf(fmaf(1.01426306e-3f, x2, -0.106775722f), x2, -2.30112134f);
-  const float e = __builtin_amdgcn_exp2f(xc * u);
+  const float e = __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x));
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
@@ -287,109 +290,167 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
 }
 
 // ---- building blocks of the LDS-pipelined bf16 kernel ---------------------------------------------------
+// gfx950 issues an MFMA and the VALU work of the SAME wavefront strictly one after the other, but overlaps
+// them across the two wavefronts of a SIMD (tools/ubench/valu_rates.hip).  So every wavefront's stream is
+// cut into pure MFMA bursts ("M slots") and pure VALU bursts ("V slots"), and the two wavefronts of a SIMD run
+// them in anti-phase (k_denoise_pipe).
 __device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
 
-// One iteration j of the SOFTWARE-PIPELINED feed-forward over PT point tiles (32 points each).  The three
-// sub-steps touch disjoint registers, so their MFMA and VALU instructions interleave freely in one stream:
-//   S3: h       += W2[:, chunk j-2] hid_old           (8 MFMAs / tile, tiles 8..11 of the stage record)
-//   S1: ag_cur   = b1[j] + W1[chunk j] xn             (16 MFMAs / tile, tiles 0..7)
-//   S2: hid_new  = bf16(a_prev * gelu(g_prev))         (VALU, chunk j-1)
-// Every A-fragment unit is read from LDS once and used for all PT point tiles.
-template <int PT, bool S1, bool S2, bool S3>
-__device__ __forceinline__ void ff_iter(v16f (&h)[PT][4], const Act<DFX_PREC_BF16> (&xn)[PT][4], v16f (&ag_cur)[PT][2],
-                                        const v16f (&ag_prev)[PT][2], Act<DFX_PREC_BF16> (&hid_new)[PT],
-                                        const Act<DFX_PREC_BF16> (&hid_old)[PT], const uint4 *ck, const float *b1,
-                                        bool no_gelu) {
+#ifndef DFX_MFMA_PRIO
+#define DFX_MFMA_PRIO 0
+#endif
+#ifndef DFX_VALU_PRIO
+#define DFX_VALU_PRIO 3
+#endif
+
+// M slot of FF record j: h += W2[:, chunk j-1] hid (S3: 8 MFMAs) then a,g = b1[j] + W1[chunk j] xn (S1: 16 MFMAs).
+// The 24 A-fragment units are fetched in batches of eight ds_read_b128 running one batch ahead of the MFMAs.
+// Slot-boundary clock stamps for tools/trace_slots.py; compiled in only with -DDFX_TRACE (the bookkeeping costs
+// ~10 scalar instructions per stamp site even when switched off at run time).
+struct Tracer {
+#ifdef DFX_TRACE
+  unsigned long long *buf;  // nullptr = off
+  int cap, count;
+  __device__ __forceinline__ void stamp(int tag) {
+    if (buf && count < cap) {
+      if ((threadIdx.x & 63) == 0) buf[count] = ((unsigned long long)tag << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull);
+      ++count;
+    }
+  }
+#else
+  __device__ __forceinline__ void stamp(int) {}
+#endif
+};
+
+template <bool S3, bool S1>
+__device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
+                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, const float *b1, Tracer &tr) {
+  uint4 A0[8], A1[8];
   if (S3) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const v8bf w = as_bf(ck[(8 + ct) * 128 + q * 64]);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-          h[pt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, hid_old[pt].f[q], h[pt][ct], 0, 0, 0);
-      }
+    for (int i = 0; i < 8; ++i) A0[i] = ck[(8 + (i >> 1)) * 128 + (i & 1) * 64];  // W2 tiles ct = i/2, unit q = i&1
   }
   if (S1) {
-    v16f ba, bg;
-    load16(ba, b1);
-    load16(bg, b1 + 32);
+    // W1 unit order: (c, q, part) -> tile part*4 + c, unit q
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      ag_cur[pt][0] = ba;
-      ag_cur[pt][1] = bg;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-          const v8bf w = as_bf(ck[(part * 4 + c) * 128 + q * 64]);
-#pragma unroll
-          for (int pt = 0; pt < PT; ++pt)
-            ag_cur[pt][part] =
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xn[pt][c].f[q], ag_cur[pt][part], 0, 0, 0);
-        }
+    for (int i = 0; i < 8; ++i) A1[i] = ck[((i & 1) * 4 + (i >> 2)) * 128 + ((i >> 1) & 1) * 64];
+    load16(a, b1);
+    load16(g, b1 + 32);
   }
-  if (S2) {
+  __builtin_amdgcn_sched_barrier(0);
+  // The MFMA burst outranks the partner's VALU burst at the issue arbiter (an MFMA needs one issue slot per
+  // 32 cycles, so the VALU wave loses almost nothing); without it the YOUNGER wave's MFMAs only get the
+  // slots the older wave's VALU stream leaves free and its M slot runs ~50 % longer.
+  tr.stamp(4);
+  if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(DFX_MFMA_PRIO);
+  if (S3) {
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      v16f hid;
+    for (int i = 0; i < 8; ++i)
+      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), hid.f[i & 1], h[i >> 1], 0, 0, 0);
+  }
+  if (S1) {
+    if (S3) __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        hid[r] = ag_prev[pt][0][r] * (no_gelu ? ag_prev[pt][1][r] : gelu_fast(ag_prev[pt][1][r]));
-      hid_new[pt].set(hid);
+    for (int i = 0; i < 8; ++i) A0[i] = ck[((i & 1) * 4 + 2 + (i >> 2)) * 128 + ((i >> 1) & 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v16f &acc = (i & 1) ? g : a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(6);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v16f &acc = (i & 1) ? g : a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
     }
   }
+  if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
-// attention for PT point tiles: P = softmax_keys(A_s LN2(h) + sbias); h += M_s P + c_t; xn = LN3(h).
-template <int PT>
-__device__ __forceinline__ void attention_pipe(v16f (&h)[PT][4], Act<DFX_PREC_BF16> (&xn)[PT][4], const uint4 *rec,
-                                               const float *sbias, const float *ct, unsigned vmask) {
+// V slot of the feed-forward: hid = bf16(a * gelu(g)).  Written stage by stage over 8 elements at a time so
+// that eight independent dependency chains are in flight (hipcc otherwise interleaves only two and every
+// instruction waits for its predecessor's result).
+__device__ __forceinline__ void ff_v(const v16f &a, const v16f &g, Act<DFX_PREC_BF16> &hid) {
+  if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
+  v16f t;
+#ifdef DFX_ABLATE_NO_GELU  // timing ablation only (wrong results)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = a[r] * g[r];
+#else
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float u[8], ag[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = gelu_sigmoid_arg(g[half * 8 + i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ag[i] = a[half * 8 + i] * g[half * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = 1.0f + u[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_rcpf(u[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[half * 8 + i] = ag[i] * u[i];
+  }
+#endif
+  hid.set(t);
+  // Pin the result here: without a use in this slot LLVM sinks the whole GELU past the record barrier into the
+  // consumer's M slot, and the two groups' VALU bursts collide instead of running in anti-phase.
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u w = __builtin_bit_cast(v4u, hid.f[q]);
+    asm volatile("" : "+v"(w));
+    hid.f[q] = __builtin_bit_cast(v8bf, w);
+  }
+  if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
+// attention M slots: sim = sbias + A_s xn (8 MFMAs);  h += M_s P (8 MFMAs)
+__device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *rec, const float *sbias) {
   uint4 A0[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) A0[i] = rec[(i >> 1) * 128 + (i & 1) * 64];
-  v16f sb;
-  load16(sb, sbias);
-  Act<DFX_PREC_BF16> pa[PT];
+  load16(sim, sbias);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    ln_to_act<DFX_PREC_BF16>(h[pt], xn[pt]);
-    v16f sim = sb;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[pt][i >> 1].f[i & 1], sim, 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float sj[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // attention.py:195-197
-      const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
-      float e[4], sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        e[j] = __expf(sj[j] - m);
-        sum += e[j];
-      }
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
-    }
-    pa[pt].set(sim);
-  }
+  for (int i = 0; i < 8; ++i)
+    sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+}
+
+__device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, const uint4 *rec) {
+  uint4 A0[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) A0[i] = rec[(4 + (i >> 1)) * 128 + (i & 1) * 64];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
+  for (int i = 0; i < 8; ++i)
+    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+}
+
+// attention V slot: masked softmax over the 4 keys of each head (registers 4g..4g+3 = keys of head 2g+hf)
+__device__ __forceinline__ void attn_softmax(v16f &sim, Act<DFX_PREC_BF16> &pa, unsigned vmask) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      h[pt][i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa[pt].f[i & 1], h[pt][i >> 1], 0, 0, 0);
-    add_cvec(h[pt], ct);
-    ln_to_act<DFX_PREC_BF16>(h[pt], xn[pt]);
+  for (int g = 0; g < 4; ++g) {
+    float sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;  // attention.py:195-197
+    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[j] = __expf(sj[j] - m);
+      sum += e[j];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
   }
+  pa.set(sim);
 }
 
 // post_norm (affine folded into W_out) + proj_out (128 -> 3) on the VALU.
@@ -545,7 +606,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 #pragma unroll 1
       for (int u = 0; u < FF_CHUNKS; ++u)
         ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane,
-                       bp.chunks + (size_t)(u + 2) * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
+                       bp.chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
       add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
     }
     float eps[3];
@@ -555,19 +616,35 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// LDS-pipelined kernel (bf16, N % 256 == 0): one workgroup = 256 points of ONE shape = 256/(32 PT) wavefronts,
-// each owning PT point tiles.  All weights stream L2 -> LDS through a ring of 24 KiB stages filled by LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wavefront-instruction, CALLS per wave per stage), two stages ahead of the
-// compute, with ONE workgroup barrier per stage and a counted s_waitcnt vmcnt (never 0 in steady state).
-// Stage sequence per transformer block: [attention record] then 18 x [FF stage record]; the FF records are
-// skewed (W1 of chunk j with W2 of chunk j-2) so that one stage = one iteration of the software pipeline.
-// The DMA is issued from inline asm so that hipcc does not serialise the ring behind vmcnt(0) waits (it cannot
-// prove the ds_reads do not alias an in-flight LDS-DMA); the data hazards are handled here:
-//   RAW: issuing wave's vmcnt(CALLS) + s_barrier before any wave reads the slot;
-//   WAR: a slot is refilled only after the barrier that every wave reaches after its last read of it.
+// LDS-pipelined kernel (bf16, N % 256 == 0): one workgroup = 8 wavefronts = 256 points of ONE shape.
+//
+// Weight streaming.  All weights stream L2 -> LDS through a 4-slot ring of 24 KiB records filled by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wavefront-instruction, 3 per wave per record), two records ahead of the
+// compute, with a counted s_waitcnt vmcnt (never 0 in steady state).  Record sequence per transformer block:
+// [attention record] then 17 x [FF record j = W1 of chunk j | W2 of chunk j-1].  The DMA is issued from inline
+// asm so that hipcc does not serialise the ring behind vmcnt(0) waits (it cannot prove that a ds_read does not
+// alias an in-flight LDS-DMA); the data hazards are handled by the slot protocol below.
+//
+// Slots.  Each wavefront alternates pure-VALU slots (V) and pure-MFMA slots (M).  Group B (waves 4-7) runs one
+// slot behind group A (waves 0-3): each record's management barrier (below) is in front of A's M slot but in
+// front of B's preceding V slot, and waves w / w+4 share a SIMD, so after every barrier one wavefront of each
+// SIMD starts an MFMA burst while its partner starts a VALU burst:
+//     block:  V0 (b2 of the previous block | step boundary | LN2)  M0 (A_s)  V1 (softmax)  M1 (M_s)  V2 (+c_t, LN3)
+//             M(F0: GEMM1 0)  V (GELU 0)  M(F1: GEMM2 0 + GEMM1 1)  V (GELU 1) ... M(F16: GEMM2 15)
+// One barrier per record per wavefront; both groups execute the same number of barriers.
+//
+// Ring protocol.  The barrier in front of the M slot that first reads record r (for group A; for B it is the
+// barrier in front of the preceding V slot — the SAME global barrier) is r's management barrier:
+//     before it  every wave waits for its own DMA pieces of r (vmcnt(CALLS): record r+1 may still be in flight)
+//     after it   every wave issues its pieces of record r+2 into slot (r+2)%4
+//   RAW: the issuing waves' vmcnt + the barrier precede every read of r (A reads first).
+//   WAR: slot (r+2)%4 held record r-2, whose last reader (B; for an attention record B's V2) finished at least
+//        one barrier earlier.
+constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
-constexpr int NSLOT = 3;
-constexpr int STAGES_PER_BLOCK = 1 + FF_STAGES;
+constexpr int NSLOT = 4;
+constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per record
+constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
 constexpr int L_BCONST = L_RING + NSLOT * SLOT_BYTES;  // 2 x block-constant record (b1', b2)
@@ -578,6 +655,7 @@ constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
 constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs
 constexpr int L_TOTAL = L_DUMMY + 1024;
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
+static_assert(CALLS == 3, "dma3 issues exactly three pieces");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
 
@@ -587,78 +665,78 @@ __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned
                : "memory");  // m0 is reserved: hipcc re-materialises it before each of its own uses
 }
 
-struct Cursor {
-  int step, b, k, seq;  // k: 0 = attention record, 1..18 = FF stage record k-1; seq = running block number
-};
-
-__device__ __forceinline__ void cursor_next(Cursor &c, int depth) {
-  if (++c.k == STAGES_PER_BLOCK) {
-    c.k = 0;
-    ++c.seq;
-    if (++c.b == depth) {
-      c.b = 0;
-      ++c.step;
-    }
-  }
-}
-
-template <int CALLS>
-__device__ __forceinline__ void issue_stage(const KParams &p, const Cursor &c, int slot, int wave, unsigned voff,
-                                            unsigned lds0, int s) {
-  const unsigned ring = lds0 + L_RING + slot * SLOT_BYTES;
-  const bool valid = c.step < p.nsteps;
-  const BlockPack &bp = p.d.blk[valid ? c.b : 0];
-#pragma unroll
-  for (int j = 0; j < CALLS; ++j) {
-    const int q = wave * CALLS + j;  // 1 KiB piece of this stage
-    const char *src = reinterpret_cast<const char *>(bp.bconst);
-    unsigned dst = lds0 + L_DUMMY;
-    if (valid) {
-      if (c.k > 0) {
-        src = reinterpret_cast<const char *>(bp.chunks) + (size_t)(c.k - 1) * SLOT_BYTES + q * 1024;
-        dst = ring + q * 1024;
-      } else if (q < 17) {
-        src = reinterpret_cast<const char *>(p.as_ms) + ((size_t)s * p.d.depth + c.b) * asms_bytes(DFX_PREC_BF16) + q * 1024;
-        dst = ring + q * 1024;
-      } else if (q < 22) {
-        src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
-        dst = lds0 + L_BCONST + (c.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
-      } else if (q == 22) {
-        src = reinterpret_cast<const char *>(bp.ct + (size_t)(p.t0 - c.step) * CT_ROW);
-        dst = ring + 17 * 1024;
-      }
-    }
-    dma1k(src, voff, dst);
-  }
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int PT>
-__global__ void __launch_bounds__(256 / PT * 2, PT == 1 ? 2 : 1) k_denoise_pipe(const KParams p) {
+// Next record to fetch (all wave-uniform).
+struct DmaState {
+  int step, b, k, seq, slot;  // k: 0 = attention record, 1..17 = FF record k-1; seq = running block number
+  const char *ff_src;         // this wave's 3 KiB window of the next FF record
+};
+
+// Issue this wave's three 1 KiB pieces (q = 3 wave + j) of the next record and advance the state.
+__device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
+  const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
+  if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
+#pragma unroll
+    for (int j = 0; j < CALLS; ++j) dma1k(p.d.blk[0].bconst, voff, lds0 + L_DUMMY);
+  } else if (st.k > 0) {  // FF record: 24 contiguous KiB (the common case: keep it lean)
+    const unsigned dst = ring + wave * (CALLS * 1024);
+#pragma unroll
+    for (int j = 0; j < CALLS; ++j) dma1k(st.ff_src + j * 1024, voff, dst + j * 1024);
+    st.ff_src += SLOT_BYTES;
+  } else {  // attention record: 17 KiB shape record | 5 KiB block constants | 1 KiB c_t row | 1 padding piece
+    const BlockPack &bp = p.d.blk[st.b];
+#pragma unroll
+    for (int j = 0; j < CALLS; ++j) {
+      const int q = wave * CALLS + j;
+      const char *src = reinterpret_cast<const char *>(bp.bconst);
+      unsigned dst = lds0 + L_DUMMY;
+      if (q < 17) {
+        src = reinterpret_cast<const char *>(p.as_ms) + ((size_t)s * p.d.depth + st.b) * asms_bytes(DFX_PREC_BF16) + q * 1024;
+        dst = ring + q * 1024;
+      } else if (q < 22) {
+        src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
+        dst = lds0 + L_BCONST + (st.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
+      } else if (q == 22) {
+        src = reinterpret_cast<const char *>(bp.ct + (size_t)(p.t0 - st.step) * CT_ROW);
+        dst = ring + 17 * 1024;
+      }
+      dma1k(src, voff, dst);
+    }
+    st.ff_src = reinterpret_cast<const char *>(bp.chunks) + wave * (CALLS * 1024);
+  }
+  st.slot = (st.slot + 1) & (NSLOT - 1);
+  if (++st.k == RECORDS_PER_BLOCK) {
+    st.k = 0;
+    ++st.seq;
+    if (++st.b == p.d.depth) {
+      st.b = 0;
+      ++st.step;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams p) {
   constexpr int PREC = DFX_PREC_BF16;
-  constexpr int NW = 8 / PT;                        // wavefronts per workgroup (256 points)
-  constexpr int CALLS = SLOT_BYTES / 1024 / NW;     // LDS-DMA instructions per wave per stage
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
-  const long long g0 = ((long long)blockIdx.x * NW + wave) * 32 * PT;
-  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * 256) / p.N));  // one shape per WG
-  const int n0 = (int)(g0 - (long long)s * p.N) + pj;
+  const long long g0 = ((long long)blockIdx.x * PIPE_NW + wave) * 32;
+  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * PIPE_NW * 32) / p.N));  // one shape per WG
+  const int n = (int)(g0 - (long long)s * p.N) + pj;
   const int depth = p.d.depth;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
+  const bool grpA = wave < PIPE_NW / 2;
 
-  // ---- prologue DMA: stages 0 and 1 in flight while the per-point state is set up ----
-  Cursor pf{0, 0, 0, 0};
-  issue_stage<CALLS>(p, pf, 0, wave, voff, lds0, s);
-  cursor_next(pf, depth);
-  issue_stage<CALLS>(p, pf, 1, wave, voff, lds0, s);
-  cursor_next(pf, depth);
+  // ---- prologue DMA: records 0 and 1 in flight while the per-point state is set up ----
+  DmaState dma{0, 0, 0, 0, 0, nullptr};
+  issue_record(p, dma, wave, voff, lds0, s);
+  issue_record(p, dma, wave, voff, lds0, s);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
   {
@@ -666,88 +744,141 @@ __global__ void __launch_bounds__(256 / PT * 2, PT == 1 ? 2 : 1) k_denoise_pipe(
     float2 *pregb = reinterpret_cast<float2 *>(pipe_smem + L_PREGB);
     float4 *wout = reinterpret_cast<float4 *>(pipe_smem + L_WOUT);
     float *cp = reinterpret_cast<float *>(pipe_smem + L_CPART);
-    for (int i = threadIdx.x; i < 128; i += NW * 64) {
-      winx[i] = p.d.win_x[i];
-      pregb[i] = p.d.pre_gb[i];
-      wout[i] = p.d.wout[i];
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+      winx[tid] = p.d.win_x[tid];
+      pregb[tid] = p.d.pre_gb[tid];
+      wout[tid] = p.d.wout[tid];
     }
-    for (int i = threadIdx.x; i < NCLS * INNER; i += NW * 64) cp[i] = p.cpart[(size_t)s * NCLS * INNER + i];
+    cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
   }
-  PointState ps[PT];
-  unsigned vmask = 0;
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) point_init(p, ps[pt], s, n0 + 32 * pt, (unsigned long long)g0 + 32 * pt + pj, vmask);
+  PointState ps;
+  unsigned vmask;
+  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
   __syncthreads();
 
-  const float *cpart0 = reinterpret_cast<const float *>(pipe_smem + L_CPART) + hf * 64;
+  const float *cpart = reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64;
   const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-  int cur = 0;  // ring slot of the stage being computed
-  int seq = 0;  // running block number (parity selects the block-constant buffer)
-  // top of every stage: my DMA pieces of this stage have landed (the next stage's CALLS may still fly),
-  // everyone's have after the barrier, and everyone is done with the slot that is refilled next.
-#define DFX_STAGE_BEGIN()                                                                   \
-  do {                                                                                      \
-    wait_vmcnt<CALLS>();                                                                    \
-    if (!(p.debug & 8)) __builtin_amdgcn_s_barrier();                                       \
-    if (!(p.debug & 2)) issue_stage<CALLS>(p, pf, cur == 0 ? 2 : cur - 1, wave, voff, lds0, s); \
-    cursor_next(pf, depth);                                                                 \
-    ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane;     \
-    cur = cur == 2 ? 0 : cur + 1;                                                           \
+  // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
+#define DFX_STAMP(tag) tr.stamp(tag)
+#ifdef DFX_LOCKSTEP  // A/B variant: a barrier at every slot boundary
+#define DFX_LOCKSTEP_BARRIER() __builtin_amdgcn_s_barrier()
+#else
+#define DFX_LOCKSTEP_BARRIER() ((void)0)
+#endif
+#define DFX_SLOT(mgmt)                                  \
+  do {                                                  \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    if (mgmt) {                                         \
+      DFX_STAMP(1);                                     \
+      wait_vmcnt<CALLS>();                              \
+      __builtin_amdgcn_s_barrier();                     \
+      DFX_STAMP(2);                                     \
+      issue_record(p, dma, wave, voff, lds0, s);        \
+    } else {                                            \
+      DFX_STAMP(3);                                     \
+      DFX_LOCKSTEP_BARRIER();                           \
+    }                                                   \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+  // pointer to this lane's view of the record in ring slot `cur`, then advance
+#define DFX_NEXT_RECORD()                                                             \
+  do {                                                                                \
+    ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane; \
+    cur = (cur + 1) & (NSLOT - 1);                                                    \
   } while (0)
 
-  const bool ng = (p.debug & 4) != 0;
-  for (int step = 0; step < p.nsteps; ++step) {
+#ifdef DFX_TRACE
+  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr,
+            p.trace_cap, 0};
+#else
+  Tracer tr;
+#endif
+#ifdef DFX_LOCKSTEP
+  if (!grpA) __builtin_amdgcn_s_barrier();  // lock-step variant: B runs one barrier behind A
+#endif
+
+  int cur = 0;  // ring slot of the next record to be consumed
+  int seq = 0;  // running block number (parity selects the block-constant buffer)
+  v16f h[4];
+  bool done = false;
+  for (int step = 0; step <= p.nsteps && !done; ++step) {
     const int t = p.t0 - step;
-    v16f h[PT][4];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) proj_in_prenorm(h[pt], ps[pt].x, cpart0 + ps[pt].sg * INNER, winx, pregb);
     for (int b = 0; b < depth; ++b, ++seq) {
-      const float *b1 = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES) + hf * 16;
+      const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
+      const float *b1 = bc + hf * 16;
       const uint4 *ck;
-      Act<PREC> xn[PT][4];
-      DFX_STAGE_BEGIN();
-      attention_pipe<PT>(h, xn, ck, reinterpret_cast<const float *>(ck - lane + 1024) + hf * 16,
-                         reinterpret_cast<const float *>(ck - lane + 1088) + hf * 64, vmask);
-      // software-pipelined feed-forward: 18 iterations; registers rotate by parity (static indexing)
-      v16f ag[2][PT][2];
-      Act<PREC> hid[2][PT];
-      DFX_STAGE_BEGIN();
-      ff_iter<PT, true, false, false>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1 + 0 * 64, ng);
-      DFX_STAGE_BEGIN();
-      ff_iter<PT, true, true, false>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1 + 1 * 64, ng);
-#pragma unroll 1
-      for (int u = 2; u < FF_CHUNKS; u += 2) {
-        DFX_STAGE_BEGIN();
-        ff_iter<PT, true, true, true>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1 + u * 64, ng);
-        DFX_STAGE_BEGIN();
-        ff_iter<PT, true, true, true>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1 + (u + 1) * 64, ng);
+      Act<PREC> xn[4];
+      // ---- V0: finish the previous block / step, start this one ----
+      DFX_SLOT(!grpA && step < p.nsteps);
+      if (seq > 0)  // b2 of the previous block (other block-constant buffer)
+        add_cvec(h, reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) +
+                        BCONST_B2_OFF + hf * 64);
+      if (b == 0) {
+        if (step > 0) {
+          float eps[3];
+          post_eps(h, wout, p.d.bout, eps);
+          done = step_epilogue(p, ps, eps, step - 1, t + 1);
+        }
+        if (step == p.nsteps) done = true;
+        if (!done) proj_in_prenorm(h, ps.x, cpart, winx, pregb);
       }
-      DFX_STAGE_BEGIN();
-      ff_iter<PT, false, true, true>(h, xn, ag[0], ag[1], hid[1], hid[0], ck, b1, ng);
-      DFX_STAGE_BEGIN();
-      ff_iter<PT, false, false, true>(h, xn, ag[1], ag[0], hid[0], hid[1], ck, b1, ng);
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) add_cvec(h[pt], b1 - hf * 16 + BCONST_B2_OFF + hf * 64);
+      if (done) break;
+      ln_to_act<PREC>(h, xn);
+      // ---- M0: sim = sbias + A_s xn ----
+      DFX_SLOT(grpA);
+      DFX_NEXT_RECORD();
+      const uint4 *rec = ck;
+      v16f sim;
+      attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16);
+      // ---- V1: softmax ----
+      DFX_SLOT(false);
+      Act<PREC> pa;
+      attn_softmax(sim, pa, vmask);
+      // ---- M1: h += M_s P ----
+      DFX_SLOT(false);
+      attn_m1(h, pa, rec);
+      // ---- V2: + c_t, LN3 ----
+      DFX_SLOT(!grpA);
+      add_cvec(h, reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
+      ln_to_act<PREC>(h, xn);
+      // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
+      v16f a, g;
+      Act<PREC> hid;
+      DFX_SLOT(grpA);
+      DFX_NEXT_RECORD();
+      ff_m<false, true>(h, xn, a, g, hid, ck, b1, tr);
+#pragma unroll 1
+      for (int j = 1; j < FF_CHUNKS; ++j) {
+        DFX_SLOT(!grpA);
+        ff_v(a, g, hid);
+        DFX_SLOT(grpA);
+        DFX_NEXT_RECORD();
+        ff_m<true, true>(h, xn, a, g, hid, ck, b1 + j * 64, tr);
+      }
+      DFX_SLOT(!grpA);
+      ff_v(a, g, hid);
+      DFX_SLOT(grpA);
+      DFX_NEXT_RECORD();
+      ff_m<true, false>(h, xn, a, g, hid, ck, b1, tr);
     }
-    bool done = false;
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      float eps[3];
-      post_eps(h[pt], wout, p.d.bout, eps);
-      done = step_epilogue(p, ps[pt], eps, step, t);
-    }
-    if (done) break;
   }
-#undef DFX_STAGE_BEGIN
+#ifdef DFX_LOCKSTEP
+  if (grpA) __builtin_amdgcn_s_barrier();  // lock-step variant: A's extra barrier
+#endif
+#undef DFX_SLOT
+#undef DFX_STAMP
+#undef DFX_NEXT_RECORD
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
 bool g_force_direct = false;
 int g_debug = 0;
-int g_pipe_pt = 1;  // point tiles per wavefront in the pipelined kernel (debug flag 16 selects 2)
+unsigned long long *g_trace = nullptr;
+int g_trace_cap = 0;
 
 int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t st) {
   ShapeCtxView v;
@@ -757,6 +888,8 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   p.cpart = v.cpart;
   p.as_ms = v.as_ms;
   p.debug = g_debug;
+  p.trace = g_trace;
+  p.trace_cap = g_trace_cap;
   constexpr int NW = 4;
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
@@ -765,17 +898,14 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   if (pipe) {
     static bool attr_set = false;
     if (!attr_set) {
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<2>),
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
       attr_set = true;
     }
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe && g_pipe_pt == 2) k_denoise_pipe<2><<<(int)(waves / 8), 256, L_TOTAL, st>>>(p);
-  else if (pipe) k_denoise_pipe<1><<<(int)(waves / 8), 512, L_TOTAL, st>>>(p);
+  if (pipe) k_denoise_pipe<<<(int)(waves / PIPE_NW), PIPE_NW * 64, L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");
@@ -822,9 +952,10 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_flags(int flags) {
-  g_debug = flags & ~16;
-  g_pipe_pt = (flags & 16) ? 2 : 1;
+void dfx_debug_flags(int flags) { g_debug = flags; }
+void dfx_debug_trace(void *device_buf, int capacity) {
+  g_trace = static_cast<unsigned long long *>(device_buf);
+  g_trace_cap = capacity;
 }
 
 int dfx_chain_num_snapshots(int num_timesteps, int ret_interval) {

@@ -104,7 +104,7 @@ __global__ void k_pack_b1(const float *__restrict__ W1, const float *__restrict_
   dst[gi] = b1[row] + acc;
 }
 
-// W2 (128 x 512) -> tiles 8+ct of stage record u+2 (software-pipeline skew, see denoiser_internal.h)
+// W2 (128 x 512) -> tiles 8+ct of stage record u+FF_SKEW (see denoiser_internal.h)
 template <int PREC>
 __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
@@ -113,7 +113,7 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   int i, kk;
   tile_decode<PREC>((int)(gi & 1023), i, kk);
   const int ct = tile & 3, u = tile >> 2;
-  const long long di = ((long long)((u + 2) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
+  const long long di = ((long long)((u + FF_SKEW) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
   tile_store<PREC>(dst, di, W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk]);
 }
 

@@ -181,8 +181,11 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
 
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
-/* Timing ablations (results become WRONG): 2 = skip LDS-DMA, 4 = skip GELU, 8 = skip stage barriers. */
+/* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */
 void dfx_debug_flags(int flags);
+/* Slot-boundary clock stamps of two wavefronts of workgroup 0 (device buffer of 2*capacity uint64; NULL = off).
+ * Only effective in a library built with -DDFX_TRACE (tools/trace_slots.py builds one). */
+void dfx_debug_trace(void *device_buf, int capacity);
 
 /* Name + average duration bookkeeping for bench.py: duration in ms of the last dfx_sample_chain /
  * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */
