@@ -1,0 +1,254 @@
+"""Host-side mirrors of the reference module API for the sampling hot path, backed by libdfx.
+
+* ``TransformerNet``      same constructor arguments, parameter names and ``forward`` signature as
+                          ``NETS['TransformerNet']`` (python/difffacto/models/diffusions/nets/attention.py:308-440);
+                          the forward pass is ONE launch of the fused HIP denoiser.
+* ``AnchoredDiffusion``   same constructor arguments and sampling methods as ``DIFFUSIONS['AnchoredDiffusion']``
+                          (python/difffacto/models/diffusions/anchored_diffusion.py:13-588): the generator
+                          ``p_sample_loop_progressive`` (one launch per step) and the fused ``sample_chain``.
+* ``decode``              ``AnchorDiffAE.decode`` (python/difffacto/models/networks/anchor_gen.py:145-169) on top of
+                          the single-launch persistent chain.
+
+``state_dict`` keys are the reference's (``pretrained/*.pth`` loads with ``load_state_dict``).  Only the option
+set of the shipped ``configs/gen_*.py`` / ``train_*.py`` is implemented natively; any other combination raises
+``NotImplementedError`` (there is no PyTorch fallback path).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import DenoiserEngine
+
+
+# ---- parameter containers with the reference's attribute names (no torch math in them) -----------------------
+class _GEGLUParams(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)          # attention.py:50-57
+
+
+class _FeedForwardParams(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.Sequential(_GEGLUParams(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim))  # :77-94
+
+
+class _CrossAttentionParams(nn.Module):
+    def __init__(self, query_dim, context_dim, heads, dim_head, dropout=0.0):
+        super().__init__()
+        inner = heads * dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)  # attention.py:170-177
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+
+
+class _BlockParams(nn.Module):
+    def __init__(self, dim, n_heads, d_head, context_dim, dropout=0.0):
+        super().__init__()
+        self.ff = _FeedForwardParams(dim, dropout=dropout)   # attention.py:279-283 (single_attn: no attn1/norm1)
+        self.attn2 = _CrossAttentionParams(dim, context_dim, n_heads, d_head, dropout)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+
+def _unsupported(what):
+    raise NotImplementedError(f"libdfx implements the shipped gen_*/train_* denoiser configuration only: {what}")
+
+
+class TransformerNet(nn.Module):
+    """Drop-in for ``NETS['TransformerNet']`` (attention.py:308-440)."""
+
+    def __init__(self, in_channels, n_heads, d_head, out_channels, depth=1, dropout=0., context_dim=None,
+                 use_linear=False, use_checkpoint=False, single_attn=False, class_cond=False, n_class=4,
+                 cat_params_to_x=False, mask_out_unreferenced_code=True, cat_class_to_x=False,
+                 use_sine_proj_in=False, add_t_to_x=False, res=False, add_class_cond=False, context_proj=False,
+                 include_std=False):
+        super().__init__()
+        if not (use_linear and single_attn and class_cond and cat_params_to_x and cat_class_to_x
+                and mask_out_unreferenced_code):
+            _unsupported("use_linear, single_attn, class_cond, cat_params_to_x, cat_class_to_x must be True")
+        if use_sine_proj_in or add_t_to_x or res or add_class_cond or context_proj or include_std:
+            _unsupported("use_sine_proj_in / add_t_to_x / res / add_class_cond / context_proj / include_std")
+        if (in_channels, out_channels, n_heads, d_head, n_class, context_dim) != (3, 3, 8, 16, 4, 262):
+            _unsupported("in/out channels 3, 8 heads x 16, n_class 4, context_dim 256+6")
+        self.n_class = n_class
+        self.in_channels = in_channels + 6 + n_class          # attention.py:330
+        self.inner_dim = inner = n_heads * d_head
+        self.context_dim = context_dim + 256 + n_class        # attention.py:335
+        self.depth = depth
+        self.pre_norm = nn.LayerNorm(inner)
+        self.post_norm = nn.LayerNorm(inner)
+        self.proj_in = nn.Linear(self.in_channels, inner)
+        self.time_embed = _FeedForwardParams(256, dropout=dropout)
+        self.transformer_blocks = nn.ModuleList(
+            [_BlockParams(inner, n_heads, d_head, self.context_dim, dropout) for _ in range(depth)])
+        self.proj_out = nn.Linear(inner, out_channels)        # in != out and not res -> not zero-initialised (:382)
+        # engine cache (frozen weights): rebuilt when any parameter is modified in place or replaced
+        self._dfx_T = 1000
+        self._dfx_betas = (1e-4, 0.02)
+        self._dfx_precision = "bf16"
+        self._engine = None
+        self._engine_key = None
+        self._ctx_cache = None
+
+    # -- libdfx plumbing --
+    def configure(self, num_timesteps=None, beta_1=None, beta_T=None, precision=None):
+        if num_timesteps is not None:
+            self._dfx_T = int(num_timesteps)
+        if beta_1 is not None and beta_T is not None:
+            self._dfx_betas = (float(beta_1), float(beta_T))
+        if precision is not None:
+            self._dfx_precision = precision
+        self._engine = None
+        return self
+
+    def engine(self):
+        params = dict(self.named_parameters())
+        key = (self._dfx_T, self._dfx_betas, self._dfx_precision,
+               tuple((p.data_ptr(), p._version) for p in params.values()))
+        if self._engine is None or key != self._engine_key:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("TransformerNet (libdfx) needs its parameters on a HIP device: CPU not supported")
+            self._engine = DenoiserEngine({k: v.detach() for k, v in params.items()}, self._dfx_T, *self._dfx_betas,
+                                          precision=self._dfx_precision, device=dev)
+            self._engine_key = key
+            self._ctx_cache = None
+        return self._engine
+
+    def shape_context(self, ctx, valid_id):
+        """ctx = [part_code (B,256,4), cat(mean, var) (B,6,4)] as built by prepare_ctx (part_encoders.py:1317-1326)."""
+        if not isinstance(ctx, (list, tuple)) or len(ctx) != 2:
+            _unsupported("ctx must be the [part_code, params] list of PartEncoderForTransformerDecoder.prepare_ctx")
+        pc, params = ctx
+        if valid_id is None:
+            valid_id = torch.ones(pc.shape[0], self.n_class, device=pc.device)
+        key = (pc.data_ptr(), pc._version, params.data_ptr(), params._version, valid_id.data_ptr(), valid_id._version)
+        eng = self.engine()
+        if self._ctx_cache is None or self._ctx_cache[0] != key:
+            sc = eng.prepare_shapes(pc, params[:, :3], params[:, 3:], valid_id.to(torch.float32))
+            self._ctx_cache = (key, sc)
+        return self._ctx_cache[1]
+
+    def forward(self, x, t, ctx, anchors=None, variances=None, valid_id=None, anchor_assignment=None, **kwargs):
+        """eps = eps_theta(x (B,3,N), t (B,), ctx).  ``anchors`` / ``variances`` (B,N,3) are accepted for signature
+        compatibility; on the reference's call path (anchored_diffusion.py:261) they are the gather of ctx[1] by
+        ``anchor_assignment``, which the kernel performs itself."""
+        if anchor_assignment is None:
+            _unsupported("anchor_assignment is required (cat_class_to_x)")
+        tt = t if isinstance(t, int) else int(t.reshape(-1)[0].item())
+        if not isinstance(t, int) and t.numel() > 1 and not bool((t == t.reshape(-1)[0]).all()):
+            _unsupported("per-sample timesteps (the sampling loop uses one t for the batch, anchored_diffusion.py:576)")
+        sc = self.shape_context(ctx, valid_id)
+        return self.engine().eps(sc, x, anchor_assignment, tt)
+
+
+class AnchoredDiffusion(nn.Module):
+    """Drop-in for ``DIFFUSIONS['AnchoredDiffusion']`` (anchored_diffusion.py:13-588), sampling side."""
+
+    def __init__(self, net, num_timesteps, beta_1, beta_T, k=1., res=True, mode='linear', use_beta=True,
+                 rescale_timesteps=False, loss_type='mse', model_mean_type='epsilon', model_var_type='fixed_small',
+                 scale_loss=False, clip_xstart=False, include_anchors=True, include_cov=False, learn_anchor=True,
+                 learn_variance=False, classifier_weight=1., guidance=False, ddim_sampling=False, ddim_nsteps=10,
+                 ddim_discretize='uniform', ddim_eta=1., precision="bf16"):
+        super().__init__()
+        if (mode != 'linear' or res or use_beta or rescale_timesteps or model_mean_type != 'epsilon'
+                or model_var_type != 'fixed_small' or clip_xstart or include_anchors or include_cov
+                or not learn_anchor or not learn_variance or guidance or ddim_sampling):
+            _unsupported("AnchoredDiffusion options other than those of configs/gen_*.py")
+        if isinstance(net, nn.Module):
+            self.model = net
+        else:
+            args = dict(net)
+            args.pop("type", None)
+            self.model = TransformerNet(**args)
+        self.num_timesteps = int(num_timesteps)
+        self.beta_1, self.beta_T = beta_1, beta_T
+        self.model.configure(self.num_timesteps, beta_1, beta_T, precision)
+        # schedule tables, float64 numpy like the reference (:62-112); the kernels use libdfx's own copy, which
+        # tests pin bit-exactly against the reference
+        betas = np.linspace(beta_1, beta_T, num=self.num_timesteps, dtype=np.float64)
+        self.betas = betas
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.steps = list(range(self.num_timesteps))
+
+    # ---- sampling ----
+    def _sc(self, ctx, valid_id):
+        return self.model.shape_context(ctx, valid_id)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, anchors, ctx=None, variance=None, anchor_assignment=None, valid_id=None, noise=None,
+                 seed=0):
+        """anchored_diffusion.py:450-484.  Returns {'sample', 'pred_xstart'} like the reference."""
+        tt = t if isinstance(t, int) else int(t.reshape(-1)[0].item())
+        sample, xs = self.model.engine().p_sample(self._sc(ctx, valid_id), x, anchor_assignment, tt, noise=noise,
+                                                  seed=seed, want_xstart=True)
+        return {"sample": sample, "pred_xstart": xs}
+
+    @torch.no_grad()
+    def p_sample_loop_progressive(self, shape, anchors, ctx=None, variance=None, anchor_assignment=None,
+                                  valid_id=None, noise=None, device=None, progress=False, seed=0):
+        """Generator of (t, {'sample': ...}) with the reference's protocol (:528-588): first (T, x_T), then one
+        p_sample per step.  One kernel launch per step; use ``sample_chain`` for the single-launch path."""
+        B, _, N = shape
+        if noise is not None:
+            pcd = noise
+        else:
+            L = torch.sqrt(variance)
+            g = torch.Generator(device=variance.device)
+            g.manual_seed(int(seed))
+            pcd = L * torch.randn(*shape, device=variance.device, generator=g) + anchors
+        yield self.num_timesteps, dict(sample=pcd)
+        for i in self.steps[::-1]:
+            out = self.p_sample(pcd, i, anchors, ctx=ctx, variance=variance, anchor_assignment=anchor_assignment,
+                                valid_id=valid_id, seed=seed)
+            yield i, out
+            pcd = out["sample"]
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, anchors, ctx=None, noise=None, variance=None, anchor_assignment=None,
+                      valid_id=None, device=None, progress=False, seed=0):
+        """:486-526 — final sample only; runs the fused chain when no explicit x_T is given."""
+        if noise is None:
+            pred, _ = self.sample_chain(ctx, anchor_assignment, valid_id, seed=seed)
+            return pred.transpose(1, 2).contiguous()
+        final = None
+        for _, sample in self.p_sample_loop_progressive(shape, anchors, ctx=ctx, variance=variance, noise=noise,
+                                                        anchor_assignment=anchor_assignment, valid_id=valid_id):
+            final = sample
+        return final["sample"]
+
+    @torch.no_grad()
+    def sample_chain(self, ctx, anchor_assignment, valid_id=None, x_T_noise=None, step_noise=None, seed=0,
+                     ret_interval=None):
+        """Whole reverse chain in ONE persistent launch: (pred (B,N,3), traj (n_keep,B,N,3) | None)."""
+        return self.model.engine().sample_chain(self._sc(ctx, valid_id), anchor_assignment, x_T_noise=x_T_noise,
+                                                step_noise=step_noise, seed=seed, ret_interval=ret_interval)
+
+    @torch.no_grad()
+    def q_sample(self, x_start, t, anchors, noise=None, variance=None):
+        """Forward process (:148-173), host-side elementwise helper (not on the sampling path)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        sa = torch.from_numpy(self.sqrt_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+        s1 = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+        return sa * (x_start - anchors) + anchors + s1 * torch.sqrt(variance) * noise
+
+
+@torch.no_grad()
+def decode(diffusion, ctx, anchor_assignments, valid_id=None, ret_traj=False, ret_interval=20, seed=0,
+           x_T_noise=None, step_noise=None):
+    """``AnchorDiffAE.decode`` (anchor_gen.py:145-169): {'pred': (B,N,3), t: (B,N,3) for t % ret_interval == 0}."""
+    pred, traj = diffusion.sample_chain(ctx, anchor_assignments, valid_id, x_T_noise=x_T_noise, step_noise=step_noise,
+                                        seed=seed, ret_interval=ret_interval if ret_traj else None)
+    final = {"pred": pred}
+    if ret_traj:
+        for k, t in enumerate(diffusion.model.engine().snapshot_times(ret_interval)):
+            final[t] = traj[k]
+    return final
