@@ -35,6 +35,18 @@ def flops_per_step(N, depth=5):
     return 2 * (N * per_point + depth * 2 * 4 * 522 * 128 + 256 * 2048 + 1024 * 256)
 
 
+def measured_traffic(T, B, N):
+    """Fabric-side bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes, see
+    profiles/README.md), which scales linearly with the number of diffusion steps; None if not applicable."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if d["B"] == B and d["N"] == N:
+            return d["bytes_per_step"] * T
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(W, N, budget_s=20.0):
     """The numpy oracle (validated against the reference model, tests/test_oracle_golden.py) timed on
     this box's host cores on a bounded sample: B shapes x Tc steps of the same workload; the chain is
@@ -175,7 +187,7 @@ def main():
                        "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
                        "weights_bcast_ms": bcast_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "kernel": "k_denoise (persistent T-step chain)", "kernel_ms": kern_ms,
+                         "traffic": measured_traffic(T, B, N), "kernel": "k_denoise_pipe (persistent T-step chain)", "kernel_ms": kern_ms,
                          "flops_per_launch": F},
         }
         if world == 1 and not args.no_cpu_baseline:
