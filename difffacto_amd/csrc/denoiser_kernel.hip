@@ -164,12 +164,13 @@ __device__ __forceinline__ void philox_normal3(unsigned long long seed, unsigned
   const float u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float u3 = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-  float sa, ca;
-  sincosf(6.28318530717958647692f * u1, &sa, &ca);
-  z[0] = ra * ca;
-  z[1] = ra * sa;
-  z[2] = rb * cosf(6.28318530717958647692f * u3);
+  // hardware transcendentals (v_log_f32; v_sin_f32 / v_cos_f32 take revolutions): plenty for a noise source and
+  // far fewer instructions than the libm versions in the persistent kernel's step epilogue
+  const float ra = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));  // -2 ln(u) = -2 ln2 log2(u)
+  const float rb = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  z[0] = ra * __builtin_amdgcn_cosf(u1);
+  z[1] = ra * __builtin_amdgcn_sinf(u1);
+  z[2] = rb * __builtin_amdgcn_cosf(u3);
 }
 
 // ----------------------------------------------------------------------------------------------
