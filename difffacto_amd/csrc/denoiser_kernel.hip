@@ -653,8 +653,8 @@ constexpr int L_WINX = L_BCONST + 2 * BCONST_BYTES;    // float4[128]
 constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
 constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
 constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
-constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs
-constexpr int L_TOTAL = L_DUMMY + 1024;
+constexpr int L_DUMMY = L_CPART + 2048;                // 3 KiB sink for padding DMAs
+constexpr int L_TOTAL = L_DUMMY + 3072;
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
 static_assert(CALLS == 3, "dma3 issues exactly three pieces");
 
@@ -664,6 +664,15 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
 __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr)
                : "memory");  // m0 is reserved: hipcc re-materialises it before each of its own uses
+}
+
+// three consecutive 1 KiB pieces: the instruction's immediate offset applies to BOTH the global and the LDS
+// address (checked on gfx950: tools/ubench/dma_offset.hip), so one M0 / one SGPR base serve all three
+__device__ __forceinline__ void dma3k(const void *gbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
+               ::"v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
 }
 
 template <int N>
@@ -681,12 +690,9 @@ struct DmaState {
 __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
   const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
   if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
-#pragma unroll
-    for (int j = 0; j < CALLS; ++j) dma1k(p.d.blk[0].bconst, voff, lds0 + L_DUMMY);
+    dma3k(p.d.blk[0].chunks, voff, lds0 + L_DUMMY);
   } else if (st.k > 0) {  // FF record: 24 contiguous KiB (the common case: keep it lean)
-    const unsigned dst = ring + wave * (CALLS * 1024);
-#pragma unroll
-    for (int j = 0; j < CALLS; ++j) dma1k(st.ff_src + j * 1024, voff, dst + j * 1024);
+    dma3k(st.ff_src, voff, ring + wave * (CALLS * 1024));
     st.ff_src += SLOT_BYTES;
   } else {  // attention record: 17 KiB shape record | 5 KiB block constants | 1 KiB c_t row | 1 padding piece
     const BlockPack &bp = p.d.blk[st.b];
