@@ -100,8 +100,13 @@ def main():
     if args.gpus > 1:
         import torch.distributed as dist
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("DFX_BENCH_BACKEND", "nccl")   # "gloo": plumbing test of the N>1 path on one GPU
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -18,6 +18,12 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _needs_cpu_staging(t):
+    """gloo moves host memory: device tensors are staged through the host (test / fallback configurations only;
+    the production backend is "nccl" = RCCL, which takes device pointers directly)."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def broadcast_params(params, src=0):
     """One collective for the whole frozen parameter set: pack -> broadcast -> unpack in place.
     `params` is an ordered dict name -> tensor, same shapes on every rank."""
@@ -25,7 +31,12 @@ def broadcast_params(params, src=0):
         return params
     names = list(params)
     flat = torch.cat([params[k].reshape(-1).to(torch.float32) for k in names])
-    dist.broadcast(flat, src=src)
+    if _needs_cpu_staging(flat):
+        host = flat.cpu()
+        dist.broadcast(host, src=src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     for k in names:
         n = params[k].numel()
@@ -40,6 +51,9 @@ def gather_clouds(pred, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return pred
     world, rank = dist.get_world_size(), dist.get_rank()
+    out_device = pred.device
+    if _needs_cpu_staging(pred):
+        pred = pred.cpu()
     sizes = [torch.zeros(1, dtype=torch.int64, device=pred.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([pred.shape[0]], dtype=torch.int64, device=pred.device))
     sizes = [int(s.item()) for s in sizes]
@@ -51,6 +65,6 @@ def gather_clouds(pred, dst=0):
     if rank == dst:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.gather(pad, gather_list=bufs, dst=dst)
-        return torch.cat([b[:n] for b, n in zip(bufs, sizes)])
+        return torch.cat([b[:n] for b, n in zip(bufs, sizes)]).to(out_device)
     dist.gather(pad, gather_list=None, dst=dst)
     return None
