@@ -52,6 +52,8 @@ SIGNATURES = {
     "dfx_three_nn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dfx_three_interpolate_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfx_three_interpolate_grad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfx_chamfer_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfx_chamfer_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfx_denoiser_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(DenoiserWeights), _I, _D, _D, _I, _P]),
     "dfx_denoiser_destroy": (None, [_P]),
     "dfx_denoiser_num_timesteps": (_I, [_P]),

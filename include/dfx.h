@@ -179,6 +179,21 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
                      const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
                      int N, dfx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Chamfer-L2 — replaces the `chamfer` extension
+ * (python/difffacto/metrics/chamfer_dist/chamfer.cu: forward :15-170, backward :173-230; bound in
+ * python/difffacto/metrics/chamfer_dist/__init__.py:14-27).
+ * ------------------------------------------------------------------------------------------ */
+
+/* chamfer.forward(xyz1 (B,N,3), xyz2 (B,M,3)) -> dist1 (B,N), dist2 (B,M) squared NN distances, idx1, idx2 int32 */
+int dfx_chamfer_forward_f32(const float *xyz1, const float *xyz2, float *dist1, float *dist2, int32_t *idx1,
+                            int32_t *idx2, int B, int N, int M, dfx_stream_t stream);
+
+/* chamfer.backward(...) -> grad_xyz1 (B,N,3), grad_xyz2 (B,M,3); both zeroed by the call, atomics like the reference */
+int dfx_chamfer_backward_f32(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
+                             const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2,
+                             int B, int N, int M, dfx_stream_t stream);
+
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

@@ -218,3 +218,41 @@ void oracle_three_interpolate_grad(int b, int c, int n, int m, const float *grad
       }
   }
 }
+
+/* ---- Chamfer-L2 (python/difffacto/metrics/chamfer_dist/chamfer.cu) ------------------------------------------ */
+/* forward :15-145: nearest neighbour of every query point, first minimum in k order (strict '<', :47,:137) */
+void oracle_chamfer_nn(int b, int n, int m, const float *query, const float *ref, float *dist, int32_t *idx) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *Q = query + (size_t)bi * n * 3;
+    const float *R = ref + (size_t)bi * m * 3;
+    for (int j = 0; j < n; ++j) {
+      float best = 0.f;
+      int besti = 0;
+      for (int k = 0; k < m; ++k) {
+        const float d = sq3(R[k * 3 + 0] - Q[j * 3 + 0], R[k * 3 + 1] - Q[j * 3 + 1], R[k * 3 + 2] - Q[j * 3 + 2]);
+        if (k == 0 || d < best) {
+          best = d;
+          besti = k;
+        }
+      }
+      dist[(size_t)bi * n + j] = best;
+      idx[(size_t)bi * n + j] = besti;
+    }
+  }
+}
+
+/* backward :173-201 (one direction; the caller runs it for both) */
+void oracle_chamfer_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_dist1,
+                         const int32_t *idx1, float *grad_xyz1, float *grad_xyz2) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < n; ++j) {
+      const size_t i = (size_t)bi * n + j;
+      const int j2 = idx1[i];
+      const float g = grad_dist1[i] * 2;
+      for (int c = 0; c < 3; ++c) {
+        const float v = g * (xyz1[i * 3 + c] - xyz2[((size_t)bi * m + j2) * 3 + c]);
+        grad_xyz1[i * 3 + c] += v;
+        grad_xyz2[((size_t)bi * m + j2) * 3 + c] -= v;
+      }
+    }
+}

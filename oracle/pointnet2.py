@@ -124,3 +124,26 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     out = np.zeros((B, C, m), _F)
     lib().oracle_three_interpolate_grad(B, C, n, m, _p(grad_out), _p(idx), _p(weight), _p(out))
     return out
+
+
+def chamfer_forward(xyz1, xyz2):
+    """dist1 (B,N), dist2 (B,M), idx1, idx2 like chamfer.forward (metrics/chamfer_dist/__init__.py:16)."""
+    xyz1, xyz2 = _c(xyz1, _F), _c(xyz2, _F)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    d1, d2 = np.zeros((B, N), _F), np.zeros((B, M), _F)
+    i1, i2 = np.zeros((B, N), _I), np.zeros((B, M), _I)
+    lib().oracle_chamfer_nn(B, N, M, _p(xyz1), _p(xyz2), _p(d1), _p(i1))
+    lib().oracle_chamfer_nn(B, M, N, _p(xyz2), _p(xyz1), _p(d2), _p(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, idx1, idx2, g1, g2):
+    xyz1, xyz2, g1, g2 = _c(xyz1, _F), _c(xyz2, _F), _c(g1, _F), _c(g2, _F)
+    idx1, idx2 = _c(idx1, _I), _c(idx2, _I)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    gx1, gx2 = np.zeros_like(xyz1), np.zeros_like(xyz2)
+    lib().oracle_chamfer_grad(B, N, M, _p(xyz1), _p(xyz2), _p(g1), _p(idx1), _p(gx1), _p(gx2))
+    lib().oracle_chamfer_grad(B, M, N, _p(xyz2), _p(xyz1), _p(g2), _p(idx2), _p(gx2), _p(gx1))
+    return gx1, gx2

@@ -161,3 +161,28 @@ def test_dtype_and_contiguity_errors(pu):
         pu.gather_operation(torch.zeros(1, 3, 8, device="cuda"), torch.zeros(1, 2, dtype=torch.int64, device="cuda"))
     with pytest.raises(RuntimeError, match="float"):
         pu.furthest_point_sample(x.double(), 4)
+
+
+@pytest.mark.parametrize("B,N,M", [(3, 2048, 2048), (2, 500, 3000), (1, 1, 7)])
+def test_chamfer_matches_oracle(pu, B, N, M):
+    from difffacto_amd.metrics import ChamferFunction, ChamferDistanceL2
+    rng = np.random.default_rng(N + M)
+    a = rng.standard_normal((B, N, 3)).astype(np.float32)
+    b = rng.standard_normal((B, M, 3)).astype(np.float32)
+    if M > 2:
+        b[:, 1] = b[:, 0]    # duplicate: strict '<' keeps the first index
+    ta, tb = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    d1, d2 = ChamferFunction.apply(ta, tb)
+    r1, r2, i1, i2 = opn.chamfer_forward(a, b)
+    assert np.array_equal(d1.detach().cpu().numpy(), r1) and np.array_equal(d2.detach().cpu().numpy(), r2)
+    g1 = rng.standard_normal((B, N)).astype(np.float32)
+    g2 = rng.standard_normal((B, M)).astype(np.float32)
+    (d1 * dev(g1)).sum().add((d2 * dev(g2)).sum()).backward()
+    gx1, gx2 = opn.chamfer_backward(a, b, i1, i2, g1, g2)
+    assert np.allclose(ta.grad.cpu().numpy(), gx1, atol=1e-4, rtol=1e-4)
+    assert np.allclose(tb.grad.cpu().numpy(), gx2, atol=2e-3, rtol=1e-3)
+    # brute-force cross-check of the value (distChamfer-style, evaluation_utils.py:93-103)
+    full = ((a[:, :, None] - b[:, None]) ** 2).sum(-1)
+    assert np.allclose(r1, full.min(2), atol=1e-5) and np.allclose(r2, full.min(1), atol=1e-5)
+    cd = ChamferDistanceL2()(dev(a), dev(b)).item()
+    assert abs(cd - (full.min(2).mean() + full.min(1).mean())) < 1e-5
