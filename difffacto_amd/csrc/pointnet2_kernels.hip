@@ -81,15 +81,38 @@ __device__ __forceinline__ int fps_unpack(unsigned long long v, int log2bs) {
   return (int)(((key & 0x3fffffu) << log2bs) | tidr);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), off, WAVE);
-    const unsigned hi = __shfl_xor((unsigned)(v >> 32), off, WAVE);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    v = o > v ? o : v;
-  }
+// 64-bit max across the wavefront with DPP lane permutes (VALU, ~6 x 5 instructions) instead of ds_bpermute
+// shuffles (~100 cycles of LDS-crossbar latency each): the selection loop is a chain of M dependent arg-max
+// reductions, so this latency IS the kernel's run time.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  const unsigned lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long o = ((unsigned long long)hi2 << 32) | lo2;
+  return o > v ? o : v;
+}
+
+// after this every lane of each 16-lane row holds the row maximum
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_u64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_u64<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_max_u64<0x140, 0xf>(v);  // row_mirror
   return v;
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+}
+
+// wave-uniform maximum of the 64 lanes
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = row_max_u64(v);
+  v = dpp_max_u64<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+  v = dpp_max_u64<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
+  return readlane_u64(v, 63);
 }
 
 // Register-resident variant: N <= NT*PPT.  LDS holds the cloud as SoA for the winner lookup when
@@ -99,8 +122,9 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
                                                           int32_t *__restrict__ idxs, int N, int M, int log2bs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / WAVE;
-  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [2][NW]
-  float *sx = reinterpret_cast<float *>(smem + 2 * NW * sizeof(unsigned long long));
+  static_assert(NW <= 16, "second-level reduction uses one 16-lane row");
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [2][16]
+  float *sx = reinterpret_cast<float *>(smem + 2 * 16 * sizeof(unsigned long long));
   float *sy = sx + N;
   float *sz = sy + N;
 
@@ -110,19 +134,21 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
   const float *ds = dataset + (size_t)blockIdx.x * N * 3;
   int32_t *out = idxs + (size_t)blockIdx.x * M;
 
+  // per-point state in registers: coordinates, running min distance, and the (constant) tie-break key
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
-  unsigned live = 0;  // bit i: point i exists and is not skipped
+  unsigned nkey[PPT];  // low half of fps_pack(): ~key32 ; 0 marks "skipped / absent" (never wins)
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = tid + i * NT;
     px[i] = py[i] = pz[i] = 0.f;
     tmp[i] = 1e10f;  // sampling.cpp:74-76
+    nkey[i] = 0u;
     if (k < N) {
       px[i] = ds[k * 3 + 0];
       py[i] = ds[k * 3 + 1];
       pz[i] = ds[k * 3 + 2];
       const float mag = sq3(px[i], py[i], pz[i]);
-      if (!(mag <= __uint_as_float(FPS_SKIP_THRESH_BITS))) live |= 1u << i;
+      if (!(mag <= __uint_as_float(FPS_SKIP_THRESH_BITS))) nkey[i] = (unsigned)(fps_pack(0.f, k, log2bs) & 0xffffffffull);
       if (COORDS_LDS) {
         sx[k] = px[i];
         sy[k] = py[i];
@@ -130,6 +156,7 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
       }
     }
   }
+  if (tid < 32) slots[tid] = 0ull;
   int old = 0;
   if (tid == 0) out[0] = 0;
   __syncthreads();
@@ -150,25 +177,17 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
     for (int i = 0; i < PPT; ++i) {
       const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
       const float d2 = fminf(d, tmp[i]);
-      if (live & (1u << i)) {
-        tmp[i] = d2;
-        const unsigned long long v = fps_pack(d2, tid + i * NT, log2bs);
-        best = v > best ? v : best;
-      }
+      // skipped points keep nkey == 0 and their packed value is forced to 0 ("no candidate")
+      tmp[i] = nkey[i] ? d2 : tmp[i];
+      const unsigned long long v = nkey[i] ? (((unsigned long long)__float_as_uint(d2) << 32) | nkey[i]) : 0ull;
+      best = v > best ? v : best;
     }
     best = wave_max_u64(best);
-    unsigned long long *slot = slots + (j & 1) * NW;
+    unsigned long long *slot = slots + (j & 1) * 16;
     if (lane == 0) slot[wave] = best;
     __syncthreads();
     unsigned long long v = lane < NW ? slot[lane] : 0ull;
-#pragma unroll
-    for (int off = NW / 2; off >= 1; off >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), off, WAVE);
-      const unsigned hi = __shfl_xor((unsigned)(v >> 32), off, WAVE);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      v = o > v ? o : v;
-    }
-    v = ((unsigned long long)__shfl((unsigned)(v >> 32), 0, WAVE) << 32) | __shfl((unsigned)(v & 0xffffffffull), 0, WAVE);
+    v = readlane_u64(row_max_u64(v), 0);
     old = fps_unpack(v, log2bs);
     if (tid == 0) out[j] = old;
   }
@@ -210,14 +229,7 @@ __global__ void __launch_bounds__(NT) fps_streaming_kernel(const float *__restri
     if (lane == 0) slot[wave] = best;
     __syncthreads();
     unsigned long long v = lane < NW ? slot[lane] : 0ull;
-#pragma unroll
-    for (int off = NW / 2; off >= 1; off >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), off, WAVE);
-      const unsigned hi = __shfl_xor((unsigned)(v >> 32), off, WAVE);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      v = o > v ? o : v;
-    }
-    v = ((unsigned long long)__shfl((unsigned)(v >> 32), 0, WAVE) << 32) | __shfl((unsigned)(v & 0xffffffffull), 0, WAVE);
+    v = readlane_u64(row_max_u64(v), 0);
     old = fps_unpack(v, log2bs);
     if (tid == 0) out[j] = old;
   }
@@ -464,7 +476,7 @@ int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, 
   if (log2bs > 9) log2bs = 9;
 #define DFX_FPS_LAUNCH(NT, PPT, LDSC)                                                                          \
   do {                                                                                                         \
-    const size_t sh = 2 * (NT / 64) * sizeof(unsigned long long) + ((LDSC) ? (size_t)N * 12 : 0);              \
+    const size_t sh = 2 * 16 * sizeof(unsigned long long) + ((LDSC) ? (size_t)N * 12 : 0);                     \
     fps_resident_kernel<NT, PPT, LDSC><<<B, NT, sh, st>>>(xyz, idx, N, M, log2bs);                             \
   } while (0)
   if (N <= 512) DFX_FPS_LAUNCH(256, 2, true);

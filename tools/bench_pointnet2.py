@@ -1,0 +1,58 @@
+"""Timing of the pointnet2 / chamfer kernels at the sizes the reference uses (GPU box).  Prints one line per op:
+average launch time (HIP events on the launch stream), algorithmic bytes moved, achieved GB/s vs the 6.3 TB/s
+achievable HBM rate, and for FPS the time per selected point (the op is a dependent chain, not a stream)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from difffacto_amd.pointnet2_ops import pointnet2_utils as pu
+from difffacto_amd.metrics import ChamferFunction
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def line(name, ms, nbytes, extra=""):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    print(f"{name:58s} {ms * 1e3:9.1f} us  {nbytes / 1e6:9.2f} MB  {gbs:8.1f} GB/s ({gbs / 6300 * 100:5.2f} % of 6.3 TB/s) {extra}")
+
+
+torch.manual_seed(0)
+dev = "cuda"
+for B, N, M in [(1, 8192, 2048), (128, 8192, 2048), (128, 2048, 512), (128, 512, 128)]:
+    xyz = torch.randn(B, N, 3, device=dev)
+    ms = timeit(lambda: pu.furthest_point_sample(xyz, M))
+    line(f"furthest_point_sample B={B} N={N} -> M={M}", ms, B * (N * 12 + M * 4), f"{ms * 1e6 / M:7.1f} ns / selected point / cloud-wave")
+for B, N, M, r, ns in [(128, 2048, 512, 0.2, 64), (128, 512, 128, 0.4, 64)]:
+    xyz = torch.rand(B, N, 3, device=dev) * 2 - 1
+    new_xyz = xyz[:, :M].contiguous()
+    ms = timeit(lambda: pu.ball_query(r, ns, xyz, new_xyz))
+    line(f"ball_query B={B} N={N} M={M} r={r} ns={ns}", ms, B * ((N + M) * 12 + M * ns * 4))
+    idx = pu.ball_query(r, ns, xyz, new_xyz)
+    for C in (3, 128):
+        feats = torch.randn(B, C, N, device=dev)
+        ms = timeit(lambda: pu.grouping_operation(feats, idx))
+        line(f"grouping_operation B={B} C={C} N={N} np={M} ns={ns}", ms, B * (M * ns * 4 + C * M * ns * 4 * 2))
+for B, C, N, M in [(128, 3, 4, 2048), (128, 3, 8192, 2048)]:
+    feats = torch.randn(B, C, N, device=dev)
+    idx = torch.randint(0, N, (B, M), device=dev, dtype=torch.int32)
+    ms = timeit(lambda: pu.gather_operation(feats, idx))
+    line(f"gather_operation B={B} C={C} N={N} M={M}", ms, B * (M * 4 + C * M * 4 * 2))
+unknown, known = torch.randn(128, 2048, 3, device=dev), torch.randn(128, 512, 3, device=dev)
+ms = timeit(lambda: pu.three_nn(unknown, known))
+line("three_nn B=128 n=2048 m=512", ms, 128 * ((2048 + 512) * 12 + 2048 * 24), f"{128 * 2048 * 512 / (ms * 1e-3) / 1e9:7.1f} G pair-dist/s")
+a, b = torch.randn(128, 2048, 3, device=dev), torch.randn(128, 2048, 3, device=dev)
+ms = timeit(lambda: ChamferFunction.apply(a, b))
+line("chamfer forward B=128 N=M=2048", ms, 128 * 2 * (2048 * 12 + 2048 * 8), f"{2 * 128 * 2048 * 2048 / (ms * 1e-3) / 1e9:7.1f} G pair-dist/s")
