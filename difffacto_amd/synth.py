@@ -65,6 +65,57 @@ def make_denoiser_weights(seed=0, depth=5):
     return W
 
 
+def latent_param_shapes(n_class=N_CLASS, flow_depth=14, flow_hidden=256, depth=5, heads=8, d_head=32, noise_dim=32):
+    """(name, shape) of the gen-path encoder parameters, reference ``state_dict`` names relative to
+    ``encoder.`` (flow.py:9-19, part_encoders.py:52-86 with configs/gen_chair.py:14-38)."""
+    s = []
+    half = ZDIM - ZDIM // 2
+    for i in range(n_class):
+        for l in range(flow_depth):
+            p = f"flow.{i}.chain.{l}.net_s_t."
+            s += [(p + "0.weight", (flow_hidden, half)), (p + "0.bias", (flow_hidden,)),
+                  (p + "2.weight", (flow_hidden, flow_hidden)), (p + "2.bias", (flow_hidden,)),
+                  (p + "4.weight", ((ZDIM - half) * 2, flow_hidden)), (p + "4.bias", ((ZDIM - half) * 2,))]
+    inner = heads * d_head
+    P = "part_aligner."
+    s += [(P + "class_emb.weight", (n_class, inner)),
+          (P + "pre_norm.weight", (inner,)), (P + "pre_norm.bias", (inner,)),
+          (P + "post_norm.weight", (inner,)), (P + "post_norm.bias", (inner,)),
+          (P + "proj_in.weight", (inner, ZDIM + noise_dim)), (P + "proj_in.bias", (inner,))]
+    for i in range(depth):
+        p = f"{P}transformer_blocks.{i}."
+        s += [(p + "ff.net.0.proj.weight", (8 * inner, inner)), (p + "ff.net.0.proj.bias", (8 * inner,)),
+              (p + "ff.net.2.weight", (inner, 4 * inner)), (p + "ff.net.2.bias", (inner,)),
+              (p + "attn2.to_q.weight", (inner, inner)), (p + "attn2.to_k.weight", (inner, inner)),
+              (p + "attn2.to_v.weight", (inner, inner)),
+              (p + "attn2.to_out.0.weight", (inner, inner)), (p + "attn2.to_out.0.bias", (inner,)),
+              (p + "norm2.weight", (inner,)), (p + "norm2.bias", (inner,)),
+              (p + "norm3.weight", (inner,)), (p + "norm3.bias", (inner,))]
+    s += [(P + "proj_out.weight", (6, inner)), (P + "proj_out.bias", (6,))]
+    return s
+
+
+def make_latent_weights(seed=0, **kw):
+    """Same init rule as ``make_denoiser_weights``; class_emb ~ N(0,1) like nn.Embedding."""
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    W = {}
+    fan = {}
+    for name, shape in latent_param_shapes(**kw):
+        if "class_emb" in name:
+            W[name] = rng.standard_normal(shape).astype(F32)
+        elif "norm" in name:
+            u = rng.uniform(-0.1, 0.1, size=shape)
+            W[name] = (u + (1.0 if name.endswith("weight") else 0.0)).astype(F32)
+        elif name.endswith("weight"):
+            bound = 1.0 / np.sqrt(shape[1])
+            fan[name[:-len("weight")]] = bound
+            W[name] = rng.uniform(-bound, bound, size=shape).astype(F32)
+        else:
+            bound = fan[name[:-len("bias")]]
+            W[name] = rng.uniform(-bound, bound, size=shape).astype(F32)
+    return W
+
+
 def chair_part_distribution():
     """Presence patterns of the 4 chair parts (back, seat, leg, arm): synthetic stand-in for
     ``shapenet_chair_part_distribution`` (datasets/dataset_utils.py:170-179); the data set is

@@ -16,6 +16,9 @@ chain_T10_*.npz      AnchoredDiffusion.p_sample_loop_progressive (anchored_diffu
                      recorded arrays, in the reference's own draw order), every step's sample,
                      and AnchorDiffAE.decode's dict (anchor_gen.py:145)
 tables_T{10,100,1000}.npz  the schedule tables as the reference casts them to fp32
+latents_*.npz        PartEncoder.sample_latents (part_encoders.py:1052-1110: flows in reverse, part
+                     aligner, fixed_id mixing, K-fold repeat, seg-mask ids), torch.randn replayed; plus
+                     one flow / the aligner called on their own
 pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
                      (models/encoders/pointnet2_utils.py:84-104,41-57)
 """
@@ -118,6 +121,53 @@ def gen_chain(model, tag, B, N, seed, all_valid, T):
     print(f"wrote chain_T{T}_{tag}", traj.shape, float(np.abs(traj[-1]).max()), sorted(dec_np))
 
 
+def load_latent_weights(model, W):
+    sd = model.encoder.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    model.encoder.load_state_dict(sd, strict=True)
+
+
+def gen_latents(model, tag, S, K, npoints, seed, fixed_id, all_valid):
+    enc = model.encoder
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w_noise = rng.standard_normal((S, enc.zdim, enc.n_class)).astype(F32)
+    a_noise = rng.standard_normal((S * K, enc.part_aligner.noise_dim)).astype(F32)
+    _, _, _, valid = synth.make_latents(S, seed=seed, all_valid=all_valid)
+    real_randn = torch.randn
+    queue = [w_noise, a_noise]
+
+    def fake_randn(*shape, **kw):   # part_encoders.py:1054, :1065 (in this order)
+        a = queue.pop(0)
+        assert tuple(shape) == a.shape, (shape, a.shape)
+        return torch.from_numpy(a)
+
+    import contextlib
+    import io
+    try:
+        torch.randn = fake_randn
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            ctx, mpp, lpp, seg, vid, lat = enc.sample_latents(S, npoints, "cpu", fixed_id=torch.tensor(fixed_id, dtype=torch.float32),
+                                                              valid_id=torch.from_numpy(valid), epoch=0, K=K)
+    finally:
+        torch.randn = real_randn
+    assert not queue
+    part_code, mean, logvar, noise = lat
+    with torch.no_grad():   # the two pieces on their own
+        flow2 = enc.flow[2](torch.from_numpy(w_noise[..., 2].copy()), reverse=True).numpy().astype(F32)
+        am, al = enc.part_aligner(torch.from_numpy(w_noise), torch.from_numpy(valid), noise=torch.from_numpy(a_noise[:S]))
+    np.savez_compressed(os.path.join(HERE, f"latents_{tag}.npz"), w_noise=w_noise, aligner_noise=a_noise, valid_in=valid,
+                        fixed_id=np.array(fixed_id, F32), K=np.array(K), npoints=np.array(npoints), weight_seed=np.array(0),
+                        ctx0=ctx[0].numpy().astype(F32), ctx1=ctx[1].numpy().astype(F32), mean_per_point=mpp.numpy().astype(F32),
+                        logvar_per_point=lpp.numpy().astype(F32), seg_mask=seg.numpy().astype(np.int32), valid_id=vid.numpy().astype(F32),
+                        part_code=part_code.numpy().astype(F32), mean=mean.numpy().astype(F32), logvar=logvar.numpy().astype(F32),
+                        noise=noise.numpy().astype(F32), flow2_reverse=flow2, aligner_mean=am.numpy().astype(F32),
+                        aligner_logvar=al.numpy().astype(F32))
+    print("wrote latents_" + tag, float(np.abs(part_code.numpy()).max()), float(np.abs(mean.numpy()).max()),
+          float(np.abs(logvar.numpy()).max()))
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -155,6 +205,11 @@ def main():
     load_denoiser_weights(model, W)
     if "--only-pn2" in sys.argv:
         gen_pn2_torch()
+        return
+    load_latent_weights(model, synth.make_latent_weights(seed=0))
+    gen_latents(model, "S3_K2_mixed", S=3, K=2, npoints=64, seed=31, fixed_id=[0, 0, 0, 0], all_valid=False)
+    gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
+    if "--only-latents" in sys.argv:
         return
     gen_eps(model, "B2_N128_mixed", B=2, N=128, seed=11, all_valid=False, ts=[0, 3, 9])
     gen_eps(model, "B2_N128_allvalid", B=2, N=128, seed=12, all_valid=True, ts=[5])

@@ -77,3 +77,28 @@ def test_seg_mask_relabels_absent_part():
     assert seg.shape == (2, 16)
     assert seg[0].tolist() == [1] * 4 + [1] * 4 + [2] * 4 + [1] * 4
     assert seg[1].tolist() == [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4
+
+
+# --------------------------------------------------------------------------- latent sampler
+@pytest.mark.parametrize("tag", ["S3_K2_mixed", "S4_K3_fixed"])
+def test_oracle_sample_latents_matches_reference(tag):
+    from difffacto_amd import synth
+    from oracle import latents as ol
+    g = np.load(os.path.join(GOLDEN, f"latents_{tag}.npz"))
+    W = synth.make_latent_weights(seed=int(g["weight_seed"]))
+    # pieces on their own
+    f2 = ol.flow_reverse(np.ascontiguousarray(g["w_noise"][..., 2]), W, 2, ol.flow_depth(W))
+    assert np.abs(f2 - g["flow2_reverse"]).max() < 1e-4 * max(1.0, np.abs(g["flow2_reverse"]).max())
+    S = g["w_noise"].shape[0]
+    m, lv = ol.part_aligner_forward(W, g["w_noise"], g["valid_in"], g["aligner_noise"][:S])
+    assert np.abs(m - g["aligner_mean"]).max() < 1e-4 and np.abs(lv - g["aligner_logvar"]).max() < 1e-4
+    # whole sample_latents
+    out = ol.sample_latents(W, g["w_noise"], g["aligner_noise"], g["valid_in"], g["fixed_id"], int(g["K"]), int(g["npoints"]))
+    assert np.array_equal(out["seg_mask"], g["seg_mask"])
+    assert np.array_equal(out["valid_id"], g["valid_id"])
+    for k, ref in (("part_code", g["part_code"]), ("mean", g["mean"]), ("logvar", g["logvar"]),
+                   ("mean_per_point", g["mean_per_point"]), ("logvar_per_point", g["logvar_per_point"]),
+                   ("noise", g["noise"])):
+        assert out[k].shape == ref.shape, k
+        assert np.abs(out[k] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+    assert np.abs(out["ctx"][0] - g["ctx0"]).max() < 1e-3 and np.abs(out["ctx"][1] - g["ctx1"]).max() < 1e-4
