@@ -16,7 +16,9 @@ def install(register_in_reference=True):
       utils/misc.py:7, shapenet_seg.py:13) resolves to the HIP kernels;
     * if the reference package ``difffacto`` is importable and ``register_in_reference``: replace
       ``NETS['TransformerNet']`` and ``DIFFUSIONS['AnchoredDiffusion']`` (utils/registry.py:49-63) by the libdfx-backed
-      classes, so ``configs/gen_*.py`` build them through ``build_from_cfg`` unchanged.
+      classes, so ``configs/gen_*.py`` build them through ``build_from_cfg`` unchanged.  The encoder registry entry
+      is left alone (its encode side serves training / reconstruction); accelerate the generation entry point of a
+      built model with ``difffacto_amd.encoders.attach(model.encoder)``.
     """
     from . import pointnet2_ops
     sys.modules["pointnet2_ops"] = pointnet2_ops

@@ -37,6 +37,23 @@ class DenoiserWeights(ctypes.Structure):
         "proj_out_w", "proj_out_b", "te0_w", "te0_b", "te2_w", "te2_b")] + [("blk", BlockWeights * DFX_MAX_DEPTH)]
 
 
+class AlignerBlockWeights(ctypes.Structure):
+    _fields_ = [(n, c_fp) for n in (
+        "norm2_w", "norm2_b", "to_q", "to_k", "to_v", "to_out_w", "to_out_b",
+        "norm3_w", "norm3_b", "ff_proj_w", "ff_proj_b", "ff_out_w", "ff_out_b")]
+
+
+class LatentWeights(ctypes.Structure):
+    _fields_ = [("n_class", ctypes.c_int32), ("zdim", ctypes.c_int32), ("flow_depth", ctypes.c_int32),
+                ("flow_hidden", ctypes.c_int32), ("flow", ctypes.POINTER(c_fp)),
+                ("depth", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("d_head", ctypes.c_int32),
+                ("cimle", ctypes.c_int32), ("noise_dim", ctypes.c_int32),
+                ("noise_scale", ctypes.c_float), ("prior_var", ctypes.c_float), ("log_scale_var", ctypes.c_float)] + \
+               [(n, c_fp) for n in ("proj_in_w", "proj_in_b", "class_emb", "pre_norm_w", "pre_norm_b", "post_norm_w",
+                                    "post_norm_b", "proj_out_w", "proj_out_b")] + \
+               [("blocks", AlignerBlockWeights * DFX_MAX_DEPTH)]
+
+
 # name -> (restype, argtypes); every symbol include/dfx.h declares
 _I, _F, _P, _U64, _SZ, _D = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_double
 SIGNATURES = {
@@ -65,6 +82,12 @@ SIGNATURES = {
     "dfx_p_sample": (_I, [_P, _P, _P, _P, _I, _P, _U64, _P, _P, _I, _I, _P]),
     "dfx_chain_num_snapshots": (_I, [_I, _I]),
     "dfx_sample_chain": (_I, [_P, _P, _P, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
+    "dfx_latents_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(LatentWeights), _P]),
+    "dfx_latents_destroy": (None, [_P]),
+    "dfx_flow_reverse": (_I, [_P, _P, _P, _I, _P]),
+    "dfx_part_aligner": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "dfx_sample_latents": (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I,
+                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfx_debug_force_direct": (None, [_I]),
     "dfx_debug_flags": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),

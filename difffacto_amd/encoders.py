@@ -1,0 +1,243 @@
+"""Host-side mirrors of the reference's gen-path encoder API, backed by libdfx.
+
+* ``CouplingLayer`` / ``SequentialFlow`` / ``build_latent_flow``  parameter containers with the reference's
+  attribute names (python/difffacto/models/encoders/flow.py:7-79)
+* ``PartAlignerTransformer``   constructor arguments, parameter names and ``forward(x, mask, noise)`` of
+  ``ENCODERS['PartAlignerTransformer']`` (python/difffacto/models/encoders/part_encoders.py:19-143)
+* ``PartEncoderForTransformerDecoder``  the generation entry point ``sample_latents`` with the reference's
+  signature and 6-tuple result (part_encoders.py:1052-1110, prepare_ctx :1317-1326)
+* ``generate``   the ``not self.training and self.gen`` branch of ``AnchorDiffAE.forward``
+  (python/difffacto/models/networks/anchor_gen.py:1034-1084): sample_latents -> decode
+
+All math runs in libdfx (``dfx_sample_latents`` / ``dfx_part_aligner`` / ``dfx_flow_reverse``); the modules only hold
+parameters under the reference's ``state_dict`` keys and draw the random inputs with ``torch.randn`` exactly where
+the reference does.  Option combinations outside the shipped ``configs/gen_*.py`` raise ``NotImplementedError``.
+The encode-side (``PointNetV2`` + ``forward``: reconstruction / training) is not part of this path.
+"""
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from .latents import LatentSampler
+from .modules import _BlockParams, decode
+
+
+def _unsupported(what):
+    raise NotImplementedError(f"libdfx implements the shipped gen_* encoder configuration only: {what}")
+
+
+class CouplingLayer(nn.Module):
+    def __init__(self, d, intermediate_dim, swap=False):
+        super().__init__()
+        if d % 2:
+            _unsupported("odd latent_dim in CouplingLayer")
+        self.d = d - (d // 2)
+        self.swap = swap
+        self.net_s_t = nn.Sequential(nn.Linear(self.d, intermediate_dim), nn.ReLU(inplace=True),
+                                     nn.Linear(intermediate_dim, intermediate_dim), nn.ReLU(inplace=True),
+                                     nn.Linear(intermediate_dim, (d - self.d) * 2))      # flow.py:13-19
+
+
+class SequentialFlow(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.chain = nn.ModuleList(layers)                                               # flow.py:54-56
+
+
+def build_latent_flow(latent_flow_depth, latent_flow_hidden_dim, latent_dim):
+    return SequentialFlow([CouplingLayer(latent_dim, latent_flow_hidden_dim, swap=(i % 2 == 0))
+                           for i in range(latent_flow_depth)])                           # flow.py:75-79
+
+
+class PartAlignerTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, out_channels, depth=1, dropout=0., use_linear=False, n_class=4,
+                 use_checkpoint=False, single_attn=False, class_cond=True, mask_out_unreferenced_code=True, cimle=False,
+                 noise_dim=32, noise_scale=10, cimle_start_epoch=0, add_class_cond=False, cond_noise_type=0,
+                 cond_noise_as_token=False):
+        super().__init__()
+        if not (use_linear and single_attn and class_cond and add_class_cond and mask_out_unreferenced_code):
+            _unsupported("PartAlignerTransformer needs use_linear, single_attn, class_cond, add_class_cond, "
+                         "mask_out_unreferenced_code")
+        if cond_noise_as_token or (cimle and cond_noise_type != 0):
+            _unsupported(f"cond_noise_type={cond_noise_type}")
+        if out_channels != 6:
+            _unsupported("out_channels != 6")
+        self.n_class, self.cimle, self.noise_scale, self.noise_dim = n_class, cimle, noise_scale, noise_dim
+        self.cimle_start_epoch, self.cond_noise_type = cimle_start_epoch, cond_noise_type
+        self.zdim = in_channels
+        self.n_heads, self.d_head = n_heads, d_head
+        self.in_channels = in_channels + int(cimle) * noise_dim                          # part_encoders.py:46
+        inner = n_heads * d_head
+        self.inner_dim = inner
+        self.class_emb = nn.Embedding(n_class, inner)
+        self.pre_norm = nn.LayerNorm(inner)
+        self.post_norm = nn.LayerNorm(inner)
+        self.proj_in = nn.Linear(self.in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([_BlockParams(inner, n_heads, d_head, inner, dropout) for _ in range(depth)])
+        self.proj_out = nn.Linear(inner, out_channels)
+
+    def forward(self, x, mask=None, noise=None):
+        """(B,zdim,n_class), (B,n_class), (B,noise_dim) -> mean (B,3,n_class), logvar (B,3,n_class)."""
+        owner = getattr(self, "_owner", None)
+        owner = owner() if owner is not None else None
+        if owner is None:
+            owner = _StandaloneAligner.of(self)
+        if self.cimle and (noise is None or noise.shape[1] != self.noise_dim):
+            noise = torch.zeros(x.shape[0], self.noise_dim, device=x.device)             # part_encoders.py:97-98
+        return owner.sampler().part_aligner(x, mask, noise if self.cimle else None)
+
+
+class _StandaloneAligner:
+    """LatentSampler for a PartAlignerTransformer used on its own (no flows)."""
+    _cache = weakref.WeakKeyDictionary()
+
+    def __init__(self, aligner):
+        self._al = weakref.ref(aligner)
+        self._s = None
+        self._ver = None
+
+    @classmethod
+    def of(cls, aligner):
+        if aligner not in cls._cache:
+            cls._cache[aligner] = cls(aligner)
+        return cls._cache[aligner]
+
+    def sampler(self):
+        al = self._al()
+        ver = tuple(p._version for p in al.parameters())
+        if self._s is None or ver != self._ver:
+            sd = {"part_aligner." + k: v for k, v in al.state_dict().items()}
+            self._s = LatentSampler(sd, n_class=al.n_class, zdim=al.zdim, n_heads=al.n_heads, d_head=al.d_head,
+                                    cimle=al.cimle, noise_dim=al.noise_dim, noise_scale=al.noise_scale,
+                                    device=next(al.parameters()).device)
+            self._ver = ver
+        return self._s
+
+
+class PartEncoderForTransformerDecoder(nn.Module):
+    def __init__(self, encoder=None, n_class=4, part_aligner=None, fit_loss_weight=1.0, include_z=True,
+                 include_part_code=False, include_params=False, use_gt_params=False, encode_ref=False, scale_var=1.0,
+                 fit_loss_type=0, origin_scale=False, kl_weight=0.001, use_flow=False, latent_flow_depth=14,
+                 latent_flow_hidden_dim=256, gen=False, prior_var=1.0, selective_noise_sampling=False,
+                 selective_noise_sampling_global=False, per_part_encoder=False, **kwargs):
+        super().__init__()
+        if not (gen and include_part_code and include_params) or include_z or use_gt_params or encode_ref or per_part_encoder:
+            _unsupported("PartEncoder needs gen, include_part_code, include_params and no include_z / use_gt_params / "
+                         "encode_ref / per_part_encoder")
+        if selective_noise_sampling or selective_noise_sampling_global:
+            _unsupported("selective_noise_sampling")
+        self.encoder_cfg = dict(encoder or {})          # PointNetV2 (encode side) is not on the generation path
+        self.zdim = int(self.encoder_cfg.get("zdim", 1024))
+        self.n_class, self.prior_var, self.gen, self.use_flow = n_class, prior_var, gen, use_flow
+        self.log_scale_var = math.log(scale_var)
+        if isinstance(part_aligner, dict):
+            cfg = dict(part_aligner)
+            cfg.pop("type", None)
+            part_aligner = PartAlignerTransformer(**cfg)
+        self.part_aligner = part_aligner
+        self.part_aligner._owner = weakref.ref(self)
+        if use_flow:
+            self.flow = nn.ModuleList([build_latent_flow(latent_flow_depth, latent_flow_hidden_dim, self.zdim)
+                                       for _ in range(n_class)])                          # part_encoders.py:388-390
+        self._sampler = None
+        self._ver = None
+
+    def sampler(self):
+        """The libdfx handle for the current parameters (rebuilt when a parameter was modified in place or reloaded)."""
+        ver = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
+        if self._sampler is None or ver != self._ver:
+            sd = {k: v for k, v in self.state_dict().items()}
+            al = self.part_aligner
+            self._sampler = LatentSampler(sd, n_class=self.n_class, zdim=self.zdim, n_heads=al.n_heads, d_head=al.d_head,
+                                          cimle=al.cimle, noise_dim=al.noise_dim, noise_scale=al.noise_scale,
+                                          prior_var=self.prior_var, log_scale_var=self.log_scale_var,
+                                          device=next(self.parameters()).device)
+            self._ver = ver
+        return self._sampler
+
+    def get_params_from_part_code(self, part_code, valid_id, noise=None, **kwargs):
+        return self.part_aligner(part_code, valid_id, noise=noise)                        # part_encoders.py:447-459
+
+    @torch.no_grad()
+    def sample_latents(self, sample_num, sample_points, device, fixed_id=None, valid_id=None, epoch=0, K=None,
+                       part_code=None, **kwargs):
+        """part_encoders.py:1052-1110.  Returns (ctx, mean_per_point, logvar_per_point, seg_mask, valid_id,
+        [part_code, mean, logvar, noise]); rows = sample_num * K."""
+        al = self.part_aligner
+        w = None
+        if part_code is None:
+            w = torch.randn(sample_num, self.zdim, self.n_class, device=device)           # :1054 (scaled in-kernel)
+        if al.cimle:
+            K = 10 if K is None else K                                                    # :1062
+            noise = torch.randn(sample_num * K, al.noise_dim, device=device)              # :1065
+            if al.cimle_start_epoch > epoch:
+                noise = torch.zeros_like(noise)
+        else:
+            K, noise = 1, None
+        if valid_id is None:
+            valid_id = torch.ones(sample_num, self.n_class, device=device)
+        fid = [0] * self.n_class if fixed_id is None else [int(v) for v in (fixed_id.tolist() if torch.is_tensor(fixed_id) else fixed_id)]
+        out = self.sampler().sample_latents(w, noise, valid_id, fixed_id=fid, K=K, npoints=sample_points, part_code=part_code)
+        ctx = [out["part_code"], out["params"]]                                            # prepare_ctx :1317-1326
+        return (ctx, out["mean_per_point"], out["logvar_per_point"], out["seg_mask"], out["valid_id"],
+                [out["part_code"], out["mean"], out["logvar"], out["noise"]])
+
+
+@torch.no_grad()
+def generate(encoder, diffusion, sample_num, npoints, valid_id=None, fixed_id=None, K=10, epoch=0, seed=0,
+             ret_traj=False, ret_interval=20):
+    """anchor_gen.py:1034-1084 (gen branch): latents once per batch, then the fused reverse chain.
+    Returns decode's dict + 'pred_seg_mask', 'anchors' (rows, npoints, 3), 'present'."""
+    device = next(encoder.parameters()).device
+    ctx, mean_pp, logvar_pp, seg, valid, latents = encoder.sample_latents(sample_num, npoints, device, fixed_id=fixed_id,
+                                                                          valid_id=valid_id, epoch=epoch, K=K)
+    pred = decode(diffusion, ctx, seg, valid_id=valid, ret_traj=ret_traj, ret_interval=ret_interval, seed=seed)
+    pred["pred_seg_mask"] = seg
+    pred["anchors"] = mean_pp.transpose(1, 2)
+    pred["present"] = valid
+    return pred
+
+
+def attach(ref_encoder):
+    """Accelerate a BUILT reference ``PartEncoderForTransformerDecoder`` in place: its ``sample_latents`` is rebound to
+    the libdfx-backed one (parameters are read from the instance's own ``state_dict``, so checkpoints loaded before or
+    after keep working); the encode side (``forward``, PointNetV2) is left untouched.  Returns the mirror module."""
+    al = ref_encoder.part_aligner
+    mirror = PartEncoderForTransformerDecoder(
+        encoder=dict(zdim=ref_encoder.zdim), n_class=ref_encoder.n_class,
+        part_aligner=PartAlignerTransformer(
+            in_channels=ref_encoder.zdim, n_heads=al.transformer_blocks[0].attn2.heads,
+            d_head=al.inner_dim // al.transformer_blocks[0].attn2.heads, out_channels=al.proj_out.out_features,
+            depth=len(al.transformer_blocks), use_linear=al.use_linear, n_class=al.n_class,
+            single_attn=al.transformer_blocks[0].single_attn, class_cond=al.class_cond,
+            mask_out_unreferenced_code=al.mask_out_unreferenced_code, cimle=al.cimle, noise_dim=al.noise_dim,
+            noise_scale=al.noise_scale, cimle_start_epoch=al.cimle_start_epoch, add_class_cond=al.add_class_cond,
+            cond_noise_type=al.cond_noise_type),
+        include_z=ref_encoder.include_z, include_part_code=ref_encoder.include_part_code,
+        include_params=ref_encoder.include_params, use_gt_params=ref_encoder.use_gt_params,
+        encode_ref=ref_encoder.encode_ref, scale_var=math.exp(ref_encoder.log_scale_var), gen=ref_encoder.gen,
+        use_flow=getattr(ref_encoder, "use_flow", False),
+        latent_flow_depth=len(ref_encoder.flow[0].chain) if getattr(ref_encoder, "use_flow", False) else 0,
+        latent_flow_hidden_dim=ref_encoder.flow[0].chain[0].net_s_t[0].out_features if getattr(ref_encoder, "use_flow", False) else 0,
+        prior_var=ref_encoder.prior_var, selective_noise_sampling=ref_encoder.selective_noise_sampling,
+        selective_noise_sampling_global=ref_encoder.selective_noise_sampling_global,
+        per_part_encoder=ref_encoder.per_part_encoder)
+    own = set(mirror.state_dict())
+    src = weakref.ref(ref_encoder)
+
+    def sync():
+        sd = {k: v for k, v in src().state_dict().items() if k in own}
+        mirror.to(next(iter(sd.values())).device)
+        mirror.load_state_dict(sd)
+
+    def sample_latents(*a, **k):
+        ver = tuple(p._version for p in src().parameters())
+        if getattr(mirror, "_src_ver", None) != ver:
+            sync()
+            mirror._src_ver = ver
+        return mirror.sample_latents(*a, **k)
+
+    ref_encoder.sample_latents = sample_latents
+    return mirror

@@ -194,6 +194,67 @@ int dfx_chamfer_backward_f32(const float *xyz1, const float *xyz2, const int32_t
                              const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2,
                              int B, int N, int M, dfx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Latent sampler — the once-per-batch producer of decode's inputs:
+ * PartEncoder.sample_latents (python/difffacto/models/encoders/part_encoders.py:1052-1110) =
+ * per-part normalising flows run in reverse (python/difffacto/models/encoders/flow.py:21-47,58-72)
+ * + PartAlignerTransformer (part_encoders.py:20-143) + seg-mask ids / per-point gathers
+ * (part_encoders.py:1105-1108, :417-428) + PartEncoderForTransformerDecoder.prepare_ctx (:1317-1326).
+ * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32); supported configuration = the shipped gen configs
+ * (class_cond + add_class_cond, use_linear, single_attn, cimle with cond_noise_type 0, or no cimle).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dfx_aligner_block_weights { /* BasicTransformerBlock(single_attn) of the aligner, device pointers */
+  const float *norm2_w, *norm2_b;   /* (inner) */
+  const float *to_q, *to_k, *to_v;  /* (inner, inner), bias-free */
+  const float *to_out_w, *to_out_b; /* (inner, inner), (inner) */
+  const float *norm3_w, *norm3_b;
+  const float *ff_proj_w, *ff_proj_b; /* (8*inner, inner), (8*inner): GEGLU */
+  const float *ff_out_w, *ff_out_b;   /* (inner, 4*inner), (inner) */
+} dfx_aligner_block_weights;
+
+typedef struct dfx_latent_weights {
+  int32_t n_class, zdim;                /* 4, 256 */
+  int32_t flow_depth, flow_hidden;      /* 14, 256; flow_depth 0 = use_flow False */
+  /* host array of n_class*flow_depth*6 device pointers, [part][layer][w0,b0,w1,b1,w2,b2] = net_s_t.{0,2,4} */
+  const float *const *flow;
+  int32_t depth, n_heads, d_head;       /* 5, 8, 32 */
+  int32_t cimle, noise_dim;             /* 1, 32 (cond_noise_type 0: noise*noise_scale concatenated per token) */
+  float noise_scale, prior_var, log_scale_var;
+  const float *proj_in_w, *proj_in_b;   /* (inner, zdim + cimle*noise_dim) */
+  const float *class_emb;               /* (n_class, inner) */
+  const float *pre_norm_w, *pre_norm_b; /* applied only when !cimle (part_encoders.py:115-131) */
+  const float *post_norm_w, *post_norm_b;
+  const float *proj_out_w, *proj_out_b; /* (6, inner) */
+  dfx_aligner_block_weights blocks[DFX_MAX_DEPTH];
+} dfx_latent_weights;
+
+typedef struct dfx_latents dfx_latents; /* opaque; owns a copy of the weights + a grow-only workspace */
+
+int dfx_latents_create(dfx_latents **out, const dfx_latent_weights *w, dfx_stream_t stream);
+void dfx_latents_destroy(dfx_latents *h);
+
+/* flow[i](w[..., i], reverse=True) for every part (part_encoders.py:1054-1060):
+ * w (S,zdim,n_class) standard normal -> part_code (S,zdim,n_class); w is scaled by sqrt(prior_var) first. */
+int dfx_flow_reverse(dfx_latents *h, const float *w, float *part_code, int S, dfx_stream_t stream);
+
+/* PartAlignerTransformer.forward (part_encoders.py:88-109): part_code (B,zdim,n_class), valid_id (B,n_class)
+ * {0,1} floats = the key mask, noise (B,noise_dim) (NULL iff !cimle) -> mean (B,3,n_class), logvar (B,3,n_class). */
+int dfx_part_aligner(dfx_latents *h, const float *part_code, const float *valid_id, const float *noise, float *mean,
+                     float *logvar, int B, dfx_stream_t stream);
+
+/* The whole sample_latents after the random draws (part_encoders.py:1052-1110; no selective sampling):
+ *   w_noise (S,zdim,n_class) randn of :1054, or part_code_in (S,zdim,n_class) given codes (then w_noise NULL)
+ *   aligner_noise (S*K,noise_dim) randn of :1065 (NULL iff !cimle; then K must be 1)
+ *   valid_id (S,n_class); fixed_id: HOST array of n_class 0/1 flags (:1072-1082)
+ * outputs, R = S*K rows (any may be NULL to skip, except those the chain needs):
+ *   part_code (R,zdim,n_class), valid_out (R,n_class), noise_out (R,noise_dim), mean/logvar (R,3,n_class),
+ *   params (R,6,n_class) = [mean | exp(logvar + log_scale_var)] (= ctx[1]), seg (R,npoints) int32,
+ *   mean_per_point / logvar_per_point (R,3,npoints) (logvar_per_point includes log_scale_var). */
+int dfx_sample_latents(dfx_latents *h, const float *w_noise, const float *part_code_in, const float *aligner_noise,
+                       const float *valid_id, const int32_t *fixed_id, int S, int K, int npoints, float *part_code,
+                       float *valid_out, float *noise_out, float *mean, float *logvar, float *params, int32_t *seg,
+                       float *mean_per_point, float *logvar_per_point, dfx_stream_t stream);
+
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

@@ -75,3 +75,47 @@ def test_keys_and_registry_against_reference():
         NETS._modules["TransformerNet"], DIFFUSIONS._modules["AnchoredDiffusion"] = saved[0], saved[1]
         for k in ("pointnet2_ops", "pointnet2_ops.pointnet2_utils", "pointnet2_ops.pointnet2_modules"):
             sys.modules[k] = saved[2][k]
+
+
+ENC_CFG = dict(
+    encoder=dict(type='PointNetV2', zdim=256, point_dim=3, per_part_mlp=True),
+    part_aligner=dict(type="PartAlignerTransformer", in_channels=256, out_channels=6, n_class=4, d_head=32, depth=5,
+                      n_heads=8, dropout=0., use_checkpoint=False, use_linear=True, class_cond=True, single_attn=True,
+                      add_class_cond=True, cimle=True, noise_scale=100, cond_noise_type=0),
+    n_class=4, kl_weight=0, fit_loss_type=4, fit_loss_weight=1.0, use_flow=True, latent_flow_depth=14,
+    latent_flow_hidden_dim=256, include_z=False, include_part_code=True, include_params=True, use_gt_params=False,
+    kl_weight_annealing=False, gen=True, prior_var=1.0)   # configs/gen_chair.py:6-47
+
+
+def test_encoder_mirror_state_dict_keys_and_unsupported_options():
+    from difffacto_amd.encoders import PartEncoderForTransformerDecoder, PartAlignerTransformer
+    enc = PartEncoderForTransformerDecoder(**ENC_CFG)
+    W = synth.make_latent_weights(0)
+    assert set(enc.state_dict()) == set(W)
+    for k, v in enc.state_dict().items():
+        assert tuple(v.shape) == W[k].shape, k
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    with pytest.raises(NotImplementedError):
+        PartAlignerTransformer(256, 8, 32, 6, depth=5, use_linear=True, single_attn=True, add_class_cond=True, cimle=True,
+                               cond_noise_type=2)
+    with pytest.raises(NotImplementedError):
+        PartEncoderForTransformerDecoder(**{**ENC_CFG, "selective_noise_sampling": True})
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python/difffacto"), reason="dev container only")
+def test_encoder_mirror_matches_reference_state_dict():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import ref_import
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, _ = ref_import.build_reference_model("gen_chair.py", 10)
+    from difffacto_amd.encoders import PartEncoderForTransformerDecoder
+    enc = PartEncoderForTransformerDecoder(**ENC_CFG)
+    ref = {k: tuple(v.shape) for k, v in model.encoder.state_dict().items() if not k.startswith("encoder.")}
+    assert ref == {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    from difffacto_amd.encoders import attach
+    mirror = attach(model.encoder)           # construction only (the first sample_latents call needs the GPU)
+    assert set(mirror.state_dict()) == set(ref) and mirror.part_aligner.noise_scale == 100
+    assert model.encoder.sample_latents.__name__ == "sample_latents"
