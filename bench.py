@@ -3,10 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over one batch: per-batch shape-context preparation +
-the full T-step reverse chain (persistent kernel, in-kernel Philox noise) for B shapes per GPU,
-plus — for N>1 — the gather of the generated clouds to rank 0.  Latents are synthetic and already
-resident in HBM when the timed region starts.  Weak scaling: B shapes per GPU, independent shapes,
+One "step" = one pass of the hot path over one batch (anchor_gen.py:1034-1084): the latent sampler
+(torch.randn draws -> flows in reverse -> part aligner -> seg ids; dfx_sample_latents), per-batch
+shape-context preparation, and the full T-step reverse chain (persistent kernel, in-kernel Philox
+noise) for B shapes per GPU, plus — for N>1 — the gather of the generated clouds to rank 0.
+Part-presence patterns (valid_id) are synthetic and already resident in HBM when the timed region starts.  Weak scaling: B shapes per GPU, independent shapes,
 no per-step collective; the frozen weights are broadcast from rank 0 once (RCCL), outside the timed
 region (reported as weights_bcast_ms).
 
@@ -119,12 +120,16 @@ def main():
     _ffi.lib().dfx_debug_flags(args.debug_flags)
     _ffi.lib().dfx_debug_force_direct(int(args.force_direct))
     names = [n for n, _ in synth.denoiser_param_shapes()]
+    lat_shapes = [("encoder." + n, s) for n, s in synth.latent_param_shapes()]
     if rank == 0:
         Wnp = synth.make_denoiser_weights(seed=0)
+        Lnp = synth.make_latent_weights(seed=0)
         params = {k: torch.from_numpy(Wnp[k]).to(dev) for k in names}
+        params.update({"encoder." + k: torch.from_numpy(v).to(dev) for k, v in Lnp.items()})
     else:
         Wnp = None
-        params = {k: torch.empty(s, dtype=torch.float32, device=dev) for k, s in synth.denoiser_param_shapes()}
+        params = {k: torch.empty(s, dtype=torch.float32, device=dev)
+                  for k, s in list(synth.denoiser_param_shapes()) + lat_shapes}
     bcast_ms = 0.0
     if dist is not None:
         torch.cuda.synchronize()
@@ -132,21 +137,26 @@ def main():
         broadcast_params(params, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
-    eng = DenoiserEngine(params, num_timesteps=T, precision=args.precision, device=dev)
+    eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=args.precision, device=dev)
+    from difffacto_amd.latents import LatentSampler
+    sampler = LatentSampler({k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")},
+                            noise_scale=100.0, device=dev)          # configs/gen_chair.py:14-31
 
-    # per-rank synthetic latents, resident in HBM (shape ids are global so results do not depend on world size)
-    part_code, mean, logvar, valid = synth.make_latents(B, seed=1000 + rank)
-    seg = torch.from_numpy(synth.make_seg_mask(valid, N)).to(dev)
-    part_code, mean, var, valid = (torch.from_numpy(a).to(dev) for a in
-                                   (part_code, mean, np.exp(logvar).astype(np.float32), valid))
+    # per-rank synthetic part-presence patterns, resident in HBM
+    valid = torch.from_numpy(synth.make_latents(B, seed=1000 + rank)[3]).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def one_step(i, timed):
-        ctx = eng.prepare_shapes(part_code, mean, var, valid)
+        w = torch.randn(B, 256, 4, device=dev, generator=gen)           # part_encoders.py:1054
+        an = torch.randn(B, 32, device=dev, generator=gen)              # :1065 (K = 1 noise per shape)
+        lat = sampler.sample_latents(w, an, valid, K=1, npoints=N)
+        ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
         if timed:
             ev[i][0].record()
-        pred, _ = eng.sample_chain(ctx, seg, seed=(rank << 32) + i)
+        pred, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=(rank << 32) + i)
         if timed:
             ev[i][1].record()
         if dist is not None:
@@ -188,7 +198,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"gen_chair decode: {B} shapes/GPU x {N} pts x 4 parts, T={T} DDPM steps, "
-                                   f"random-init denoiser (depth 5, inner 128), in-kernel Philox noise",
+                                   f"random-init flows + part aligner + denoiser (depth 5, inner 128), in-kernel Philox noise",
                        "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
                        "weights_bcast_ms": bcast_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
