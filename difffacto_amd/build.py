@@ -17,7 +17,7 @@ SO = os.path.join(HERE, "libdfx.so")
 BUILD = os.path.join(HERE, "_build")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]  # contraction is spelled explicitly (fmaf) where wanted: parity with the oracle
+         "-ffp-contract=off", "-fno-slp-vectorize"]  # contraction is spelled explicitly (fmaf) where wanted: parity with the oracle
 
 
 def _hipcc():
