@@ -291,10 +291,15 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
 }
 
 // ---- building blocks of the LDS-pipelined bf16 kernel ---------------------------------------------------
-// gfx950 issues an MFMA and the VALU work of the SAME wavefront strictly one after the other, but overlaps
-// them across the two wavefronts of a SIMD (tools/ubench/valu_rates.hip).  So every wavefront's stream is
-// cut into pure MFMA bursts ("M slots") and pure VALU bursts ("V slots"), and the two wavefronts of a SIMD run
-// them in anti-phase (k_denoise_pipe).
+// Every wavefront's stream is cut into pure MFMA bursts ("M slots") and pure VALU bursts ("V slots"), and the two
+// wavefronts of a SIMD run them in anti-phase (k_denoise_pipe), so that the matrix pipe of a SIMD always has one
+// wavefront feeding it while the other one does the fp32 work.  Measured rules behind the structure
+// (tools/ubench/agpr_overlap.hip, stage_mix.hip, lds_bw.hip):
+//   * a VALU instruction next to MFMAs costs ~3.1 cycles of SIMD issue (transcendentals ~10), every MFMA takes
+//     ~18 cycles of VALU issue away: T(SIMD) ~ max(32.6 nMFMA, 3.1 nVALU + 10 nTRANS + 18 nMFMA);
+//   * packed fp32 VALU (v_pk_mul/fma/add_f32) serialises against the matrix pipe: never next to MFMAs
+//     (the library is built with -fno-slp-vectorize, +10 %);
+//   * LDS delivers ~240 B/clk/CU with eight wavefronts reading; one wavefront sustains ~32 B/clk (latency bound).
 __device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
 
 #ifndef DFX_MFMA_PRIO
@@ -335,8 +340,8 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
     // W1 unit order: (c, q, part) -> tile part*4 + c, unit q
 #pragma unroll
     for (int i = 0; i < 8; ++i) A1[i] = ck[((i & 1) * 4 + (i >> 2)) * 128 + ((i >> 1) & 1) * 64];
-    load16(a, b1);
-    load16(g, b1 + 32);
+    // a, g already hold b1 of this chunk: loaded at the end of the preceding V slot (ff_v / V2), where the LDS
+    // reads cost nothing on the M slot's operand-fetch critical path (+1 %)
   }
   __builtin_amdgcn_sched_barrier(0);
   // The MFMA burst outranks the partner's VALU burst at the issue arbiter (an MFMA needs one issue slot per
@@ -374,7 +379,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
 // V slot of the feed-forward: hid = bf16(a * gelu(g)).  Written stage by stage over 8 elements at a time so
 // that eight independent dependency chains are in flight (hipcc otherwise interleaves only two and every
 // instruction waits for its predecessor's result).
-__device__ __forceinline__ void ff_v(const v16f &a, const v16f &g, Act<DFX_PREC_BF16> &hid) {
+__device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, const float *b1_next) {
   if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
   v16f t;
 #ifdef DFX_ABLATE_NO_GELU  // timing ablation only (wrong results)
@@ -407,6 +412,10 @@ __device__ __forceinline__ void ff_v(const v16f &a, const v16f &g, Act<DFX_PREC_
     v4u w = __builtin_bit_cast(v4u, hid.f[q]);
     asm volatile("" : "+v"(w));
     hid.f[q] = __builtin_bit_cast(v8bf, w);
+  }
+  if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
+    load16(a, b1_next);
+    load16(g, b1_next + 32);
   }
   if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(0);
 }
@@ -855,19 +864,21 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
       v16f a, g;
       Act<PREC> hid;
+      load16(a, b1);  // accumulator initialisers of chunk 0 (block constants: resident since the attention record)
+      load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<false, true>(h, xn, a, g, hid, ck, b1, tr);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
-        ff_v(a, g, hid);
+        ff_v(a, g, hid, b1 + j * 64);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
         ff_m<true, true>(h, xn, a, g, hid, ck, b1 + j * 64, tr);
       }
       DFX_SLOT(!grpA);
-      ff_v(a, g, hid);
+      ff_v(a, g, hid, nullptr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<true, false>(h, xn, a, g, hid, ck, b1, tr);
