@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Golden vectors for the PointNet++ set-abstraction / feature-propagation MODULES.
+
+    python tests/golden/make_golden_sa.py          # dev container only; writes tests/golden/sa_*.npz, fp_*.npz
+
+Runs the REFERENCE's own Python classes (pointnet2_ops_lib/pointnet2_ops/pointnet2_{utils,modules}.py:
+QueryAndGroup, GroupAll, PointnetSAModule, PointnetFPModule, build_shared_mlp) on CPU tensors in eval mode.  Their CUDA
+extension ``pointnet2_ops._ext`` cannot be built here (nvcc absent), so it is replaced by a shim over the C oracle
+(oracle/pointnet2.c) — the fixtures therefore pin the Python-level composition (centre subtraction, channel order of
+[xyz | features], Conv2d + BatchNorm2d(eval) + ReLU stack, max over the neighbourhood, inverse-distance weights),
+which is exactly what the fused HIP kernel restates; the per-op semantics are covered by test_oracle_pointnet2_cpu.py.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("DFX_REFERENCE_ROOT", "/root/reference")
+
+from oracle import pointnet2 as o  # noqa: E402
+
+F32 = np.float32
+
+
+def install_ext_shim():
+    ext = types.ModuleType("pointnet2_ops._ext")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    n = lambda x: x.detach().cpu().numpy()
+    ext.furthest_point_sampling = lambda xyz, npoint: t(o.furthest_point_sampling(n(xyz), npoint))
+    ext.gather_points = lambda feats, idx: t(o.gather_points(n(feats), n(idx)))
+    ext.gather_points_grad = lambda g, idx, N: t(o.gather_points_grad(n(g), n(idx), N))
+    ext.ball_query = lambda new_xyz, xyz, radius, nsample: t(o.ball_query(radius, nsample, n(xyz), n(new_xyz)))
+    ext.group_points = lambda feats, idx: t(o.group_points(n(feats), n(idx)))
+    ext.group_points_grad = lambda g, idx, N: t(o.group_points_grad(n(g), n(idx), N))
+
+    def three_nn(unknown, known):
+        d2, idx = o.three_nn(n(unknown), n(known))
+        return t(d2), t(idx)
+
+    ext.three_nn = three_nn
+    ext.three_interpolate = lambda feats, idx, w: t(o.three_interpolate(n(feats), n(idx), n(w)))
+    ext.three_interpolate_grad = lambda g, idx, w, m: t(o.three_interpolate_grad(n(g), n(idx), n(w), m))
+    sys.modules["pointnet2_ops._ext"] = ext
+    sys.path.insert(0, os.path.join(REF, "pointnet2_ops_lib"))
+    for k in [k for k in sys.modules if k == "pointnet2_ops" or k.startswith("pointnet2_ops.p")]:
+        del sys.modules[k]
+    import pointnet2_ops.pointnet2_modules as pm  # the reference's own file
+    assert pm.__file__.startswith(REF), pm.__file__
+    return pm
+
+
+def randomize(module, rng):
+    """Random conv weights / BN affine + running statistics so that every term of the folded form is exercised."""
+    sd = module.state_dict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, size=tuple(v.shape))
+        elif k.endswith("running_mean") or k.endswith("bias"):
+            a = rng.uniform(-0.2, 0.2, size=tuple(v.shape))
+        elif v.dim() == 1:
+            a = rng.uniform(0.8, 1.2, size=tuple(v.shape))
+        else:
+            bound = 1.0 / np.sqrt(v.shape[1])
+            a = rng.uniform(-bound, bound, size=tuple(v.shape))
+        sd[k] = torch.from_numpy(a.astype(F32))
+    module.load_state_dict(sd)
+    return {k: v.numpy().copy() for k, v in module.state_dict().items() if not k.endswith("num_batches_tracked")}
+
+
+def gen_sa(pm, tag, B, N, C, mlp, npoint, radius, nsample, bn, use_xyz, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xyz = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    feats = rng.standard_normal((B, C, N)).astype(F32) if C else None
+    mod = pm.PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=radius, nsample=nsample, bn=bn, use_xyz=use_xyz).eval()
+    W = randomize(mod, rng)
+    with torch.no_grad():
+        new_xyz, new_feats = mod(torch.from_numpy(xyz), None if feats is None else torch.from_numpy(feats))
+    out = dict(xyz=xyz, new_features=new_feats.numpy().astype(F32), mlp=np.array(mlp), npoint=np.array(-1 if npoint is None else npoint),
+               radius=np.array(0.0 if radius is None else radius, F32), nsample=np.array(-1 if nsample is None else nsample),
+               bn=np.array(int(bn)), use_xyz=np.array(int(use_xyz)))
+    if feats is not None:
+        out["features"] = feats
+    if new_xyz is not None:
+        out["new_xyz"] = new_xyz.numpy().astype(F32)
+    out.update({"w." + k: v for k, v in W.items()})
+    np.savez_compressed(os.path.join(HERE, f"sa_{tag}.npz"), **out)
+    print("wrote sa_" + tag, new_feats.shape, float(new_feats.abs().max()))
+
+
+def gen_fp(pm, tag, B, n, m, C1, C2, mlp, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    unknown = rng.uniform(-1, 1, size=(B, n, 3)).astype(F32)
+    known = rng.uniform(-1, 1, size=(B, m, 3)).astype(F32)
+    uf = rng.standard_normal((B, C1, n)).astype(F32)
+    kf = rng.standard_normal((B, C2, m)).astype(F32)
+    mod = pm.PointnetFPModule(mlp=list(mlp)).eval()
+    W = randomize(mod, rng)
+    with torch.no_grad():
+        out_f = mod(*map(torch.from_numpy, (unknown, known, uf, kf)))
+    out = dict(unknown=unknown, known=known, unknow_feats=uf, known_feats=kf, new_features=out_f.numpy().astype(F32), mlp=np.array(mlp))
+    out.update({"w." + k: v for k, v in W.items()})
+    np.savez_compressed(os.path.join(HERE, f"fp_{tag}.npz"), **out)
+    print("wrote fp_" + tag, out_f.shape)
+
+
+def main():
+    torch.manual_seed(0)
+    pm = install_ext_shim()
+    # PointNet2SSG's three layers at reduced size (python/difffacto/models/encoders/pointnet2.py:18-45)
+    gen_sa(pm, "ssg1_small", B=2, N=256, C=4, mlp=[4, 64, 64, 128], npoint=64, radius=0.4, nsample=64, bn=True, use_xyz=True, seed=41)
+    gen_sa(pm, "ssg2_small", B=2, N=96, C=128, mlp=[128, 128, 128, 256], npoint=24, radius=0.7, nsample=64, bn=True, use_xyz=True, seed=42)
+    gen_sa(pm, "groupall", B=3, N=40, C=16, mlp=[16, 32, 64], npoint=None, radius=None, nsample=None, bn=True, use_xyz=True, seed=43)
+    gen_sa(pm, "nobn_noxyz_ragged", B=2, N=100, C=5, mlp=[5, 24, 40], npoint=10, radius=0.5, nsample=20, bn=False, use_xyz=False, seed=44)
+    gen_sa(pm, "xyz_only", B=1, N=128, C=0, mlp=[0, 16, 32], npoint=16, radius=0.6, nsample=16, bn=True, use_xyz=True, seed=45)
+    gen_fp(pm, "small", B=2, n=50, m=20, C1=6, C2=10, mlp=[16, 32, 24], seed=46)
+
+
+if __name__ == "__main__":
+    main()

@@ -119,3 +119,34 @@ def test_empty_inputs():
     assert opn.gather_points(np.zeros((0, 3, 4), np.float32), np.zeros((0, 2), np.int32)).shape == (0, 3, 2)
     assert opn.ball_query(0.1, 4, np.zeros((1, 0, 3), np.float32), np.zeros((1, 2, 3), np.float32)).tolist() == [[[0] * 4] * 2]
     assert opn.furthest_point_sampling(np.ones((1, 5, 3), np.float32), 0).shape == (1, 0)
+
+
+# ------------------------------------------------------------------ SA / FP modules vs the reference's Python classes
+import glob as _glob
+
+
+def _weights(g):
+    return {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sa_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_sa_module_matches_reference_python(path):
+    from oracle import pointnet2_modules as om
+    g = np.load(path)
+    npoint = int(g["npoint"])
+    new_xyz, nf = om.sa_module_forward(
+        _weights(g), g["xyz"], g["features"] if "features" in g.files else None, n_layers=len(g["mlp"]) - 1,
+        npoint=None if npoint < 0 else npoint, radius=float(g["radius"]), nsample=int(g["nsample"]), bn=bool(g["bn"]),
+        use_xyz=bool(g["use_xyz"]))
+    if npoint >= 0:
+        assert np.array_equal(new_xyz, g["new_xyz"])
+    assert nf.shape == g["new_features"].shape
+    assert np.abs(nf - g["new_features"]).max() < 2e-5
+
+
+def test_oracle_fp_module_matches_reference_python():
+    from oracle import pointnet2_modules as om
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fp_small.npz"))
+    out = om.fp_module_forward(_weights(g), g["unknown"], g["known"], g["unknow_feats"], g["known_feats"], n_layers=len(g["mlp"]) - 1)
+    assert np.abs(out - g["new_features"]).max() < 2e-5
