@@ -88,6 +88,11 @@ SIGNATURES = {
     "dfx_part_aligner": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "dfx_sample_latents": (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfx_shared_mlp_create": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_fp)] * 6 + [_F, _P]),
+    "dfx_shared_mlp_destroy": (None, [_P]),
+    "dfx_shared_mlp_is_fused": (_I, [_P]),
+    "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfx_fp_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
     "dfx_debug_flags": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),

@@ -1,0 +1,91 @@
+// Generic row-batched fp32 linear layer on the exact fp32 matrix pipe (v_mfma_f32_32x32x2_f32), shared by the latent
+// sampler (latents_kernels.hip) and the PointNet++ shared-MLP path (sa_kernels.hip).
+//
+// Evaluated transposed like the denoiser: output channels on the MFMA M axis (accumulator registers), rows / tokens /
+// points on the N axis (lanes), so that the epilogues are in-lane.  The K axis is consumed 8 at a time with one 16-byte
+// load per operand and lane: lane (j, hf) holds k = k0 + 4 hf + s for the s-th MFMA of a block.
+#pragma once
+#include "dfx_common.h"
+
+namespace dfx {
+namespace lin {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_COUPLING = 3, EPI_GEGLU = 4 };
+
+struct LinArgs {
+  const float *X; long long x_gs; int ldx;   // activations (M, K) rows, leading dimension ldx, group stride
+  const float *W; long long w_gs;            // weights (N or 2N, K) row-major (nn.Linear layout)
+  const float *b; long long b_gs;            // bias (N or 2N) or nullptr
+  float *Y; long long y_gs; int ldy;         // output (M, N); COUPLING: the half of x updated in place
+  const float *R; int ldr; int r_mod;        // RESID: Y = acc + b + R[(r_mod ? m % r_mod : m)][n]
+  int M, N, K;                               // N = output columns (dual epilogues read 2N weight rows)
+};
+
+template <int EPI>
+static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
+  constexpr bool DUAL = (EPI == EPI_COUPLING || EPI == EPI_GEGLU);
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, g = blockIdx.z;
+  const int mrow = min(m0 + j, a.M - 1), nrow = min(n0 + j, a.N - 1);   // clamped rows are never stored
+  const float *xp = a.X + g * a.x_gs + (size_t)mrow * a.ldx + 4 * hf;
+  const float *wp = a.W + g * a.w_gs + (size_t)nrow * a.K + 4 * hf;
+  const float *wq = wp + (size_t)a.N * a.K;
+  v16f acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+  auto block = [&](const v4f xv, const v4f wv, const v4f uv) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], xv[s], acc0, 0, 0, 0);
+    if (DUAL) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(uv[s], xv[s], acc1, 0, 0, 0);
+    }
+  };
+  auto ld = [](const float *p) { return *reinterpret_cast<const v4f *>(p); };
+  int k = 0;
+  for (; k + 32 <= a.K; k += 32) {   // 4 K-blocks of 8 per trip: 8-12 loads in flight ahead of 16-32 MFMAs
+    v4f xv[4], wv[4], uv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xv[u] = ld(xp + k + 8 * u), wv[u] = ld(wp + k + 8 * u);
+      uv[u] = DUAL ? ld(wq + k + 8 * u) : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) block(xv[u], wv[u], uv[u]);
+  }
+  for (; k < a.K; k += 8) block(ld(xp + k), ld(wp + k), DUAL ? ld(wq + k) : v4f{0.f, 0.f, 0.f, 0.f});
+  const int m = m0 + j;
+  if (m >= a.M) return;
+  const float *bp = a.b ? a.b + g * a.b_gs : nullptr;
+  float *yp = a.Y + g * a.y_gs + (size_t)m * a.ldy;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hf;   // 32x32 C/D layout
+    if (n >= a.N) continue;
+    float v = acc0[r] + (bp ? bp[n] : 0.f);
+    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+    if (EPI == EPI_RESID) v += a.R[(size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr + n];
+    if (EPI == EPI_COUPLING) {   // flow.py:30-31,40: y1 = (x2 - shift) / sigmoid(s + 2)
+      const float shift = acc1[r] + (bp ? bp[a.N + n] : 0.f);
+      const float scale = 1.f / (1.f + expf(-(v + 2.f)));
+      v = (yp[n] - shift) / scale;
+    }
+    if (EPI == EPI_GEGLU) {      // attention.py:55-57: x * F.gelu(gate), exact erf form
+      const float gate = acc1[r] + (bp ? bp[a.N + n] : 0.f);
+      v = v * (0.5f * gate * (1.f + erff(gate * 0.70710678118654752440f)));
+    }
+    yp[n] = v;
+  }
+}
+
+template <int EPI>
+inline void launch(hipStream_t st, int groups, const LinArgs &a) {
+  dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, groups);
+  k_lin<EPI><<<grid, 64, 0, st>>>(a);
+}
+
+}  // namespace lin
+}  // namespace dfx

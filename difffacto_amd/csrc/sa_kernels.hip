@@ -1,0 +1,484 @@
+// PointNet++ set-abstraction / feature-propagation layers in eval mode: the part of
+// pointnet2_ops that the reference leaves to PyTorch — QueryAndGroup / GroupAll + shared MLP (Conv2d 1x1 +
+// BatchNorm2d + ReLU stack) + max over the neighbourhood, and the FP module's interpolate + concat + MLP.
+//
+//   reference                                                                   here
+//   pointnet2_utils.py:296-333 QueryAndGroup ([xyz - centre | features])        k_sa_fused / k_sa_rows (gather in-kernel)
+//   pointnet2_utils.py:349-381 GroupAll                                         same kernels, M = 1, ns = N, no centring
+//   pointnet2_modules.py:9-19  build_shared_mlp (conv + BN(eval) + ReLU)        folded at create time: y = relu(W' x + b')
+//   pointnet2_modules.py:62-70 max_pool2d over nsample                          wave max (DPP) + atomicMax (values >= 0)
+//   pointnet2_modules.py:170-209 PointnetFPModule                               k_fp_rows + linear layers
+//
+// Two native paths behind one entry point:
+//  * fused (2-3 layers, hidden widths <= 128, output <= 256: SA1 / SA2 of PointNet2SSG): one wavefront = one tile of
+//    32 neighbours of one centre; the gathered inputs feed the first layer's MFMAs directly, the layer outputs stay in
+//    accumulator registers and chain into the next layer as the B operand (weights pre-permuted at create time, the
+//    same trick as the denoiser), the last layer is reduced over the 32 lanes and merged across tiles with an integer
+//    atomicMax (post-ReLU values are >= 0, so the IEEE bit patterns order like integers).  The (B, C+3, M, ns) grouped
+//    tensor and the per-neighbour activations never exist in memory.
+//  * general (any widths / depth, e.g. SA3 with 1024 outputs, and the FP module): rows materialised once, one
+//    row-batched MFMA linear layer per MLP layer (mfma_linear.h), then a max over the neighbourhood.
+// All fp32 on v_mfma_f32_32x32x2_f32.
+#include <algorithm>
+#include <vector>
+
+#include "dfx_common.h"
+#include "mfma_linear.h"
+
+using namespace dfx::lin;
+
+namespace {
+
+constexpr int MAX_LAYERS = 4;
+
+__device__ __forceinline__ constexpr int rho(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+// ---- create-time folding / packing --------------------------------------------------------------------------------
+// W'(n, k) = W(n, k) * inv(n), b'(n) = (bconv(n) - mean(n)) * inv(n) + beta(n), inv = gamma / sqrt(var + eps)
+// natural layout: (N, Kpad) row-major zero-padded (general path);
+// packed layout (fused path): [out tile][K unit][lane][4]: lane (i, hf), element e of unit u holds W'(32 ot + i, k(u, e, hf))
+//   first layer:  k = 8 u + 2 e + hf              (B operand built from gathers in channel order)
+//   later layers: k = 32 (u >> 2) + rho(4 (u & 3) + e, hf)   (B operand = accumulator registers of the previous layer)
+__global__ void k_fold(const float *__restrict__ w, const float *__restrict__ cb, const float *__restrict__ gamma,
+                       const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ var,
+                       float eps, float *__restrict__ wn, float *__restrict__ bn_, float *__restrict__ wp, int N, int K,
+                       int Kpad, int first) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Npad = (N + 31) & ~31;
+  if (t >= Npad * Kpad) return;
+  const int n = t / Kpad, k = t % Kpad;
+  float inv = 1.f, v = 0.f;
+  if (n < N) {
+    if (gamma) inv = gamma[n] / sqrtf(var[n] + eps);
+    if (k < K) v = w[(size_t)n * K + k] * inv;
+    if (k == 0) bn_[n] = gamma ? ((cb ? cb[n] : 0.f) - mean[n]) * inv + beta[n] : (cb ? cb[n] : 0.f);
+    wn[(size_t)n * Kpad + k] = v;
+  } else if (k == 0) {
+    bn_[n] = 0.f;
+  }
+  if (wp) {   // scatter into the packed position: invert k -> (u, e, hf)
+    int u, e, hf;
+    if (first) {
+      u = k >> 3, e = (k & 7) >> 1, hf = k & 1;
+    } else {
+      const int kk = k & 31, r_hf = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);   // kk = (r&3) + 8 (r>>2) + 4 hf
+      u = 4 * (k >> 5) + (r >> 2), e = r & 3, hf = r_hf;
+    }
+    const int ot = n >> 5, i = n & 31, U = Kpad >> 3;
+    wp[(((size_t)ot * U + u) * 64 + (i + 32 * hf)) * 4 + e] = v;
+  }
+}
+
+// ---- general path ----------------------------------------------------------------------------------------------------
+// X[(b M + m) ns + j][k] = grouped input channel k of neighbour j of centre m (zero for k >= C0)
+__global__ void k_sa_rows(const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat,
+                          const int32_t *__restrict__ idx, float *__restrict__ X, int N, int M, int ns, int C, int use_xyz,
+                          int Kpad, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int k = t % Kpad;
+  const long long row = t / Kpad;
+  const int j = row % ns, m = (row / ns) % M, b = row / ((long long)ns * M);
+  const int pid = idx ? idx[((size_t)b * M + m) * ns + j] : j;
+  const int nx = use_xyz ? 3 : 0;
+  float v = 0.f;
+  if (k < nx) {
+    v = xyz[((size_t)b * N + pid) * 3 + k];
+    if (new_xyz) v -= new_xyz[((size_t)b * M + m) * 3 + k];
+  } else if (k < nx + C) {
+    v = feat[((size_t)b * C + (k - nx)) * N + pid];
+  }
+  X[t] = v;
+}
+
+// out[b][c][m] = max_j Y[(b M + m) ns + j][c]
+__global__ void k_rowmax(const float *__restrict__ Y, float *__restrict__ out, int M, int ns, int Cout, int ld,
+                         long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = t % Cout;
+  const long long bm = t / Cout;
+  const float *y = Y + bm * ns * ld + c;
+  float v = y[0];
+  for (int j = 1; j < ns; ++j) v = fmaxf(v, y[(size_t)j * ld]);
+  const int m = bm % M;
+  const long long b = bm / M;
+  out[((size_t)b * Cout + c) * M + m] = v;
+}
+
+// FP module rows: X[b n + i][k] = k < C2 ? sum_q w_q known_feats[b][k][idx_q] : unknow_feats[b][k - C2][i]
+// with w_q = (1 / (sqrt(d2_q) + 1e-8)) / sum_q (pointnet2_modules.py:190-194; ThreeNN returns sqrt, pointnet2_utils.py:125)
+__global__ void k_fp_rows(const float *__restrict__ d2, const int32_t *__restrict__ idx, const float *__restrict__ kf,
+                          const float *__restrict__ uf, float *__restrict__ X, int n, int m, int C1, int C2, int Kpad,
+                          long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int k = t % Kpad;
+  const long long row = t / Kpad;
+  const int i = row % n;
+  const long long b = row / n;
+  float v = 0.f;
+  if (k < C2) {
+    if (idx) {
+      const float r0 = 1.0f / (sqrtf(d2[row * 3 + 0]) + 1e-8f), r1 = 1.0f / (sqrtf(d2[row * 3 + 1]) + 1e-8f),
+                  r2 = 1.0f / (sqrtf(d2[row * 3 + 2]) + 1e-8f);
+      const float norm = (r0 + r1) + r2;   // torch.sum over 3 elements: sequential
+      const float *p = kf + ((size_t)b * C2 + k) * m;
+      float acc = p[idx[row * 3 + 0]] * (r0 / norm);
+      acc = fmaf(p[idx[row * 3 + 1]], r1 / norm, acc);   // interpolate_gpu.cu:72-101 (stated nvcc -fmad contraction)
+      acc = fmaf(p[idx[row * 3 + 2]], r2 / norm, acc);
+      v = acc;
+    } else {
+      v = kf[((size_t)b * C2 + k)];   // known is None: known_feats (B, C2, 1) expanded (pointnet2_modules.py:196-199)
+    }
+  } else if (k < C2 + C1) {
+    v = uf[((size_t)b * C1 + (k - C2)) * n + i];
+  }
+  X[t] = v;
+}
+
+// (rows = B n, ld) -> (B, C, n)
+__global__ void k_rows_to_channels(const float *__restrict__ Y, float *__restrict__ out, int n, int C, int ld, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int i = t % n, c = (t / n) % C;
+  const long long b = t / ((long long)n * C);
+  out[t] = Y[(b * n + i) * ld + c];
+}
+
+// ---- fused path ----------------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const float *xyz, *new_xyz, *feat;
+  const int32_t *idx;
+  float *out;                 // (B, Cout, M), zero-initialised
+  const float *wp[3], *b[3];  // packed weights / folded bias per layer
+  int L;                      // 2 or 3
+  int U0;                     // K units (of 8) of the first layer
+  int nt[3];                  // output tiles (of 32 channels) per layer
+  int cout;                   // real output channels of the last layer
+  int N, M, ns, C, use_xyz, tiles_per_centre;
+  long long total_tiles;
+};
+
+__device__ __forceinline__ v16f bias_tile(const float *b, int t, int hf) {
+  v16f a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = b[32 * t + rho(r, hf)];
+  return a;
+}
+
+__device__ __forceinline__ v16f relu16(v16f a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
+  return a;
+}
+
+// one output tile of a register-chained layer: acc = b + sum over the input tiles (nin of them, <= 4)
+__device__ __forceinline__ v16f chain_tile(const v16f (&in)[4], int nin, const float *wp, int ot, int lane, const float *b,
+                                           int hf) {
+  v16f acc = bias_tile(b, ot, hf);
+  const v4f *w = reinterpret_cast<const v4f *>(wp) + (size_t)ot * (nin * 4) * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nin) {
+      v4f u[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) u[r4] = w[(t * 4 + r4) * 64];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u[r4][e], in[t][4 * r4 + e], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// max over the 32 lanes of each half-wave (row_shr butterflies stay inside a row of 16; the last step crosses rows)
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64));
+  v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64));
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+
+// last layer: one output tile at a time -> ReLU -> max over this tile's neighbours -> atomic max across tiles
+__device__ __forceinline__ void pooled_last_layer(const FusedArgs &a, const v16f (&hin)[4], int nin, int li, int lane, bool valid,
+                                                  int b, int m) {
+  const int j = lane & 31, hf = lane >> 5;
+  for (int ot = 0; ot < a.nt[li]; ++ot) {
+    const v16f y = relu16(chain_tile(hin, nin, a.wp[li], ot, lane, a.b[li], hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = half_max(valid ? y[r] : 0.f);   // padding neighbours contribute 0 <= the true maximum
+      const int c = 32 * ot + rho(r, hf);
+      if (j == 0 && c < a.cout)   // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
+        atomicMax(reinterpret_cast<unsigned *>(a.out) + ((size_t)b * a.cout + c) * a.M + m, __float_as_uint(v) & 0x7fffffffu);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
+  const int lane = threadIdx.x & 63, j = lane & 31, hf = lane >> 5;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.total_tiles) return;
+  const int tl = tile % a.tiles_per_centre;
+  const long long bm = tile / a.tiles_per_centre;
+  const int m = bm % a.M;
+  const int b = bm / a.M;
+  const int nb = tl * 32 + j;
+  const bool valid = nb < a.ns;
+  const int pid = valid ? (a.idx ? a.idx[((size_t)b * a.M + m) * a.ns + nb] : nb) : 0;
+  const int nx = a.use_xyz ? 3 : 0, C0 = nx + a.C;
+
+  // ---- layer 0: B operand straight from the gathers, channel k = 8 u + 2 e + hf ----
+  v16f h0[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < a.nt[0]) h0[t] = bias_tile(a.b[0], t, hf);
+  const v4f *w0 = reinterpret_cast<const v4f *>(a.wp[0]) + lane;
+  for (int u = 0; u < a.U0; ++u) {
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 8 * u + 2 * e + hf;
+      float v = 0.f;
+      if (valid && k < C0) {
+        if (k < nx) {
+          v = a.xyz[((size_t)b * a.N + pid) * 3 + k];
+          if (a.new_xyz) v -= a.new_xyz[((size_t)b * a.M + m) * 3 + k];
+        } else {
+          v = a.feat[((size_t)b * a.C + (k - nx)) * a.N + pid];
+        }
+      }
+      x[e] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < a.nt[0]) {
+        const v4f wv = w0[((size_t)t * a.U0 + u) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], x[e], h0[t], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < a.nt[0]) h0[t] = relu16(h0[t]);
+
+  // ---- optional middle layer (register-chained), then the pooled last layer ----
+  if (a.L == 3) {
+    v16f h1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < a.nt[1]) h1[t] = relu16(chain_tile(h0, a.nt[0], a.wp[1], t, lane, a.b[1], hf));
+    pooled_last_layer(a, h1, a.nt[1], 2, lane, valid, b, m);
+  } else {
+    pooled_last_layer(a, h0, a.nt[0], 1, lane, valid, b, m);
+  }
+}
+
+inline int nblk(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+
+}  // namespace
+
+struct dfx_shared_mlp {
+  int L = 0;
+  int ch[MAX_LAYERS + 1] = {0};
+  int kpad[MAX_LAYERS] = {0};
+  float *wbuf = nullptr;
+  size_t wn[MAX_LAYERS] = {0}, bn[MAX_LAYERS] = {0}, wp[MAX_LAYERS] = {0};
+  bool fused_ok = false;
+  float *ws = nullptr;
+  size_t ws_floats = 0;
+  int reserve(size_t floats) {
+    if (floats <= ws_floats) return DFX_OK;
+    if (ws) (void)hipFree(ws);
+    ws = nullptr, ws_floats = 0;
+    if (hipMalloc(&ws, floats * sizeof(float)) != hipSuccess)
+      return dfx::set_error(DFX_ERR_ALLOC, "shared_mlp: %zu bytes of workspace", floats * sizeof(float));
+    ws_floats = floats;
+    return DFX_OK;
+  }
+};
+
+namespace {
+
+// X (rows, ld = kpad[0]) -> last layer output Y (rows, ld_out); returns pointer + ld through refs.  Uses ws beyond `used`.
+int run_layers(dfx_shared_mlp *h, float *X, long long rows, float *bufA, float *bufB, float **Yout, int *ld_out,
+               hipStream_t st) {
+  float *in = X, *out = bufA;
+  for (int l = 0; l < h->L; ++l) {
+    const int N = h->ch[l + 1], ldy = (l + 1 < h->L) ? h->kpad[l + 1] : ((N + 7) & ~7);
+    if (ldy != N) DFX_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)rows * ldy, st));   // zero K padding
+    LinArgs a{};
+    a.M = (int)rows, a.N = N, a.K = h->kpad[l];
+    a.X = in, a.ldx = h->kpad[l];
+    a.W = h->wbuf + h->wn[l], a.b = h->wbuf + h->bn[l];
+    a.Y = out, a.ldy = ldy;
+    launch<EPI_RELU>(st, 1, a);
+    in = out;
+    out = (out == bufA) ? bufB : bufA;
+    *ld_out = ldy;
+  }
+  *Yout = in;
+  return dfx::check_launch("shared_mlp layers");
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfx_shared_mlp_create(dfx_shared_mlp **out, int n_layers, const int32_t *channels, const float *const *conv_w,
+                          const float *const *conv_b, const float *const *bn_w, const float *const *bn_b,
+                          const float *const *bn_mean, const float *const *bn_var, float eps, dfx_stream_t stream) {
+  DFX_REQUIRE(out && channels && conv_w, "shared_mlp_create: null argument");
+  *out = nullptr;
+  DFX_REQUIRE(n_layers >= 1 && n_layers <= MAX_LAYERS, "shared_mlp_create: %d layers outside [1,%d]", n_layers, MAX_LAYERS);
+  for (int l = 0; l <= n_layers; ++l) DFX_REQUIRE(channels[l] >= 1 && channels[l] <= 4096, "shared_mlp_create: bad width %d", channels[l]);
+  hipStream_t st = dfx::as_stream(stream);
+  dfx_shared_mlp *h = new dfx_shared_mlp();
+  h->L = n_layers;
+  size_t cur = 0;
+  bool fused = n_layers == 2 || n_layers == 3;
+  for (int l = 0; l <= n_layers; ++l) h->ch[l] = channels[l];
+  for (int l = 0; l < n_layers; ++l) {
+    // general path: K padded to 8; fused path: later layers consume whole 32-channel tiles of the previous layer
+    h->kpad[l] = (channels[l] + 7) & ~7;
+    const int npad = (channels[l + 1] + 31) & ~31;
+    h->wn[l] = cur, cur += (size_t)npad * h->kpad[l];
+    h->bn[l] = cur, cur += npad;
+    if (l + 1 < n_layers && channels[l + 1] > 128) fused = false;
+    if (l + 1 == n_layers && channels[l + 1] > 256) fused = false;
+  }
+  if (channels[0] > 160) fused = false;
+  h->fused_ok = fused;
+  int kp_fused[MAX_LAYERS];
+  if (fused)
+    for (int l = 0; l < n_layers; ++l) {
+      kp_fused[l] = l == 0 ? h->kpad[0] : ((channels[l] + 31) & ~31);
+      h->wp[l] = cur, cur += (size_t)((channels[l + 1] + 31) & ~31) * kp_fused[l];
+    }
+  if (hipMalloc(&h->wbuf, cur * sizeof(float)) != hipSuccess) {
+    delete h;
+    return dfx::set_error(DFX_ERR_ALLOC, "shared_mlp_create: %zu bytes", cur * sizeof(float));
+  }
+  (void)hipMemsetAsync(h->wbuf, 0, cur * sizeof(float), st);
+  for (int l = 0; l < n_layers; ++l) {
+    const bool has_bn = bn_w && bn_w[l];
+    if (!conv_w[l] || (has_bn && !(bn_b && bn_b[l] && bn_mean && bn_mean[l] && bn_var && bn_var[l]))) {
+      (void)hipFree(h->wbuf);
+      delete h;
+      return dfx::set_error(DFX_ERR_INVALID_ARG, "shared_mlp_create: null parameter of layer %d", l);
+    }
+    const int N = channels[l + 1], K = channels[l], npad = (N + 31) & ~31;
+    const float *cb = conv_b ? conv_b[l] : nullptr;
+    // natural layout (Kpad = multiple of 8)
+    k_fold<<<nblk((long long)npad * h->kpad[l]), 256, 0, st>>>(conv_w[l], cb, has_bn ? bn_w[l] : nullptr, has_bn ? bn_b[l] : nullptr,
+                                                               has_bn ? bn_mean[l] : nullptr, has_bn ? bn_var[l] : nullptr, eps,
+                                                               h->wbuf + h->wn[l], h->wbuf + h->bn[l],
+                                                               (fused && kp_fused[l] == h->kpad[l]) ? h->wbuf + h->wp[l] : nullptr, N, K,
+                                                               h->kpad[l], l == 0);
+    if (fused && kp_fused[l] != h->kpad[l]) {   // packed layout needs the 32-padded K: second pass into a scratch natural copy
+      float *scratch = nullptr;
+      if (hipMalloc(&scratch, ((size_t)npad * kp_fused[l] + npad) * sizeof(float)) != hipSuccess) {
+        (void)hipFree(h->wbuf);
+        delete h;
+        return dfx::set_error(DFX_ERR_ALLOC, "shared_mlp_create: scratch");
+      }
+      k_fold<<<nblk((long long)npad * kp_fused[l]), 256, 0, st>>>(conv_w[l], cb, has_bn ? bn_w[l] : nullptr, has_bn ? bn_b[l] : nullptr,
+                                                                  has_bn ? bn_mean[l] : nullptr, has_bn ? bn_var[l] : nullptr, eps, scratch,
+                                                                  scratch + (size_t)npad * kp_fused[l], h->wbuf + h->wp[l], N, K,
+                                                                  kp_fused[l], l == 0);
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(scratch);
+    }
+  }
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+    (void)hipFree(h->wbuf);
+    delete h;
+    return dfx::set_error(DFX_ERR_HIP, "shared_mlp_create: fold kernels failed");
+  }
+  *out = h;
+  return DFX_OK;
+}
+
+void dfx_shared_mlp_destroy(dfx_shared_mlp *h) {
+  if (!h) return;
+  if (h->wbuf) (void)hipFree(h->wbuf);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+}
+
+int dfx_shared_mlp_is_fused(const dfx_shared_mlp *h) { return h && h->fused_ok ? 1 : 0; }
+
+int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz, const float *features,
+                       const int32_t *idx, int use_xyz, float *out, int B, int N, int M, int ns, int C, int force_general,
+                       dfx_stream_t stream) {
+  DFX_REQUIRE(h && B >= 0 && N > 0 && M > 0 && ns > 0 && C >= 0, "sa_forward: bad sizes");
+  if (B == 0) return DFX_OK;
+  DFX_REQUIRE(xyz && out, "sa_forward: null pointer");
+  DFX_REQUIRE(C == 0 || features, "sa_forward: features missing");
+  DFX_REQUIRE(use_xyz || C > 0, "sa_forward: nothing to group (no features and use_xyz = 0)");
+  DFX_REQUIRE((use_xyz ? 3 : 0) + C == h->ch[0], "sa_forward: %d input channels, the MLP expects %d", (use_xyz ? 3 : 0) + C, h->ch[0]);
+  DFX_REQUIRE(idx || (M == 1 && ns == N), "sa_forward: without idx (GroupAll) M must be 1 and ns = N");
+  hipStream_t st = dfx::as_stream(stream);
+  const int Cout = h->ch[h->L];
+  if (h->fused_ok && !force_general) {
+    DFX_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * M, st));
+    FusedArgs a{};
+    a.xyz = xyz, a.new_xyz = new_xyz, a.feat = features, a.idx = idx, a.out = out;
+    a.L = h->L, a.U0 = h->kpad[0] >> 3, a.cout = Cout;
+    for (int l = 0; l < h->L; ++l) a.wp[l] = h->wbuf + h->wp[l], a.b[l] = h->wbuf + h->bn[l], a.nt[l] = (h->ch[l + 1] + 31) >> 5;
+    a.N = N, a.M = M, a.ns = ns, a.C = C, a.use_xyz = use_xyz;
+    a.tiles_per_centre = (ns + 31) >> 5;
+    a.total_tiles = (long long)B * M * a.tiles_per_centre;
+    DFX_REQUIRE(a.total_tiles / 4 + 1 < 0x7fffffffLL, "sa_forward: too many tiles");
+    k_sa_fused<<<(int)((a.total_tiles + 3) / 4), 256, 0, st>>>(a);
+    return dfx::check_launch("sa_forward (fused)");
+  }
+  const long long rows = (long long)B * M * ns;
+  size_t wmax = 0;
+  for (int l = 0; l < h->L; ++l) wmax = std::max<size_t>(wmax, (size_t)((h->ch[l + 1] + 7) & ~7));
+  const size_t nX = (size_t)rows * h->kpad[0], nY = (size_t)rows * wmax;
+  if (int e = h->reserve(nX + 2 * nY)) return e;
+  float *X = h->ws, *bufA = X + nX, *bufB = bufA + nY;
+  k_sa_rows<<<nblk((long long)nX), 256, 0, st>>>(xyz, new_xyz, features, idx, X, N, M, ns, C, use_xyz, h->kpad[0], (long long)nX);
+  float *Y;
+  int ld;
+  if (int e = run_layers(h, X, rows, bufA, bufB, &Y, &ld, st)) return e;
+  const long long tot = (long long)B * M * Cout;
+  k_rowmax<<<nblk(tot), 256, 0, st>>>(Y, out, M, ns, Cout, ld, tot);
+  return dfx::check_launch("sa_forward (general)");
+}
+
+int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *known, const float *unknow_feats,
+                       const float *known_feats, float *out, int B, int n, int m, int C1, int C2, dfx_stream_t stream) {
+  DFX_REQUIRE(h && B >= 0 && n > 0 && C1 >= 0 && C2 > 0, "fp_forward: bad sizes");
+  if (B == 0) return DFX_OK;
+  DFX_REQUIRE(known_feats && out && (C1 == 0 || unknow_feats), "fp_forward: null pointer");
+  DFX_REQUIRE(C1 + C2 == h->ch[0], "fp_forward: %d input channels, the MLP expects %d", C1 + C2, h->ch[0]);
+  DFX_REQUIRE(!known || (unknown && m >= 1), "fp_forward: bad known/unknown");
+  hipStream_t st = dfx::as_stream(stream);
+  const long long rows = (long long)B * n;
+  size_t wmax = 0;
+  for (int l = 0; l < h->L; ++l) wmax = std::max<size_t>(wmax, (size_t)((h->ch[l + 1] + 7) & ~7));
+  const size_t nX = (size_t)rows * h->kpad[0], nY = (size_t)rows * wmax, nD = (size_t)rows * 3;
+  if (int e = h->reserve(nX + 2 * nY + 2 * nD)) return e;
+  float *X = h->ws, *bufA = X + nX, *bufB = bufA + nY, *d2 = bufB + nY;
+  int32_t *idx = reinterpret_cast<int32_t *>(d2 + nD);
+  if (known) {
+    if (int e = dfx_three_nn_f32(unknown, known, d2, idx, B, n, m, stream)) return e;
+  }
+  k_fp_rows<<<nblk((long long)nX), 256, 0, st>>>(d2, known ? idx : nullptr, known_feats, unknow_feats, X, n, m, C1, C2, h->kpad[0],
+                                                 (long long)nX);
+  float *Y;
+  int ld;
+  if (int e = run_layers(h, X, rows, bufA, bufB, &Y, &ld, st)) return e;
+  const int Cout = h->ch[h->L];
+  const long long tot = rows * Cout;
+  k_rows_to_channels<<<nblk(tot), 256, 0, st>>>(Y, out, n, Cout, ld, tot);
+  return dfx::check_launch("fp_forward");
+}
+
+}  // extern "C"

@@ -255,6 +255,37 @@ int dfx_sample_latents(dfx_latents *h, const float *w_noise, const float *part_c
                        float *valid_out, float *noise_out, float *mean, float *logvar, float *params, int32_t *seg,
                        float *mean_per_point, float *logvar_per_point, dfx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * PointNet++ set-abstraction / feature-propagation layers, eval mode — the part of
+ * pointnet2_ops the reference leaves to PyTorch: QueryAndGroup / GroupAll
+ * (pointnet2_ops_lib/pointnet2_ops/pointnet2_utils.py:296-333, :349-381) + build_shared_mlp's Conv2d 1x1 +
+ * BatchNorm2d + ReLU stack (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:9-19) + max_pool2d over nsample
+ * (:62-70), and PointnetFPModule.forward (:170-209).  BatchNorm uses its running statistics (folded into the
+ * convolution at create time); training-mode statistics are not this path.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dfx_shared_mlp dfx_shared_mlp; /* opaque; owns folded/packed weights + a grow-only workspace */
+
+/* n_layers <= 4; channels[n_layers+1]; per layer device pointers: conv_w (Cout,Cin) [Conv2d weight (Cout,Cin,1,1)],
+ * conv_b (Cout) or NULL, and either all of bn_w/bn_b/bn_mean/bn_var (Cout) or bn_w[l] == NULL (no BatchNorm). */
+int dfx_shared_mlp_create(dfx_shared_mlp **out, int n_layers, const int32_t *channels, const float *const *conv_w,
+                          const float *const *conv_b, const float *const *bn_w, const float *const *bn_b,
+                          const float *const *bn_mean, const float *const *bn_var, float eps, dfx_stream_t stream);
+void dfx_shared_mlp_destroy(dfx_shared_mlp *h);
+int dfx_shared_mlp_is_fused(const dfx_shared_mlp *h); /* 1: the gather+MLP+max-pool kernel serves this MLP in one launch */
+
+/* _PointnetSAModuleBase.forward after the centres are known: grouper -> mlp -> max over nsample.
+ *   xyz (B,N,3); new_xyz (B,M,3) centres (NULL: no centring, GroupAll); features (B,C,N) or NULL (C = 0);
+ *   idx (B,M,ns) int32 from ball_query, or NULL = GroupAll (M = 1, ns = N, every point);
+ *   out (B, C_out, M).  force_general != 0 selects the layer-by-layer path (A/B and parity of the two paths). */
+int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz, const float *features,
+                       const int32_t *idx, int use_xyz, float *out, int B, int N, int M, int ns, int C, int force_general,
+                       dfx_stream_t stream);
+
+/* PointnetFPModule.forward: unknown (B,n,3), known (B,m,3) or NULL, unknow_feats (B,C1,n) or NULL (C1 = 0),
+ * known_feats (B,C2,m) [(B,C2,1) when known is NULL] -> out (B, C_out, n). */
+int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *known, const float *unknow_feats,
+                       const float *known_feats, float *out, int B, int n, int m, int C1, int C2, dfx_stream_t stream);
+
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

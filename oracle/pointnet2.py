@@ -100,13 +100,20 @@ def group_points_grad(grad_out, idx, N):
 
 
 def three_nn(unknown, known):
+    """ThreeNN.forward (pointnet2_utils.py:104-128): (sqrt(dist2), idx)."""
+    d2, idx = three_nn_dist2(unknown, known)
+    return np.sqrt(d2), idx
+
+
+def three_nn_dist2(unknown, known):
+    """What ``_ext.three_nn`` returns (interpolate_gpu.cu:13-69): squared distances."""
     unknown, known = _c(unknown, _F), _c(known, _F)
     B, n, _ = unknown.shape
     m = known.shape[1]
     d2 = np.zeros((B, n, 3), _F)
     idx = np.zeros((B, n, 3), _I)
     lib().oracle_three_nn(B, n, m, _p(unknown), _p(known), _p(d2), _p(idx))
-    return np.sqrt(d2), idx
+    return d2, idx
 
 
 def three_interpolate(points, idx, weight):

@@ -71,8 +71,7 @@ def sa_module_forward(W, xyz, features, n_layers, npoint=None, radius=None, nsam
 
 
 def fp_module_forward(W, unknown, known, unknow_feats, known_feats, n_layers, bn=True, prefix="mlp."):
-    d2, idx = o.three_nn(unknown, known)
-    d = np.sqrt(d2).astype(F32)                     # ThreeNN.forward returns sqrt(dist2) (pointnet2_utils.py:124-125)
+    d, idx = o.three_nn(unknown, known)             # ThreeNN.forward returns sqrt(dist2) (pointnet2_utils.py:124-125)
     rec = (F32(1.0) / (d + F32(1e-8))).astype(F32)
     w = (rec / rec.sum(axis=2, keepdims=True, dtype=F32)).astype(F32)
     f = o.three_interpolate(known_feats, idx, w)

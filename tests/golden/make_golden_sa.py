@@ -39,7 +39,7 @@ def install_ext_shim():
     ext.group_points_grad = lambda g, idx, N: t(o.group_points_grad(n(g), n(idx), N))
 
     def three_nn(unknown, known):
-        d2, idx = o.three_nn(n(unknown), n(known))
+        d2, idx = o.three_nn_dist2(n(unknown), n(known))   # _ext returns squared distances
         return t(d2), t(idx)
 
     ext.three_nn = three_nn

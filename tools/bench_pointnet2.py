@@ -56,3 +56,31 @@ line("three_nn B=128 n=2048 m=512", ms, 128 * ((2048 + 512) * 12 + 2048 * 24), f
 a, b = torch.randn(128, 2048, 3, device=dev), torch.randn(128, 2048, 3, device=dev)
 ms = timeit(lambda: ChamferFunction.apply(a, b))
 line("chamfer forward B=128 N=M=2048", ms, 128 * 2 * (2048 * 12 + 2048 * 8), f"{2 * 128 * 2048 * 2048 / (ms * 1e-3) / 1e9:7.1f} G pair-dist/s")
+
+# ---- set-abstraction layers of PointNet2SSG (python/difffacto/models/encoders/pointnet2.py:18-45), eval mode ----
+import numpy as np  # noqa: E402
+from difffacto_amd.pointnet2_ops.pointnet2_modules import PointnetSAModule  # noqa: E402
+
+B = 128
+xyz = torch.rand(B, 2048, 3, device=dev) * 2 - 1
+feats = torch.randn(B, 4, 2048, device=dev)
+specs = [dict(npoint=512, radius=0.2, nsample=64, mlp=[4, 64, 64, 128]), dict(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256]),
+         dict(mlp=[256, 256, 512, 1024])]
+with torch.no_grad():
+    for k, sp in enumerate(specs):
+        mod = PointnetSAModule(**{**sp, "mlp": list(sp["mlp"])}).to(dev).eval()
+        mlp = [sp["mlp"][0] + 3] + sp["mlp"][1:]
+        new_xyz = mod._centres(xyz)
+        M = 1 if new_xyz is None else new_xyz.shape[1]
+        ns = xyz.shape[1] if new_xyz is None else sp["nsample"]
+        rows = B * M * ns
+        flops = 2 * rows * sum(a * b for a, b in zip(mlp[:-1], mlp[1:]))
+        for name, fg in (("fused" if k < 2 else "general", False), ("general", True)):
+            if k == 2 and not fg:
+                continue
+            ms = timeit(lambda: mod._forward_native(0, xyz, new_xyz, feats, force_general=fg), iters=10)
+            print(f"SA{k + 1} group+MLP{mlp}+maxpool ({name:7s}) B={B} M={M} ns={ns}: {ms * 1e3:9.1f} us  {flops / (ms * 1e-3) / 1e12:6.1f} TFLOP/s fp32 "
+                  f"({flops / (ms * 1e-3) / 1e12 / 157.3 * 100:4.1f} % of the 157.3 TFLOP/s fp32 matrix peak); grouped tensor that never exists: {rows * mlp[0] * 4 / 1e6:.0f} MB")
+        ms = timeit(lambda: mod(xyz, feats), iters=5)
+        print(f"SA{k + 1} whole module (FPS + gather + ball query + fused MLP/pool): {ms * 1e3:9.1f} us")
+        xyz, feats = mod(xyz, feats)
