@@ -54,6 +54,14 @@ class LatentWeights(ctypes.Structure):
                [("blocks", AlignerBlockWeights * DFX_MAX_DEPTH)]
 
 
+class PointNetV2Weights(ctypes.Structure):
+    _fields_ = [("num_anchors", ctypes.c_int32), ("zdim", ctypes.c_int32), ("reweight_by_anchor", ctypes.c_int32),
+                ("bn_eps", ctypes.c_float)] + \
+               [(n, c_fp * 4) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var")] + \
+               [(n, (c_fp * 3) * 2) for n in ("head_w", "head_b")] + \
+               [(n, (c_fp * 2) * 2) for n in ("head_bn_w", "head_bn_b", "head_bn_mean", "head_bn_var")]
+
+
 # name -> (restype, argtypes); every symbol include/dfx.h declares
 _I, _F, _P, _U64, _SZ, _D = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_double
 SIGNATURES = {
@@ -88,7 +96,10 @@ SIGNATURES = {
     "dfx_part_aligner": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "dfx_sample_latents": (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dfx_shared_mlp_create": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_fp)] * 6 + [_F, _P]),
+    "dfx_shared_mlp_create": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_fp)] * 6 + [_F, ctypes.c_uint32, _P]),
+    "dfx_pointnet_v2_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(PointNetV2Weights), _P]),
+    "dfx_pointnet_v2_destroy": (None, [_P]),
+    "dfx_pointnet_v2_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_shared_mlp_destroy": (None, [_P]),
     "dfx_shared_mlp_is_fused": (_I, [_P]),
     "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

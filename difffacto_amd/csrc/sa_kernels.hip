@@ -278,6 +278,32 @@ __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
   }
 }
 
+// PointNetV2 pooling (pointnet.py:194-198): pooled[b][j][c] = max_n Y[b N + n][c] * attn[b][n][j] * scale
+// (points outside part j contribute 0 * x = 0, exactly as in the reference)
+template <int A>
+__global__ void k_masked_max(const float *__restrict__ Y, const float *__restrict__ attn, float *__restrict__ pooled, int N, int C,
+                             int ld, float scale, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = t % C;
+  const long long b = t / C;
+  float mx[A];
+#pragma unroll
+  for (int j = 0; j < A; ++j) mx[j] = -3.402823466e38f;
+  const float *y = Y + b * N * ld + c;
+  const float *w = attn + b * N * A;
+  for (int n = 0; n < N; ++n) {
+    const float v = y[(size_t)n * ld];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+#pragma clang fp contract(off)
+      mx[j] = fmaxf(mx[j], v * w[n * A + j] * scale);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < A; ++j) pooled[(b * A + j) * C + c] = mx[j];
+}
+
 inline int nblk(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -288,6 +314,7 @@ struct dfx_shared_mlp {
   int kpad[MAX_LAYERS] = {0};
   float *wbuf = nullptr;
   size_t wn[MAX_LAYERS] = {0}, bn[MAX_LAYERS] = {0}, wp[MAX_LAYERS] = {0};
+  unsigned relu_mask = ~0u;   // bit l: ReLU after layer l
   bool fused_ok = false;
   float *ws = nullptr;
   size_t ws_floats = 0;
@@ -316,7 +343,8 @@ int run_layers(dfx_shared_mlp *h, float *X, long long rows, float *bufA, float *
     a.X = in, a.ldx = h->kpad[l];
     a.W = h->wbuf + h->wn[l], a.b = h->wbuf + h->bn[l];
     a.Y = out, a.ldy = ldy;
-    launch<EPI_RELU>(st, 1, a);
+    if ((h->relu_mask >> l) & 1u) launch<EPI_RELU>(st, 1, a);
+    else launch<EPI_NONE>(st, 1, a);
     in = out;
     out = (out == bufA) ? bufB : bufA;
     *ld_out = ldy;
@@ -327,11 +355,22 @@ int run_layers(dfx_shared_mlp *h, float *X, long long rows, float *bufA, float *
 
 }  // namespace
 
+struct dfx_pointnet_v2 {
+  int A = 0, zdim = 0;
+  float scale = 1.f;
+  dfx_shared_mlp *trunk = nullptr;
+  float *hbuf = nullptr;                // folded head weights
+  size_t hw[2][3] = {{0}}, hb[2][3] = {{0}};
+  float *ws = nullptr;
+  size_t ws_floats = 0;
+};
+
 extern "C" {
 
 int dfx_shared_mlp_create(dfx_shared_mlp **out, int n_layers, const int32_t *channels, const float *const *conv_w,
                           const float *const *conv_b, const float *const *bn_w, const float *const *bn_b,
-                          const float *const *bn_mean, const float *const *bn_var, float eps, dfx_stream_t stream) {
+                          const float *const *bn_mean, const float *const *bn_var, float eps, uint32_t relu_mask,
+                          dfx_stream_t stream) {
   DFX_REQUIRE(out && channels && conv_w, "shared_mlp_create: null argument");
   *out = nullptr;
   DFX_REQUIRE(n_layers >= 1 && n_layers <= MAX_LAYERS, "shared_mlp_create: %d layers outside [1,%d]", n_layers, MAX_LAYERS);
@@ -339,8 +378,10 @@ int dfx_shared_mlp_create(dfx_shared_mlp **out, int n_layers, const int32_t *cha
   hipStream_t st = dfx::as_stream(stream);
   dfx_shared_mlp *h = new dfx_shared_mlp();
   h->L = n_layers;
+  h->relu_mask = relu_mask;
   size_t cur = 0;
-  bool fused = n_layers == 2 || n_layers == 3;
+  const unsigned all = (1u << n_layers) - 1u;
+  bool fused = (n_layers == 2 || n_layers == 3) && (relu_mask & all) == all;   // the pooled atomicMax needs values >= 0
   for (int l = 0; l <= n_layers; ++l) h->ch[l] = channels[l];
   for (int l = 0; l < n_layers; ++l) {
     // general path: K padded to 8; fused path: later layers consume whole 32-channel tiles of the previous layer
@@ -479,6 +520,114 @@ int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *kno
   const long long tot = rows * Cout;
   k_rows_to_channels<<<nblk(tot), 256, 0, st>>>(Y, out, n, Cout, ld, tot);
   return dfx::check_launch("fp_forward");
+}
+
+int dfx_pointnet_v2_create(dfx_pointnet_v2 **out, const dfx_pointnet_v2_weights *w, dfx_stream_t stream) {
+  DFX_REQUIRE(out && w, "pointnet_v2_create: null argument");
+  *out = nullptr;
+  DFX_REQUIRE(w->num_anchors >= 1 && w->num_anchors <= 8, "pointnet_v2_create: num_anchors %d outside [1,8]", w->num_anchors);
+  DFX_REQUIRE(w->zdim >= 8 && w->zdim % 8 == 0, "pointnet_v2_create: zdim %d must be a multiple of 8", w->zdim);
+  hipStream_t st = dfx::as_stream(stream);
+  dfx_pointnet_v2 *h = new dfx_pointnet_v2();
+  h->A = w->num_anchors, h->zdim = w->zdim, h->scale = w->reweight_by_anchor ? (float)w->num_anchors : 1.f;
+  const int32_t ch[5] = {3, 128, 128, 256, 512};
+  if (int e = dfx_shared_mlp_create(&h->trunk, 4, ch, w->conv_w, w->conv_b, w->bn_w, w->bn_b, w->bn_mean, w->bn_var, w->bn_eps,
+                                    0x7u /* no ReLU after bn4 (pointnet.py:193) */, stream)) {
+    delete h;
+    return e;
+  }
+  const int A = h->A, cin[3] = {512, 256, 128}, cout[3] = {256, 128, w->zdim};
+  size_t cur = 0;
+  for (int k = 0; k < 2; ++k)
+    for (int l = 0; l < 3; ++l) {   // rows padded to a multiple of 32: k_fold zero-fills the padding rows / biases
+      const size_t npad = ((size_t)A * cout[l] + 31) & ~(size_t)31;
+      h->hw[k][l] = cur, cur += npad * cin[l], h->hb[k][l] = cur, cur += npad;
+    }
+  if (hipMalloc(&h->hbuf, cur * sizeof(float)) != hipSuccess) {
+    dfx_shared_mlp_destroy(h->trunk);
+    delete h;
+    return dfx::set_error(DFX_ERR_ALLOC, "pointnet_v2_create: %zu bytes", cur * sizeof(float));
+  }
+  bool ok = true;
+  for (int k = 0; k < 2 && ok; ++k)
+    for (int l = 0; l < 3 && ok; ++l) {
+      const bool bn = l < 2;
+      ok = w->head_w[k][l] && w->head_b[k][l] && (!bn || (w->head_bn_w[k][l] && w->head_bn_b[k][l] && w->head_bn_mean[k][l] && w->head_bn_var[k][l]));
+      if (!ok) break;
+      const int N = A * cout[l], K = cin[l];   // grouped conv weight (A*Cout, Cin): group g = rows g*Cout.. (contiguous)
+      k_fold<<<nblk((long long)((N + 31) & ~31) * K), 256, 0, st>>>(w->head_w[k][l], w->head_b[k][l], bn ? w->head_bn_w[k][l] : nullptr,
+                                                                  bn ? w->head_bn_b[k][l] : nullptr, bn ? w->head_bn_mean[k][l] : nullptr,
+                                                                  bn ? w->head_bn_var[k][l] : nullptr, w->bn_eps, h->hbuf + h->hw[k][l],
+                                                                  h->hbuf + h->hb[k][l], nullptr, N, K, K, 0);
+    }
+  if (!ok || hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+    (void)hipFree(h->hbuf);
+    dfx_shared_mlp_destroy(h->trunk);
+    delete h;
+    return dfx::set_error(ok ? DFX_ERR_HIP : DFX_ERR_INVALID_ARG, "pointnet_v2_create: %s", ok ? "fold kernels failed" : "null head parameter");
+  }
+  *out = h;
+  return DFX_OK;
+}
+
+void dfx_pointnet_v2_destroy(dfx_pointnet_v2 *h) {
+  if (!h) return;
+  dfx_shared_mlp_destroy(h->trunk);
+  if (h->hbuf) (void)hipFree(h->hbuf);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+}
+
+int dfx_pointnet_v2_forward_f32(dfx_pointnet_v2 *h, const float *x, const float *attn, float *m, float *v, int B, int N,
+                                dfx_stream_t stream) {
+  DFX_REQUIRE(h && B >= 0 && N > 0, "pointnet_v2_forward: bad sizes");
+  if (B == 0) return DFX_OK;
+  DFX_REQUIRE(x && attn && m && v, "pointnet_v2_forward: null pointer");
+  hipStream_t st = dfx::as_stream(stream);
+  dfx_shared_mlp *t = h->trunk;
+  const long long rows = (long long)B * N;
+  const int A = h->A;
+  // trunk: rows (B N, 8) -> 128 -> 128 -> 256 -> 512
+  const size_t nX = (size_t)rows * t->kpad[0], nY = (size_t)rows * 512;
+  if (int e = t->reserve(nX + 2 * nY)) return e;
+  float *X = t->ws, *bufA = X + nX, *bufB = bufA + nY;
+  k_sa_rows<<<nblk((long long)nX), 256, 0, st>>>(x, nullptr, nullptr, nullptr, X, N, 1, N, 0, 1, t->kpad[0], (long long)nX);
+  float *Y;
+  int ld;
+  if (int e = run_layers(t, X, rows, bufA, bufB, &Y, &ld, st)) return e;
+  // pooled (B, A, 512) + head activations
+  const size_t nP = (size_t)B * A * 512, nH1 = (size_t)B * A * 256, nH2 = (size_t)B * A * 128;
+  if (nP + nH1 + nH2 > h->ws_floats) {
+    if (h->ws) (void)hipFree(h->ws);
+    h->ws = nullptr, h->ws_floats = 0;
+    if (hipMalloc(&h->ws, (nP + nH1 + nH2) * sizeof(float)) != hipSuccess) return dfx::set_error(DFX_ERR_ALLOC, "pointnet_v2_forward: workspace");
+    h->ws_floats = nP + nH1 + nH2;
+  }
+  float *P = h->ws, *H1 = P + nP, *H2 = H1 + nH1;
+  const long long tot = (long long)B * 512;
+  switch (A) {
+#define DFX_CASE(a) case a: k_masked_max<a><<<nblk(tot), 256, 0, st>>>(Y, attn, P, N, 512, ld, h->scale, tot); break;
+    DFX_CASE(1) DFX_CASE(2) DFX_CASE(3) DFX_CASE(4) DFX_CASE(5) DFX_CASE(6) DFX_CASE(7) DFX_CASE(8)
+#undef DFX_CASE
+  }
+  // per-part heads: grouped 1x1 convolutions = one linear layer per part (blockIdx.z = part)
+  const int cin[3] = {512, 256, 128}, cout[3] = {256, 128, h->zdim};
+  for (int k = 0; k < 2; ++k) {
+    const float *in = P;
+    float *outs[3] = {H1, H2, k == 0 ? m : v};
+    for (int l = 0; l < 3; ++l) {
+      LinArgs a{};
+      a.M = B, a.N = cout[l], a.K = cin[l];
+      a.X = in, a.ldx = A * cin[l], a.x_gs = cin[l];
+      a.W = h->hbuf + h->hw[k][l], a.w_gs = (long long)cout[l] * cin[l];
+      a.b = h->hbuf + h->hb[k][l], a.b_gs = cout[l];
+      a.Y = outs[l], a.ldy = A * cout[l], a.y_gs = cout[l];
+      if (l < 2) launch<EPI_RELU>(st, A, a);
+      else launch<EPI_NONE>(st, A, a);
+      in = outs[l];
+    }
+  }
+  return dfx::check_launch("pointnet_v2_forward");
 }
 
 }  // extern "C"

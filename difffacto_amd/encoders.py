@@ -12,20 +12,122 @@
 All math runs in libdfx (``dfx_sample_latents`` / ``dfx_part_aligner`` / ``dfx_flow_reverse``); the modules only hold
 parameters under the reference's ``state_dict`` keys and draw the random inputs with ``torch.randn`` exactly where
 the reference does.  Option combinations outside the shipped ``configs/gen_*.py`` raise ``NotImplementedError``.
-The encode-side (``PointNetV2`` + ``forward``: reconstruction / training) is not part of this path.
+``PointNetV2`` (the encode-side part encoder) is native in inference as well; the training losses of
+``PartEncoder.forward`` are not part of this path.
 """
+import ctypes
 import math
 import weakref
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import _ffi
 from .latents import LatentSampler
 from .modules import _BlockParams, decode
 
 
 def _unsupported(what):
     raise NotImplementedError(f"libdfx implements the shipped gen_* encoder configuration only: {what}")
+
+
+class PointNetV2(nn.Module):
+    """``ENCODERS['PointNetV2']`` (python/difffacto/models/encoders/pointnet.py:124-213): per-point MLP, attention-weighted
+    max-pool per part, per-part heads -> (m, v) of shape (B, num_anchors, zdim).  Same constructor arguments and parameter
+    names.  In inference (eval + no_grad) the whole forward is ``dfx_pointnet_v2_forward_f32``; with gradients / batch
+    statistics it runs on the module's own torch layers."""
+
+    def __init__(self, point_dim=3, zdim=1024, num_anchors=4, reweight_by_anchor=True, use_ln=False, per_part_mlp=False):
+        super().__init__()
+        if use_ln or not per_part_mlp or point_dim != 3:
+            _unsupported("PointNetV2 needs per_part_mlp=True, use_ln=False, point_dim=3 (configs/gen_*.py)")
+        self.reweight_by_anchor, self.per_part_mlp, self.zdim, self.num_anchors, self.use_ln = \
+            reweight_by_anchor, per_part_mlp, zdim, num_anchors, use_ln
+        widths = (point_dim, 128, 128, 256, 512)
+        for i in range(4):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        for i in range(4):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(widths[i + 1]))
+        A = num_anchors
+
+        def head():
+            return nn.Sequential(nn.Conv1d(512 * A, 256 * A, 1, groups=A), nn.BatchNorm1d(256 * A), nn.ReLU(),
+                                 nn.Conv1d(256 * A, 128 * A, 1, groups=A), nn.BatchNorm1d(128 * A), nn.ReLU(),
+                                 nn.Conv1d(128 * A, zdim * A, 1, groups=A))
+        self.mlp_m, self.mlp_v = head(), head()
+
+    # ---- libdfx handle, rebuilt when a parameter / buffer changes ----
+    def _handle(self):
+        ts = [t for t in list(self.parameters()) + list(self.buffers()) if t.dtype == torch.float32]
+        ver = tuple((t._version, t.data_ptr()) for t in ts)
+        if self.__dict__.get("_h") is None or self.__dict__.get("_ver") != ver:
+            self._close()
+            keep = []
+
+            def dp(t):
+                t = t.detach().to(torch.float32).contiguous()
+                keep.append(t)
+                return t.data_ptr()
+
+            w = _ffi.PointNetV2Weights()
+            w.num_anchors, w.zdim, w.reweight_by_anchor, w.bn_eps = self.num_anchors, self.zdim, int(self.reweight_by_anchor), self.bn1.eps
+            for i in range(4):
+                conv, bn = getattr(self, f"conv{i + 1}"), getattr(self, f"bn{i + 1}")
+                w.conv_w[i], w.conv_b[i] = dp(conv.weight), dp(conv.bias)
+                w.bn_w[i], w.bn_b[i], w.bn_mean[i], w.bn_var[i] = dp(bn.weight), dp(bn.bias), dp(bn.running_mean), dp(bn.running_var)
+            for k, head in enumerate((self.mlp_m, self.mlp_v)):
+                for l, ci in enumerate((0, 3, 6)):
+                    w.head_w[k][l], w.head_b[k][l] = dp(head[ci].weight), dp(head[ci].bias)
+                for l, bi in enumerate((1, 4)):
+                    bn = head[bi]
+                    w.head_bn_w[k][l], w.head_bn_b[k][l] = dp(bn.weight), dp(bn.bias)
+                    w.head_bn_mean[k][l], w.head_bn_var[k][l] = dp(bn.running_mean), dp(bn.running_var)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.conv1.weight.device):
+                rc = _ffi.lib().dfx_pointnet_v2_create(ctypes.byref(h), ctypes.byref(w), _ffi.current_stream())
+            _ffi.check(rc, "dfx_pointnet_v2_create")
+            self.__dict__["_h"], self.__dict__["_ver"] = h, ver
+        return self.__dict__["_h"]
+
+    def _close(self):
+        if self.__dict__.get("_h") is not None:
+            _ffi.lib().dfx_pointnet_v2_destroy(self.__dict__["_h"])
+            self.__dict__["_h"] = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def forward(self, x, attn_weight):
+        """x (B,N,3), attn_weight (B,N,num_anchors) -> (m, v), each (B, num_anchors, zdim)."""
+        B, N, _ = x.shape
+        A = self.num_anchors
+        if not self.training and not torch.is_grad_enabled():
+            if not x.is_cuda:
+                raise RuntimeError("PointNetV2: CPU not supported")
+            x = x.detach().to(torch.float32).contiguous()
+            attn_weight = attn_weight.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            m = torch.empty(B, A, self.zdim, dtype=torch.float32, device=x.device)
+            v = torch.empty_like(m)
+            with torch.cuda.device(x.device):
+                rc = _ffi.lib().dfx_pointnet_v2_forward_f32(self._handle(), _ffi.ptr(x), _ffi.ptr(attn_weight), _ffi.ptr(m), _ffi.ptr(v),
+                                                            B, N, _ffi.current_stream())
+            _ffi.check(rc, "dfx_pointnet_v2_forward_f32")
+            return m, v
+        # autograd / batch-statistics path on the module's own layers
+        h = x.transpose(1, 2)
+        for i in (1, 2, 3):
+            h = F.relu(getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h)))
+        h = self.bn4(self.conv4(h))
+        wx = h.unsqueeze(-1) * attn_weight.unsqueeze(1)
+        if self.reweight_by_anchor:
+            wx = wx * A
+        pooled = wx.max(dim=2)[0]                                  # (B, 512, A)
+        z = pooled.transpose(1, 2).reshape(B, -1, 1)
+        return self.mlp_m(z).reshape(B, A, -1), self.mlp_v(z).reshape(B, A, -1)
 
 
 class CouplingLayer(nn.Module):
@@ -128,8 +230,11 @@ class PartEncoderForTransformerDecoder(nn.Module):
                          "encode_ref / per_part_encoder")
         if selective_noise_sampling or selective_noise_sampling_global:
             _unsupported("selective_noise_sampling")
-        self.encoder_cfg = dict(encoder or {})          # PointNetV2 (encode side) is not on the generation path
+        self.encoder_cfg = dict(encoder or {})
         self.zdim = int(self.encoder_cfg.get("zdim", 1024))
+        if self.encoder_cfg.get("type", None) == "PointNetV2":   # encode side (get_part_code); not on the generation path
+            cfg = {k: v for k, v in self.encoder_cfg.items() if k != "type"}
+            self.encoder = PointNetV2(num_anchors=n_class, **cfg)
         self.n_class, self.prior_var, self.gen, self.use_flow = n_class, prior_var, gen, use_flow
         self.log_scale_var = math.log(scale_var)
         if isinstance(part_aligner, dict):
@@ -146,9 +251,10 @@ class PartEncoderForTransformerDecoder(nn.Module):
 
     def sampler(self):
         """The libdfx handle for the current parameters (rebuilt when a parameter was modified in place or reloaded)."""
-        ver = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
+        own = [p for n, p in self.named_parameters() if not n.startswith("encoder.")]
+        ver = tuple(p._version for p in own) + (own[0].device,)
         if self._sampler is None or ver != self._ver:
-            sd = {k: v for k, v in self.state_dict().items()}
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.")}
             al = self.part_aligner
             self._sampler = LatentSampler(sd, n_class=self.n_class, zdim=self.zdim, n_heads=al.n_heads, d_head=al.d_head,
                                           cimle=al.cimle, noise_dim=al.noise_dim, noise_scale=al.noise_scale,
@@ -156,6 +262,10 @@ class PartEncoderForTransformerDecoder(nn.Module):
                                           device=next(self.parameters()).device)
             self._ver = ver
         return self._sampler
+
+    def get_part_code(self, input, seg_flag):
+        """part_encoders.py:429-445 (per_part_encoder=False): (means, logvars) of the part codes, each (B, n_class, zdim)."""
+        return self.encoder(input, seg_flag)
 
     def get_params_from_part_code(self, part_code, valid_id, noise=None, **kwargs):
         return self.part_aligner(part_code, valid_id, noise=noise)                        # part_encoders.py:447-459
@@ -224,13 +334,13 @@ def attach(ref_encoder):
         prior_var=ref_encoder.prior_var, selective_noise_sampling=ref_encoder.selective_noise_sampling,
         selective_noise_sampling_global=ref_encoder.selective_noise_sampling_global,
         per_part_encoder=ref_encoder.per_part_encoder)
-    own = set(mirror.state_dict())
+    own = {k for k in mirror.state_dict() if not k.startswith("encoder.")}
     src = weakref.ref(ref_encoder)
 
     def sync():
         sd = {k: v for k, v in src().state_dict().items() if k in own}
         mirror.to(next(iter(sd.values())).device)
-        mirror.load_state_dict(sd)
+        mirror.load_state_dict(sd, strict=False)
 
     def sample_latents(*a, **k):
         ver = tuple(p._version for p in src().parameters())

@@ -83,7 +83,7 @@ class _NativeMLP:
             dev = self.layers[0][0].weight.device
             with torch.cuda.device(dev):
                 rc = _ffi.lib().dfx_shared_mlp_create(ctypes.byref(h), L, ch, *[ctypes.cast(a, ctypes.POINTER(_ffi.c_fp)) for a in args],
-                                                      float(eps), _ffi.current_stream())
+                                                      float(eps), 0xFFFFFFFF, _ffi.current_stream())
             _ffi.check(rc, "dfx_shared_mlp_create")
             self._h, self._ver = h, ver
         return self._h

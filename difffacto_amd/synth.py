@@ -116,6 +116,39 @@ def make_latent_weights(seed=0, **kw):
     return W
 
 
+def pointnet_v2_param_shapes(zdim=ZDIM, num_anchors=N_CLASS):
+    """(name, shape) of ``PointNetV2(per_part_mlp=True)`` (python/difffacto/models/encoders/pointnet.py:124-185), BN buffers included."""
+    s = []
+    for i, (cin, cout) in enumerate(((3, 128), (128, 128), (128, 256), (256, 512)), 1):
+        s += [(f"conv{i}.weight", (cout, cin, 1)), (f"conv{i}.bias", (cout,))]
+    for i, c in enumerate((128, 128, 256, 512), 1):
+        s += [(f"bn{i}.weight", (c,)), (f"bn{i}.bias", (c,)), (f"bn{i}.running_mean", (c,)), (f"bn{i}.running_var", (c,))]
+    A = num_anchors
+    for name in ("mlp_m", "mlp_v"):
+        for idx, (cin, cout) in ((0, (512, 256)), (3, (256, 128)), (6, (128, zdim))):
+            s += [(f"{name}.{idx}.weight", (cout * A, cin, 1)), (f"{name}.{idx}.bias", (cout * A,))]
+            if idx < 6:
+                s += [(f"{name}.{idx + 1}.{k}", (cout * A,)) for k in ("weight", "bias", "running_mean", "running_var")]
+    return s
+
+
+def make_pointnet_v2_weights(seed=0, **kw):
+    """Conv weights U(+-1/sqrt(fan_in)); biases / BN shifts / running means U(+-0.2); BN scales U(.8,1.2); running vars U(.5,1.5)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 177))
+    W = {}
+    for name, shape in pointnet_v2_param_shapes(**kw):
+        if name.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, size=shape)
+        elif name.endswith("running_mean") or name.endswith("bias"):
+            a = rng.uniform(-0.2, 0.2, size=shape)
+        elif len(shape) == 1:
+            a = rng.uniform(0.8, 1.2, size=shape)
+        else:
+            a = rng.uniform(-1, 1, size=shape) / np.sqrt(shape[1])
+        W[name] = a.astype(F32)
+    return W
+
+
 def chair_part_distribution():
     """Presence patterns of the 4 chair parts (back, seat, leg, arm): synthetic stand-in for
     ``shapenet_chair_part_distribution`` (datasets/dataset_utils.py:170-179); the data set is

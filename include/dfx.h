@@ -269,7 +269,8 @@ typedef struct dfx_shared_mlp dfx_shared_mlp; /* opaque; owns folded/packed weig
  * conv_b (Cout) or NULL, and either all of bn_w/bn_b/bn_mean/bn_var (Cout) or bn_w[l] == NULL (no BatchNorm). */
 int dfx_shared_mlp_create(dfx_shared_mlp **out, int n_layers, const int32_t *channels, const float *const *conv_w,
                           const float *const *conv_b, const float *const *bn_w, const float *const *bn_b,
-                          const float *const *bn_mean, const float *const *bn_var, float eps, dfx_stream_t stream);
+                          const float *const *bn_mean, const float *const *bn_var, float eps, uint32_t relu_mask,
+                          dfx_stream_t stream); /* relu_mask bit l: ReLU after layer l (build_shared_mlp: all ones) */
 void dfx_shared_mlp_destroy(dfx_shared_mlp *h);
 int dfx_shared_mlp_is_fused(const dfx_shared_mlp *h); /* 1: the gather+MLP+max-pool kernel serves this MLP in one launch */
 
@@ -285,6 +286,26 @@ int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz
  * known_feats (B,C2,m) [(B,C2,1) when known is NULL] -> out (B, C_out, n). */
 int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *known, const float *unknow_feats,
                        const float *known_feats, float *out, int B, int n, int m, int C1, int C2, dfx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PointNetV2 masked max-pool part encoder, eval mode — python/difffacto/models/encoders/pointnet.py:124-213
+ * with per_part_mlp=True: conv1..4 + BN (ReLU after the first three) over the points, x * attn_weight (* num_anchors)
+ * max-pooled over N per part (:194-198), per-part grouped-Conv1d heads 512 -> 256 -> 128 -> zdim for m and v (:200-203).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dfx_pointnet_v2_weights { /* fp32 device pointers, reference state_dict tensors */
+  int32_t num_anchors, zdim, reweight_by_anchor;
+  float bn_eps;
+  const float *conv_w[4], *conv_b[4];                           /* conv{1..4}.weight (Cout,Cin,1), .bias */
+  const float *bn_w[4], *bn_b[4], *bn_mean[4], *bn_var[4];      /* bn{1..4} */
+  const float *head_w[2][3], *head_b[2][3];                     /* [0] = mlp_m, [1] = mlp_v: .0 / .3 / .6 weight (A*Cout,Cin,1), bias */
+  const float *head_bn_w[2][2], *head_bn_b[2][2], *head_bn_mean[2][2], *head_bn_var[2][2]; /* .1 / .4 */
+} dfx_pointnet_v2_weights;
+typedef struct dfx_pointnet_v2 dfx_pointnet_v2;
+int dfx_pointnet_v2_create(dfx_pointnet_v2 **out, const dfx_pointnet_v2_weights *w, dfx_stream_t stream);
+void dfx_pointnet_v2_destroy(dfx_pointnet_v2 *h);
+/* x (B,N,3), attn_weight (B,N,num_anchors) -> m, v (B,num_anchors,zdim) */
+int dfx_pointnet_v2_forward_f32(dfx_pointnet_v2 *h, const float *x, const float *attn, float *m, float *v, int B, int N,
+                                dfx_stream_t stream);
 
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);

@@ -19,6 +19,7 @@ tables_T{10,100,1000}.npz  the schedule tables as the reference casts them to fp
 latents_*.npz        PartEncoder.sample_latents (part_encoders.py:1052-1110: flows in reverse, part
                      aligner, fixed_id mixing, K-fold repeat, seg-mask ids), torch.randn replayed; plus
                      one flow / the aligner called on their own
+pointnet_v2_*.npz    PointNetV2.forward (pointnet.py:187-213, eval-mode BatchNorm), the encode-side part encoder
 pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
                      (models/encoders/pointnet2_utils.py:84-104,41-57)
 """
@@ -168,6 +169,29 @@ def gen_latents(model, tag, S, K, npoints, seed, fixed_id, all_valid):
           float(np.abs(logvar.numpy()).max()))
 
 
+def gen_pointnet_v2(model, tag, B, N, seed):
+    """PointNetV2.forward (pointnet.py:187-213) in eval mode with randomised BN statistics."""
+    enc = model.encoder.encoder
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = synth.make_pointnet_v2_weights(seed=0)
+    sd = enc.state_dict()
+    assert {k for k in sd if not k.endswith("num_batches_tracked")} == set(W)
+    for k, a in W.items():
+        assert tuple(sd[k].shape) == a.shape, k
+        sd[k] = torch.from_numpy(a.copy())
+    enc.load_state_dict(sd)
+    enc.eval()
+    x = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    seg = rng.integers(0, 4, size=(B, N))
+    seg[0][seg[0] == 3] = 0                      # shape 0 has no part 3: its pooled features are max(0 * x) = 0
+    attn = np.eye(4, dtype=F32)[seg]
+    with torch.no_grad():
+        m, v = enc(torch.from_numpy(x), torch.from_numpy(attn))
+    np.savez_compressed(os.path.join(HERE, f"pointnet_v2_{tag}.npz"), x=x, attn=attn, m=m.numpy().astype(F32), v=v.numpy().astype(F32),
+                        weight_seed=np.array(0))
+    print("wrote pointnet_v2_" + tag, m.shape, float(m.abs().max()))
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -209,6 +233,7 @@ def main():
     load_latent_weights(model, synth.make_latent_weights(seed=0))
     gen_latents(model, "S3_K2_mixed", S=3, K=2, npoints=64, seed=31, fixed_id=[0, 0, 0, 0], all_valid=False)
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
+    gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
     if "--only-latents" in sys.argv:
         return
     gen_eps(model, "B2_N128_mixed", B=2, N=128, seed=11, all_valid=False, ts=[0, 3, 9])

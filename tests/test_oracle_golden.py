@@ -102,3 +102,12 @@ def test_oracle_sample_latents_matches_reference(tag):
         assert out[k].shape == ref.shape, k
         assert np.abs(out[k] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
     assert np.abs(out["ctx"][0] - g["ctx0"]).max() < 1e-3 and np.abs(out["ctx"][1] - g["ctx1"]).max() < 1e-4
+
+
+def test_oracle_pointnet_v2_matches_reference():
+    from oracle import pointnet_v2 as opv
+    g = np.load(os.path.join(GOLDEN, "pointnet_v2_B3_N200.npz"))
+    W = synth.make_pointnet_v2_weights(seed=int(g["weight_seed"]))
+    m, v = opv.forward(W, g["x"], g["attn"])
+    assert m.shape == g["m"].shape == (3, 4, 256)
+    assert np.abs(m - g["m"]).max() < 2e-5 and np.abs(v - g["v"]).max() < 2e-5
