@@ -118,4 +118,5 @@ struct dfx_denoiser {
   const float *win, *bin;   // proj_in weight (128,13), bias
   const float *const *wptrs_dev = nullptr;  // device array [depth][6] = {wq, wk, wv, wo, g2, be2}
   float *host_tables = nullptr;             // [8][T] fp32, order of dfx_denoiser_get_tables
+  double *host_ac_pv = nullptr;             // [2][T] float64: alphas_cumprod, posterior_variance (DDIM coefficients per call)
 };

@@ -12,6 +12,8 @@
 // tile as the A operand and the register-resident activation as the B operand, so consecutive GEMMs
 // chain register-to-register.  LayerNorm / softmax / GELU / posterior are fp32 VALU on the same
 // registers; the 4-key attention needs no q/k/v at run time (folded into A_s / M_s at prepare time).
+#include <cmath>
+
 #include "denoiser_internal.h"
 
 #pragma clang fp contract(fast)
@@ -26,6 +28,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 enum { MODE_EPS = 0, MODE_PSAMPLE = 1, MODE_CHAIN = 2 };
+constexpr int DDIM_MAX_STEPS = 128;
 
 struct KParams {
   DenoiserDev d;
@@ -41,6 +44,12 @@ struct KParams {
   float *xstart;         // p_sample: optional pred_xstart (B,3,N)
   unsigned long long seed;
   int B, N, t0, nsteps, ret_interval, mode;
+  // DDIM branch (anchored_diffusion.py:114-124, :368-377, :480-481): ddim_n > 0 = the executed timestep list
+  // (descending, e.g. 'quad' [32,23,16,10,5,2,0,0]) and xt_dir_coeff[t] = sqrt(1 - acp[t] - eta^2 posterior_variance[t])
+  int ddim_n;
+  float ddim_eta;
+  int ddim_t[DDIM_MAX_STEPS];
+  float ddim_xdc[DDIM_MAX_STEPS];
   unsigned long long *trace;  // debug: s_memtime stamps of waves 0 and 4 of workgroup 0 at every slot boundary
   int trace_cap;
   int debug;  // reserved (dfx_debug_flags)
@@ -484,6 +493,12 @@ __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout,
   eps[2] = e2 + xhalf(e2) + bout[2];
 }
 
+// Timestep of the step-th executed step (wave-uniform): T-1, T-2, ... for DDPM, the list for DDIM.
+__device__ __forceinline__ int step_t(const KParams &p, int step) {
+  if (p.ddim_n > 0) return p.ddim_t[step < p.ddim_n ? step : p.ddim_n - 1];
+  return p.t0 - step;
+}
+
 // Per-point state that lives in registers for the whole chain.
 struct PointState {
   float x[3], anc[3], var[3], L[3];
@@ -552,13 +567,21 @@ __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, 
     const float *tb = p.d.tab + (size_t)t * 8;
     const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
     const float nz = t != 0 ? 1.0f : 0.0f;
+    const bool ddim = p.ddim_n > 0;
+    const float sap = sqrtf(tb[6]);   // torch.sqrt of the fp32 alphas_cumprod_prev[t] (:481)
+    const float xdc = ddim ? p.ddim_xdc[step < p.ddim_n ? step : p.ddim_n - 1] : 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float x0 = sra * (ps.x[i] - ps.anc[i]) + ps.anc[i] - srm1 * ps.L[i] * eps[i];
       if (p.xstart && hf == 0) p.xstart[((size_t)s * 3 + i) * p.N + n] = x0;
-      const float mu = c1 * x0 + c2 * ps.x[i] + c3 * ps.anc[i];
       const float mv = pv * ps.var[i];
-      ps.x[i] = mu + nz * sqrtf(mv) * z[i];
+      if (ddim) {   // (x0 - a) sqrt(acp_prev) + a + L xt_dir_coeff eps + eta 1[t != 0] sqrt(var) z
+        const float xt_dir = ps.L[i] * xdc * eps[i];
+        ps.x[i] = (x0 - ps.anc[i]) * sap + ps.anc[i] + xt_dir + p.ddim_eta * nz * sqrtf(mv) * z[i];
+      } else {
+        const float mu = c1 * x0 + c2 * ps.x[i] + c3 * ps.anc[i];
+        ps.x[i] = mu + nz * sqrtf(mv) * z[i];
+      }
     }
   }
   if (p.mode == MODE_PSAMPLE) {
@@ -603,7 +626,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
   const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
 
   for (int step = 0; step < p.nsteps; ++step) {
-    const int t = p.t0 - step;
+    const int t = step_t(p, step);
     v16f h[4];
     proj_in_prenorm(h, ps.x, cpart, p.d.win_x + hf * 64, p.d.pre_gb + hf * 64);
     for (int b = 0; b < depth; ++b) {
@@ -717,7 +740,7 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
         src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
         dst = lds0 + L_BCONST + (st.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
       } else if (q == 22) {
-        src = reinterpret_cast<const char *>(bp.ct + (size_t)(p.t0 - st.step) * CT_ROW);
+        src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step) * CT_ROW);
         dst = ring + 17 * 1024;
       }
       dma1k(src, voff, dst);
@@ -822,7 +845,6 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   v16f h[4];
   bool done = false;
   for (int step = 0; step <= p.nsteps && !done; ++step) {
-    const int t = p.t0 - step;
     for (int b = 0; b < depth; ++b, ++seq) {
       const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
       const float *b1 = bc + hf * 16;
@@ -837,7 +859,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
         if (step > 0) {
           float eps[3];
           post_eps(h, wout, p.d.bout, eps);
-          done = step_epilogue(p, ps, eps, step - 1, t + 1);
+          done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1));
         }
         if (step == p.nsteps) done = true;
         if (!done) proj_in_prenorm(h, ps.x, cpart, winx, pregb);
@@ -966,6 +988,52 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
   KParams p{};
   p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed;
   p.B = B; p.N = N; p.t0 = t; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_PSAMPLE;
+  return launch(d, shape_ctx, p, as_stream(stream));
+}
+
+// DDIM coefficient list of a launch: steps are given ASCENDING like the reference's `self.steps` (:117-122) and
+// executed in reverse (:566); xt_dir_coeff in float64 like numpy (:116), cast to fp32 at use (extract_into_tensor).
+static int fill_ddim(const dfx_denoiser *d, KParams &p, const int32_t *steps, int n_steps, float eta, const char *who) {
+  DFX_REQUIRE(steps && n_steps >= 1 && n_steps <= DDIM_MAX_STEPS, "%s: 1..%d DDIM steps", who, DDIM_MAX_STEPS);
+  const int T = d->dev.T;
+  p.ddim_n = n_steps;
+  p.ddim_eta = eta;
+  for (int i = 0; i < n_steps; ++i) {
+    const int t = steps[n_steps - 1 - i];
+    DFX_REQUIRE(t >= 0 && t < T, "%s: step %d outside [0,%d)", who, t, T);
+    p.ddim_t[i] = t;
+    p.ddim_xdc[i] = (float)std::sqrt(1.0 - d->host_ac_pv[t] - (double)eta * (double)eta * d->host_ac_pv[(size_t)T + t]);
+  }
+  return DFX_OK;
+}
+
+int dfx_p_sample_ddim(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t, float eta,
+                      const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                      dfx_stream_t stream) {
+  const int rc = check_common(d, shape_ctx, seg, B, N, "p_sample_ddim");
+  if (rc) return rc < 0 ? rc : DFX_OK;
+  DFX_REQUIRE(x && x_prev, "p_sample_ddim: null pointer");
+  KParams p{};
+  const int32_t one[1] = {t};
+  if (int e = fill_ddim(d, p, one, 1, eta, "p_sample_ddim")) return e;
+  p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed;
+  p.B = B; p.N = N; p.t0 = t; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_PSAMPLE;
+  return launch(d, shape_ctx, p, as_stream(stream));
+}
+
+int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *steps,
+                          int n_steps, float eta, const float *x_T_noise, const float *step_noise, uint64_t seed,
+                          int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream) {
+  const int rc = check_common(d, shape_ctx, seg, B, N, "sample_chain_ddim");
+  if (rc) return rc < 0 ? rc : DFX_OK;
+  DFX_REQUIRE(pred, "sample_chain_ddim: null pred");
+  DFX_REQUIRE(!traj || ret_interval >= 1, "sample_chain_ddim: ret_interval must be >= 1 when traj is given");
+  KParams p{};
+  if (int e = fill_ddim(d, p, steps, n_steps, eta, "sample_chain_ddim")) return e;
+  DFX_REQUIRE(steps[0] == 0, "sample_chain_ddim: the step list must start at 0 (decode keeps the t == 0 sample as 'pred')");
+  p.seg = seg; p.noise = step_noise; p.xT_noise = x_T_noise; p.out = pred; p.traj = traj; p.seed = seed;
+  p.B = B; p.N = N; p.t0 = p.ddim_t[0]; p.nsteps = n_steps; p.ret_interval = ret_interval >= 1 ? ret_interval : 1;
+  p.mode = MODE_CHAIN;
   return launch(d, shape_ctx, p, as_stream(stream));
 }
 

@@ -234,7 +234,8 @@ struct Bump {
 inline int nblk(long long total) { return (int)((total + 255) / 256); }
 
 // anchored_diffusion.py:62-112, float64, then .float() as diffusion_utils.py:42-66 does at every use
-void host_tables(int T, double beta_1, double beta_T, std::vector<float> &tabs /* [8][T] */) {
+void host_tables(int T, double beta_1, double beta_T, std::vector<float> &tabs /* [8][T] */, std::vector<float> &acp_f32,
+                 std::vector<double> &ac_pv /* [2][T] */) {
   std::vector<double> betas(T), ac(T), acp(T);
   // np.linspace(beta_1, beta_T, num=T): arange(T) * step + start, last element forced to stop
   const double step = T > 1 ? (beta_T - beta_1) / (double)(T - 1) : 0.0;
@@ -250,7 +251,12 @@ void host_tables(int T, double beta_1, double beta_T, std::vector<float> &tabs /
     acp[i] = i ? ac[i - 1] : 1.0;
   }
   tabs.assign((size_t)8 * T, 0.f);
+  acp_f32.assign(T, 0.f);
+  ac_pv.assign((size_t)2 * T, 0.0);
   for (int i = 0; i < T; ++i) {
+    acp_f32[i] = (float)acp[i];
+    ac_pv[i] = ac[i];
+    ac_pv[(size_t)T + i] = betas[i] * (1.0 - acp[i]) / (1.0 - ac[i]);
     const double alpha = 1.0 - betas[i];
     const double sra = std::sqrt(1.0 / ac[i]);
     const double srm1 = std::sqrt(1.0 / ac[i] - 1);
@@ -350,6 +356,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     (void)hipStreamSynchronize(st);
     (void)hipFree(d->pool);
     delete[] d->host_tables;
+    delete[] d->host_ac_pv;
     delete d;
     return code;
   };
@@ -364,14 +371,18 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   } while (0)
 
   // ---- schedule tables (host, float64) ----
-  std::vector<float> tabs;
-  host_tables(T, beta_1, beta_T, tabs);
+  std::vector<float> tabs, acp_f32;
+  std::vector<double> ac_pv;
+  host_tables(T, beta_1, beta_T, tabs, acp_f32, ac_pv);
   d->host_tables = new float[(size_t)8 * T];
   std::memcpy(d->host_tables, tabs.data(), sizeof(float) * 8 * T);
+  d->host_ac_pv = new double[(size_t)2 * T];
+  std::memcpy(d->host_ac_pv, ac_pv.data(), sizeof(double) * 2 * T);
   std::vector<float> tab_dev((size_t)T * 8, 0.f);
   for (int i = 0; i < T; ++i) {
     for (int k = 0; k < 5; ++k) tab_dev[(size_t)i * 8 + k] = tabs[(size_t)k * T + i];
     tab_dev[(size_t)i * 8 + 5] = tabs[(size_t)5 * T + i];  // posterior_variance (sqrt taken with the point variance in-kernel)
+    tab_dev[(size_t)i * 8 + 6] = acp_f32[i];               // alphas_cumprod_prev (DDIM, anchored_diffusion.py:481)
   }
   TRY_HIP(hipMemcpyAsync(cv.tab, tab_dev.data(), sizeof(float) * T * 8, hipMemcpyHostToDevice, st));
 
@@ -482,6 +493,7 @@ void dfx_denoiser_destroy(dfx_denoiser *d) {
   if (!d) return;
   if (d->pool) (void)hipFree(d->pool);
   delete[] d->host_tables;
+  delete[] d->host_ac_pv;
   delete d;
 }
 

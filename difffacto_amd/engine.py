@@ -189,6 +189,47 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_sample_chain")
         return pred, traj
 
+    def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=0, want_xstart=False):
+        """One DDIM update (anchored_diffusion.py:368-377, :480-481)."""
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        seg = self._seg(seg, self.device)
+        B, _, N = x.shape
+        if noise is not None:
+            noise = noise.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            assert noise.shape == x.shape
+        out = torch.empty_like(x)
+        xs = torch.empty_like(x) if want_xstart else None
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_p_sample_ddim(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t), float(eta),
+                                             _ffi.ptr(noise), int(seed), _ffi.ptr(out), _ffi.ptr(xs), B, N,
+                                             _ffi.current_stream())
+        _ffi.check(rc, "dfx_p_sample_ddim")
+        return (out, xs) if want_xstart else out
+
+    def sample_chain_ddim(self, ctx, seg, steps, eta, x_T_noise=None, step_noise=None, seed=0, ret_interval=None):
+        """DDIM chain in one launch over the ascending step list ``steps`` (executed in reverse).  Returns
+        (pred, traj or None); traj slots follow ``snapshot_times``; only timesteps in ``steps`` are written."""
+        seg = self._seg(seg, self.device)
+        B, N = seg.shape
+        steps = [int(v) for v in steps]
+        f = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        x_T_noise, step_noise = f(x_T_noise), f(step_noise)
+        if step_noise is not None:
+            assert tuple(step_noise.shape) == (len(steps), B, 3, N)
+        pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
+        traj, ri = None, 0
+        if ret_interval:
+            ri = int(ret_interval)
+            traj = torch.zeros(_ffi.lib().dfx_chain_num_snapshots(self.num_timesteps, ri), B, N, 3, dtype=torch.float32,
+                               device=self.device)
+        arr = (ctypes.c_int32 * len(steps))(*steps)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_sample_chain_ddim(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), arr, len(steps), float(eta),
+                                                 _ffi.ptr(x_T_noise), _ffi.ptr(step_noise), int(seed), ri, _ffi.ptr(traj),
+                                                 _ffi.ptr(pred), B, N, _ffi.current_stream())
+        _ffi.check(rc, "dfx_sample_chain_ddim")
+        return pred, traj
+
     def snapshot_times(self, ret_interval):
         T = self.num_timesteps
         nk = T // ret_interval

@@ -163,7 +163,7 @@ class AnchoredDiffusion(nn.Module):
         super().__init__()
         if (mode != 'linear' or res or use_beta or rescale_timesteps or model_mean_type != 'epsilon'
                 or model_var_type != 'fixed_small' or clip_xstart or include_anchors or include_cov
-                or not learn_anchor or not learn_variance or guidance or ddim_sampling):
+                or not learn_anchor or not learn_variance or guidance):
             _unsupported("AnchoredDiffusion options other than those of configs/gen_*.py")
         if isinstance(net, nn.Module):
             self.model = net
@@ -183,7 +183,18 @@ class AnchoredDiffusion(nn.Module):
         self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
         self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
-        self.steps = list(range(self.num_timesteps))
+        self.ddim_sampling = bool(ddim_sampling)
+        if self.ddim_sampling:   # :114-124
+            import math
+            self.ddim_eta = ddim_eta
+            if ddim_discretize == 'uniform':
+                self.steps = list(range(0, self.num_timesteps, self.num_timesteps // ddim_nsteps))
+            elif ddim_discretize == 'quad':
+                self.steps = (np.linspace(0., math.sqrt(self.num_timesteps * 0.8), ddim_nsteps) ** 2).astype(np.int32).tolist()
+            else:
+                _unsupported(f"ddim_discretize={ddim_discretize!r}")
+        else:
+            self.steps = list(range(self.num_timesteps))
 
     # ---- sampling ----
     def _sc(self, ctx, valid_id):
@@ -194,6 +205,10 @@ class AnchoredDiffusion(nn.Module):
                  seed=0):
         """anchored_diffusion.py:450-484.  Returns {'sample', 'pred_xstart'} like the reference."""
         tt = t if isinstance(t, int) else int(t.reshape(-1)[0].item())
+        if self.ddim_sampling:
+            sample, xs = self.model.engine().p_sample_ddim(self._sc(ctx, valid_id), x, anchor_assignment, tt, self.ddim_eta,
+                                                           noise=noise, seed=seed, want_xstart=True)
+            return {"sample": sample, "pred_xstart": xs}
         sample, xs = self.model.engine().p_sample(self._sc(ctx, valid_id), x, anchor_assignment, tt, noise=noise,
                                                   seed=seed, want_xstart=True)
         return {"sample": sample, "pred_xstart": xs}
@@ -235,6 +250,10 @@ class AnchoredDiffusion(nn.Module):
     def sample_chain(self, ctx, anchor_assignment, valid_id=None, x_T_noise=None, step_noise=None, seed=0,
                      ret_interval=None):
         """Whole reverse chain in ONE persistent launch: (pred (B,N,3), traj (n_keep,B,N,3) | None)."""
+        if self.ddim_sampling:
+            return self.model.engine().sample_chain_ddim(self._sc(ctx, valid_id), anchor_assignment, self.steps, self.ddim_eta,
+                                                         x_T_noise=x_T_noise, step_noise=step_noise, seed=seed,
+                                                         ret_interval=ret_interval)
         return self.model.engine().sample_chain(self._sc(ctx, valid_id), anchor_assignment, x_T_noise=x_T_noise,
                                                 step_noise=step_noise, seed=seed, ret_interval=ret_interval)
 
@@ -256,6 +275,8 @@ def decode(diffusion, ctx, anchor_assignments, valid_id=None, ret_traj=False, re
                                         seed=seed, ret_interval=ret_interval if ret_traj else None)
     final = {"pred": pred}
     if ret_traj:
+        visited = set(diffusion.steps) | {diffusion.num_timesteps}   # the prior sample t = T is always yielded (:565)
         for k, t in enumerate(diffusion.model.engine().snapshot_times(ret_interval)):
-            final[t] = traj[k]
+            if t in visited:
+                final[t] = traj[k]
     return final

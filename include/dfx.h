@@ -179,6 +179,20 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
                      const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
                      int N, dfx_stream_t stream);
 
+/* DDIM branch (anchored_diffusion.py:114-124 step lists, :368-377 xt_dir, :480-481 update):
+ *   x_prev = (x0 - a) sqrt(acp_prev[t]) + a + L xt_dir_coeff[t] eps + eta 1[t != 0] sqrt(variance) z,
+ *   xt_dir_coeff = sqrt(1 - acp - eta^2 posterior_variance) (float64 on the host).
+ * `steps` is a HOST array, ascending like the reference's self.steps (e.g. 'quad': [0,0,2,5,10,16,23,32]); it is
+ * executed in reverse; n_steps <= 128; steps[0] must be 0 for the chain.  step_noise is (n_steps,B,3,N) or NULL.
+ * traj slot k still means t = (T / ret_interval - k) * ret_interval; slots of timesteps that are not visited are
+ * left untouched. */
+int dfx_p_sample_ddim(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t, float eta,
+                      const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                      dfx_stream_t stream);
+int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *steps,
+                          int n_steps, float eta, const float *x_T_noise, const float *step_noise, uint64_t seed,
+                          int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Chamfer-L2 — replaces the `chamfer` extension
  * (python/difffacto/metrics/chamfer_dist/chamfer.cu: forward :15-170, backward :173-230; bound in

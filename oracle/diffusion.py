@@ -26,7 +26,8 @@ F32 = np.float32
 class Tables:
     """anchored_diffusion.py:62-112 (mode='linear')."""
 
-    def __init__(self, num_timesteps, beta_1=1e-4, beta_T=0.02):
+    def __init__(self, num_timesteps, beta_1=1e-4, beta_T=0.02, ddim_sampling=False, ddim_nsteps=10,
+                 ddim_discretize="uniform", ddim_eta=1.0):
         T = int(num_timesteps)
         self.T = T
         betas = np.linspace(beta_1, beta_T, num=T, dtype=np.float64)
@@ -43,7 +44,18 @@ class Tables:
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef3 = 1.0 + ((np.sqrt(self.alphas_cumprod) - 1.0)
                                            * (np.sqrt(self.alphas_cumprod_prev) + np.sqrt(alphas))) / (1.0 - self.alphas_cumprod)
-        self.steps = list(range(T))  # ddim_sampling=False (:126)
+        self.ddim_sampling = bool(ddim_sampling)
+        self.ddim_eta = float(ddim_eta)
+        if ddim_sampling:   # :114-124
+            self.xt_dir_coeff = np.sqrt(1.0 - self.alphas_cumprod - ddim_eta * ddim_eta * self.posterior_variance)
+            if ddim_discretize == "uniform":
+                self.steps = list(range(0, T, T // ddim_nsteps))
+            elif ddim_discretize == "quad":
+                self.steps = (np.linspace(0.0, np.sqrt(T * 0.8), ddim_nsteps) ** 2).astype(np.int32).tolist()
+            else:
+                raise NotImplementedError(ddim_discretize)
+        else:
+            self.steps = list(range(T))  # :126
 
     def f32(self, name, t):
         """extract_into_tensor: float64 table -> .float() -> index (diffusion_utils.py:42-66)."""
@@ -78,16 +90,23 @@ def p_mean_variance(tb, W, x, t, anchors, ctx, variance, anchor_assignment, vali
 
 
 def p_sample(tb, W, x, t, anchors, ctx, variance, anchor_assignment, valid_id, noise):
-    """:450-484 — ``sample = mean + 1[t!=0] * sqrt(variance) * noise``."""
+    """:450-484 — ``sample = mean + 1[t!=0] * sqrt(variance) * noise``; with ddim_sampling (:368-377, :480-481)
+    ``(x0 - a) sqrt(acp_prev[t]) + a + L xt_dir_coeff[t] eps + eta 1[t!=0] sqrt(variance) noise``."""
     out = p_mean_variance(tb, W, x, t, anchors, ctx, variance, anchor_assignment, valid_id)
     nz = F32(1.0 if t != 0 else 0.0)
-    sample = (out["mean"] + nz * np.sqrt(out["variance"]).astype(F32) * noise).astype(F32)
+    if tb.ddim_sampling:
+        L = np.sqrt(variance).astype(F32)
+        xt_dir = (L * tb.f32("xt_dir_coeff", t) * out["eps"]).astype(F32)
+        sample = ((out["pred_xstart"] - anchors) * np.sqrt(tb.f32("alphas_cumprod_prev", t)).astype(F32) + anchors + xt_dir
+                  + F32(tb.ddim_eta) * nz * np.sqrt(out["variance"]).astype(F32) * noise).astype(F32)
+    else:
+        sample = (out["mean"] + nz * np.sqrt(out["variance"]).astype(F32) * noise).astype(F32)
     return dict(sample=sample, pred_xstart=out["pred_xstart"], eps=out["eps"])
 
 
 def p_sample_loop_progressive(tb, W, anchors, ctx, variance, anchor_assignment, valid_id, x_T_noise, step_noise):
     """:528-588.  ``x_T_noise`` (B,3,N) is the randn of :564; ``step_noise[i]`` is the
-    randn_like drawn inside the i-th executed p_sample call (i = 0 for t = T-1), shape (T,B,3,N)."""
+    randn_like drawn inside the i-th executed p_sample call (i = 0 for t = T-1), shape (len(steps),B,3,N)."""
     pcd = (np.sqrt(variance).astype(F32) * x_T_noise + anchors).astype(F32)
     yield tb.T, dict(sample=pcd)
     for n, i in enumerate(tb.steps[::-1]):

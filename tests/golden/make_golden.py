@@ -80,14 +80,15 @@ def gen_eps(model, tag, B, N, seed, all_valid, ts):
     print("wrote denoiser_eps_" + tag, {k: float(np.abs(v).max()) for k, v in out.items()})
 
 
-def gen_chain(model, tag, B, N, seed, all_valid, T):
+def gen_chain(model, tag, B, N, seed, all_valid, T, prefix="chain"):
     assert model.diffusion.num_timesteps == T
+    T_exec = len(model.diffusion.steps)
     case = make_case(B, N, seed, all_valid)
     anchors, variance, ctx, va, sg = to_ref_inputs(*case)
     rng = np.random.Generator(np.random.PCG64(seed + 200))
     x_T_noise = rng.standard_normal((B, 3, N)).astype(F32)
-    step_noise = rng.standard_normal((T, B, 3, N)).astype(F32)
-    queue = [torch.from_numpy(step_noise[i]) for i in range(T)]
+    step_noise = rng.standard_normal((T_exec, B, 3, N)).astype(F32)
+    queue = [torch.from_numpy(step_noise[i]) for i in range(T_exec)]
     real_randn, real_randn_like = torch.randn, torch.randn_like
 
     def fake_randn(*shape, **kw):   # anchored_diffusion.py:564
@@ -97,7 +98,7 @@ def gen_chain(model, tag, B, N, seed, all_valid, T):
     def fake_randn_like(x):         # anchored_diffusion.py:476 (drawn every step incl. t=0)
         return queue.pop(0)
 
-    samples = {}
+    samples, seq = {}, []
     try:
         torch.randn, torch.randn_like = fake_randn, fake_randn_like
         with torch.no_grad():
@@ -105,21 +106,27 @@ def gen_chain(model, tag, B, N, seed, all_valid, T):
                     [B, 3, N], anchors=anchors, variance=variance, ctx=ctx, noise=None,
                     anchor_assignment=sg.to(torch.int32), valid_id=va, device="cpu"):
                 samples[t] = out["sample"].numpy().astype(F32)
+                seq.append(out["sample"].numpy().astype(F32))
         assert not queue
         # decode dict through the network-level entry point (anchor_gen.py:145-169)
-        queue = [torch.from_numpy(step_noise[i]) for i in range(T)]
+        queue = [torch.from_numpy(step_noise[i]) for i in range(T_exec)]
         model.ret_traj, model.ret_interval = True, 5
         with torch.no_grad():
             dec = model.decode(anchors, ctx=ctx, variance=variance, anchor_assignments=sg.to(torch.int32),
                                valid_id=va, device="cpu")
     finally:
         torch.randn, torch.randn_like = real_randn, real_randn_like
-    traj = np.stack([samples[t] for t in range(T, -1, -1)])   # index 0 = x_T, index T = x_0
+    order = [T] + list(model.diffusion.steps[::-1])            # executed t sequence (DDPM: T, T-1, ..., 0)
+    if prefix == "chain":
+        traj = np.stack([samples[t] for t in range(T, -1, -1)])   # index 0 = x_T, index T = x_0
+    else:
+        traj = np.stack(seq)                                    # execution order; 'quad' may visit t = 0 twice
     dec_np = {f"decode_{k}": v.numpy().astype(F32) for k, v in dec.items()}
-    np.savez_compressed(os.path.join(HERE, f"chain_T{T}_{tag}.npz"), part_code=case[0], mean=case[1], logvar=case[2],
+    extra = {} if prefix == "chain" else {"steps": np.array(model.diffusion.steps), "ddim_eta": np.array(model.diffusion.ddim_eta, F32)}
+    np.savez_compressed(os.path.join(HERE, f"{prefix}_T{T}_{tag}.npz"), **extra, part_code=case[0], mean=case[1], logvar=case[2],
                         valid=case[3], seg=case[4], x_T_noise=x_T_noise, step_noise=step_noise, traj=traj,
                         ret_interval=np.array(5), weight_seed=np.array(0), **dec_np)
-    print(f"wrote chain_T{T}_{tag}", traj.shape, float(np.abs(traj[-1]).max()), sorted(dec_np))
+    print(f"wrote {prefix}_T{T}_{tag}", traj.shape, float(np.abs(traj[-1]).max()), sorted(dec_np))
 
 
 def load_latent_weights(model, W):
@@ -234,6 +241,18 @@ def main():
     gen_latents(model, "S3_K2_mixed", S=3, K=2, npoints=64, seed=31, fixed_id=[0, 0, 0, 0], all_valid=False)
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
     gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
+    if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:
+        from difffacto.config.config import get_cfg
+        from difffacto.utils.registry import build_from_cfg, MODELS
+        cfg = get_cfg()
+        for name, kw in (("quad8_eta1", dict(ddim_nsteps=8, ddim_discretize="quad", ddim_eta=1.0)),
+                         ("uniform5_eta0", dict(ddim_nsteps=5, ddim_discretize="uniform", ddim_eta=0.0))):
+            cfg.model["num_timesteps"] = 40
+            cfg.model["diffusion"].update(ddim_sampling=True, **kw)
+            dm = build_from_cfg(cfg.model, MODELS).eval()
+            load_denoiser_weights(dm, W)
+            gen_chain(dm, name + "_B2_N64", B=2, N=64, seed=61, all_valid=False, T=40, prefix="ddim")
+        cfg.model["diffusion"].update(ddim_sampling=False)
     if "--only-latents" in sys.argv:
         return
     gen_eps(model, "B2_N128_mixed", B=2, N=128, seed=11, all_valid=False, ts=[0, 3, 9])

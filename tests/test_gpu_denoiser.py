@@ -209,3 +209,53 @@ def test_argument_validation(eng10):
     # empty batch is a no-op
     out = eng10.eps(ctx, torch.zeros(0, 3, 64), torch.zeros(0, 64, dtype=torch.int32), 0)
     assert out.shape == (0, 3, 64)
+
+
+# ------------------------------------------------------------------------------------------------ DDIM
+DDIM_CASES = {"quad8_eta1": dict(ddim_nsteps=8, ddim_discretize="quad", ddim_eta=1.0),
+              "uniform5_eta0": dict(ddim_nsteps=5, ddim_discretize="uniform", ddim_eta=0.0)}
+
+
+@pytest.mark.parametrize("name", sorted(DDIM_CASES))
+def test_ddim_chain_f32_vs_reference_golden(W, name):
+    """The reference's ddim_sampling branch (its own p_sample_loop_progressive / decode, T = 40) vs dfx_sample_chain_ddim
+    (one launch) and dfx_p_sample_ddim (generator protocol); 'quad' visits t = 0 twice."""
+    g = np.load(os.path.join(GOLDEN, f"ddim_T40_{name}_B2_N64.npz"))
+    eng = _engine(W, 40, "f32")
+    ctx = _prep(eng, g)
+    seg = torch.from_numpy(g["seg"])
+    steps, eta, ri = g["steps"].tolist(), float(g["ddim_eta"]), int(g["ret_interval"])
+    pred, traj = eng.sample_chain_ddim(ctx, seg, steps, eta, x_T_noise=torch.from_numpy(g["x_T_noise"]),
+                                       step_noise=torch.from_numpy(g["step_noise"]), ret_interval=ri)
+    assert np.abs(pred.cpu().numpy() - g["decode_pred"]).max() < TOL_F32_CHAIN
+    for k, t in enumerate(eng.snapshot_times(ri)):
+        if f"decode_{t}" in g.files:
+            assert np.abs(traj[k].cpu().numpy() - g[f"decode_{t}"]).max() < TOL_F32_CHAIN, t
+    x = torch.from_numpy(g["traj"][0]).cuda()
+    for i, t in enumerate(steps[::-1]):
+        x = eng.p_sample_ddim(ctx, x, seg, t, eta, noise=torch.from_numpy(g["step_noise"][i]))
+        assert np.abs(x.cpu().numpy() - g["traj"][i + 1]).max() < TOL_F32_CHAIN, (i, t)
+
+
+def test_ddim_pipelined_bf16_vs_f32_and_module_api(W):
+    """N = 256 takes the LDS-pipelined bf16 kernel: compare with the exact fp32 path on identical noise, through the
+    AnchoredDiffusion mirror built with the reference's ddim arguments."""
+    from difffacto_amd.modules import AnchoredDiffusion, decode
+    from test_modules_cpu import DIFF_CFG
+    B, N, T = 4, 256, 100
+    out = {}
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=9)
+    seg = torch.from_numpy(synth.make_seg_mask(valid, N)).cuda()
+    ctx = [torch.from_numpy(part_code).cuda(), torch.from_numpy(np.concatenate([mean, np.exp(logvar)], 1).astype(np.float32)).cuda()]
+    rng = np.random.Generator(np.random.PCG64(4))
+    xT = torch.from_numpy(rng.standard_normal((B, 3, N)).astype(np.float32))
+    for prec in ("f32", "bf16"):
+        d = AnchoredDiffusion(num_timesteps=T, precision=prec, **{**DIFF_CFG, "ddim_sampling": True, "ddim_nsteps": 25,
+                                                                  "ddim_discretize": "quad", "ddim_eta": 1.0})
+        d.model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+        d = d.cuda().eval()
+        sn = torch.from_numpy(rng.standard_normal((len(d.steps), B, 3, N)).astype(np.float32)) if prec == "f32" else sn
+        out[prec] = decode(d, ctx, seg, valid_id=torch.from_numpy(valid).cuda(), ret_traj=True, ret_interval=10, x_T_noise=xT, step_noise=sn)
+        assert sorted(k for k in out[prec] if k != "pred") == sorted({t for t in d.steps if t and t % 10 == 0} | {T})
+    err = (out["f32"]["pred"] - out["bf16"]["pred"]).abs().max().item()
+    assert torch.isfinite(out["bf16"]["pred"]).all() and err < 5e-2, err

@@ -111,3 +111,25 @@ def test_oracle_pointnet_v2_matches_reference():
     m, v = opv.forward(W, g["x"], g["attn"])
     assert m.shape == g["m"].shape == (3, 4, 256)
     assert np.abs(m - g["m"]).max() < 2e-5 and np.abs(v - g["v"]).max() < 2e-5
+
+
+DDIM_CASES = {"quad8_eta1": dict(ddim_nsteps=8, ddim_discretize="quad", ddim_eta=1.0),
+              "uniform5_eta0": dict(ddim_nsteps=5, ddim_discretize="uniform", ddim_eta=0.0)}
+
+
+@pytest.mark.parametrize("name", sorted(DDIM_CASES))
+def test_ddim_chain_matches_reference(W, name):
+    """the ddim_sampling branch (anchored_diffusion.py:114-124, :368-377, :480-481), T = 40."""
+    g = np.load(os.path.join(GOLDEN, f"ddim_T40_{name}_B2_N64.npz"))
+    tb = df.Tables(40, ddim_sampling=True, **DDIM_CASES[name])
+    assert tb.steps == g["steps"].tolist()
+    anchors, variance = _per_point(g)
+    traj = np.stack([out["sample"] for _, out in df.p_sample_loop_progressive(
+        tb, W, anchors, _ctx(g), variance, g["seg"], g["valid"], g["x_T_noise"], g["step_noise"])])
+    assert traj.shape == g["traj"].shape
+    assert np.abs(traj - g["traj"]).max() < TOL_CHAIN
+    dec = df.decode(tb, W, anchors, _ctx(g), variance, g["seg"], g["valid"], g["x_T_noise"], g["step_noise"],
+                    ret_traj=True, ret_interval=int(g["ret_interval"]))
+    assert sorted("decode_" + str(k) for k in dec) == sorted(k for k in g.files if k.startswith("decode_"))
+    for k, v in dec.items():
+        assert np.abs(v - g["decode_" + str(k)]).max() < TOL_CHAIN
