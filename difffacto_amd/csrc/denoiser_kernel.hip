@@ -28,7 +28,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 enum { MODE_EPS = 0, MODE_PSAMPLE = 1, MODE_CHAIN = 2 };
+#ifdef DFX_AB_NO_DDIM   // A/B build without the DDIM branch (tools/ab.sh)
+constexpr int DDIM_MAX_STEPS = 1;
+#else
 constexpr int DDIM_MAX_STEPS = 128;
+#endif
 
 struct KParams {
   DenoiserDev d;
@@ -495,7 +499,9 @@ __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout,
 
 // Timestep of the step-th executed step (wave-uniform): T-1, T-2, ... for DDPM, the list for DDIM.
 __device__ __forceinline__ int step_t(const KParams &p, int step) {
+#ifndef DFX_AB_NO_DDIM
   if (p.ddim_n > 0) return p.ddim_t[step < p.ddim_n ? step : p.ddim_n - 1];
+#endif
   return p.t0 - step;
 }
 
@@ -567,7 +573,11 @@ __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, 
     const float *tb = p.d.tab + (size_t)t * 8;
     const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
     const float nz = t != 0 ? 1.0f : 0.0f;
+#ifdef DFX_AB_NO_DDIM
+    const bool ddim = false;
+#else
     const bool ddim = p.ddim_n > 0;
+#endif
     const float sap = sqrtf(tb[6]);   // torch.sqrt of the fp32 alphas_cumprod_prev[t] (:481)
     const float xdc = ddim ? p.ddim_xdc[step < p.ddim_n ? step : p.ddim_n - 1] : 0.f;
 #pragma unroll

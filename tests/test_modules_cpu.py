@@ -39,7 +39,9 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         TransformerNet(**bad)
     with pytest.raises(NotImplementedError):
-        AnchoredDiffusion(num_timesteps=10, **{**DIFF_CFG, "ddim_sampling": True})
+        AnchoredDiffusion(num_timesteps=10, **{**DIFF_CFG, "model_mean_type": "start_x"})
+    d = AnchoredDiffusion(num_timesteps=1000, **{**DIFF_CFG, "ddim_sampling": True, "ddim_nsteps": 25, "ddim_discretize": "quad"})
+    assert d.steps[:4] == [0, 1, 5, 12] and len(d.steps) == 25 and d.steps[-1] == 800   # anchored_diffusion.py:120-122
 
 
 def test_cpu_forward_is_rejected():
