@@ -125,9 +125,43 @@ __device__ __forceinline__ void ln_stats(const v16f (&h)[4], float &mean, float 
   rstd = 1.0f / sqrtf(q * (1.0f / 128.0f) + 1e-5f);  // nn.LayerNorm eps (attention.py:348-349, 286-287)
 }
 
+// bf16 path: single pass over the registers (sum and sum of squares on four independent chains each), variance as
+// E[x^2] - mean^2 in fp32 — the normalised value is rounded to bf16 right after, so the cancellation error
+// (<= 2^-24 E[x^2] / var relative) is far below the operand rounding — and one FMA per element for the normalisation.
+__device__ __forceinline__ void ln_stats_fast(const v16f (&h)[4], float &mean, float &rstd) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r & 3] += h[c][r];
+      q[r & 3] = fmaf(h[c][r], h[c][r], q[r & 3]);
+    }
+  float st = (s[0] + s[1]) + (s[2] + s[3]), qt = (q[0] + q[1]) + (q[2] + q[3]);
+  st += xhalf(st);
+  qt += xhalf(qt);
+  mean = st * (1.0f / 128.0f);
+  const float var = fmaxf(fmaf(-mean, mean, qt * (1.0f / 128.0f)), 0.f);
+  rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+}
+
 template <int PREC>
 __device__ __forceinline__ void ln_to_act(const v16f (&h)[4], Act<PREC> (&xn)[4]) {
   float mean, rstd;
+#if !defined(DFX_LN_TWO_PASS)
+  if (PREC == DFX_PREC_BF16) {
+    ln_stats_fast(h, mean, rstd);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v16f t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(h[c][r], rstd, nmr);
+      xn[c].set(t);
+    }
+    return;
+  }
+#endif
   ln_stats(h, mean, rstd);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -192,6 +226,7 @@ __device__ __forceinline__ void philox_normal3(unsigned long long seed, unsigned
 
 // proj_in (13 -> 128) + pre_norm.  x-columns on the VALU; the 10 per-part-constant inputs
 // (anchors | variances | onehot, attention.py:398-408) are pre-folded into cpart[seg].
+template <bool FAST = false>
 __device__ __forceinline__ void proj_in_prenorm(v16f (&h)[4], const float (&x)[3], const float *cpart,
                                                 const float4 *winx, const float2 *pregb) {
 #pragma unroll
@@ -207,7 +242,8 @@ __device__ __forceinline__ void proj_in_prenorm(v16f (&h)[4], const float (&x)[3
       }
     }
   float mean, rstd;
-  ln_stats(h, mean, rstd);
+  if (FAST) ln_stats_fast(h, mean, rstd);
+  else ln_stats(h, mean, rstd);
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -477,17 +513,20 @@ __device__ __forceinline__ void attn_softmax(v16f &sim, Act<DFX_PREC_BF16> &pa, 
 }
 
 // post_norm (affine folded into W_out) + proj_out (128 -> 3) on the VALU.
+template <bool FAST = false>
 __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout, const float (&bout)[4],
                                          float (&eps)[3]) {
   float mean, rstd;
-  ln_stats(h, mean, rstd);
+  if (FAST) ln_stats_fast(h, mean, rstd);
+  else ln_stats(h, mean, rstd);
+  const float nmr = -mean * rstd;
   float e0 = 0.f, e1 = 0.f, e2 = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float4 w = wout[c * 16 + r];
-      const float v = (h[c][r] - mean) * rstd;
+      const float v = FAST ? fmaf(h[c][r], rstd, nmr) : (h[c][r] - mean) * rstd;
       e0 = fmaf(w.x, v, e0);
       e1 = fmaf(w.y, v, e1);
       e2 = fmaf(w.z, v, e2);
@@ -868,11 +907,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       if (b == 0) {
         if (step > 0) {
           float eps[3];
-          post_eps(h, wout, p.d.bout, eps);
+          post_eps<true>(h, wout, p.d.bout, eps);
           done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1));
         }
         if (step == p.nsteps) done = true;
-        if (!done) proj_in_prenorm(h, ps.x, cpart, winx, pregb);
+        if (!done) proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
       }
       if (done) break;
       ln_to_act<PREC>(h, xn);
