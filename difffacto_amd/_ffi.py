@@ -104,6 +104,9 @@ SIGNATURES = {
     "dfx_shared_mlp_is_fused": (_I, [_P]),
     "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfx_fp_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfx_q_sample_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dfx_denoise_eps_t": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dfx_masked_mse_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_p_sample_ddim": (_I, [_P, _P, _P, _P, _I, _F, _P, _U64, _P, _P, _I, _I, _P]),
     "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),

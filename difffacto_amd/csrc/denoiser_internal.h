@@ -81,7 +81,8 @@ struct DenoiserDev {
   const float2 *pre_gb;  // cvec order {gamma, beta} of pre_norm
   const float4 *wout;    // cvec order {W_out[0][ch] g, W_out[1][ch] g, W_out[2][ch] g, 0}, g = post_norm gamma
   float bout[4];         // proj_out bias + W_out beta_post
-  const float *tab;      // [T][8]: sra, srm1, c1, c2, c3, sqrt(post_var), 0, 0
+  const float *tab;      // [T][8]: sra, srm1, c1, c2, c3, posterior_variance, alphas_cumprod_prev, 0
+  const float *qtab;     // [T][2]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod (q_sample)
 };
 
 // Per-batch shape context (regions inside the caller's buffer).

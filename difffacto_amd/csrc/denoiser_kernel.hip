@@ -50,6 +50,7 @@ struct KParams {
   int B, N, t0, nsteps, ret_interval, mode;
   // DDIM branch (anchored_diffusion.py:114-124, :368-377, :480-481): ddim_n > 0 = the executed timestep list
   // (descending, e.g. 'quad' [32,23,16,10,5,2,0,0]) and xt_dir_coeff[t] = sqrt(1 - acp[t] - eta^2 posterior_variance[t])
+  const int32_t *t_shape;  // MODE_EPS only: per-shape timestep (B,), training-style evaluation (anchored_diffusion.py:760-853)
   int ddim_n;
   float ddim_eta;
   int ddim_t[DDIM_MAX_STEPS];
@@ -537,7 +538,8 @@ __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout,
 }
 
 // Timestep of the step-th executed step (wave-uniform): T-1, T-2, ... for DDPM, the list for DDIM.
-__device__ __forceinline__ int step_t(const KParams &p, int step) {
+__device__ __forceinline__ int step_t(const KParams &p, int step, int s) {
+  if (p.t_shape) return __builtin_amdgcn_readfirstlane(p.t_shape[s]);   // wave-uniform (one shape per wave)
 #ifndef DFX_AB_NO_DDIM
   if (p.ddim_n > 0) return p.ddim_t[step < p.ddim_n ? step : p.ddim_n - 1];
 #endif
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
   const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
 
   for (int step = 0; step < p.nsteps; ++step) {
-    const int t = step_t(p, step);
+    const int t = step_t(p, step, s);
     v16f h[4];
     proj_in_prenorm(h, ps.x, cpart, p.d.win_x + hf * 64, p.d.pre_gb + hf * 64);
     for (int b = 0; b < depth; ++b) {
@@ -789,7 +791,7 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
         src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
         dst = lds0 + L_BCONST + (st.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
       } else if (q == 22) {
-        src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step) * CT_ROW);
+        src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step, s) * CT_ROW);
         dst = ring + 17 * 1024;
       }
       dma1k(src, voff, dst);
@@ -908,7 +910,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
         if (step > 0) {
           float eps[3];
           post_eps<true>(h, wout, p.d.bout, eps);
-          done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1));
+          done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1, s));
         }
         if (step == p.nsteps) done = true;
         if (!done) proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
@@ -962,6 +964,46 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #undef DFX_STAMP
 #undef DFX_NEXT_RECORD
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
+}
+
+// q_sample (anchored_diffusion.py:148-173): x_t = sqrt_acp[t] (x0 - a) + a + sqrt_1m_acp[t] L noise, per-shape t,
+// anchors / variances of the point's part from the shape context (learn_anchor, learn_variance)
+__global__ void k_q_sample(const float *__restrict__ part, const float *__restrict__ qtab, const int32_t *__restrict__ seg,
+                           const int32_t *__restrict__ t, const float *__restrict__ x0, const float *__restrict__ noise,
+                           float *__restrict__ out, int N, int T, long long total) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = i % N, c = (i / N) % 3;
+  const long long b = i / ((long long)3 * N);
+  const int sg = seg[b * N + n];
+  int tt = t[b];
+  tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+  const float a = part[b * 32 + c * 4 + sg], L = sqrtf(part[b * 32 + 12 + c * 4 + sg]);
+  out[i] = qtab[tt * 2] * (x0[i] - a) + a + qtab[tt * 2 + 1] * L * noise[i];
+}
+
+// ((target - pred)^2 * flags).mean(1).sum() / flags.sum()  (anchored_diffusion.py:840-847); float64 accumulation
+__global__ void k_masked_mse(const float *__restrict__ target, const float *__restrict__ pred, const float *__restrict__ flags,
+                             double *__restrict__ acc, int N, long long total) {
+  double s = 0.0, f = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / N;
+    const int n = i % N;
+    float m = 0.f;
+    const float fl = flags ? flags[i] : 1.f;
+    for (int c = 0; c < 3; ++c) {
+      const float dlt = target[(b * 3 + c) * N + n] - pred[(b * 3 + c) * N + n];
+      m += dlt * dlt * fl;
+    }
+    s += (double)(flags ? m / 3.0f : m);
+    f += (double)fl;
+  }
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o), f += __shfl_xor(f, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, s), atomicAdd(acc + 1, f);
+}
+__global__ void k_mse_finish(const double *acc, float *loss, int has_flags, double count) {
+  *loss = (float)(has_flags ? acc[0] / acc[1] : acc[0] / count);
 }
 
 bool g_force_direct = false;
@@ -1084,6 +1126,42 @@ int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const in
   p.B = B; p.N = N; p.t0 = p.ddim_t[0]; p.nsteps = n_steps; p.ret_interval = ret_interval >= 1 ? ret_interval : 1;
   p.mode = MODE_CHAIN;
   return launch(d, shape_ctx, p, as_stream(stream));
+}
+
+int dfx_denoise_eps_t(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, const int32_t *t,
+                      float *eps, int B, int N, dfx_stream_t stream) {
+  const int rc = check_common(d, shape_ctx, seg, B, N, "denoise_eps_t");
+  if (rc) return rc < 0 ? rc : DFX_OK;
+  DFX_REQUIRE(x && eps && t, "denoise_eps_t: null pointer");
+  KParams p{};
+  p.x_in = x; p.seg = seg; p.out = eps; p.t_shape = t;
+  p.B = B; p.N = N; p.t0 = 0; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_EPS;
+  return launch(d, shape_ctx, p, as_stream(stream));
+}
+
+int dfx_q_sample_f32(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *t, const float *x_start,
+                     const float *noise, float *x_t, int B, int N, dfx_stream_t stream) {
+  const int rc = check_common(d, shape_ctx, seg, B, N, "q_sample");
+  if (rc) return rc < 0 ? rc : DFX_OK;
+  DFX_REQUIRE(t && x_start && noise && x_t, "q_sample: null pointer");
+  ShapeCtxView v;
+  shape_ctx_view(&v, const_cast<void *>(shape_ctx), B, d->dev.depth, d->dev.prec);
+  const long long total = (long long)B * 3 * N;
+  k_q_sample<<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>(v.part, d->dev.qtab, seg, t, x_start, noise, x_t, N, d->dev.T, total);
+  return check_launch("q_sample");
+}
+
+int dfx_masked_mse_f32(const float *target, const float *pred, const float *flags, double *workspace2, float *loss, int B,
+                       int N, dfx_stream_t stream) {
+  DFX_REQUIRE(B >= 1 && N >= 1 && target && pred && workspace2 && loss, "masked_mse: bad argument");
+  hipStream_t st = as_stream(stream);
+  DFX_HIP_TRY(hipMemsetAsync(workspace2, 0, 2 * sizeof(double), st));
+  const long long total = (long long)B * N;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  k_masked_mse<<<(int)blocks, 256, 0, st>>>(target, pred, flags, workspace2, N, total);
+  k_mse_finish<<<1, 1, 0, st>>>(workspace2, loss, flags != nullptr, (double)B * 3.0 * N);
+  return check_launch("masked_mse");
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }

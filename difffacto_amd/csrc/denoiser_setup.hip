@@ -305,7 +305,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
 
   // two passes over the same carving code: measure, then place
   struct Carve {
-    float *sinus, *h1, *h2, *temb, *vt, *y, *tab;
+    float *sinus, *h1, *h2, *temb, *vt, *y, *tab, *qtab;
     float4 *win_x, *wout;
     float2 *pre_gb;
     float *win, *bin;
@@ -324,6 +324,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     cv.vt = bp.take<float>((size_t)T * INNER);
     cv.y = bp.take<float>((size_t)T * INNER);
     cv.tab = bp.take<float>((size_t)T * 8);
+    cv.qtab = bp.take<float>((size_t)T * 2);
     cv.win_x = bp.take<float4>(INNER);
     cv.wout = bp.take<float4>(INNER);
     cv.pre_gb = bp.take<float2>(INNER);
@@ -385,6 +386,9 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     tab_dev[(size_t)i * 8 + 6] = acp_f32[i];               // alphas_cumprod_prev (DDIM, anchored_diffusion.py:481)
   }
   TRY_HIP(hipMemcpyAsync(cv.tab, tab_dev.data(), sizeof(float) * T * 8, hipMemcpyHostToDevice, st));
+  std::vector<float> qtab_dev((size_t)T * 2);
+  for (int i = 0; i < T; ++i) qtab_dev[(size_t)i * 2] = tabs[(size_t)6 * T + i], qtab_dev[(size_t)i * 2 + 1] = tabs[(size_t)7 * T + i];
+  TRY_HIP(hipMemcpyAsync(cv.qtab, qtab_dev.data(), sizeof(float) * T * 2, hipMemcpyHostToDevice, st));
 
   // ---- sinusoidal embedding (host; nets/utils.py:7-24) ----
   std::vector<float> sinus((size_t)T * TEMB);
@@ -482,6 +486,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   d->dev.pre_gb = cv.pre_gb;
   d->dev.wout = cv.wout;
   d->dev.tab = cv.tab;
+  d->dev.qtab = cv.qtab;
   d->win = cv.win;
   d->bin = cv.bin;
   d->wptrs_dev = cv.wptrs;

@@ -189,6 +189,49 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_sample_chain")
         return pred, traj
 
+    # ---- training-style forward evaluation (no dropout, no gradients) ----
+    def _tvec(self, t, B):
+        t = torch.as_tensor(t).detach().to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        assert t.numel() == B
+        return t
+
+    def q_sample(self, ctx, seg, x_start, t, noise):
+        """anchored_diffusion.py:148-173 with per-shape t (B,)."""
+        f = lambda a: a.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        x_start, noise, seg = f(x_start), f(noise), self._seg(seg, self.device)
+        B, _, N = x_start.shape
+        out = torch.empty_like(x_start)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_q_sample_f32(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), _ffi.ptr(self._tvec(t, B)), _ffi.ptr(x_start),
+                                            _ffi.ptr(noise), _ffi.ptr(out), B, N, _ffi.current_stream())
+        _ffi.check(rc, "dfx_q_sample_f32")
+        return out
+
+    def eps_t(self, ctx, x, seg, t):
+        """TransformerNet.forward with one timestep per shape: t (B,)."""
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        seg = self._seg(seg, self.device)
+        B, _, N = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_denoise_eps_t(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), _ffi.ptr(self._tvec(t, B)),
+                                             _ffi.ptr(out), B, N, _ffi.current_stream())
+        _ffi.check(rc, "dfx_denoise_eps_t")
+        return out
+
+    def masked_mse(self, target, pred, flags=None):
+        """((target - pred)^2 * flags).mean(1).sum() / flags.sum() (anchored_diffusion.py:840-847) -> 0-dim tensor."""
+        f = lambda a: None if a is None else a.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        target, pred, flags = f(target), f(pred), f(flags)
+        B, _, N = target.shape
+        ws = torch.empty(2, dtype=torch.float64, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _ffi.lib().dfx_masked_mse_f32(_ffi.ptr(target), _ffi.ptr(pred), _ffi.ptr(flags), _ffi.ptr(ws), _ffi.ptr(loss), B, N,
+                                              _ffi.current_stream())
+        _ffi.check(rc, "dfx_masked_mse_f32")
+        return loss[0]
+
     def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=0, want_xstart=False):
         """One DDIM update (anchored_diffusion.py:368-377, :480-481)."""
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()

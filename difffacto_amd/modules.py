@@ -257,6 +257,24 @@ class AnchoredDiffusion(nn.Module):
         return self.model.engine().sample_chain(self._sc(ctx, valid_id), anchor_assignment, x_T_noise=x_T_noise,
                                                 step_noise=step_noise, seed=seed, ret_interval=ret_interval)
 
+    def training_losses(self, x_start, t, anchors=None, variance=None, ctx=None, reduce=True, anchor_assignment=None,
+                        valid_id=None, flags=None, noise=None):
+        """anchored_diffusion.py:760-853, forward value only: {'mse_loss'} of the epsilon objective at per-shape
+        timesteps ``t`` (B,), evaluated natively (q_sample -> denoiser -> masked MSE).  Available in inference
+        (``eval()`` + ``no_grad``): gradients / dropout are training and not libdfx's path."""
+        if self.training or torch.is_grad_enabled():
+            _unsupported("training_losses with gradients or in train() mode (dropout, autograd)")
+        if not reduce:
+            _unsupported("training_losses(reduce=False)")
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        eng = self.model.engine()
+        sc = self._sc(ctx, valid_id)
+        x_t = eng.q_sample(sc, anchor_assignment, x_start, t, noise)
+        eps = eng.eps_t(sc, x_t, anchor_assignment, t)
+        fl = None if flags is None else flags.reshape(flags.shape[0], -1)
+        return {"mse_loss": eng.masked_mse(noise, eps, fl)}
+
     @torch.no_grad()
     def q_sample(self, x_start, t, anchors, noise=None, variance=None):
         """Forward process (:148-173), host-side elementwise helper (not on the sampling path)."""

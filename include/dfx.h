@@ -179,6 +179,19 @@ int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t
                      const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
                      int N, dfx_stream_t stream);
 
+/* Training-style forward evaluation (forward only; anchored_diffusion.py:760-853 in eval mode):
+ *   dfx_q_sample_f32    x_t = sqrt_acp[t_b] (x0 - a) + a + sqrt(1 - acp[t_b]) L noise   (:148-173), t (B,) int32 on the device
+ *   dfx_denoise_eps_t   dfx_denoise_eps with one timestep per shape
+ *   dfx_masked_mse_f32  ((target - pred)^2 * flags).mean(1).sum() / flags.sum()  (:840-847; flags (B,N) or NULL = plain mean);
+ *                       workspace2 = 2 doubles on the device, loss = 1 float on the device
+ * Dropout and gradients are not part of this path. */
+int dfx_q_sample_f32(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *t, const float *x_start,
+                     const float *noise, float *x_t, int B, int N, dfx_stream_t stream);
+int dfx_denoise_eps_t(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, const int32_t *t,
+                      float *eps, int B, int N, dfx_stream_t stream);
+int dfx_masked_mse_f32(const float *target, const float *pred, const float *flags, double *workspace2, float *loss, int B,
+                       int N, dfx_stream_t stream);
+
 /* DDIM branch (anchored_diffusion.py:114-124 step lists, :368-377 xt_dir, :480-481 update):
  *   x_prev = (x0 - a) sqrt(acp_prev[t]) + a + L xt_dir_coeff[t] eps + eta 1[t != 0] sqrt(variance) z,
  *   xt_dir_coeff = sqrt(1 - acp - eta^2 posterior_variance) (float64 on the host).

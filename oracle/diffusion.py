@@ -144,3 +144,19 @@ def gather_params(seg, mean, var):
     a = np.take_along_axis(mean, np.broadcast_to(idx, (mean.shape[0], 3, idx.shape[2])), axis=2)
     v = np.take_along_axis(var, np.broadcast_to(idx, (var.shape[0], 3, idx.shape[2])), axis=2)
     return a.astype(F32), v.astype(F32)
+
+
+def training_losses(tb, W, x_start, t, anchors, variance, ctx, anchor_assignment, valid_id, flags, noise):
+    """:760-853 in eval mode (no dropout) for the shipped config (EPSILON target, fixed_small, reduce=True):
+    x_t = q_sample(x0, t); eps_hat = model(x_t, t); loss = ((noise - eps_hat)^2 * flags).mean(1).sum() / flags.sum().
+    ``t`` is a per-shape int array (B,); flags (B,1,N) or None."""
+    x_t = q_sample(tb, x_start, t, anchors, noise, variance)
+    eps = dn.transformer_net_forward(W, x_t, np.asarray(t, dtype=np.int64), ctx, anchors.transpose(0, 2, 1),
+                                     variance.transpose(0, 2, 1), valid_id, anchor_assignment)
+    d = ((noise - eps) ** 2).astype(F32)
+    if flags is not None:
+        d = (d * flags).astype(F32)
+        loss = d.mean(axis=1, dtype=F32).sum(dtype=F32) / flags.sum(dtype=F32)
+    else:
+        loss = d.mean(dtype=F32)
+    return dict(mse_loss=F32(loss), x_t=x_t, eps=eps)

@@ -19,6 +19,8 @@ tables_T{10,100,1000}.npz  the schedule tables as the reference casts them to fp
 latents_*.npz        PartEncoder.sample_latents (part_encoders.py:1052-1110: flows in reverse, part
                      aligner, fixed_id mixing, K-fold repeat, seg-mask ids), torch.randn replayed; plus
                      one flow / the aligner called on their own
+train_fwd_*.npz      AnchoredDiffusion.training_losses / q_sample (anchored_diffusion.py:760-853, :148-173) in eval mode
+                     (dropout off), per-shape timesteps, with and without flags
 pointnet_v2_*.npz    PointNetV2.forward (pointnet.py:187-213, eval-mode BatchNorm), the encode-side part encoder
 pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
                      (models/encoders/pointnet2_utils.py:84-104,41-57)
@@ -199,6 +201,27 @@ def gen_pointnet_v2(model, tag, B, N, seed):
     print("wrote pointnet_v2_" + tag, m.shape, float(m.abs().max()))
 
 
+def gen_training_losses(model, tag, B, N, seed, T):
+    """AnchoredDiffusion.training_losses (anchored_diffusion.py:760-853) in eval mode (dropout off), per-shape t."""
+    case = make_case(B, N, seed, False)
+    anchors, variance, ctx, va, sg = to_ref_inputs(*case)
+    rng = np.random.Generator(np.random.PCG64(seed + 300))
+    x0 = (np.sqrt(variance.numpy()) * rng.standard_normal((B, 3, N)).astype(F32) * 0.5 + anchors.numpy()).astype(F32)
+    noise = rng.standard_normal((B, 3, N)).astype(F32)
+    t = rng.integers(0, T, size=(B,)).astype(np.int64)
+    flags = (rng.uniform(size=(B, 1, N)) > 0.2).astype(F32)
+    out = {}
+    with torch.no_grad():
+        for name, fl in (("flags", torch.from_numpy(flags)), ("noflags", None)):
+            r = model.diffusion.training_losses(torch.from_numpy(x0), torch.from_numpy(t), anchors=anchors, variance=variance, ctx=ctx,
+                                                anchor_assignment=sg.to(torch.int32), valid_id=va, flags=fl, noise=torch.from_numpy(noise))
+            out["mse_loss_" + name] = np.array(float(r["mse_loss"]), F32)
+        x_t = model.diffusion.q_sample(torch.from_numpy(x0), torch.from_numpy(t), anchors, noise=torch.from_numpy(noise), variance=variance)
+    np.savez_compressed(os.path.join(HERE, f"train_fwd_{tag}.npz"), part_code=case[0], mean=case[1], logvar=case[2], valid=case[3], seg=case[4],
+                        x_start=x0, noise=noise, t=t, flags=flags, x_t=x_t.numpy().astype(F32), weight_seed=np.array(0), **out)
+    print("wrote train_fwd_" + tag, out)
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -241,6 +264,7 @@ def main():
     gen_latents(model, "S3_K2_mixed", S=3, K=2, npoints=64, seed=31, fixed_id=[0, 0, 0, 0], all_valid=False)
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
     gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
+    gen_training_losses(model, "B3_N64_T10", B=3, N=64, seed=71, T=10)
     if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:
         from difffacto.config.config import get_cfg
         from difffacto.utils.registry import build_from_cfg, MODELS

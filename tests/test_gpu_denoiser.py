@@ -259,3 +259,44 @@ def test_ddim_pipelined_bf16_vs_f32_and_module_api(W):
         assert sorted(k for k in out[prec] if k != "pred") == sorted({t for t in d.steps if t and t % 10 == 0} | {T})
     err = (out["f32"]["pred"] - out["bf16"]["pred"]).abs().max().item()
     assert torch.isfinite(out["bf16"]["pred"]).all() and err < 5e-2, err
+
+
+# ---------------------------------------------------------------------- training-style forward (eval mode)
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16", 5e-3)])
+def test_training_losses_forward_vs_reference_golden(W, prec, tol):
+    """q_sample + per-shape-t denoiser + masked MSE vs the reference's own training_losses (eval mode, dropout off)."""
+    from difffacto_amd.modules import AnchoredDiffusion
+    from test_modules_cpu import DIFF_CFG
+    g = np.load(os.path.join(GOLDEN, "train_fwd_B3_N64_T10.npz"))
+    d = AnchoredDiffusion(num_timesteps=10, precision=prec, **DIFF_CFG)
+    d.model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    d = d.cuda().eval()
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ctx = [c(g["part_code"]), c(np.concatenate([g["mean"], np.exp(g["logvar"])], 1).astype(np.float32))]
+    seg, valid = c(g["seg"]), c(g["valid"])
+    eng = d.model.engine()
+    sc = d._sc(ctx, valid)
+    x_t = eng.q_sample(sc, seg, c(g["x_start"]), g["t"], c(g["noise"]))
+    assert np.abs(x_t.cpu().numpy() - g["x_t"]).max() < 1e-6
+    with torch.no_grad():
+        for name, fl in (("flags", c(g["flags"])), ("noflags", None)):
+            r = d.training_losses(c(g["x_start"]), c(g["t"]), ctx=ctx, anchor_assignment=seg, valid_id=valid, flags=fl, noise=c(g["noise"]))
+            ref = float(g["mse_loss_" + name])
+            assert abs(float(r["mse_loss"]) - ref) < tol * max(1.0, ref), (name, float(r["mse_loss"]), ref)
+    with pytest.raises(NotImplementedError):
+        d.training_losses(c(g["x_start"]), c(g["t"]), ctx=ctx, anchor_assignment=seg, valid_id=valid, noise=c(g["noise"]))   # grad mode
+    # the pipelined kernel (N % 256 == 0) with per-shape t agrees with the direct kernel
+    B, N = 4, 256
+    pc, mean, logvar, va = synth.make_latents(B, seed=3)
+    e = _engine(W, 100, "bf16")
+    cx = e.prepare_shapes(*map(torch.from_numpy, (pc, mean, np.exp(logvar).astype(np.float32), va)))
+    sg = torch.from_numpy(synth.make_seg_mask(va, N))
+    x = torch.randn(B, 3, N)
+    tt = torch.tensor([0, 37, 99, 5])
+    from difffacto_amd import _ffi
+    a = e.eps_t(cx, x, sg, tt)
+    _ffi.lib().dfx_debug_force_direct(1)
+    b = e.eps_t(cx, x, sg, tt)
+    _ffi.lib().dfx_debug_force_direct(0)
+    one = torch.stack([e.eps(cx, x, sg, int(t))[i] for i, t in enumerate(tt)])
+    assert (a - b).abs().max().item() < 2e-2 and (a - one).abs().max().item() == 0.0   # `one` also takes the pipelined kernel

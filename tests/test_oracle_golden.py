@@ -133,3 +133,14 @@ def test_ddim_chain_matches_reference(W, name):
     assert sorted("decode_" + str(k) for k in dec) == sorted(k for k in g.files if k.startswith("decode_"))
     for k, v in dec.items():
         assert np.abs(v - g["decode_" + str(k)]).max() < TOL_CHAIN
+
+
+def test_training_losses_forward_matches_reference(W):
+    """SURVEY §8 A18 (forward, eval mode): q_sample + per-shape-t denoiser + masked MSE."""
+    g = np.load(os.path.join(GOLDEN, "train_fwd_B3_N64_T10.npz"))
+    tb = df.Tables(10)
+    anchors, variance = _per_point(g)
+    for name, fl in (("flags", g["flags"]), ("noflags", None)):
+        r = df.training_losses(tb, W, g["x_start"], g["t"], anchors, variance, _ctx(g), g["seg"], g["valid"], fl, g["noise"])
+        assert np.abs(r["x_t"] - g["x_t"]).max() < 1e-6
+        assert abs(float(r["mse_loss"]) - float(g["mse_loss_" + name])) < 1e-5 * max(1.0, float(g["mse_loss_" + name])), name
