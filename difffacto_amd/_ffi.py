@@ -104,6 +104,9 @@ SIGNATURES = {
     "dfx_shared_mlp_is_fused": (_I, [_P]),
     "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfx_fp_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfx_emd_workspace_bytes": (_SZ, [_I, _I]),
+    "dfx_emd_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "dfx_emd_backward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_q_sample_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_denoise_eps_t": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_masked_mse_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

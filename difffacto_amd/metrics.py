@@ -76,3 +76,48 @@ def chamfer_l2(a, b):
     """Per-cloud symmetric Chamfer-L2 (B,) between (B,N,3) and (B,M,3): mean_i d1 + mean_j d2."""
     d1, d2 = ChamferFunction.apply(a, b)
     return d1.mean(dim=1) + d2.mean(dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Approximate EMD by auction — mirrors ``emdFunction`` / ``EMD`` of python/difffacto/metrics/emd/emd_module.py:17-70
+class emdFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps, iters):
+        """xyz1, xyz2 (B,n,3) in [0,1]^3 -> (dist (B,n) squared matched distances, assignment (B,n) int32)."""
+        assert xyz1.shape == xyz2.shape and xyz1.shape[-1] == 3
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        _chk(xyz1, "xyz1"), _chk(xyz2, "xyz2")
+        B, n, _ = xyz1.shape
+        dist = torch.empty(B, n, device=xyz1.device)
+        assignment = torch.empty(B, n, dtype=torch.int32, device=xyz1.device)
+        ws = torch.empty(max(_ffi.lib().dfx_emd_workspace_bytes(B, n), 4), dtype=torch.uint8, device=xyz1.device)
+        with torch.cuda.device(xyz1.device):
+            _ffi.check(_ffi.lib().dfx_emd_forward_f32(_ffi.ptr(xyz1), _ffi.ptr(xyz2), _ffi.ptr(dist), _ffi.ptr(assignment), _ffi.ptr(ws),
+                                                      B, n, float(eps), int(iters), _ffi.current_stream()), "dfx_emd_forward_f32")
+        ctx.save_for_backward(xyz1, xyz2, assignment)
+        ctx.mark_non_differentiable(assignment)
+        return dist, assignment
+
+    @staticmethod
+    def backward(ctx, graddist, gradidx):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        graddist = graddist.contiguous()
+        B, n, _ = xyz1.shape
+        g1 = torch.empty_like(xyz1)
+        with torch.cuda.device(xyz1.device):
+            _ffi.check(_ffi.lib().dfx_emd_backward_f32(_ffi.ptr(xyz1), _ffi.ptr(xyz2), _ffi.ptr(graddist), _ffi.ptr(assignment),
+                                                       _ffi.ptr(g1), B, n, _ffi.current_stream()), "dfx_emd_backward_f32")
+        return g1, torch.zeros_like(xyz2), None, None   # the reference leaves grad_xyz2 at zero (emd_module.py:46-50)
+
+
+class EMD(torch.nn.Module):
+    """``METRICS['EMD']``: ``dist_only`` -> sqrt(dist).mean(1) per cloud pair (evaluation_utils.py:84-89 uses
+    EMD(0.002, 10000, True)); otherwise (dist, assignment)."""
+
+    def __init__(self, eps, iters, dist_only=False):
+        super().__init__()
+        self.eps, self.iters, self.dist_only = eps, iters, dist_only
+
+    def forward(self, input1, input2):
+        out = emdFunction.apply(input1, input2, self.eps, self.iters)
+        return torch.sqrt(out[0]).mean(1) if self.dist_only else out

@@ -334,6 +334,19 @@ void dfx_pointnet_v2_destroy(dfx_pointnet_v2 *h);
 int dfx_pointnet_v2_forward_f32(dfx_pointnet_v2 *h, const float *x, const float *attn, float *m, float *v, int B, int N,
                                 dfx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Approximate EMD by auction — replaces the `emd` extension
+ * (python/difffacto/metrics/emd/emd_cuda.cu: forward :236-284, backward :286-316; bound in emd_module.py:17-51).
+ * xyz1, xyz2 (B,n,3) in [0,1]^3 -> dist (B,n) squared distance of point j to its matched target, assignment (B,n) int32.
+ * One persistent workgroup per cloud pair; n <= 8192 (any n, not only multiples of 1024; B unbounded).
+ * workspace: dfx_emd_workspace_bytes(B, n) device bytes.  emd_backward: grad_xyz1 (B,n,3) (grad_xyz2 is zero in the reference).
+ * ------------------------------------------------------------------------------------------ */
+size_t dfx_emd_workspace_bytes(int B, int n);
+int dfx_emd_forward_f32(const float *xyz1, const float *xyz2, float *dist, int32_t *assignment, void *workspace, int B, int n,
+                        float eps, int iters, dfx_stream_t stream);
+int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad_dist, const int32_t *assignment,
+                         float *grad_xyz1, int B, int n, dfx_stream_t stream);
+
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

@@ -256,3 +256,84 @@ void oracle_chamfer_grad(int b, int n, int m, const float *xyz1, const float *xy
       }
     }
 }
+
+/* ---- approximate EMD by auction (python/difffacto/metrics/emd/emd_cuda.cu, emd_module.py:17-41) -------------------- */
+/* One iteration = calc_unass_* :29-100 (list the unassigned points), Bid :102-186, GetMax :188-201, Assign :203-223;
+ * after `iters` iterations CalcDist :225-234.  Sequential restatement with the kernels' scan order:
+ *   - value of target k for bidder j: d = 3.0 - sqrtf(|x2_k - x1_j|^2) - price[k], evaluated in DOUBLE and rounded to
+ *     float (`3.0` is a double literal, :151); the squared norm with nvcc's contraction (mul, fma, fma);
+ *   - best = FIRST maximum in k order (strict '>' in the per-thread scans :152-160 and in the ordered merge :171-178),
+ *     better = the second largest value; increment = best - better + eps (float);
+ *   - GetMax lets every bidder whose increment is within 1e-6 (double compare, :195) of the target's maximum write
+ *     max_idx: a data race in the reference; here the LARGEST bidder index wins (stated deviation, ties are rare);
+ *   - the last iteration assigns every still-unassigned bidder to its bid without evicting (:209-211).
+ * Iterations stop early once nothing is unassigned (no kernel changes any state after that). */
+void oracle_emd_forward(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
+                        int32_t *assignment) {
+  int32_t *ass_inv = (int32_t *)malloc(sizeof(int32_t) * n), *bid = (int32_t *)malloc(sizeof(int32_t) * n),
+          *max_idx = (int32_t *)malloc(sizeof(int32_t) * n);
+  float *price = (float *)malloc(sizeof(float) * n), *bid_inc = (float *)malloc(sizeof(float) * n),
+        *max_inc = (float *)malloc(sizeof(float) * n);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *A = xyz1 + (size_t)bi * n * 3, *Bp = xyz2 + (size_t)bi * n * 3;
+    int32_t *as = assignment + (size_t)bi * n;
+    for (int j = 0; j < n; ++j) as[j] = -1, ass_inv[j] = -1, price[j] = 0.f, max_inc[j] = 0.f, max_idx[j] = 0, bid[j] = 0, bid_inc[j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+      const int last = it == iters - 1;
+      int any = 0;
+      for (int j = 0; j < n; ++j) {
+        if (as[j] != -1) continue;
+        any = 1;
+        float best = -1e9f, better = -1e9f;
+        int best_i = -1;
+        const float x1 = A[j * 3], y1 = A[j * 3 + 1], z1 = A[j * 3 + 2];
+        for (int k = 0; k < n; ++k) {
+          const float x2 = Bp[k * 3] - x1, y2 = Bp[k * 3 + 1] - y1, z2 = Bp[k * 3 + 2] - z1;
+          const float s = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+          const float d = (float)(3.0 - (double)sqrtf(s) - (double)price[k]);
+          if (d > best) better = best, best = d, best_i = k;
+          else if (d > better) better = d;
+        }
+        bid[j] = best_i;
+        bid_inc[j] = best - better + eps;
+        if (bid_inc[j] > max_inc[best_i]) max_inc[best_i] = bid_inc[j];
+      }
+      if (!any) break;
+      for (int j = 0; j < n; ++j) {   /* GetMax: ascending j, the largest matching bidder index stays */
+        if (as[j] != -1) continue;
+        const float mi = max_inc[bid[j]];
+        if ((double)bid_inc[j] - 1e-6 <= (double)mi && (double)mi <= (double)bid_inc[j] + 1e-6) max_idx[bid[j]] = j;
+      }
+      for (int j = 0; j < n; ++j) {   /* Assign: decisions use the state before this phase (threads are independent) */
+        if (as[j] != -1) continue;
+        const int k = bid[j];
+        if (last || max_idx[k] == j) {
+          const int prev = ass_inv[k];
+          if (!last && prev != -1) as[prev] = -1;
+          ass_inv[k] = j;
+          as[j] = k;
+          price[k] += bid_inc[j];
+          max_inc[k] = -1e9f;
+        }
+      }
+    }
+    for (int j = 0; j < n; ++j) {
+      const int k = as[j];
+      const float dx = A[j * 3] - Bp[k * 3], dy = A[j * 3 + 1] - Bp[k * 3 + 1], dz = A[j * 3 + 2] - Bp[k * 3 + 2];
+      dist[(size_t)bi * n + j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+  }
+  free(ass_inv); free(bid); free(max_idx); free(price); free(bid_inc); free(max_inc);
+}
+
+/* NmDistanceGradKernel :286-301: grad_xyz1[j] += 2 grad_dist[j] (x1_j - x2_assignment[j]); grad_xyz2 stays zero */
+void oracle_emd_backward(int b, int n, const float *xyz1, const float *xyz2, const float *grad_dist, const int32_t *assignment,
+                         float *grad_xyz1) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < n; ++j) {
+      const size_t i = (size_t)bi * n + j;
+      const int k = assignment[i];
+      const float g = grad_dist[i] * 2;
+      for (int c = 0; c < 3; ++c) grad_xyz1[i * 3 + c] += g * (xyz1[i * 3 + c] - xyz2[((size_t)bi * n + k) * 3 + c]);
+    }
+}

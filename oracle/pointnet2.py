@@ -154,3 +154,22 @@ def chamfer_backward(xyz1, xyz2, idx1, idx2, g1, g2):
     lib().oracle_chamfer_grad(B, N, M, _p(xyz1), _p(xyz2), _p(g1), _p(idx1), _p(gx1), _p(gx2))
     lib().oracle_chamfer_grad(B, M, N, _p(xyz2), _p(xyz1), _p(g2), _p(idx2), _p(gx2), _p(gx1))
     return gx1, gx2
+
+
+def emd_forward(xyz1, xyz2, eps, iters):
+    """emdFunction.forward (metrics/emd/emd_module.py:17-41): (dist (B,n) squared distances to the matched point, assignment (B,n))."""
+    xyz1, xyz2 = _c(xyz1, _F), _c(xyz2, _F)
+    B, n, _ = xyz1.shape
+    assert xyz2.shape == xyz1.shape
+    dist = np.zeros((B, n), _F)
+    assignment = np.zeros((B, n), _I)
+    lib().oracle_emd_forward(B, n, _p(xyz1), _p(xyz2), ctypes.c_float(eps), int(iters), _p(dist), _p(assignment))
+    return dist, assignment
+
+
+def emd_backward(xyz1, xyz2, grad_dist, assignment):
+    xyz1, xyz2, grad_dist, assignment = _c(xyz1, _F), _c(xyz2, _F), _c(grad_dist, _F), _c(assignment, _I)
+    B, n, _ = xyz1.shape
+    g = np.zeros_like(xyz1)
+    lib().oracle_emd_backward(B, n, _p(xyz1), _p(xyz2), _p(grad_dist), _p(assignment), _p(g))
+    return g

@@ -150,3 +150,22 @@ def test_oracle_fp_module_matches_reference_python():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fp_small.npz"))
     out = om.fp_module_forward(_weights(g), g["unknown"], g["known"], g["unknow_feats"], g["known_feats"], n_layers=len(g["mlp"]) - 1)
     assert np.abs(out - g["new_features"]).max() < 2e-5
+
+
+def test_oracle_emd_auction_properties():
+    """The EMD oracle has no reference output to pin against (CUDA source unbuildable): check the auction's own invariants —
+    converged assignment is a permutation within n*eps of the optimal cost; early iterations keep assignment/inverse consistent."""
+    from scipy.optimize import linear_sum_assignment
+    from scipy.spatial.distance import cdist
+    rng = np.random.Generator(np.random.PCG64(11))
+    a, b = rng.uniform(0, 1, (2, 256, 3)).astype(np.float32), rng.uniform(0, 1, (2, 256, 3)).astype(np.float32)
+    d, asg = opn.emd_forward(a, b, 0.002, 20000)
+    for i in range(2):
+        assert sorted(asg[i].tolist()) == list(range(256))
+        C = cdist(a[i], b[i])
+        r, c = linear_sum_assignment(C)
+        got = np.sqrt(d[i]).mean()
+        assert C[r, c].mean() - 1e-6 <= got <= C[r, c].mean() + 0.002 + 1e-6
+        assert np.allclose(d[i], ((a[i] - b[i][asg[i]]) ** 2).sum(1), atol=1e-6)
+    d1, as1 = opn.emd_forward(a, b, 0.002, 1)   # one iteration = the forced last assignment: everybody gets its best target
+    assert (as1 >= 0).all() and np.array_equal(as1[0], cdist(a[0], b[0]).argmin(1))
