@@ -10,7 +10,7 @@ import torch
 
 from difffacto_amd import synth
 from difffacto_amd.engine import DenoiserEngine
-from difffacto_amd.metrics import chamfer_l2
+from difffacto_amd.metrics import EMD, chamfer_l2
 
 B, N = 4, 2048
 W = {k: torch.from_numpy(v) for k, v in synth.make_denoiser_weights(0).items()}
@@ -33,7 +33,14 @@ for T in (100, 1000):
     d = (out["f32"] - out["bf16"]).abs()
     cd = chamfer_l2(out["f32"], out["bf16"])
     cd_ind = chamfer_l2(out["f32"], other)
+
+    def emd_pair(x, y):   # the evaluation's normalisation-free call (datasets/evaluation_utils.py:84-89) on clouds scaled into [0,1]^3
+        lo = torch.minimum(x.amin((1, 2), keepdim=True), y.amin((1, 2), keepdim=True))
+        hi = torch.maximum(x.amax((1, 2), keepdim=True), y.amax((1, 2), keepdim=True))
+        return EMD(0.002, 10000, True)((x - lo) / (hi - lo), (y - lo) / (hi - lo))
+    emd, emd_ind = emd_pair(out["f32"], out["bf16"]), emd_pair(out["f32"], other)
     print(f"T={T} B={B} N={N}: max-abs {d.max().item():.3e}  mean-abs {d.mean().item():.3e}  "
           f"Chamfer-L2(bf16, fp32) mean {cd.mean().item():.3e} max {cd.max().item():.3e}  |  "
           f"Chamfer-L2 between two independent fp32 samples {cd_ind.mean().item():.3e}  "
-          f"(part sigma ~{float(np.sqrt(np.exp(lv)).mean()):.3f})")
+          f"(part sigma ~{float(np.sqrt(np.exp(lv)).mean()):.3f})  |  EMD(bf16, fp32) on the unit-box-normalised clouds "
+          f"{emd.mean().item():.3e} vs {emd_ind.mean().item():.3e} between independent samples")
