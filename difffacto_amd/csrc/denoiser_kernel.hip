@@ -378,50 +378,90 @@ struct Tracer {
 #endif
 };
 
+// Fragment indices (uint4 units relative to this lane's record pointer).  FF record: W2 tile ct = i/2, unit q = i&1;
+// W1 unit order (c, q, part) -> tile part*4 + c, unit q (half 0: c = 0,1; half 1: c = 2,3).  Attention record: A_s tiles
+// 0..3, M_s tiles 4..7.
+__device__ __forceinline__ constexpr int w2_frag(int i) { return (8 + (i >> 1)) * 128 + (i & 1) * 64; }
+__device__ __forceinline__ constexpr int w1_frag(int i, int half) { return ((i & 1) * 4 + 2 * half + (i >> 2)) * 128 + ((i >> 1) & 1) * 64; }
+__device__ __forceinline__ constexpr int as_frag(int i) { return (i >> 1) * 128 + (i & 1) * 64; }
+__device__ __forceinline__ constexpr int ms_frag(int i) { return (4 + (i >> 1)) * 128 + (i & 1) * 64; }
+
+// Tail prefetch: every M slot finds the A fragments of its first eight MFMAs in registers (P): they are read at the
+// TAIL of the previous M slot of the same wavefront — after its last MFMA has been issued, while the matrix pipe drains
+// and the wave has nothing else to issue — so the burst starts without the LDS round trip (~300 cycles per slot) and the
+// VALU-bound V slot in between carries no extra LDS instructions.  Needs the next record complete in LDS one management
+// barrier earlier: the ring runs three records ahead in five slots.
+#ifdef DFX_NO_TAIL_PREFETCH   // A/B build (tools/ab.sh): 4-slot ring, every M slot fetches all of its operands itself (-4 %)
+constexpr bool TAILP = false;
+#else
+constexpr bool TAILP = true;
+#endif
+enum { NEXT_W2 = 0, NEXT_AS = 1, NEXT_MS = 2, NEXT_W1 = 3 };
+template <int KIND>
+__device__ __forceinline__ void tail_prefetch(uint4 (&P)[8], const uint4 *ck) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P[i] = ck[KIND == NEXT_W2 ? w2_frag(i) : KIND == NEXT_AS ? as_frag(i) : KIND == NEXT_MS ? ms_frag(i) : w1_frag(i, 0)];
+}
+
 template <bool S3, bool S1>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
-                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, const float *b1, Tracer &tr) {
-  uint4 A0[8], A1[8];
-  if (S3) {
+                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr) {
+  uint4 A1[8];
+  if (!TAILP) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) A0[i] = ck[(8 + (i >> 1)) * 128 + (i & 1) * 64];  // W2 tiles ct = i/2, unit q = i&1
+    for (int i = 0; i < 8; ++i) P[i] = ck[S3 ? w2_frag(i) : w1_frag(i, 0)];
   }
   if (S1) {
-    // W1 unit order: (c, q, part) -> tile part*4 + c, unit q
-#pragma unroll
-    for (int i = 0; i < 8; ++i) A1[i] = ck[((i & 1) * 4 + (i >> 2)) * 128 + ((i >> 1) & 1) * 64];
     // a, g already hold b1 of this chunk: loaded at the end of the preceding V slot (ff_v / V2), where the LDS
     // reads cost nothing on the M slot's operand-fetch critical path (+1 %)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A1[i] = ck[w1_frag(i, S3 ? 0 : 1)];
   }
   __builtin_amdgcn_sched_barrier(0);
-  // The MFMA burst outranks the partner's VALU burst at the issue arbiter (an MFMA needs one issue slot per
-  // 32 cycles, so the VALU wave loses almost nothing); without it the YOUNGER wave's MFMAs only get the
-  // slots the older wave's VALU stream leaves free and its M slot runs ~50 % longer.
   tr.stamp(4);
   if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(DFX_MFMA_PRIO);
   if (S3) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), hid.f[i & 1], h[i >> 1], 0, 0, 0);
+      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), hid.f[i & 1], h[i >> 1], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v16f &acc = (i & 1) ? g : a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
+    }
   }
   if (S1) {
-    if (S3) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     tr.stamp(5);
+    if (S3) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) A0[i] = ck[((i & 1) * 4 + 2 + (i >> 2)) * 128 + ((i >> 1) & 1) * 64];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i) P[i] = ck[w1_frag(i, 1)];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v16f &acc = (i & 1) ? g : a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        v16f &acc = (i & 1) ? g : a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      tr.stamp(6);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v16f &acc = (i & 1) ? g : a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v16f &acc = (i & 1) ? g : a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
+      }
     }
+  }
+  if (TAILP) {   // the next M slot of this wave: FF record -> its W2 batch; last FF record of the block -> A_s of the next block
     __builtin_amdgcn_sched_barrier(0);
-    tr.stamp(6);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v16f &acc = (i & 1) ? g : a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
-    }
+    if (S1) tail_prefetch<NEXT_W2>(P, ck_next);
+    else tail_prefetch<NEXT_AS>(P, ck_next);
   }
   if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
 }
@@ -471,25 +511,37 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, 
 }
 
 // attention M slots: sim = sbias + A_s xn (8 MFMAs);  h += M_s P (8 MFMAs)
-__device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *rec, const float *sbias) {
-  uint4 A0[8];
+__device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *rec, const float *sbias,
+                                        uint4 (&P)[8], bool have_p) {
+  if (!TAILP || !have_p) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) A0[i] = rec[(i >> 1) * 128 + (i & 1) * 64];
+    for (int i = 0; i < 8; ++i) P[i] = rec[as_frag(i)];
+  }
   load16(sim, sbias);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+    sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+  if (TAILP) {
+    __builtin_amdgcn_sched_barrier(0);
+    tail_prefetch<NEXT_MS>(P, rec);
+  }
 }
 
-__device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, const uint4 *rec) {
-  uint4 A0[8];
+__device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, const uint4 *rec, uint4 (&P)[8],
+                                        const uint4 *ck_next) {
+  if (!TAILP) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) A0[i] = rec[(4 + (i >> 1)) * 128 + (i & 1) * 64];
+    for (int i = 0; i < 8; ++i) P[i] = rec[ms_frag(i)];
+  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A0[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+  if (TAILP) {
+    __builtin_amdgcn_sched_barrier(0);
+    tail_prefetch<NEXT_W1>(P, ck_next);
+  }
 }
 
 // attention V slot: masked softmax over the 4 keys of each head (registers 4g..4g+3 = keys of head 2g+hf)
@@ -702,12 +754,12 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 // ----------------------------------------------------------------------------------------------
 // LDS-pipelined kernel (bf16, N % 256 == 0): one workgroup = 8 wavefronts = 256 points of ONE shape.
 //
-// Weight streaming.  All weights stream L2 -> LDS through a 4-slot ring of 24 KiB records filled by LDS-DMA
-// (global_load_lds_dwordx4: 1 KiB per wavefront-instruction, 3 per wave per record), two records ahead of the
+// Weight streaming.  All weights stream L2 -> LDS through a 5-slot ring of 24 KiB records filled by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wavefront-instruction, 3 per wave per record), three records ahead of the
 // compute, with a counted s_waitcnt vmcnt (never 0 in steady state).  Record sequence per transformer block:
-// [attention record] then 17 x [FF record j = W1 of chunk j | W2 of chunk j-1].  The DMA is issued from inline
-// asm so that hipcc does not serialise the ring behind vmcnt(0) waits (it cannot prove that a ds_read does not
-// alias an in-flight LDS-DMA); the data hazards are handled by the slot protocol below.
+// [attention record] then 17 x [FF record j = W1 of chunk j | W2 of chunk j-1].  The DMA is issued from inline asm so
+// that hipcc does not serialise the ring behind vmcnt(0) waits (it cannot prove that a ds_read does not alias an
+// in-flight LDS-DMA); the data hazards are handled by the slot protocol below.
 //
 // Slots.  Each wavefront alternates pure-VALU slots (V) and pure-MFMA slots (M).  Group B (waves 4-7) runs one
 // slot behind group A (waves 0-3): each record's management barrier (below) is in front of A's M slot but in
@@ -715,18 +767,19 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 // SIMD starts an MFMA burst while its partner starts a VALU burst:
 //     block:  V0 (b2 of the previous block | step boundary | LN2)  M0 (A_s)  V1 (softmax)  M1 (M_s)  V2 (+c_t, LN3)
 //             M(F0: GEMM1 0)  V (GELU 0)  M(F1: GEMM2 0 + GEMM1 1)  V (GELU 1) ... M(F16: GEMM2 15)
-// One barrier per record per wavefront; both groups execute the same number of barriers.
+// One barrier per record per wavefront; both groups execute the same number of barriers.  Every M slot ends by reading
+// the first eight A fragments of the wave's NEXT M slot (tail prefetch, ff_m / attn_m0 / attn_m1).
 //
 // Ring protocol.  The barrier in front of the M slot that first reads record r (for group A; for B it is the
 // barrier in front of the preceding V slot — the SAME global barrier) is r's management barrier:
-//     before it  every wave waits for its own DMA pieces of r (vmcnt(CALLS): record r+1 may still be in flight)
-//     after it   every wave issues its pieces of record r+2 into slot (r+2)%4
-//   RAW: the issuing waves' vmcnt + the barrier precede every read of r (A reads first).
-//   WAR: slot (r+2)%4 held record r-2, whose last reader (B; for an attention record B's V2) finished at least
-//        one barrier earlier.
+//     before it  every wave waits for its own DMA pieces of r+1 (vmcnt(CALLS): record r+2 may still be in flight)
+//     after it   every wave issues its pieces of record r+3 into slot (r+3)%5
+//   RAW: the issuing waves' vmcnt + the barrier precede every read of r and every tail-prefetch read of r+1.
+//   WAR: slot (r+3)%5 held record r-2, whose last reader (B; for an attention record B's V2, which ends before the
+//        management barrier of r) finished at least one barrier earlier.
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
-constexpr int NSLOT = 4;
+constexpr int NSLOT = TAILP ? 5 : 4;   // records in flight ahead of the compute: NSLOT - 2
 constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per record
 constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
@@ -798,7 +851,7 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
     }
     st.ff_src = reinterpret_cast<const char *>(bp.chunks) + wave * (CALLS * 1024);
   }
-  st.slot = (st.slot + 1) & (NSLOT - 1);
+  st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
   if (++st.k == RECORDS_PER_BLOCK) {
     st.k = 0;
     ++st.seq;
@@ -827,6 +880,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   DmaState dma{0, 0, 0, 0, 0, nullptr};
   issue_record(p, dma, wave, voff, lds0, s);
   issue_record(p, dma, wave, voff, lds0, s);
+  if (TAILP) issue_record(p, dma, wave, voff, lds0, s);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
   {
@@ -878,7 +932,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #define DFX_NEXT_RECORD()                                                             \
   do {                                                                                \
     ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane; \
-    cur = (cur + 1) & (NSLOT - 1);                                                    \
+    cur = cur + 1 == NSLOT ? 0 : cur + 1;                                             \
   } while (0)
 
 #ifdef DFX_TRACE
@@ -891,6 +945,10 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   if (!grpA) __builtin_amdgcn_s_barrier();  // lock-step variant: B runs one barrier behind A
 #endif
 
+  // the record that the next DFX_NEXT_RECORD() will hand out (with DFX_TAIL_PREFETCH: complete in LDS since the previous
+  // management barrier)
+#define DFX_PEEK_RECORD() (reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane)
+  uint4 P[8];   // first MFMA batch of the next M slot (tail prefetch)
   int cur = 0;  // ring slot of the next record to be consumed
   int seq = 0;  // running block number (parity selects the block-constant buffer)
   v16f h[4];
@@ -922,14 +980,14 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       DFX_NEXT_RECORD();
       const uint4 *rec = ck;
       v16f sim;
-      attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16);
+      attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0);
       // ---- V1: softmax ----
       DFX_SLOT(false);
       Act<PREC> pa;
       attn_softmax(sim, pa, vmask);
       // ---- M1: h += M_s P ----
       DFX_SLOT(false);
-      attn_m1(h, pa, rec);
+      attn_m1(h, pa, rec, P, DFX_PEEK_RECORD());
       // ---- V2: + c_t, LN3 ----
       DFX_SLOT(!grpA);
       add_cvec(h, reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
@@ -941,20 +999,20 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<false, true>(h, xn, a, g, hid, ck, b1, tr);
+      ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
         ff_v(a, g, hid, b1 + j * 64);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
-        ff_m<true, true>(h, xn, a, g, hid, ck, b1 + j * 64, tr);
+        ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
       }
       DFX_SLOT(!grpA);
       ff_v(a, g, hid, nullptr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<true, false>(h, xn, a, g, hid, ck, b1, tr);
+      ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
     }
   }
 #ifdef DFX_LOCKSTEP
@@ -963,6 +1021,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #undef DFX_SLOT
 #undef DFX_STAMP
 #undef DFX_NEXT_RECORD
+#undef DFX_PEEK_RECORD
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
