@@ -403,9 +403,12 @@ __device__ __forceinline__ void tail_prefetch(uint4 (&P)[8], const uint4 *ck) {
   for (int i = 0; i < 8; ++i) P[i] = ck[KIND == NEXT_W2 ? w2_frag(i) : KIND == NEXT_AS ? as_frag(i) : KIND == NEXT_MS ? ms_frag(i) : w1_frag(i, 0)];
 }
 
-template <bool S3, bool S1>
+// `issue` = hook for the A/B variant that issues the ring's DMA from inside the M slot, behind the first MFMA batch,
+// instead of right after the management barrier (-DDFX_ISSUE_IN_M; measured 1 % slower, so the default hook is empty).
+template <bool S3, bool S1, class Issue>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
-                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr) {
+                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
+                                     Issue &issue) {
   uint4 A1[8];
   if (!TAILP) {
 #pragma unroll
@@ -431,6 +434,8 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  issue();
   if (S1) {
     __builtin_amdgcn_sched_barrier(0);
     tr.stamp(5);
@@ -511,8 +516,9 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, 
 }
 
 // attention M slots: sim = sbias + A_s xn (8 MFMAs);  h += M_s P (8 MFMAs)
+template <class Issue>
 __device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *rec, const float *sbias,
-                                        uint4 (&P)[8], bool have_p) {
+                                        uint4 (&P)[8], bool have_p, Issue &issue) {
   if (!TAILP || !have_p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) P[i] = rec[as_frag(i)];
@@ -522,6 +528,8 @@ __device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  issue();
   if (TAILP) {
     __builtin_amdgcn_sched_barrier(0);
     tail_prefetch<NEXT_MS>(P, rec);
@@ -906,6 +914,17 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
+  // DMA of the record three ahead: right after the management barrier (default), or from inside the M slot that
+  // follows it, behind the first MFMA batch (-DDFX_ISSUE_IN_M, the A/B variant: 1 % slower)
+  auto issue_now = [&]() { issue_record(p, dma, wave, voff, lds0, s); };
+  [[maybe_unused]] auto issue_nop = []() {};
+#ifdef DFX_ISSUE_IN_M
+#define DFX_ISSUE_HERE() ((void)0)
+  auto &issue_in_m = issue_now;
+#else
+#define DFX_ISSUE_HERE() issue_now()
+  auto &issue_in_m = issue_nop;
+#endif
   // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
 #define DFX_STAMP(tag) tr.stamp(tag)
 #ifdef DFX_LOCKSTEP  // A/B variant: a barrier at every slot boundary
@@ -921,7 +940,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       wait_vmcnt<CALLS>();                              \
       __builtin_amdgcn_s_barrier();                     \
       DFX_STAMP(2);                                     \
-      issue_record(p, dma, wave, voff, lds0, s);        \
+      DFX_ISSUE_HERE();                                 \
     } else {                                            \
       DFX_STAMP(3);                                     \
       DFX_LOCKSTEP_BARRIER();                           \
@@ -980,7 +999,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       DFX_NEXT_RECORD();
       const uint4 *rec = ck;
       v16f sim;
-      attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0);
+      attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0, issue_in_m);
       // ---- V1: softmax ----
       DFX_SLOT(false);
       Act<PREC> pa;
@@ -999,20 +1018,20 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
+      ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
         ff_v(a, g, hid, b1 + j * 64);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
-        ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
+        ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);
       ff_v(a, g, hid, nullptr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr);
+      ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
     }
   }
 #ifdef DFX_LOCKSTEP
@@ -1022,6 +1041,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #undef DFX_STAMP
 #undef DFX_NEXT_RECORD
 #undef DFX_PEEK_RECORD
+#undef DFX_ISSUE_HERE
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
