@@ -918,9 +918,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   // follows it, behind the first MFMA batch (-DDFX_ISSUE_IN_M, the A/B variant: 1 % slower)
   auto issue_now = [&]() { issue_record(p, dma, wave, voff, lds0, s); };
   [[maybe_unused]] auto issue_nop = []() {};
-#ifdef DFX_ISSUE_IN_M
+#if defined(DFX_ISSUE_IN_M)
 #define DFX_ISSUE_HERE() ((void)0)
   auto &issue_in_m = issue_now;
+#elif defined(DFX_ISSUE_IN_M_GROUP_B)   // group A at the barrier (start of its M slot), group B inside its M slot
+#define DFX_ISSUE_HERE() do { if (grpA) issue_now(); } while (0)
+  auto issue_in_m = [&]() { if (!grpA) issue_now(); };
 #else
 #define DFX_ISSUE_HERE() issue_now()
   auto &issue_in_m = issue_nop;
