@@ -84,3 +84,14 @@ def test_engine_cache_follows_parameter_updates(diffusion):
     assert torch.allclose(e1, e0 + 1.0, atol=1e-5)
     with torch.no_grad():
         diffusion.model.proj_out.bias.sub_(1.0)
+
+
+def test_example_script_end_to_end():
+    """examples/generate.py: mirrors built from the shipped config values, DDIM + metrics, small sizes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "generate.py"), "--shapes", "4", "--K", "2", "--timesteps", "40",
+                        "--ddim", "8", "--metrics"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "8 clouds x 2048 points, 8 DDIM steps" in r.stdout and "finite: True" in r.stdout and "1-NN-CD-acc" in r.stdout
