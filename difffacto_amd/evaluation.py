@@ -51,26 +51,25 @@ def _pairwise_EMD_CD_(sample_pcs, ref_pcs, batch_size, accelerated_cd=True, verb
 
 
 def knn(Mxx, Mxy, Myy, k, sqrt=False, one_way=False):
-    """Leave-one-out k-NN two-sample test on the stacked distance matrix (1-NNA for k = 1)."""
-    n0, n1 = Mxx.size(0), Myy.size(0)
-    label = torch.cat((torch.ones(n0), torch.zeros(n1))).to(Mxx)
-    M = torch.cat([torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.transpose(0, 1), Myy), 1)], 0)
+    """Leave-one-out k-NN two-sample test (1-NNA for k = 1) on the block matrix [[Mxx, Mxy], [Mxy^T, Myy]]: a cloud is
+    predicted to belong to set x when at least k/2 of its k nearest other clouds do.  Returns the reference's dict
+    (tp, fp, fn, tn, precision, recall, acc_t, acc_f, acc) as 0-dim tensors."""
+    nx, ny = Mxx.size(0), Myy.size(0)
+    is_x = torch.cat((torch.ones(nx), torch.zeros(ny))).to(Mxx)
+    D = torch.cat([torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.t(), Myy), 1)], 0)
     if sqrt:
-        M = M.abs().sqrt()
-    _, idx = (M + torch.diag(float("inf") * torch.ones(n0 + n1).to(Mxx))).topk(k, 0, False)
-    count = torch.zeros(n0 + n1).to(Mxx)
-    for i in range(k):
-        count = count + label.index_select(0, idx[i])
-    pred = torch.ge(count, (float(k) / 2) * torch.ones(n0 + n1).to(Mxx)).float()
+        D = D.abs().sqrt()
+    D = D + torch.diag(torch.full((nx + ny,), float("inf")).to(Mxx))           # exclude the cloud itself
+    nearest = D.topk(k, dim=0, largest=False).indices                           # (k, nx + ny)
+    votes = is_x[nearest].sum(0)
+    pred = (votes >= k / 2.0).float()
     if one_way:
-        pred = pred[:n0]
-        label = pred[:n0]
-    s = {"tp": (pred * label).sum(), "fp": (pred * (1 - label)).sum(), "fn": ((1 - pred) * label).sum(),
-         "tn": ((1 - pred) * (1 - label)).sum()}
-    s.update({"precision": s["tp"] / (s["tp"] + s["fp"] + 1e-10), "recall": s["tp"] / (s["tp"] + s["fn"] + 1e-10),
-              "acc_t": s["tp"] / (s["tp"] + s["fn"] + 1e-10), "acc_f": s["tn"] / (s["tn"] + s["fp"] + 1e-10),
-              "acc": torch.eq(label, pred).float().mean()})
-    return s
+        pred = pred[:nx]
+        is_x = pred[:nx]   # as in the reference (:229-231): the one-way variant scores the x block against itself
+    tp, fp = (pred * is_x).sum(), (pred * (1 - is_x)).sum()
+    fn, tn = ((1 - pred) * is_x).sum(), ((1 - pred) * (1 - is_x)).sum()
+    return {"tp": tp, "fp": fp, "fn": fn, "tn": tn, "precision": tp / (tp + fp + 1e-10), "recall": tp / (tp + fn + 1e-10),
+            "acc_t": tp / (tp + fn + 1e-10), "acc_f": tn / (tn + fp + 1e-10), "acc": (is_x == pred).float().mean()}
 
 
 def lgan_mmd_cov(all_dist, thresh=1000):
