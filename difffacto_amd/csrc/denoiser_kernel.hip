@@ -875,8 +875,24 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
-  const long long g0 = ((long long)blockIdx.x * PIPE_NW + wave) * 32;
-  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)blockIdx.x * PIPE_NW * 32) / p.N));  // one shape per WG
+  // XCD-aware placement: workgroups are handed to the 8 XCDs round-robin by blockIdx, and every XCD has its own 4 MiB
+  // L2.  All workgroups stream the same block weights (2 MiB per step), but the attention records are per shape
+  // (85 KiB each): with the natural order the wpg workgroups of one shape land on wpg different XCDs and every L2 sees
+  // every shape.  Remap so that consecutive workgroups of ONE XCD walk through the workgroups of one shape.
+  int bid = blockIdx.x;
+#ifndef DFX_NO_XCD_REMAP
+  {
+    const int wpg = p.N / (PIPE_NW * 32);          // workgroups per shape
+    const int per = 8 * wpg;                        // workgroups of 8 shapes = one remap period
+    const int full = ((int)gridDim.x / per) * per;  // the tail (B % 8 shapes) keeps the natural order
+    if (bid < full) {
+      const int x = bid & 7, q = (bid % per) >> 3;  // XCD, position on that XCD within the period (0 .. wpg-1)
+      bid = (bid / per) * per + x * wpg + q;        // shape (period*8 + x), workgroup q of it
+    }
+  }
+#endif
+  const long long g0 = ((long long)bid * PIPE_NW + wave) * 32;
+  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)bid * PIPE_NW * 32) / p.N));  // one shape per WG
   const int n = (int)(g0 - (long long)s * p.N) + pj;
   const int depth = p.d.depth;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -958,7 +974,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   } while (0)
 
 #ifdef DFX_TRACE
-  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr,
+  Tracer tr{(p.trace != nullptr && bid == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr,
             p.trace_cap, 0};
 #else
   Tracer tr;
