@@ -798,7 +798,10 @@ constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
 constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
 constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
 constexpr int L_DUMMY = L_CPART + 2048;                // 3 KiB sink for padding DMAs
-constexpr int L_TOTAL = L_DUMMY + 3072;
+constexpr int L_PSTATE = L_DUMMY + 3072;               // per-point chain state parked between steps: float[13][256]
+constexpr int PSTATE_FIELDS = 13;                      // x[3] anc[3] var[3] L[3] seg
+constexpr int L_TOTAL = L_PSTATE + PSTATE_FIELDS * 256 * 4;
+static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
 static_assert(CALLS == 3, "dma3 issues exactly three pieces");
 
@@ -870,6 +873,36 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
   }
 }
 
+// The per-point state (x_t, anchor, variance, sqrt(variance), part id) is touched once per diffusion step; parked in LDS
+// in between (13 KiB per workgroup) it costs no VGPRs during the 90 record slots of a step — hipcc would otherwise keep
+// it in scratch memory (80 B per lane: ~8 MB of write-back traffic per step and launch).
+__device__ __forceinline__ void pstate_store(float *ps_lds, int pt, const PointState &ps, bool all) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ps_lds[i * 256 + pt] = ps.x[i];
+  if (all) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ps_lds[(3 + i) * 256 + pt] = ps.anc[i];
+      ps_lds[(6 + i) * 256 + pt] = ps.var[i];
+      ps_lds[(9 + i) * 256 + pt] = ps.L[i];
+    }
+    ps_lds[12 * 256 + pt] = __int_as_float(ps.sg);
+  }
+}
+__device__ __forceinline__ void pstate_load(const float *ps_lds, int pt, PointState &ps, bool all) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ps.x[i] = ps_lds[i * 256 + pt];
+  if (all) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ps.anc[i] = ps_lds[(3 + i) * 256 + pt];
+      ps.var[i] = ps_lds[(6 + i) * 256 + pt];
+      ps.L[i] = ps_lds[(9 + i) * 256 + pt];
+    }
+  }
+  ps.sg = __float_as_int(ps_lds[12 * 256 + pt]);
+}
+
 __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams p) {
   constexpr int PREC = DFX_PREC_BF16;
   const int lane = threadIdx.x & 63;
@@ -920,12 +953,16 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     }
     cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
   }
-  PointState ps;
   unsigned vmask;
-  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + L_PSTATE);
+  const int pt = wave * 32 + pj;   // point slot inside the workgroup (both half-waves hold the same point)
+  {
+    PointState ps0;
+    point_init(p, ps0, s, n, (unsigned long long)g0 + pj, vmask);
+    pstate_store(ps_lds, pt, ps0, true);   // both half-waves hold the same point: identical values
+  }
   __syncthreads();
 
-  const float *cpart = reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64;
   const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
@@ -1003,13 +1040,20 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
         add_cvec(h, reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) +
                         BCONST_B2_OFF + hf * 64);
       if (b == 0) {
+        PointState ps;
+        ps.s = s, ps.n = n, ps.gid = (unsigned long long)g0 + pj;
+        pstate_load(ps_lds, pt, ps, step > 0);
         if (step > 0) {
           float eps[3];
           post_eps<true>(h, wout, p.d.bout, eps);
           done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1, s));
+          if (!done) pstate_store(ps_lds, pt, ps, false);   // both half-waves hold the same point and write the same x
         }
         if (step == p.nsteps) done = true;
-        if (!done) proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
+        if (!done) {
+          const float *cpart = reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64;
+          proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
+        }
       }
       if (done) break;
       ln_to_act<PREC>(h, xn);
