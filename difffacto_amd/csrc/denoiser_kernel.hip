@@ -788,7 +788,14 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
 constexpr int NSLOT = TAILP ? 5 : 4;   // records in flight ahead of the compute: NSLOT - 2
-constexpr int CALLS = SLOT_BYTES / 1024 / PIPE_NW;  // LDS-DMA instructions per wave per record
+// Which wavefronts feed the ring: all eight (3 pieces each), or only group A (6 pieces each, -DDFX_DMA_GROUP_A): group B's
+// VALU slot, which is on the critical path of a record, then starts without the issue code.
+#ifdef DFX_DMA_GROUP_A
+constexpr int ISSUE_WAVES = 4;
+#else
+constexpr int ISSUE_WAVES = PIPE_NW;
+#endif
+constexpr int CALLS = SLOT_BYTES / 1024 / ISSUE_WAVES;  // LDS-DMA instructions per issuing wave per record
 constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
@@ -797,13 +804,14 @@ constexpr int L_WINX = L_BCONST + 2 * BCONST_BYTES;    // float4[128]
 constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
 constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
 constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
-constexpr int L_DUMMY = L_CPART + 2048;                // 3 KiB sink for padding DMAs
-constexpr int L_PSTATE = L_DUMMY + 3072;               // per-point chain state parked between steps: float[13][256]
+constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs (CALLS KiB)
+constexpr int L_DUMMY6 = L_DUMMY;
+constexpr int L_PSTATE = L_DUMMY + CALLS * 1024;               // per-point chain state parked between steps: float[13][256]
 constexpr int PSTATE_FIELDS = 13;                      // x[3] anc[3] var[3] L[3] seg
 constexpr int L_TOTAL = L_PSTATE + PSTATE_FIELDS * 256 * 4;
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
-static_assert(CALLS == 3, "dma3 issues exactly three pieces");
+static_assert(CALLS == 3 || CALLS == 6, "dmaNk issues three or six pieces");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
 
@@ -822,6 +830,19 @@ __device__ __forceinline__ void dma3k(const void *gbase, unsigned voff, unsigned
                : "memory");
 }
 
+__device__ __forceinline__ void dma6k(const void *gbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:3072\n\tglobal_load_lds_dwordx4 %0, %1 offset:4096\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:5120"
+               ::"v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void dma_calls(const void *gbase, unsigned voff, unsigned lds_addr) {
+  if (CALLS == 3) dma3k(gbase, voff, lds_addr);
+  else dma6k(gbase, voff, lds_addr);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -833,13 +854,15 @@ struct DmaState {
   const char *ff_src;         // this wave's 3 KiB window of the next FF record
 };
 
-// Issue this wave's three 1 KiB pieces (q = 3 wave + j) of the next record and advance the state.
+// Issue this wave's CALLS 1 KiB pieces (q = CALLS wave + j) of the next record and advance the state.
 __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
   const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
-  if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
-    dma3k(p.d.blk[0].chunks, voff, lds0 + L_DUMMY);
+  const bool mine = wave < ISSUE_WAVES;   // non-issuing waves only advance the state
+  if (!mine) {
+  } else if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
+    dma_calls(p.d.blk[0].chunks, voff, lds0 + L_DUMMY6);
   } else if (st.k > 0) {  // FF record: 24 contiguous KiB (the common case: keep it lean)
-    dma3k(st.ff_src, voff, ring + wave * (CALLS * 1024));
+    dma_calls(st.ff_src, voff, ring + wave * (CALLS * 1024));
     st.ff_src += SLOT_BYTES;
   } else {  // attention record: 17 KiB shape record | 5 KiB block constants | 1 KiB c_t row | 1 padding piece
     const BlockPack &bp = p.d.blk[st.b];
@@ -993,7 +1016,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     __builtin_amdgcn_sched_barrier(0);                  \
     if (mgmt) {                                         \
       DFX_STAMP(1);                                     \
-      wait_vmcnt<CALLS>();                              \
+      if (wave < ISSUE_WAVES) wait_vmcnt<CALLS>();      \
       __builtin_amdgcn_s_barrier();                     \
       DFX_STAMP(2);                                     \
       DFX_ISSUE_HERE();                                 \
