@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 //
 // Ring protocol.  The barrier in front of the M slot that first reads record r (for group A; for B it is the
 // barrier in front of the preceding V slot — the SAME global barrier) is r's management barrier:
-//     before it  every wave waits for its own DMA pieces of r+1 (vmcnt(CALLS): record r+2 may still be in flight)
+//     before it  every wave waits for its own DMA pieces of r+1 (vmcnt(its pieces per record): r+2 may still be in flight)
 //     after it   every wave issues its pieces of record r+3 into slot (r+3)%5
 //   RAW: the issuing waves' vmcnt + the barrier precede every read of r and every tail-prefetch read of r+1.
 //   WAR: slot (r+3)%5 held record r-2, whose last reader (B; for an attention record B's V2, which ends before the
@@ -788,14 +788,15 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
 constexpr int NSLOT = TAILP ? 5 : 4;   // records in flight ahead of the compute: NSLOT - 2
-// Which wavefronts feed the ring: all eight (3 pieces each), or only group A (6 pieces each, -DDFX_DMA_GROUP_A): group B's
-// VALU slot, which is on the critical path of a record, then starts without the issue code.
-#ifdef DFX_DMA_GROUP_A
-constexpr int ISSUE_WAVES = 4;
-#else
-constexpr int ISSUE_WAVES = PIPE_NW;
+// Ring DMA: 24 pieces of 1 KiB per record, CALLS_A per wave of group A (waves 0-3) and CALLS_B per wave of group B
+// (4 CALLS_A + 4 CALLS_B = 24).  Group B's V slot is on the critical path of a record, so it may carry fewer pieces
+// (-DDFX_DMA_SPLIT=AB, e.g. 42 or 60).
+#ifndef DFX_DMA_SPLIT
+#define DFX_DMA_SPLIT 33
 #endif
-constexpr int CALLS = SLOT_BYTES / 1024 / ISSUE_WAVES;  // LDS-DMA instructions per issuing wave per record
+constexpr int CALLS_A = DFX_DMA_SPLIT / 10, CALLS_B = DFX_DMA_SPLIT % 10;
+static_assert(4 * CALLS_A + 4 * CALLS_B == SLOT_BYTES / 1024, "24 pieces per record");
+constexpr int CALLS_MAX = CALLS_A > CALLS_B ? CALLS_A : CALLS_B;
 constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
@@ -804,14 +805,12 @@ constexpr int L_WINX = L_BCONST + 2 * BCONST_BYTES;    // float4[128]
 constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
 constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
 constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
-constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs (CALLS KiB)
-constexpr int L_DUMMY6 = L_DUMMY;
-constexpr int L_PSTATE = L_DUMMY + CALLS * 1024;               // per-point chain state parked between steps: float[13][256]
+constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs
+constexpr int L_PSTATE = L_DUMMY + CALLS_MAX * 1024;               // per-point chain state parked between steps: float[13][256]
 constexpr int PSTATE_FIELDS = 13;                      // x[3] anc[3] var[3] L[3] seg
 constexpr int L_TOTAL = L_PSTATE + PSTATE_FIELDS * 256 * 4;
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
-static_assert(CALLS == 3 || CALLS == 6, "dmaNk issues three or six pieces");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
 
@@ -821,26 +820,20 @@ __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned
                : "memory");  // m0 is reserved: hipcc re-materialises it before each of its own uses
 }
 
-// three consecutive 1 KiB pieces: the instruction's immediate offset applies to BOTH the global and the LDS
-// address (checked on gfx950: tools/ubench/dma_offset.hip), so one M0 / one SGPR base serve all three
-__device__ __forceinline__ void dma3k(const void *gbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
-               ::"v"(voff), "s"(gbase), "s"(lds_addr)
-               : "memory");
-}
-
-__device__ __forceinline__ void dma6k(const void *gbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:3072\n\tglobal_load_lds_dwordx4 %0, %1 offset:4096\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:5120"
-               ::"v"(voff), "s"(gbase), "s"(lds_addr)
-               : "memory");
-}
-__device__ __forceinline__ void dma_calls(const void *gbase, unsigned voff, unsigned lds_addr) {
-  if (CALLS == 3) dma3k(gbase, voff, lds_addr);
-  else dma6k(gbase, voff, lds_addr);
+// N consecutive 1 KiB pieces: the instruction's immediate offset applies to BOTH the global and the LDS address
+// (checked on gfx950: tools/ubench/dma_offset.hip), so one M0 / one SGPR base serve all of them
+#define DFX_DMA_HEAD "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+#define DFX_DMA_MORE(off) "\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #off
+#define DFX_DMA_ASM(str) asm volatile(str ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory")
+template <int N>
+__device__ __forceinline__ void dma_nk(const void *gbase, unsigned voff, unsigned lds_addr) {   // ONE asm block: M0 stays ours
+  static_assert(N >= 0 && N <= 6, "pieces per wave");
+  if (N == 1) DFX_DMA_ASM(DFX_DMA_HEAD);
+  if (N == 2) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024));
+  if (N == 3) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048));
+  if (N == 4) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072));
+  if (N == 5) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072) DFX_DMA_MORE(4096));
+  if (N == 6) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072) DFX_DMA_MORE(4096) DFX_DMA_MORE(5120));
 }
 
 template <int N>
@@ -851,24 +844,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Next record to fetch (all wave-uniform).
 struct DmaState {
   int step, b, k, seq, slot;  // k: 0 = attention record, 1..17 = FF record k-1; seq = running block number
-  const char *ff_src;         // this wave's 3 KiB window of the next FF record
+  const char *ff_src;         // this wave's window of the next FF record
 };
 
-// Issue this wave's CALLS 1 KiB pieces (q = CALLS wave + j) of the next record and advance the state.
-__device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
+// Issue this wave's pieces (CALLS_A / CALLS_B of them, starting at piece q0) of the next record and advance the state.
+template <int NC>
+__device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int q0, unsigned voff, unsigned lds0, int s) {
   const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
-  const bool mine = wave < ISSUE_WAVES;   // non-issuing waves only advance the state
-  if (!mine) {
+  if (NC == 0) {
   } else if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
-    dma_calls(p.d.blk[0].chunks, voff, lds0 + L_DUMMY6);
+    dma_nk<NC>(p.d.blk[0].chunks, voff, lds0 + L_DUMMY);
   } else if (st.k > 0) {  // FF record: 24 contiguous KiB (the common case: keep it lean)
-    dma_calls(st.ff_src, voff, ring + wave * (CALLS * 1024));
+    dma_nk<NC>(st.ff_src, voff, ring + q0 * 1024);
     st.ff_src += SLOT_BYTES;
   } else {  // attention record: 17 KiB shape record | 5 KiB block constants | 1 KiB c_t row | 1 padding piece
     const BlockPack &bp = p.d.blk[st.b];
 #pragma unroll
-    for (int j = 0; j < CALLS; ++j) {
-      const int q = wave * CALLS + j;
+    for (int j = 0; j < NC; ++j) {
+      const int q = q0 + j;
       const char *src = reinterpret_cast<const char *>(bp.bconst);
       unsigned dst = lds0 + L_DUMMY;
       if (q < 17) {
@@ -883,8 +876,13 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
       }
       dma1k(src, voff, dst);
     }
-    st.ff_src = reinterpret_cast<const char *>(bp.chunks) + wave * (CALLS * 1024);
+    st.ff_src = reinterpret_cast<const char *>(bp.chunks) + q0 * 1024;
   }
+}
+
+__device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
+  if (wave < PIPE_NW / 2) issue_pieces<CALLS_A>(p, st, wave * CALLS_A, voff, lds0, s);
+  else issue_pieces<CALLS_B>(p, st, 4 * CALLS_A + (wave - PIPE_NW / 2) * CALLS_B, voff, lds0, s);
   st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
   if (++st.k == RECORDS_PER_BLOCK) {
     st.k = 0;
@@ -1016,7 +1014,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     __builtin_amdgcn_sched_barrier(0);                  \
     if (mgmt) {                                         \
       DFX_STAMP(1);                                     \
-      if (wave < ISSUE_WAVES) wait_vmcnt<CALLS>();      \
+      if (grpA) wait_vmcnt<CALLS_A>();                  \
+      else wait_vmcnt<CALLS_B>();                       \
       __builtin_amdgcn_s_barrier();                     \
       DFX_STAMP(2);                                     \
       DFX_ISSUE_HERE();                                 \
