@@ -474,7 +474,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
 // V slot of the feed-forward: hid = bf16(a * gelu(g)).  Written stage by stage over 8 elements at a time so
 // that eight independent dependency chains are in flight (hipcc otherwise interleaves only two and every
 // instruction waits for its predecessor's result).
-__device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, const float *b1_next) {
+__device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, const float *b1_next, Tracer &tr) {
   if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
   v16f t;
 #ifdef DFX_ABLATE_NO_GELU  // timing ablation only (wrong results)
@@ -508,6 +508,7 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, 
     asm volatile("" : "+v"(w));
     hid.f[q] = __builtin_bit_cast(v8bf, w);
   }
+  tr.stamp(8);
   if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
     load16(a, b1_next);
     load16(g, b1_next + 32);
@@ -1019,6 +1020,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       __builtin_amdgcn_s_barrier();                     \
       DFX_STAMP(2);                                     \
       DFX_ISSUE_HERE();                                 \
+      DFX_STAMP(7);                                     \
     } else {                                            \
       DFX_STAMP(3);                                     \
       DFX_LOCKSTEP_BARRIER();                           \
@@ -1107,13 +1109,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
-        ff_v(a, g, hid, b1 + j * 64);
+        ff_v(a, g, hid, b1 + j * 64, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
         ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);
-      ff_v(a, g, hid, nullptr);
+      ff_v(a, g, hid, nullptr, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
