@@ -49,33 +49,57 @@ def measured_traffic(T, B, N):
 
 
 def cpu_baseline(W, N, budget_s=20.0):
-    """The numpy oracle (validated against the reference model, tests/test_oracle_golden.py) timed on
-    this box's host cores on a bounded sample: B shapes x Tc steps of the same workload; the chain is
+    """PyTorch-CPU restatement of the reference's p_sample (oracle/torch_cpu.py: the same unfused op sequence the
+    reference's modules run, pinned to the reference goldens in tests/test_oracle_golden.py) timed on this box's host cores
+    with torch's own intra-op threading, on a bounded sample: B shapes x a few steps of the same workload; the chain is
     strictly sequential in t, so shapes/s at T=1000 is extrapolated linearly from s/step/shape."""
     from oracle import diffusion as odf
-    B, Tc = 4, 5
+    from oracle import torch_cpu as tc
+    B, Tc = 16, 2
     part_code, mean, logvar, valid = synth.make_latents(B, seed=7)
     var = np.exp(logvar).astype(np.float32)
     seg = synth.make_seg_mask(valid, N)
     anchors, variance = odf.gather_params(seg, mean, var)
-    ctx = [part_code, np.concatenate([mean, var], 1)]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ctx = [tt(part_code), tt(np.concatenate([mean, var], 1))]
+    Wt = {k: tt(v) for k, v in W.items()}
     tb = odf.Tables(1000)
-    rng = np.random.default_rng(0)
-    x = (np.sqrt(variance) * rng.standard_normal((B, 3, N)).astype(np.float32) + anchors).astype(np.float32)
-    z = rng.standard_normal((B, 3, N)).astype(np.float32)
-    odf.p_sample(tb, W, x, 999, anchors, ctx, variance, seg, valid, z)   # warm-up (BLAS threads, page-in)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        for i in range(Tc):
-            x = odf.p_sample(tb, W, x, 999 - i, anchors, ctx, variance, seg, valid, z)["sample"]
-        n += Tc
-        if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
-            break
+    g = torch.Generator().manual_seed(0)
+    anchors, variance, seg_t, valid_t = tt(anchors), tt(variance), tt(seg), tt(valid)
+    x = torch.sqrt(variance) * torch.randn(B, 3, N, generator=g) + anchors
+    z = torch.randn(B, 3, N, generator=g)
+    def steps(k, x):
+        t0 = time.perf_counter()
+        for i in range(k):
+            x, _ = tc.p_sample(tb, Wt, x, 999 - i, anchors, ctx, variance, seg_t, valid_t, z)
+        return time.perf_counter() - t0, x
+
+    default_threads = torch.get_num_threads()
+    with torch.no_grad():
+        # torch's default (one thread per physical core) oversubscribes these mid-size GEMMs on a 128-core host: probe a few
+        # thread counts with one step each and keep the fastest
+        best = None
+        for nt in sorted({min(default_threads, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            steps(1, x)                          # warm-up (thread pool, page-in)
+            d1, _ = steps(1, x)
+            if best is None or d1 < best[0]:
+                best = (d1, nt)
+        threads = best[1]
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            d, x = steps(Tc, x)
+            n += Tc
+            if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
+                break
+    torch.set_num_threads(default_threads)
     dt = time.perf_counter() - t0
     s_per_step_shape = dt / (n * B)
-    return {"value": 1.0 / (s_per_step_shape * 1000), "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"numpy fp32 oracle, B={B} shapes x {n} p_sample steps at N={N} ({dt:.1f}s), "
+    return {"value": 1.0 / (s_per_step_shape * 1000), "unit": "shapes/s", "cores": threads, "kind": "port",
+            "sample": f"PyTorch-CPU restatement of the reference's p_sample (oracle/torch_cpu.py), fp32, {threads} intra-op threads (fastest of the probed counts) of "
+                      f"{os.cpu_count()} logical cores, B={B} shapes x {n} steps at N={N} ({dt:.1f}s), "
                       f"{s_per_step_shape * 1e3:.1f} ms/step/shape extrapolated to T=1000",
             "ms_per_step_per_shape": s_per_step_shape * 1e3}
 

@@ -144,3 +144,25 @@ def test_training_losses_forward_matches_reference(W):
         r = df.training_losses(tb, W, g["x_start"], g["t"], anchors, variance, _ctx(g), g["seg"], g["valid"], fl, g["noise"])
         assert np.abs(r["x_t"] - g["x_t"]).max() < 1e-6
         assert abs(float(r["mse_loss"]) - float(g["mse_loss_" + name])) < 1e-5 * max(1.0, float(g["mse_loss_" + name])), name
+
+
+def test_torch_cpu_oracle_matches_reference(W):
+    """The PyTorch-CPU restatement (bench.py's cpu_baseline) against the same reference goldens as the numpy oracle."""
+    import torch
+    from oracle import torch_cpu as tc
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    g = np.load(os.path.join(GOLDEN, "denoiser_eps_B2_N128_mixed.npz"))
+    anchors, variance = _per_point(g)
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ctx = [t_(c) for c in _ctx(g)]
+    for t in g["ts"]:
+        eps = tc.transformer_net_forward(Wt, t_(g["x"]), torch.full((2,), int(t)), ctx, t_(anchors).transpose(1, 2), t_(variance).transpose(1, 2),
+                                         t_(g["valid"]), t_(g["seg"]))
+        assert np.abs(eps.numpy() - g[f"eps_t{int(t)}"]).max() < TOL_EPS
+    c = np.load(os.path.join(GOLDEN, "chain_T10_B2_N128_mixed.npz"))
+    anchors, variance = _per_point(c)
+    x = t_(c["traj"][0])
+    tb = df.Tables(10)
+    for i, t in enumerate(range(9, -1, -1)):
+        x, _ = tc.p_sample(tb, Wt, x, t, t_(anchors), [t_(v) for v in _ctx(c)], t_(variance), t_(c["seg"]), t_(c["valid"]), t_(c["step_noise"][i]))
+        assert np.abs(x.numpy() - c["traj"][i + 1]).max() < TOL_CHAIN
