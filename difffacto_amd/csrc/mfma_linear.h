@@ -81,8 +81,68 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
   }
 }
 
+// Wide variant for the plain epilogues when N is a multiple of 128: one wavefront = 32 rows x 128 output channels (four
+// accumulator tiles share every activation fragment), four wavefronts per workgroup = 128 rows on the same weight tile
+// (shared through the L1), 16-byte stores.  2-3x the throughput of k_lin on the large row counts of the PointNet paths.
+template <int EPI>
+static __global__ __launch_bounds__(256) void k_lin_wide(LinArgs a) {
+  static_assert(EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID, "plain epilogues only");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int n0 = blockIdx.x * 128, m0 = (blockIdx.y * 4 + wave) * 32, g = blockIdx.z;
+  if (m0 >= a.M) return;
+  const int mrow = min(m0 + j, a.M - 1);
+  const float *xp = a.X + g * a.x_gs + (size_t)mrow * a.ldx + 4 * hf;
+  const float *wp = a.W + g * a.w_gs + (size_t)(n0 + j) * a.K + 4 * hf;
+  const size_t wt = (size_t)32 * a.K;   // next 32-channel tile
+  v16f acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto ld = [](const float *p) { return *reinterpret_cast<const v4f *>(p); };
+#pragma unroll 2
+  for (int k = 0; k < a.K; k += 8) {
+    const v4f xv = ld(xp + k);
+    v4f wv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wv[t] = ld(wp + t * wt + k);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], xv[s], acc[t], 0, 0, 0);
+  }
+  const int m = m0 + j;
+  if (m >= a.M) return;
+  const float *bp = a.b ? a.b + g * a.b_gs : nullptr;
+  float *yp = a.Y + g * a.y_gs + (size_t)m * a.ldy;
+  const float *rp = EPI == EPI_RESID ? a.R + (size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr : nullptr;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 32 * t + 8 * q + 4 * hf;   // registers 4q..4q+3 of the 32x32 C/D layout: four consecutive channels
+      v4f v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = acc[t][4 * q + e] + (bp ? bp[n + e] : 0.f);
+        if (EPI == EPI_RELU) y = fmaxf(y, 0.f);
+        if (EPI == EPI_RESID) y += rp[n + e];
+        v[e] = y;
+      }
+      *reinterpret_cast<v4f *>(yp + n) = v;
+    }
+}
+
 template <int EPI>
 inline void launch(hipStream_t st, int groups, const LinArgs &a) {
+  constexpr bool plain = (EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID);
+  if constexpr (plain) {
+    if (a.N % 128 == 0 && a.M >= 512 && a.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (a.y_gs % 4) == 0) {
+      dim3 grid(a.N / 128, (a.M + 127) / 128, groups);
+      k_lin_wide<EPI><<<grid, 256, 0, st>>>(a);
+      return;
+    }
+  }
   dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, groups);
   k_lin<EPI><<<grid, 64, 0, st>>>(a);
 }

@@ -92,3 +92,13 @@ emd = EMD(0.002, 10000, True)
 ms = timeit(lambda: emd(a, b), iters=3, warmup=1)
 print(f"EMD auction (eps 0.002, up to 10000 iterations, one persistent workgroup per pair) B=32 n=2048: {ms:9.1f} ms  "
       f"(the reference issues 70 000 kernel launches for the same call)")
+
+# ---- PointNetV2 part encoder (python/difffacto/models/encoders/pointnet.py:187-213), eval mode, B = 128 x 2048 points ----
+from difffacto_amd.encoders import PointNetV2  # noqa: E402
+enc = PointNetV2(zdim=256, point_dim=3, per_part_mlp=True, num_anchors=4).to(dev).eval()
+x = torch.rand(128, 2048, 3, device=dev) * 2 - 1
+attn = torch.eye(4, device=dev)[torch.randint(0, 4, (128, 2048), device=dev)]
+with torch.no_grad():
+    ms = timeit(lambda: enc(x, attn), iters=10)
+fl = 2 * 128 * 2048 * (3 * 128 + 128 * 128 + 128 * 256 + 256 * 512) + 2 * 2 * 128 * 4 * (512 * 256 + 256 * 128 + 128 * 256)
+print(f"PointNetV2 forward (trunk rows = 262144, masked max-pool, grouped heads): {ms * 1e3:9.1f} us  {fl / (ms * 1e-3) / 1e12:6.1f} TFLOP/s fp32")
