@@ -74,6 +74,18 @@ struct BlockPack {
   const float *ct;       // [T][CT_ROW]
 };
 
+// bf16 path, feed-forward: the GELU runs in packed fp16 (two hidden values per VALU instruction: v_pk_*_f16 does not
+// contend with the matrix pipe, unlike v_pk_*_f32) and its output is the fp16 B operand of GEMM2
+// (v_mfma_f32_32x32x16_f16), so W2 is packed as fp16.  To keep a * g inside the fp16 range the `a` half of W1 / b1 is
+// pre-scaled by FF_A_SCALE and W2 by its inverse (exact powers of two).  -DDFX_GELU_F32 restores the all-bf16 variant.
+#ifdef DFX_GELU_F32
+constexpr bool GELU_F16 = false;
+constexpr float FF_A_SCALE = 1.0f;
+#else
+constexpr bool GELU_F16 = true;
+constexpr float FF_A_SCALE = 0.0625f;
+#endif
+
 struct DenoiserDev {
   int depth, T, prec;
   BlockPack blk[DFX_MAX_DEPTH];

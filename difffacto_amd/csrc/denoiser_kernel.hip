@@ -26,6 +26,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 enum { MODE_EPS = 0, MODE_PSAMPLE = 1, MODE_CHAIN = 2 };
 #ifdef DFX_AB_NO_DDIM   // A/B build without the DDIM branch (tools/ab.sh)
@@ -317,6 +319,76 @@ __device__ __forceinline__ float gelu_for(float x) {
   return PREC == DFX_PREC_BF16 ? gelu_fast(x) : gelu_erf(x);
 }
 
+// ---- packed-fp16 GELU (bf16 path; see denoiser_internal.h) ----------------------------------------------------------
+// B operand of GEMM2: 16 hidden values of this lane as fp16 (or bf16 with -DDFX_GELU_F32), same element order as Act.
+struct HidAct {
+  uint4 f[2];
+};
+__device__ __forceinline__ h2 pk_f16(float lo, float hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+// Eight packed pairs through the transcendental unit: the low halves first, then the high halves written into the upper
+// half of the same registers in place (SDWA, no repacking).  gfx950 needs wait states between a transcendental write and a
+// VALU read of that register (hipcc inserts them for its own code; inline asm has to): the eight instructions in between
+// cover the in-place update, one s_nop covers the first consumer after the block.
+#define DFX_TRANS8(op)                                                                                                    \
+  asm("v_" op "_f16_e32 %0, %8\n\tv_" op "_f16_e32 %1, %9\n\tv_" op "_f16_e32 %2, %10\n\tv_" op "_f16_e32 %3, %11\n\t"  \
+      "v_" op "_f16_e32 %4, %12\n\tv_" op "_f16_e32 %5, %13\n\tv_" op "_f16_e32 %6, %14\n\tv_" op "_f16_e32 %7, %15\n\t" \
+      "v_" op "_f16_sdwa %0, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+      "v_" op "_f16_sdwa %1, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+      "v_" op "_f16_sdwa %2, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
+      "v_" op "_f16_sdwa %3, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
+      "v_" op "_f16_sdwa %4, %12 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
+      "v_" op "_f16_sdwa %5, %13 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
+      "v_" op "_f16_sdwa %6, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
+      "v_" op "_f16_sdwa %7, %15 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 1"                  \
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])            \
+      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]))
+__device__ __forceinline__ void exp2_h2x8(h2 (&y)[8]) {
+  h2 o[8];
+  DFX_TRANS8("exp");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = o[i];
+}
+__device__ __forceinline__ void rcp_h2x8(h2 (&y)[8]) {
+  h2 o[8];
+  DFX_TRANS8("rcp");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = o[i];
+}
+#undef DFX_TRANS8
+// hid = a' * g * sigmoid(g (c1 + c3 g^2)) for 16 (a', g) pairs, a' = a * FF_A_SCALE: 4 packed VALU + 2 conversions per
+// PAIR of values + one exp and one rcp per value (the fp32 version: 6 VALU + exp + rcp per value).  fp16 overflow is
+// benign: |g| > 255 makes g^2 = inf, the argument -+inf and the sigmoid exactly 1 / 0.
+__device__ __forceinline__ void gelu16_f16(const v16f &a, const v16f &g, HidAct &hid) {
+  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  h2 gg[8], y[8], ag[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gg[i] = pk_f16(g[2 * i], g[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = gg[i] * gg[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = __builtin_elementwise_fma(y[i], c3, c1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = gg[i] * y[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ag[i] = pk_f16(a[2 * i], a[2 * i + 1]) * gg[i];
+  exp2_h2x8(y);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = one + y[i];
+  rcp_h2x8(y);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = ag[i] * y[i];
+  hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
+                        __builtin_bit_cast(unsigned, y[3]));
+  hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
+                        __builtin_bit_cast(unsigned, y[7]));
+}
+// h_tile += W2 fragment (A, from LDS / L2) x hid fragment (B)
+__device__ __forceinline__ v16f mma_hid(const uint4 &w, const uint4 &hid, v16f acc) {
+  if (GELU_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, hid), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, hid), acc, 0, 0, 0);
+}
+
 // One hidden chunk (32 units) of the GEGLU feed-forward (attention.py:50-57,77-94):
 //   a = W1a xn + b1a; g = W1g xn + b1g; hid = a * gelu(g); h += W2[:, chunk] hid.  Hidden stays in registers.
 template <int PREC>
@@ -334,6 +406,23 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
   v16f hid;
 #pragma unroll
   for (int r = 0; r < 16; ++r) hid[r] = a[r] * gelu_for<PREC>(g[r]);
+  if (PREC == DFX_PREC_BF16 && GELU_F16) {   // `a` arrives pre-scaled, W2 is fp16 (denoiser_internal.h)
+    HidAct hf16;
+    h2 y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = pk_f16(hid[2 * i], hid[2 * i + 1]);
+    hf16.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
+                           __builtin_bit_cast(unsigned, y[3]));
+    hf16.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
+                           __builtin_bit_cast(unsigned, y[7]));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint4 *w = ck2 + (8 + t) * TSTRIDE;
+      h[t] = mma_hid(w[0], hf16.f[0], h[t]);
+      h[t] = mma_hid(w[64], hf16.f[1], h[t]);
+    }
+    return;
+  }
   Act<PREC> ha;
   ha.set(hid);
 #pragma unroll
@@ -407,7 +496,7 @@ __device__ __forceinline__ void tail_prefetch(uint4 (&P)[8], const uint4 *ck) {
 // instead of right after the management barrier (-DDFX_ISSUE_IN_M; measured 1 % slower, so the default hook is empty).
 template <bool S3, bool S1, class Issue>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
-                                     const Act<DFX_PREC_BF16> &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
+                                     const HidAct &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
                                      Issue &issue) {
   uint4 A1[8];
   if (!TAILP) {
@@ -426,7 +515,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
   if (S3) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), hid.f[i & 1], h[i >> 1], 0, 0, 0);
+      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
   } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -471,34 +560,36 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
   if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
-// V slot of the feed-forward: hid = bf16(a * gelu(g)).  Written stage by stage over 8 elements at a time so
-// that eight independent dependency chains are in flight (hipcc otherwise interleaves only two and every
-// instruction waits for its predecessor's result).
-__device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, const float *b1_next, Tracer &tr) {
+// V slot of the feed-forward: hid = a * gelu(g) as the B operand of GEMM2 (fp16 pairs, or bf16 with -DDFX_GELU_F32).
+// Written stage by stage over 8 elements at a time so that eight independent dependency chains are in flight (hipcc
+// otherwise interleaves only two and every instruction waits for its predecessor's result).
+__device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float *b1_next, Tracer &tr) {
   if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
-  v16f t;
-#ifdef DFX_ABLATE_NO_GELU  // timing ablation only (wrong results)
+  if (GELU_F16) {
+    gelu16_f16(a, g, hid);
+  } else {
+    v16f t;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = a[r] * g[r];
-#else
+    for (int half = 0; half < 2; ++half) {
+      float u[8], ag[8];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float u[8], ag[8];
+      for (int i = 0; i < 8; ++i) u[i] = gelu_sigmoid_arg(g[half * 8 + i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = gelu_sigmoid_arg(g[half * 8 + i]);
+      for (int i = 0; i < 8; ++i) ag[i] = a[half * 8 + i] * g[half * 8 + i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ag[i] = a[half * 8 + i] * g[half * 8 + i];
+      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);
+      for (int i = 0; i < 8; ++i) u[i] = 1.0f + u[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = 1.0f + u[i];
+      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_rcpf(u[i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_rcpf(u[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[half * 8 + i] = ag[i] * u[i];
+      for (int i = 0; i < 8; ++i) t[half * 8 + i] = ag[i] * u[i];
+    }
+    Act<DFX_PREC_BF16> hb;
+    hb.set(t);
+    hid.f[0] = __builtin_bit_cast(uint4, hb.f[0]);
+    hid.f[1] = __builtin_bit_cast(uint4, hb.f[1]);
   }
-#endif
-  hid.set(t);
   // Pin the result here: without a use in this slot LLVM sinks the whole GELU past the record barrier into the
   // consumer's M slot, and the two groups' VALU bursts collide instead of running in anti-phase.
 #pragma unroll
@@ -506,7 +597,7 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, Act<DFX_PREC_BF16> &hid, 
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     v4u w = __builtin_bit_cast(v4u, hid.f[q]);
     asm volatile("" : "+v"(w));
-    hid.f[q] = __builtin_bit_cast(v8bf, w);
+    hid.f[q] = __builtin_bit_cast(uint4, w);
   }
   tr.stamp(8);
   if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
@@ -1100,7 +1191,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       ln_to_act<PREC>(h, xn);
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
       v16f a, g;
-      Act<PREC> hid;
+      HidAct hid;
       load16(a, b1);  // accumulator initialisers of chunk 0 (block constants: resident since the attention record)
       load16(g, b1 + 32);
       DFX_SLOT(grpA);

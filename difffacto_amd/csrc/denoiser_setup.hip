@@ -89,19 +89,20 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   const int c = tile & 3, part = (tile >> 2) & 1, u = tile >> 3;
   const int row = part * FF_HID + 32 * u + i, col = 32 * c + kk;
   const long long di = ((long long)(u * CHUNK_TILES + part * 4 + c) << 10) + (gi & 1023);
-  tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col]);
+  const float sc = (PREC == DFX_PREC_BF16 && part == 0) ? FF_A_SCALE : 1.0f;   // `a` rows (denoiser_internal.h)
+  tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col] * sc);
 }
 
 // b1' = b1 + W1 beta3, stored [u][part][hf][16]
 __global__ void k_pack_b1(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ be3,
-                          float *__restrict__ dst) {
+                          float *__restrict__ dst, float a_scale) {
   const int gi = blockIdx.x * 256 + threadIdx.x;
   if (gi >= FF_CHUNKS * 2 * 32) return;
   const int r = gi & 15, hf = (gi >> 4) & 1, part = (gi >> 5) & 1, u = gi >> 6;
   const int row = part * FF_HID + 32 * u + rho(r, hf);
   float acc = 0.f;
   for (int k = 0; k < INNER; ++k) acc = fmaf(W1[(size_t)row * INNER + k], be3[k], acc);
-  dst[gi] = b1[row] + acc;
+  dst[gi] = (b1[row] + acc) * (part == 0 ? a_scale : 1.0f);
 }
 
 // W2 (128 x 512) -> tiles 8+ct of stage record u+FF_SKEW (see denoiser_internal.h)
@@ -114,7 +115,9 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   tile_decode<PREC>((int)(gi & 1023), i, kk);
   const int ct = tile & 3, u = tile >> 2;
   const long long di = ((long long)((u + FF_SKEW) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
-  tile_store<PREC>(dst, di, W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk]);
+  const float w = W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk];
+  if (PREC == DFX_PREC_BF16 && GELU_F16) reinterpret_cast<_Float16 *>(dst)[di] = (_Float16)(w * (1.0f / FF_A_SCALE));
+  else tile_store<PREC>(dst, di, w);
 }
 
 // proj_in x-columns, pre_norm affine, post_norm-folded proj_out, all in cvec order
@@ -459,7 +462,8 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     TRY_LAUNCH("ct_cvec");
     k_to_cvec<<<1, 256, 0, st>>>(k.ff2_b, nullptr, c.bconst + BCONST_B2_OFF, 1, INNER);
     TRY_LAUNCH("b2_cvec");
-    k_pack_b1<<<nblk(FF_CHUNKS * 2 * 32), 256, 0, st>>>(k.ff0_w, k.ff0_b, k.norm3_b, c.bconst);
+    k_pack_b1<<<nblk(FF_CHUNKS * 2 * 32), 256, 0, st>>>(k.ff0_w, k.ff0_b, k.norm3_b, c.bconst,
+                                                        precision == DFX_PREC_BF16 ? FF_A_SCALE : 1.0f);
     TRY_LAUNCH("pack_b1");
     if (precision == DFX_PREC_BF16) {
       k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);

@@ -8,6 +8,8 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 #define FMA6 "v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
 #define MIX6 "v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_exp_f32 %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_rcp_f32 %7, %7\n"
+#define PKH3 "v_pk_fma_f16 %2, %2, %2, %2\n v_pk_fma_f16 %3, %3, %3, %3\n v_pk_fma_f16 %4, %4, %4, %4\n"
+#define MIXH6 "v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_exp_f16 %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_rcp_f16 %7, %7\n"
 #define PK3 "v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n v_pk_fma_f32 %4, %4, %4, %4\n"
 
 // MODE: 0 = MFMA only (VGPR acc), 1 = MFMA only (AGPR acc), 2 = MFMA(V) + 6 fma, 3 = MFMA(A) + 6 fma, 4 = 6 fma only,
@@ -64,6 +66,16 @@ __global__ void __launch_bounds__(512) k(float *out, int iters, float seed) {
       } else if (MODE == 14) {   // MFMA + ds_read_b128 + 5 fma
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %8, %9, %0\n ds_read_b128 %10, %11\n" FMA6 "v_mfma_f32_32x32x16_bf16 %1, %8, %9, %1\n ds_read_b128 %10, %11 offset:4096\n" FMA6 "s_waitcnt lgkmcnt(0)\n"
                      : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(A), "v"(B), "v"(L), "v"(laddr));
+      } else if (MODE == 15) {   // MFMA + 3 packed-f16 FMAs
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, %0\n" PKH3 "v_mfma_f32_32x32x16_bf16 %1, %5, %6, %1\n" PKH3
+                     : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2) : "v"(A), "v"(B));
+      } else if (MODE == 16) {
+        asm volatile(PKH3 PKH3 : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2));
+      } else if (MODE == 17) {   // f16 transcendentals in the mix
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %8, %9, %0\n" MIXH6 "v_mfma_f32_32x32x16_bf16 %1, %8, %9, %1\n" MIXH6
+                     : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(A), "v"(B));
+      } else if (MODE == 18) {
+        asm volatile(MIXH6 MIXH6 : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5));
       } else if (MODE == 9) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %8, %9, %0\n" FMA6 FMA6 "v_mfma_f32_32x32x16_bf16 %1, %8, %9, %1\n" FMA6 FMA6
                      : "+v"(acc0), "+v"(acc1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(A), "v"(B));
@@ -92,13 +104,15 @@ int main() {
   const int it = 200000;
   const char *names[] = {"MFMA only (VGPR acc)", "MFMA only (AGPR acc)", "MFMA(V) + 6 fma", "MFMA(A) + 6 fma", "6 fma only",
                          "MFMA(A) + 3 pk_fma", "3 pk_fma only", "MFMA(A) + 12 fma", "12 fma only", "MFMA(V) + 12 fma",
-                         "MFMA(1 acc) + 6 fma", "MFMA(V) + 4fma+exp+rcp", "4fma+exp+rcp only", "MFMA only (1 acc)", "MFMA(V)+ds_read+6fma"};
+                         "MFMA(1 acc) + 6 fma", "MFMA(V) + 4fma+exp+rcp", "4fma+exp+rcp only", "MFMA only (1 acc)", "MFMA(V)+ds_read+6fma",
+                         "MFMA + 3 pk_fma_f16", "3 pk_fma_f16 only", "MFMA + 4fma+exp_f16+rcp_f16", "4fma+exp_f16+rcp_f16 only"};
   for (int threads : {256, 512}) {
     printf("== %d waves per SIMD\n", threads / 256);
-    float r[15] = {run<0>(d, it, threads), run<1>(d, it, threads), run<2>(d, it, threads), run<3>(d, it, threads), run<4>(d, it, threads),
+    float r[19] = {run<0>(d, it, threads), run<1>(d, it, threads), run<2>(d, it, threads), run<3>(d, it, threads), run<4>(d, it, threads),
                    run<5>(d, it, threads), run<6>(d, it, threads), run<7>(d, it, threads), run<8>(d, it, threads), run<9>(d, it, threads),
-                   run<10>(d, it, threads), run<11>(d, it, threads), run<12>(d, it, threads), run<13>(d, it, threads), run<14>(d, it, threads)};
-    for (int i = 0; i < 15; ++i) printf("%-24s %7.2f ns per group  (%.1f cycles @2.4GHz)\n", names[i], r[i], r[i] * 2.4f);
+                   run<10>(d, it, threads), run<11>(d, it, threads), run<12>(d, it, threads), run<13>(d, it, threads), run<14>(d, it, threads),
+                   run<15>(d, it, threads), run<16>(d, it, threads), run<17>(d, it, threads), run<18>(d, it, threads)};
+    for (int i = 0; i < 19; ++i) printf("%-24s %7.2f ns per group  (%.1f cycles @2.4GHz)\n", names[i], r[i], r[i] * 2.4f);
   }
   return 0;
 }
