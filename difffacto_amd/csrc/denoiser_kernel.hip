@@ -494,11 +494,80 @@ __device__ __forceinline__ void tail_prefetch(uint4 (&P)[8], const uint4 *ck) {
 
 // `issue` = hook for the A/B variant that issues the ring's DMA from inside the M slot, behind the first MFMA batch,
 // instead of right after the management barrier (-DDFX_ISSUE_IN_M; measured 1 % slower, so the default hook is empty).
+// Interleaved M slots (default; -DDFX_M_BATCHED restores the batch-of-eight form): every MFMA is followed by ONE LDS read
+// that refills the fragment register it has just consumed with the fragment needed eight MFMAs later (in place: the
+// MFMA reads its A operand at issue), so the wavefront's read instructions issue while the matrix pipe works instead of
+// in bursts during which it drains.  The last eight refills are the tail prefetch for the next M slot.
+#ifdef DFX_M_BATCHED
+constexpr bool M_INTERLEAVED = false;
+#else
+constexpr bool M_INTERLEAVED = TAILP;
+#endif
+
 template <bool S3, bool S1, class Issue>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
                                      const HidAct &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
                                      Issue &issue) {
   uint4 A1[8];
+  if (M_INTERLEAVED) {
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(4);
+    if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(DFX_MFMA_PRIO);
+    auto gemm1 = [&](int i, int half, const uint4 &w) {
+      v16f &acc = (i & 1) ? g : a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
+    };
+    if (S3 && S1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // GEMM2 of the previous chunk on the prefetched W2 fragments; fetch W1 (first half)
+        h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+        issue.at(i, 24);
+        A1[i] = ck[w1_frag(i, 0)];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // GEMM1 first half; refill in place with the second half
+        gemm1(i, 0, A1[i]);
+        issue.at(8 + i, 24);
+        A1[i] = ck[w1_frag(i, 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // GEMM1 second half; tail prefetch of the next record's W2 fragments
+        gemm1(i, 1, A1[i]);
+        issue.at(16 + i, 24);
+        P[i] = ck_next[w2_frag(i)];
+      }
+    } else if (S1) {                  // first FF record of a block: P holds W1 (first half)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        gemm1(i, 0, P[i]);
+        issue.at(i, 16);
+        A1[i] = ck[w1_frag(i, 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        gemm1(i, 1, A1[i]);
+        issue.at(8 + i, 16);
+        P[i] = ck_next[w2_frag(i)];
+      }
+    } else {                          // last FF record of a block: GEMM2 only; tail prefetch = A_s of the next block
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+        issue.at(i, 8);
+        P[i] = ck_next[as_frag(i)];
+      }
+    }
+    // keep the program order MFMA, read, MFMA, read, ...
+#pragma unroll
+    for (int i = 0; i < (S3 && S1 ? 24 : S1 ? 16 : 8); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue();
+    if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+    return;
+  }
   if (!TAILP) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) P[i] = ck[S3 ? w2_frag(i) : w1_frag(i, 0)];
@@ -617,6 +686,22 @@ __device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn
   }
   load16(sim, sbias);
   __builtin_amdgcn_sched_barrier(0);
+  if (M_INTERLEAVED) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
+      issue.at(i, 8);
+      P[i] = rec[ms_frag(i)];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue();
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
@@ -635,6 +720,20 @@ __device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &
     for (int i = 0; i < 8; ++i) P[i] = rec[ms_frag(i)];
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (M_INTERLEAVED) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+      P[i] = ck_next[w1_frag(i, 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
@@ -972,9 +1071,46 @@ __device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int
   }
 }
 
-__device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
-  if (wave < PIPE_NW / 2) issue_pieces<CALLS_A>(p, st, wave * CALLS_A, voff, lds0, s);
-  else issue_pieces<CALLS_B>(p, st, 4 * CALLS_A + (wave - PIPE_NW / 2) * CALLS_B, voff, lds0, s);
+// The same bookkeeping, but only the (wave-uniform) source / destination of this wave's pieces: the loads themselves are
+// issued one at a time from inside the wave's next M slot (DFX_ISSUE_SPREAD).
+struct Pieces {
+  const char *src[CALLS_MAX];
+  unsigned dst[CALLS_MAX];
+};
+template <int NC>
+__device__ __forceinline__ void prepare_pieces(const KParams &p, DmaState &st, int q0, unsigned lds0, int s, Pieces &pc) {
+  const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
+  if (st.step >= p.nsteps) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pc.src[j] = reinterpret_cast<const char *>(p.d.blk[0].chunks), pc.dst[j] = lds0 + L_DUMMY;
+  } else if (st.k > 0) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pc.src[j] = st.ff_src + j * 1024, pc.dst[j] = ring + (q0 + j) * 1024;
+    st.ff_src += SLOT_BYTES;
+  } else {
+    const BlockPack &bp = p.d.blk[st.b];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int q = q0 + j;
+      const char *src = reinterpret_cast<const char *>(bp.bconst);
+      unsigned dst = lds0 + L_DUMMY;
+      if (q < 17) {
+        src = reinterpret_cast<const char *>(p.as_ms) + ((size_t)s * p.d.depth + st.b) * asms_bytes(DFX_PREC_BF16) + q * 1024;
+        dst = ring + q * 1024;
+      } else if (q < 22) {
+        src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024;
+        dst = lds0 + L_BCONST + (st.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
+      } else if (q == 22) {
+        src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step, s) * CT_ROW);
+        dst = ring + 17 * 1024;
+      }
+      pc.src[j] = src, pc.dst[j] = dst;
+    }
+    st.ff_src = reinterpret_cast<const char *>(bp.chunks) + q0 * 1024;
+  }
+}
+
+__device__ __forceinline__ void advance_record(const KParams &p, DmaState &st) {
   st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
   if (++st.k == RECORDS_PER_BLOCK) {
     st.k = 0;
@@ -985,6 +1121,68 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
     }
   }
 }
+
+__device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
+  if (wave < PIPE_NW / 2) issue_pieces<CALLS_A>(p, st, wave * CALLS_A, voff, lds0, s);
+  else issue_pieces<CALLS_B>(p, st, 4 * CALLS_A + (wave - PIPE_NW / 2) * CALLS_B, voff, lds0, s);
+  advance_record(p, st);
+}
+
+// Where the DMA of the record three ahead is issued:
+//   DFX_ISSUE_AT_BARRIER     all of a wave's pieces right after the record's management barrier.  The eight waves'
+//                            24 KiB hit the texture-address path (64 B/clk) at once: every wave sits ~400 cycles in
+//                            the issue stall, on the critical path of the record period (slot trace, tools/run_trace.sh)
+//   default (spread)         one piece at a time from inside the wave's own M slot, between MFMAs (the two groups' M
+//                            slots are in anti-phase, so at most four waves issue at a time, one KiB per ~250 cycles)
+//   DFX_ISSUE_IN_M[_GROUP_B] earlier A/B variants: all pieces behind the first MFMA batch of the M slot
+#if defined(DFX_ISSUE_IN_M) || defined(DFX_ISSUE_IN_M_GROUP_B) || defined(DFX_ISSUE_AT_BARRIER)
+constexpr bool ISSUE_SPREAD = false;
+#else
+constexpr bool ISSUE_SPREAD = M_INTERLEAVED;
+#endif
+struct Issuer {
+  const KParams &p;
+  DmaState &st;
+  int wave;
+  unsigned voff, lds0;
+  int s;
+  bool grpA;
+  Pieces pc;
+  __device__ __forceinline__ void whole() { issue_record(p, st, wave, voff, lds0, s); }
+  // right after the management barrier
+  __device__ __forceinline__ void at_barrier() {
+#if defined(DFX_ISSUE_IN_M)
+#elif defined(DFX_ISSUE_IN_M_GROUP_B)
+    if (grpA) whole();
+#else
+    if (!ISSUE_SPREAD) whole();
+#endif
+  }
+  // start of an M slot that consumes a record
+  __device__ __forceinline__ void m_begin() {
+    if (ISSUE_SPREAD) {
+      static_assert(!ISSUE_SPREAD || CALLS_A == CALLS_B, "spread issue: same piece count in both groups");
+      prepare_pieces<CALLS_A>(p, st, wave * CALLS_A, lds0, s, pc);
+      advance_record(p, st);
+    }
+  }
+  // behind the first MFMA batch of the M slot (A/B variants)
+  __device__ __forceinline__ void operator()() {
+#if defined(DFX_ISSUE_IN_M)
+    whole();
+#elif defined(DFX_ISSUE_IN_M_GROUP_B)
+    if (!grpA) whole();
+#endif
+  }
+  // after MFMA i of the n of an M slot
+  __device__ __forceinline__ void at(int i, int n) {
+    if (ISSUE_SPREAD) {
+#pragma unroll
+      for (int k = 0; k < CALLS_A; ++k)
+        if (i == (k * n) / CALLS_A) dma1k(pc.src[k], voff, pc.dst[k]);
+    }
+  }
+};
 
 // The per-point state (x_t, anchor, variance, sqrt(variance), part id) is touched once per diffusion step; parked in LDS
 // in between (13 KiB per workgroup) it costs no VGPRs during the 90 record slots of a step — hipcc would otherwise keep
@@ -1082,18 +1280,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 
   // DMA of the record three ahead: right after the management barrier (default), or from inside the M slot that
   // follows it, behind the first MFMA batch (-DDFX_ISSUE_IN_M, the A/B variant: 1 % slower)
-  auto issue_now = [&]() { issue_record(p, dma, wave, voff, lds0, s); };
-  [[maybe_unused]] auto issue_nop = []() {};
-#if defined(DFX_ISSUE_IN_M)
-#define DFX_ISSUE_HERE() ((void)0)
-  auto &issue_in_m = issue_now;
-#elif defined(DFX_ISSUE_IN_M_GROUP_B)   // group A at the barrier (start of its M slot), group B inside its M slot
-#define DFX_ISSUE_HERE() do { if (grpA) issue_now(); } while (0)
-  auto issue_in_m = [&]() { if (!grpA) issue_now(); };
-#else
-#define DFX_ISSUE_HERE() issue_now()
-  auto &issue_in_m = issue_nop;
-#endif
+  Issuer issue_in_m{p, dma, wave, voff, lds0, s, grpA, {}};
+#define DFX_ISSUE_HERE() issue_in_m.at_barrier()
   // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
 #define DFX_STAMP(tag) tr.stamp(tag)
 #ifdef DFX_LOCKSTEP  // A/B variant: a barrier at every slot boundary
@@ -1175,6 +1363,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       // ---- M0: sim = sbias + A_s xn ----
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
+      issue_in_m.m_begin();
       const uint4 *rec = ck;
       v16f sim;
       attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0, issue_in_m);
@@ -1196,6 +1385,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
+      issue_in_m.m_begin();
       ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
@@ -1203,12 +1393,14 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
         ff_v(a, g, hid, b1 + j * 64, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
+        issue_in_m.m_begin();
         ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);
       ff_v(a, g, hid, nullptr, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
+      issue_in_m.m_begin();
       ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
     }
   }
