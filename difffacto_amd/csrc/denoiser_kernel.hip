@@ -358,12 +358,18 @@ __device__ __forceinline__ void rcp_h2x8(h2 (&y)[8]) {
 // hid = a' * g * sigmoid(g (c1 + c3 g^2)) for 16 (a', g) pairs, a' = a * FF_A_SCALE: 4 packed VALU + 2 conversions per
 // PAIR of values + one exp and one rcp per value (the fp32 version: 6 VALU + exp + rcp per value).  fp16 overflow is
 // benign: |g| > 255 makes g^2 = inf, the argument -+inf and the sigmoid exactly 1 / 0.
-__device__ __forceinline__ void gelu16_f16(const v16f &a, const v16f &g, HidAct &hid) {
-  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
-  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  h2 gg[8], y[8], ag[8];
+// (a, g) -> packed fp16 first: after these sixteen conversions the accumulators are dead and their next initialisers
+// (b1 of the next chunk) can be fetched from LDS underneath the GELU arithmetic instead of after it.
+__device__ __forceinline__ void gelu16_f16_cvt(const v16f &a, const v16f &g, h2 (&aa)[8], h2 (&gg)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) gg[i] = pk_f16(g[2 * i], g[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) aa[i] = pk_f16(a[2 * i], a[2 * i + 1]);
+}
+__device__ __forceinline__ void gelu16_f16_math(const h2 (&aa)[8], const h2 (&gg)[8], HidAct &hid) {
+  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  h2 y[8], ag[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = gg[i] * gg[i];
 #pragma unroll
@@ -371,7 +377,7 @@ __device__ __forceinline__ void gelu16_f16(const v16f &a, const v16f &g, HidAct 
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = gg[i] * y[i];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ag[i] = pk_f16(a[2 * i], a[2 * i + 1]) * gg[i];
+  for (int i = 0; i < 8; ++i) ag[i] = aa[i] * gg[i];
   exp2_h2x8(y);
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = one + y[i];
@@ -634,8 +640,31 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
 // otherwise interleaves only two and every instruction waits for its predecessor's result).
 __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float *b1_next, Tracer &tr) {
   if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
+  bool b1_loaded = false;
   if (GELU_F16) {
-    gelu16_f16(a, g, hid);
+    h2 aa[8], gg[8];
+    gelu16_f16_cvt(a, g, aa, gg);
+#ifdef DFX_B1_EARLY   // A/B variant (1.4 % slower: the eight reads delay the slot's first VALU results)
+    if (b1_next) {
+      // the address goes through an asm statement that consumes the sixteen packed values: the reads cannot be placed
+      // above the conversions (where they would need 32 more VGPRs), and the sched_barrier keeps them above the math
+      typedef __attribute__((address_space(3))) const float lds_cf;
+      unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1_next;
+      asm volatile("" : "+v"(addr) : "v"(gg[0]), "v"(gg[1]), "v"(gg[2]), "v"(gg[3]), "v"(gg[4]), "v"(gg[5]), "v"(gg[6]), "v"(gg[7]),
+                   "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]));
+      const float *src = (const float *)(lds_cf *)(uintptr_t)addr;
+      load16(a, src);
+      load16(g, src + 32);
+      __builtin_amdgcn_sched_barrier(0);
+      b1_loaded = true;
+    }
+#endif
+#ifdef DFX_ABL_NO_GELU   // timing ablation only (wrong results): no GELU arithmetic
+    hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, aa[0]), __builtin_bit_cast(unsigned, aa[1]), __builtin_bit_cast(unsigned, gg[2]), __builtin_bit_cast(unsigned, gg[3]));
+    hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, aa[4]), __builtin_bit_cast(unsigned, aa[5]), __builtin_bit_cast(unsigned, gg[6]), __builtin_bit_cast(unsigned, gg[7]));
+#else
+    gelu16_f16_math(aa, gg, hid);
+#endif
   } else {
     v16f t;
 #pragma unroll
@@ -669,7 +698,7 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float 
     hid.f[q] = __builtin_bit_cast(uint4, w);
   }
   tr.stamp(8);
-  if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
+  if (b1_next && !b1_loaded) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
     load16(a, b1_next);
     load16(g, b1_next + 32);
   }
@@ -1179,7 +1208,11 @@ struct Issuer {
     if (ISSUE_SPREAD) {
 #pragma unroll
       for (int k = 0; k < CALLS_A; ++k)
+#ifndef DFX_ABL_NO_DMA   // timing ablation only (wrong results): the ring is never refilled
         if (i == (k * n) / CALLS_A) dma1k(pc.src[k], voff, pc.dst[k]);
+#else
+        ;
+#endif
     }
   }
 };
@@ -1242,7 +1275,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
+#ifdef DFX_SYMMETRIC   // A/B variant: no anti-phase groups, every wave takes the record barrier at the start of its M slot
+  const bool grpA = true;
+#else
   const bool grpA = wave < PIPE_NW / 2;
+#endif
 
   // ---- prologue DMA: records 0 and 1 in flight while the per-point state is set up ----
   DmaState dma{0, 0, 0, 0, 0, nullptr};
@@ -1282,6 +1319,14 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   // follows it, behind the first MFMA batch (-DDFX_ISSUE_IN_M, the A/B variant: 1 % slower)
   Issuer issue_in_m{p, dma, wave, voff, lds0, s, grpA, {}};
 #define DFX_ISSUE_HERE() issue_in_m.at_barrier()
+  // the (scalar) bookkeeping of the pieces a wave issues in an M slot runs in the V slot before it, beside the VALU work
+#ifdef DFX_PREP_IN_M
+#define DFX_M_BEGIN_EARLY() ((void)0)
+#define DFX_M_BEGIN_LATE() issue_in_m.m_begin()
+#else
+#define DFX_M_BEGIN_EARLY() issue_in_m.m_begin()
+#define DFX_M_BEGIN_LATE() ((void)0)
+#endif
   // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
 #define DFX_STAMP(tag) tr.stamp(tag)
 #ifdef DFX_LOCKSTEP  // A/B variant: a barrier at every slot boundary
@@ -1339,6 +1384,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       Act<PREC> xn[4];
       // ---- V0: finish the previous block / step, start this one ----
       DFX_SLOT(!grpA && step < p.nsteps);
+      DFX_M_BEGIN_EARLY();
       if (seq > 0)  // b2 of the previous block (other block-constant buffer)
         add_cvec(h, reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) +
                         BCONST_B2_OFF + hf * 64);
@@ -1363,7 +1409,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       // ---- M0: sim = sbias + A_s xn ----
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      issue_in_m.m_begin();
+      DFX_M_BEGIN_LATE();
       const uint4 *rec = ck;
       v16f sim;
       attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0, issue_in_m);
@@ -1376,6 +1422,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       attn_m1(h, pa, rec, P, DFX_PEEK_RECORD());
       // ---- V2: + c_t, LN3 ----
       DFX_SLOT(!grpA);
+      DFX_M_BEGIN_EARLY();
       add_cvec(h, reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
       ln_to_act<PREC>(h, xn);
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
@@ -1385,22 +1432,24 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      issue_in_m.m_begin();
+      DFX_M_BEGIN_LATE();
       ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
+        DFX_M_BEGIN_EARLY();
         ff_v(a, g, hid, b1 + j * 64, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
-        issue_in_m.m_begin();
+        DFX_M_BEGIN_LATE();
         ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);
+      DFX_M_BEGIN_EARLY();
       ff_v(a, g, hid, nullptr, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      issue_in_m.m_begin();
+      DFX_M_BEGIN_LATE();
       ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
     }
   }
@@ -1412,6 +1461,8 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #undef DFX_NEXT_RECORD
 #undef DFX_PEEK_RECORD
 #undef DFX_ISSUE_HERE
+#undef DFX_M_BEGIN_EARLY
+#undef DFX_M_BEGIN_LATE
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
