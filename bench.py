@@ -36,6 +36,9 @@ def flops_per_step(N, depth=5):
     return 2 * (N * per_point + depth * 2 * 4 * 522 * 128 + 256 * 2048 + 1024 * 256)
 
 
+SUSTAINED_BF16_TFLOPS = 1630.0   # 24 x 8 x 256 MFMAs of 32768 FLOP per 988 ns record (profiles/r01_ubench_power.txt)
+
+
 def measured_traffic(T, B, N):
     """Fabric-side bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes, see
     profiles/README.md), which scales linearly with the number of diffusion steps; None if not applicable."""
@@ -229,6 +232,11 @@ def main():
                          "traffic": measured_traffic(T, B, N), "kernel": "k_denoise_pipe (persistent T-step chain)", "kernel_ms": kern_ms,
                          "flops_per_launch": F},
         }
+        if args.precision == "bf16":
+            # the same MFMA + LDS-fragment-read stream with random bf16 operands, no other work (tools/ubench/swp_law.hip
+            # power -> profiles/r01_ubench_power.txt): the chip throttles its clock on real data, this is what it sustains
+            res["roofline"]["sustained_mfma_tflops_random_operands"] = SUSTAINED_BF16_TFLOPS
+            res["roofline"]["frac_of_sustained"] = achieved / SUSTAINED_BF16_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(Wnp, N)
         print(json.dumps(res), flush=True)

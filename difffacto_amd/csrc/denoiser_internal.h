@@ -77,18 +77,27 @@ struct BlockPack {
 // bf16 path, feed-forward: the GELU runs in packed fp16 (two hidden values per VALU instruction: v_pk_*_f16 does not
 // contend with the matrix pipe, unlike v_pk_*_f32) and its output is the fp16 B operand of GEMM2
 // (v_mfma_f32_32x32x16_f16), so W2 is packed as fp16.  To keep a * g inside the fp16 range the `a` half of W1 / b1 is
-// pre-scaled by FF_A_SCALE and W2 by its inverse (exact powers of two).  -DDFX_GELU_F32 restores the all-bf16 variant.
+// pre-scaled by FF_A_SCALE (and the `g` half by FF_G_SCALE for the polynomial variant, which works on g/2) and W2 by
+// the inverse of their product (exact powers of two).
+//   -DDFX_GELU_F32   the all-bf16 variant (fp32 GELU arithmetic, bf16 hidden operand)
+//   -DDFX_GELU_POLY  packed fp16 with a transcendental-free polynomial Phi(g) instead of the exp/rcp sigmoid form
+//                    (same accuracy, same speed: the chain kernel is power-limited); g is then
+//                    pre-scaled by FF_G_SCALE = 1/2 as well
 #ifdef DFX_GELU_F32
-constexpr bool GELU_F16 = false;
-constexpr float FF_A_SCALE = 1.0f;
+constexpr bool GELU_F16 = false, GELU_POLY = false;
+constexpr float FF_A_SCALE = 1.0f, FF_G_SCALE = 1.0f;
+#elif defined(DFX_GELU_POLY)
+constexpr bool GELU_F16 = true, GELU_POLY = true;
+constexpr float FF_A_SCALE = 0.0625f, FF_G_SCALE = 0.5f;
 #else
-constexpr bool GELU_F16 = true;
-constexpr float FF_A_SCALE = 0.0625f;
+constexpr bool GELU_F16 = true, GELU_POLY = false;
+constexpr float FF_A_SCALE = 0.0625f, FF_G_SCALE = 1.0f;
 #endif
 
 struct DenoiserDev {
   int depth, T, prec;
   BlockPack blk[DFX_MAX_DEPTH];
+  long long blk_stride;  // bytes from block b's chunks / bconst / ct to block b+1's (one carve per block: uniform)
   const float4 *win_x;   // cvec order, {W_in[ch][0], W_in[ch][1], W_in[ch][2], 0}
   const float2 *pre_gb;  // cvec order {gamma, beta} of pre_norm
   const float4 *wout;    // cvec order {W_out[0][ch] g, W_out[1][ch] g, W_out[2][ch] g, 0}, g = post_norm gamma

@@ -358,6 +358,48 @@ __device__ __forceinline__ void rcp_h2x8(h2 (&y)[8]) {
 // hid = a' * g * sigmoid(g (c1 + c3 g^2)) for 16 (a', g) pairs, a' = a * FF_A_SCALE: 4 packed VALU + 2 conversions per
 // PAIR of values + one exp and one rcp per value (the fp32 version: 6 VALU + exp + rcp per value).  fp16 overflow is
 // benign: |g| > 255 makes g^2 = inf, the argument -+inf and the sigmoid exactly 1 / 0.
+// Polynomial form (-DDFX_GELU_POLY): gelu(g) = g Phi(g),  Phi(g) ~ 1/2 + u R(u^2 - m),  u = clamp(g / 2, -+1.8), R of degree 5
+// (minimax fit of g Phi(g) on [-6, 6]: 3.9e-4 in exact arithmetic; evaluated in fp16 with the centred argument
+// z = u^2 - m the error of a * gelu(g) is the same as that of the exp/rcp sigmoid form: rms 8.5e-4 for a, g ~ N(0, 1.5),
+// tools/fit_gelu_poly.py).  Eleven packed instructions per PAIR of values and no transcendental: a dependent chain of
+// plain v_pk_* operations hides completely behind the MFMAs of the same wavefront (tools/ubench/swp_law.hip), the
+// exp/rcp chain (12 instructions, 4 of them quarter-rate with wait states) does not.  g arrives as g/2 (FF_G_SCALE).
+struct GeluPoly {
+  h2 u, r, z;
+};
+__device__ __forceinline__ h2 h2c(float v) { return h2{(_Float16)v, (_Float16)v}; }
+__device__ __forceinline__ void gelu_poly_half0(GeluPoly &t, h2 gp) {
+  t.u = __builtin_elementwise_min(__builtin_elementwise_max(gp, h2c(-1.8f)), h2c(1.8f));
+  t.z = __builtin_elementwise_fma(t.u, t.u, h2c(-1.62f));
+  h2 r = __builtin_elementwise_fma(t.z, h2c(-0.0011402554f), h2c(0.0057853916f));
+  r = __builtin_elementwise_fma(r, t.z, h2c(-0.0158536041f));
+  t.r = __builtin_elementwise_fma(r, t.z, h2c(0.0409006897f));
+}
+// the same chain in four quarters: two pairs run side by side behind four MFMAs of the software-pipelined stage, so
+// that consecutive instructions are independent (a dependent packed op costs a wait state on gfx950)
+template <int Q>
+__device__ __forceinline__ void gelu_poly_quarter(GeluPoly &t, h2 ap, h2 gp, h2 &out) {
+  if (Q == 0) {
+    t.u = __builtin_elementwise_min(__builtin_elementwise_max(gp, h2c(-1.8f)), h2c(1.8f));
+    t.z = __builtin_elementwise_fma(t.u, t.u, h2c(-1.62f));
+  } else if (Q == 1) {
+    h2 r = __builtin_elementwise_fma(t.z, h2c(-0.0011402554f), h2c(0.0057853916f));
+    r = __builtin_elementwise_fma(r, t.z, h2c(-0.0158536041f));
+    t.r = __builtin_elementwise_fma(r, t.z, h2c(0.0409006897f));
+  } else if (Q == 2) {
+    h2 r = __builtin_elementwise_fma(t.r, t.z, h2c(-0.1098130657f));
+    r = __builtin_elementwise_fma(r, t.z, h2c(0.3885767652f));
+    t.r = __builtin_elementwise_fma(t.u, r, h2c(0.5f));   // Phi
+  } else {
+    out = (ap * gp) * t.r;
+  }
+}
+__device__ __forceinline__ h2 gelu_poly_half1(const GeluPoly &t, h2 ap, h2 gp) {
+  h2 r = __builtin_elementwise_fma(t.r, t.z, h2c(-0.1098130657f));
+  r = __builtin_elementwise_fma(r, t.z, h2c(0.3885767652f));
+  const h2 phi = __builtin_elementwise_fma(t.u, r, h2c(0.5f));
+  return (ap * gp) * phi;
+}
 // (a, g) -> packed fp16 first: after these sixteen conversions the accumulators are dead and their next initialisers
 // (b1 of the next chunk) can be fetched from LDS underneath the GELU arithmetic instead of after it.
 __device__ __forceinline__ void gelu16_f16_cvt(const v16f &a, const v16f &g, h2 (&aa)[8], h2 (&gg)[8]) {
@@ -367,23 +409,33 @@ __device__ __forceinline__ void gelu16_f16_cvt(const v16f &a, const v16f &g, h2 
   for (int i = 0; i < 8; ++i) aa[i] = pk_f16(a[2 * i], a[2 * i + 1]);
 }
 __device__ __forceinline__ void gelu16_f16_math(const h2 (&aa)[8], const h2 (&gg)[8], HidAct &hid) {
-  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
-  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  h2 y[8], ag[8];
+  h2 y[8];
+  if (GELU_POLY) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = gg[i] * gg[i];
+    for (int i = 0; i < 8; ++i) {
+      GeluPoly t;
+      gelu_poly_half0(t, gg[i]);
+      y[i] = gelu_poly_half1(t, aa[i], gg[i]);
+    }
+  } else {
+    const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    h2 ag[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = __builtin_elementwise_fma(y[i], c3, c1);
+    for (int i = 0; i < 8; ++i) y[i] = gg[i] * gg[i];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = gg[i] * y[i];
+    for (int i = 0; i < 8; ++i) y[i] = __builtin_elementwise_fma(y[i], c3, c1);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ag[i] = aa[i] * gg[i];
-  exp2_h2x8(y);
+    for (int i = 0; i < 8; ++i) y[i] = gg[i] * y[i];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = one + y[i];
-  rcp_h2x8(y);
+    for (int i = 0; i < 8; ++i) ag[i] = aa[i] * gg[i];
+    exp2_h2x8(y);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = ag[i] * y[i];
+    for (int i = 0; i < 8; ++i) y[i] = one + y[i];
+    rcp_h2x8(y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = ag[i] * y[i];
+  }
   hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
                         __builtin_bit_cast(unsigned, y[3]));
   hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
@@ -411,7 +463,12 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
   }
   v16f hid;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) hid[r] = a[r] * gelu_for<PREC>(g[r]);
+  for (int r = 0; r < 16; ++r) {
+    if (PREC == DFX_PREC_BF16 && FF_G_SCALE != 1.0f)   // g arrives pre-scaled, hid carries the same factor (denoiser_internal.h)
+      hid[r] = a[r] * gelu_for<PREC>(g[r] * (1.0f / FF_G_SCALE)) * FF_G_SCALE;
+    else
+      hid[r] = a[r] * gelu_for<PREC>(g[r]);
+  }
   if (PREC == DFX_PREC_BF16 && GELU_F16) {   // `a` arrives pre-scaled, W2 is fp16 (denoiser_internal.h)
     HidAct hf16;
     h2 y[8];
@@ -1008,6 +1065,172 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
 constexpr int NSLOT = TAILP ? 5 : 4;   // records in flight ahead of the compute: NSLOT - 2
+// ---- software-pipelined feed-forward (-DDFX_SWP) ----------------------------------------------------------------
+// No M/V slots and no anti-phase groups: every wavefront runs, for FF record j,
+//     stage A   GEMM1 of chunk j (16 MFMAs)      beside   GELU of chunk j-1 (VALU / transcendental, packed fp16)
+//     stage B   GEMM2 of chunk j-1 (8 MFMAs)     beside   (a, g) of chunk j -> packed fp16, b1 of chunk j+1 -> (a, g)
+// in ONE instruction stream: GEMM1(j) does not depend on GELU(j-1), so the wavefront's own VALU work fills the issue
+// cycles between its MFMAs (measured rule: next to MFMAs a VALU instruction costs ~3 cycles, a transcendental ~10), and
+// the serial chain of a record shrinks from M + V to about max(M, V).  The transcendentals are compiler-generated
+// here (three instructions per pair instead of two) so that the scheduler can spread them between the MFMAs.
+#ifdef DFX_SWP
+constexpr bool SWP = true;
+#else
+constexpr bool SWP = false;
+#endif
+__device__ __forceinline__ void gelu16_f16_math_c(const h2 (&aa)[8], const h2 (&gg)[8], HidAct &hid) {
+  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  h2 y[8], ag[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    y[i] = gg[i] * gg[i];
+    y[i] = __builtin_elementwise_fma(y[i], c3, c1);
+    y[i] = gg[i] * y[i];
+    ag[i] = aa[i] * gg[i];
+    y[i] = __builtin_elementwise_exp2(y[i]);
+    y[i] = one + y[i];
+    h2 r;
+    r[0] = __builtin_amdgcn_rcph(y[i][0]);
+    r[1] = __builtin_amdgcn_rcph(y[i][1]);
+    y[i] = ag[i] * r;
+  }
+  hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
+                        __builtin_bit_cast(unsigned, y[3]));
+  hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
+                        __builtin_bit_cast(unsigned, y[7]));
+}
+template <int KIND>
+__device__ __forceinline__ constexpr int next_frag(int i) {
+  return KIND == NEXT_W2 ? w2_frag(i) : KIND == NEXT_AS ? as_frag(i) : KIND == NEXT_MS ? ms_frag(i) : w1_frag(i, 0);
+}
+#ifndef DFX_SWP_VALU_PER_MFMA
+#define DFX_SWP_VALU_PER_MFMA 5
+#endif
+#ifndef DFX_SWP_TRANS_PER_MFMA
+#define DFX_SWP_TRANS_PER_MFMA 2
+#endif
+// FIRST: record F0 (no chunk before it); LAST: record F16 (no chunk after it); NEXT: what the first eight MFMAs of the
+// wave's next record need (tail prefetch): W1 of the next chunk, W2 if the next record is the last, A_s after the last.
+// GELU of one packed pair, in two halves (so that one half fits behind each MFMA of stage A)
+struct GeluPair {
+  h2 y, ag;
+};
+__device__ __forceinline__ void gelu_half0(GeluPair &t, h2 aa, h2 gg) {
+  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
+  h2 y = gg * gg;
+  y = __builtin_elementwise_fma(y, c3, c1);
+  y = gg * y;
+  t.ag = aa * gg;
+  t.y = __builtin_elementwise_exp2(y);
+}
+__device__ __forceinline__ h2 gelu_half1(const GeluPair &t) {
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  const h2 y = one + t.y;
+  h2 r;
+  r[0] = __builtin_amdgcn_rcph(y[0]);
+  r[1] = __builtin_amdgcn_rcph(y[1]);
+  return t.ag * r;
+}
+// FIRST: record F0 (no chunk before it); LAST: record F16 (no chunk after it); NEXT: what the first eight MFMAs of the
+// wave's next record need (tail prefetch): W1 of the next chunk, W2 if the next record is the last, A_s after the last.
+// The interleaving is written out in source order and pinned with a sched_barrier after every MFMA group (LLVM's
+// sched_group_barrier pipelines would not spread the VALU work between the MFMAs here).
+template <bool FIRST, bool LAST, int NEXT, class Issue>
+__device__ __forceinline__ void ff_swp(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g, h2 (&aa)[8],
+                                       h2 (&gg)[8], const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next,
+                                       const float *b1_next, Issue &issue) {
+  constexpr int NM = (LAST ? 0 : 16) + (FIRST ? 0 : 8);
+  h2 hv[8];
+  GeluPair t;
+  GeluPoly tp, tq;
+  __builtin_amdgcn_sched_barrier(0);
+  if (!LAST) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = i & 7, half = i >> 3;
+      v16f &acc = (k & 1) ? g : a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[k]), xn[2 * half + (k >> 2)].f[(k >> 1) & 1], acc, 0, 0, 0);
+      issue.at(i, NM);
+#ifndef DFX_ABL_NO_LDSREAD
+      P[k] = half == 0 ? ck[w1_frag(k, 1)] : FIRST ? ck_next[next_frag<NEXT>(k)] : ck[w2_frag(k)];
+#endif
+#ifndef DFX_ABL_NO_GELU
+      if (!FIRST) {
+        if (GELU_POLY) {
+          const int e0 = 2 * (i >> 2), e1 = e0 + 1;
+          switch (i & 3) {
+            case 0: gelu_poly_quarter<0>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<0>(tq, aa[e1], gg[e1], hv[e1]); break;
+            case 1: gelu_poly_quarter<1>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<1>(tq, aa[e1], gg[e1], hv[e1]); break;
+            case 2: gelu_poly_quarter<2>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<2>(tq, aa[e1], gg[e1], hv[e1]); break;
+            default: gelu_poly_quarter<3>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<3>(tq, aa[e1], gg[e1], hv[e1]); break;
+          }
+        } else {
+          if ((i & 1) == 0) gelu_half0(t, aa[i >> 1], gg[i >> 1]);
+          else hv[i >> 1] = gelu_half1(t);
+        }
+      }
+#else
+      if (!FIRST) hv[i >> 1] = aa[i >> 1];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (GELU_POLY) {
+        gelu_poly_half0(tp, gg[e]);
+        hv[e] = gelu_poly_half1(tp, aa[e], gg[e]);
+      } else {
+        gelu_half0(t, aa[e], gg[e]);
+        hv[e] = gelu_half1(t);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!FIRST) {
+    HidAct hid;
+    hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, hv[0]), __builtin_bit_cast(unsigned, hv[1]),
+                          __builtin_bit_cast(unsigned, hv[2]), __builtin_bit_cast(unsigned, hv[3]));
+    hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, hv[4]), __builtin_bit_cast(unsigned, hv[5]),
+                          __builtin_bit_cast(unsigned, hv[6]), __builtin_bit_cast(unsigned, hv[7]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+      issue.at((LAST ? 0 : 16) + i, NM);
+#ifndef DFX_ABL_NO_LDSREAD
+      P[i] = ck_next[next_frag<NEXT>(i)];
+#endif
+      if (!LAST) {
+        // (a, g) of this chunk: `a` got its last MFMA 3+ MFMAs ago at i = 2, `g` 5+ at i = 4: the results are there.
+        // Their next initialisers (b1 of the next chunk) are fetched behind the last two MFMAs, a barrier and the
+        // start of the next record away from their first use.
+        if (i == 2 || i == 3) {
+#pragma unroll
+          for (int e = 4 * (i - 2); e < 4 * (i - 2) + 4; ++e) aa[e] = pk_f16(a[2 * e], a[2 * e + 1]);
+        }
+        if (i == 4 || i == 5) {
+#pragma unroll
+          for (int e = 4 * (i - 4); e < 4 * (i - 4) + 4; ++e) gg[e] = pk_f16(g[2 * e], g[2 * e + 1]);
+        }
+#ifndef DFX_ABL_NO_B1
+        if (i == 6 && b1_next) load16(a, b1_next);
+        if (i == 7 && b1_next) load16(g, b1_next + 32);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    gelu16_f16_cvt(a, g, aa, gg);
+    __builtin_amdgcn_sched_barrier(0);
+    if (b1_next) {
+      load16(a, b1_next);
+      load16(g, b1_next + 32);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Ring DMA: 24 pieces of 1 KiB per record, CALLS_A per wave of group A (waves 0-3) and CALLS_B per wave of group B
 // (4 CALLS_A + 4 CALLS_B = 24).  Group B's V slot is on the critical path of a record, so it may carry fewer pieces
 // (-DDFX_DMA_SPLIT=AB, e.g. 42 or 60).
@@ -1061,6 +1284,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Block b's pack = block 0's + b * stride: plain scalar arithmetic instead of a look-up in the kernel-argument table
+// (an s_load whose s_waitcnt lgkmcnt(0) also drains every LDS read in flight, once per record).
+__device__ __forceinline__ BlockPack block_pack(const KParams &p, int b) {
+  const long long off = (long long)b * p.d.blk_stride;
+  return BlockPack{reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(p.d.blk[0].chunks) + off),
+                   reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.d.blk[0].bconst) + off),
+                   reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.d.blk[0].ct) + off)};
+}
+
 // Next record to fetch (all wave-uniform).
 struct DmaState {
   int step, b, k, seq, slot;  // k: 0 = attention record, 1..17 = FF record k-1; seq = running block number
@@ -1078,7 +1310,7 @@ __device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int
     dma_nk<NC>(st.ff_src, voff, ring + q0 * 1024);
     st.ff_src += SLOT_BYTES;
   } else {  // attention record: 17 KiB shape record | 5 KiB block constants | 1 KiB c_t row | 1 padding piece
-    const BlockPack &bp = p.d.blk[st.b];
+    const BlockPack bp = block_pack(p, st.b);
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int q = q0 + j;
@@ -1117,7 +1349,7 @@ __device__ __forceinline__ void prepare_pieces(const KParams &p, DmaState &st, i
     for (int j = 0; j < NC; ++j) pc.src[j] = st.ff_src + j * 1024, pc.dst[j] = ring + (q0 + j) * 1024;
     st.ff_src += SLOT_BYTES;
   } else {
-    const BlockPack &bp = p.d.blk[st.b];
+    const BlockPack bp = block_pack(p, st.b);
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int q = q0 + j;
@@ -1275,7 +1507,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
-#ifdef DFX_SYMMETRIC   // A/B variant: no anti-phase groups, every wave takes the record barrier at the start of its M slot
+#if defined(DFX_SYMMETRIC) || defined(DFX_SWP)   // A/B variant: no anti-phase groups, every wave takes the record barrier at the start of its M slot
   const bool grpA = true;
 #else
   const bool grpA = wave < PIPE_NW / 2;
@@ -1334,6 +1566,11 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #else
 #define DFX_LOCKSTEP_BARRIER() ((void)0)
 #endif
+#ifdef DFX_ABL_NO_BARRIER   // timing ablation only (racy)
+#define DFX_ABL_BARRIER() ((void)0)
+#else
+#define DFX_ABL_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define DFX_SLOT(mgmt)                                  \
   do {                                                  \
     __builtin_amdgcn_sched_barrier(0);                  \
@@ -1341,7 +1578,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       DFX_STAMP(1);                                     \
       if (grpA) wait_vmcnt<CALLS_A>();                  \
       else wait_vmcnt<CALLS_B>();                       \
-      __builtin_amdgcn_s_barrier();                     \
+      DFX_ABL_BARRIER();                                \
       DFX_STAMP(2);                                     \
       DFX_ISSUE_HERE();                                 \
       DFX_STAMP(7);                                     \
@@ -1425,6 +1662,33 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       DFX_M_BEGIN_EARLY();
       add_cvec(h, reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
       ln_to_act<PREC>(h, xn);
+#ifdef DFX_SWP
+      // ---- feed-forward, software-pipelined: records F0 .. F16 ----
+      {
+        v16f a, g;
+        h2 aa[8], gg[8];
+        load16(a, b1);  // accumulator initialisers of chunk 0 (block constants: resident since the attention record)
+        load16(g, b1 + 32);
+        DFX_SLOT(true);   // (the pieces of this record's M stage were prepared in V2)
+        DFX_NEXT_RECORD();
+        ff_swp<true, false, NEXT_W1>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), b1 + 64, issue_in_m);
+#pragma unroll 1
+        for (int j = 1; j < FF_CHUNKS - 1; ++j) {
+          issue_in_m.m_begin();
+          DFX_SLOT(true);
+          DFX_NEXT_RECORD();
+          ff_swp<false, false, NEXT_W1>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), b1 + (j + 1) * 64, issue_in_m);
+        }
+        issue_in_m.m_begin();
+        DFX_SLOT(true);
+        DFX_NEXT_RECORD();
+        ff_swp<false, false, NEXT_W2>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), nullptr, issue_in_m);
+        issue_in_m.m_begin();
+        DFX_SLOT(true);
+        DFX_NEXT_RECORD();
+        ff_swp<false, true, NEXT_AS>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), nullptr, issue_in_m);
+      }
+#else
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
       v16f a, g;
       HidAct hid;
@@ -1451,6 +1715,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       DFX_NEXT_RECORD();
       DFX_M_BEGIN_LATE();
       ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
+#endif
     }
   }
 #ifdef DFX_LOCKSTEP

@@ -89,20 +89,20 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   const int c = tile & 3, part = (tile >> 2) & 1, u = tile >> 3;
   const int row = part * FF_HID + 32 * u + i, col = 32 * c + kk;
   const long long di = ((long long)(u * CHUNK_TILES + part * 4 + c) << 10) + (gi & 1023);
-  const float sc = (PREC == DFX_PREC_BF16 && part == 0) ? FF_A_SCALE : 1.0f;   // `a` rows (denoiser_internal.h)
+  const float sc = PREC != DFX_PREC_BF16 ? 1.0f : part == 0 ? FF_A_SCALE : FF_G_SCALE;   // (denoiser_internal.h)
   tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col] * sc);
 }
 
 // b1' = b1 + W1 beta3, stored [u][part][hf][16]
 __global__ void k_pack_b1(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ be3,
-                          float *__restrict__ dst, float a_scale) {
+                          float *__restrict__ dst, float a_scale, float g_scale) {
   const int gi = blockIdx.x * 256 + threadIdx.x;
   if (gi >= FF_CHUNKS * 2 * 32) return;
   const int r = gi & 15, hf = (gi >> 4) & 1, part = (gi >> 5) & 1, u = gi >> 6;
   const int row = part * FF_HID + 32 * u + rho(r, hf);
   float acc = 0.f;
   for (int k = 0; k < INNER; ++k) acc = fmaf(W1[(size_t)row * INNER + k], be3[k], acc);
-  dst[gi] = (b1[row] + acc) * (part == 0 ? a_scale : 1.0f);
+  dst[gi] = (b1[row] + acc) * (part == 0 ? a_scale : g_scale);
 }
 
 // W2 (128 x 512) -> tiles 8+ct of stage record u+FF_SKEW (see denoiser_internal.h)
@@ -116,7 +116,7 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   const int ct = tile & 3, u = tile >> 2;
   const long long di = ((long long)((u + FF_SKEW) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
   const float w = W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk];
-  if (PREC == DFX_PREC_BF16 && GELU_F16) reinterpret_cast<_Float16 *>(dst)[di] = (_Float16)(w * (1.0f / FF_A_SCALE));
+  if (PREC == DFX_PREC_BF16 && GELU_F16) reinterpret_cast<_Float16 *>(dst)[di] = (_Float16)(w * (1.0f / (FF_A_SCALE * FF_G_SCALE)));
   else tile_store<PREC>(dst, di, w);
 }
 
@@ -463,7 +463,8 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     k_to_cvec<<<1, 256, 0, st>>>(k.ff2_b, nullptr, c.bconst + BCONST_B2_OFF, 1, INNER);
     TRY_LAUNCH("b2_cvec");
     k_pack_b1<<<nblk(FF_CHUNKS * 2 * 32), 256, 0, st>>>(k.ff0_w, k.ff0_b, k.norm3_b, c.bconst,
-                                                        precision == DFX_PREC_BF16 ? FF_A_SCALE : 1.0f);
+                                                        precision == DFX_PREC_BF16 ? FF_A_SCALE : 1.0f,
+                                                        precision == DFX_PREC_BF16 ? FF_G_SCALE : 1.0f);
     TRY_LAUNCH("pack_b1");
     if (precision == DFX_PREC_BF16) {
       k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);
@@ -484,6 +485,15 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
 #undef TRY_LAUNCH
 
   d->dev.depth = depth;
+  d->dev.blk_stride = depth > 1 ? reinterpret_cast<const char *>(d->dev.blk[1].chunks) - reinterpret_cast<const char *>(d->dev.blk[0].chunks) : 0;
+  for (int b = 1; b < depth; ++b) {   // the pipelined kernel addresses block b as block 0 + b * stride (no table look-up)
+    const long long off = (long long)b * d->dev.blk_stride;
+    if (reinterpret_cast<const char *>(d->dev.blk[b].chunks) != reinterpret_cast<const char *>(d->dev.blk[0].chunks) + off ||
+        reinterpret_cast<const char *>(d->dev.blk[b].bconst) != reinterpret_cast<const char *>(d->dev.blk[0].bconst) + off ||
+        reinterpret_cast<const char *>(d->dev.blk[b].ct) != reinterpret_cast<const char *>(d->dev.blk[0].ct) + off) {
+      return fail(set_error(DFX_ERR_UNSUPPORTED, "denoiser_create: block packs are not uniformly strided"));
+    }
+  }
   d->dev.T = T;
   d->dev.prec = precision;
   d->dev.win_x = cv.win_x;

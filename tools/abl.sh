@@ -1,0 +1,11 @@
+#!/bin/bash
+# Timing ablations of the chain kernel on one box: tools/abl.sh "<common flags>" "<flags 1>" "<flags 2>" ...
+C="$1"; shift
+for F in "" "$@"; do
+  python - <<PY
+from difffacto_amd import build
+build.build(force=True, verbose=False, extra_flags="$C $F".split())
+PY
+  echo -n "[$C $F]: "
+  python bench.py --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('kernel_ms %.3f' % d['roofline']['kernel_ms'])"
+done

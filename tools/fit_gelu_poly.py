@@ -1,0 +1,101 @@
+import numpy as np
+from scipy.special import erf
+from scipy.optimize import least_squares
+f16=np.float16
+def gelu(x): return 0.5*x*(1+erf(x/np.sqrt(2)))
+def rnd(x): return np.asarray(x,dtype=np.float64).astype(f16).astype(np.float64)
+def fit(deg,L,GS):
+    # variable: gp = g*GS ; u = clamp(gp, -L*GS, L*GS); s = u*u; phi = 0.5 + u*R(s)
+    x=np.linspace(-6,6,12001)
+    def model(c,x):
+        u=np.clip(x*GS,-L*GS,L*GS); s=u*u
+        r=np.zeros_like(s)+c[-1]
+        for k in range(len(c)-2,-1,-1): r=r*s+c[k]
+        return x*(0.5+u*r)
+    c=np.zeros(deg+1); c[0]=0.39/GS
+    w=np.ones_like(x)
+    for it in range(80):
+        res=least_squares(lambda c: w*(model(c,x)-gelu(x)), c)
+        c=res.x; e=np.abs(model(c,x)-gelu(x)); w=w*(1+4*e/e.max()); w/=w.mean()
+    return c, np.abs(model(c,x)-gelu(x)).max()
+def eval_f16(c,L,GS,g,a):
+    # g, a: true fp32 values of gate / value (before scaling). kernel sees gp = f16(g*GS), ap = f16(a*AS)
+    AS=1/16
+    gp=rnd(g*GS); ap=rnd(a*AS)
+    cc=[rnd(v) for v in c]; Lc=rnd(L*GS)
+    u=np.minimum(np.maximum(gp,-Lc),Lc)
+    s=rnd(u*u)
+    r=np.full_like(s,cc[-1])
+    for k in range(len(c)-2,-1,-1): r=rnd(r*s+cc[k])
+    phi=rnd(u*r+0.5)
+    ag=rnd(ap*gp)
+    out=rnd(ag*phi)      # = a*g*phi * AS*GS
+    return out/(AS*GS)
+rng=np.random.default_rng(0)
+g=rng.normal(0,1.5,400000); a=rng.normal(0,1.5,400000)
+gg=np.linspace(-8,8,160001); 
+ref=lambda a,g: a*gelu(g)
+# current method for comparison: tanh/sigmoid form in f16
+def cur_f16(g,a):
+    AS=1/16
+    gp=rnd(g); ap=rnd(a*AS)
+    c1=rnd(-2.30876530); c3=rnd(-0.100125614)
+    y=rnd(gp*gp); y=rnd(y*c3+c1); y=rnd(gp*y); ag=rnd(ap*gp)
+    e=rnd(np.exp2(y)); e=rnd(1+e); r=rnd(1/e); return rnd(ag*r)/AS
+print("current f16 sigmoid form: max|err| a=1 sweep %.2e ; random rms %.2e max %.2e"%(np.abs(cur_f16(gg,np.ones_like(gg))-ref(1,gg)).max(), np.sqrt(np.mean((cur_f16(g,a)-ref(a,g))**2)), np.abs(cur_f16(g,a)-ref(a,g)).max()))
+for deg in (3,4,5):
+  for L in (3.0,3.2,3.4,3.6,3.8):
+    for GS in (1.0,0.5):
+      c,e=fit(deg,L,GS)
+      e16=np.abs(eval_f16(c,L,GS,gg,np.ones_like(gg))-ref(1,gg))
+      er=eval_f16(c,L,GS,g,a)-ref(a,g)
+      print("deg %d L %.1f GS %.2f: exact-arith max err %.2e | f16 sweep(a=1) max %.2e (|g|<4: %.2e) | random rms %.2e max %.2e | coeffs %s"%(deg,L,GS,e,e16.max(),e16[np.abs(gg)<4].max(),np.sqrt(np.mean(er**2)),np.abs(er).max(),np.array2string(c,precision=6)))
+print("---- centred basis z = u*u - m ----")
+def fitz(deg,L,GS,m):
+    x=np.linspace(-6,6,12001)
+    def model(c,x):
+        u=np.clip(x*GS,-L*GS,L*GS); z=u*u-m
+        r=np.zeros_like(z)+c[-1]
+        for k in range(len(c)-2,-1,-1): r=r*z+c[k]
+        return x*(0.5+u*r)
+    c=np.zeros(deg+1); c[0]=0.25/GS
+    w=np.ones_like(x)
+    for it in range(80):
+        res=least_squares(lambda c: w*(model(c,x)-gelu(x)), c)
+        c=res.x; e=np.abs(model(c,x)-gelu(x)); w=w*(1+4*e/e.max()); w/=w.mean()
+    return c, np.abs(model(c,x)-gelu(x)).max()
+def evalz_f16(c,L,GS,m,g,a):
+    AS=1/16
+    gp=rnd(g*GS); ap=rnd(a*AS)
+    cc=[rnd(v) for v in c]; Lc=rnd(L*GS); mc=rnd(m)
+    u=np.minimum(np.maximum(gp,-Lc),Lc)
+    z=rnd(u*u-mc)
+    r=np.full_like(z,cc[-1])
+    for k in range(len(c)-2,-1,-1): r=rnd(r*z+cc[k])
+    phi=rnd(u*r+0.5)
+    ag=rnd(ap*gp)
+    return rnd(ag*phi)/(AS*GS)
+for deg in (3,4):
+  for L in (3.0,3.2,3.4):
+    for GS in (1.0,0.5):
+      for mf in (0.35,0.5):
+        m=(L*GS)**2*mf
+        c,e=fitz(deg,L,GS,m)
+        e16=np.abs(evalz_f16(c,L,GS,m,gg,np.ones_like(gg))-ref(1,gg))
+        er=evalz_f16(c,L,GS,m,g,a)-ref(a,g)
+        print("deg %d L %.1f GS %.2f m %.3f: exact max err %.2e | f16 sweep max %.2e | random rms %.2e max %.2e | %s"%(deg,L,GS,m,e,e16.max(),np.sqrt(np.mean(er**2)),np.abs(er).max(),np.array2string(c,precision=6)))
+print("---- centred, GS=0.5, more options ----")
+g1=rng.normal(0,1.0,400000); a1=rng.normal(0,1.0,400000)
+er=cur_f16(g1,a1)-ref(a1,g1); print("current sigmoid f16, N(0,1): rms %.2e max %.2e"%(np.sqrt(np.mean(er**2)),np.abs(er).max()))
+for deg in (4,5):
+  for L in (3.2,3.4,3.6,3.8,4.0):
+      GS=0.5; m=(L*GS)**2*0.5
+      c,e=fitz(deg,L,GS,m)
+      e16=np.abs(evalz_f16(c,L,GS,m,gg,np.ones_like(gg))-ref(1,gg))
+      er=evalz_f16(c,L,GS,m,g,a)-ref(a,g); er1=evalz_f16(c,L,GS,m,g1,a1)-ref(a1,g1)
+      print("deg %d L %.1f: exact max %.2e | f16 sweep max %.2e | N(0,1.5) rms %.2e max %.2e | N(0,1) rms %.2e max %.2e | m=%.5f c=%s"%(deg,L,e,e16.max(),np.sqrt(np.mean(er**2)),np.abs(er).max(),np.sqrt(np.mean(er1**2)),np.abs(er1).max(),m,np.array2string(c,precision=7)))
+print("---- final ----")
+L,GS,deg=3.6,0.5,5; m=1.62
+c,e=fitz(deg,L,GS,m)
+np.set_printoptions(precision=10)
+print(repr(c), e, "f16:", [float(rnd(v)) for v in c], float(rnd(m)), float(rnd(L*GS)))

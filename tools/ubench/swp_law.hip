@@ -1,0 +1,97 @@
+// Micro-benchmark: the issue law of one software-pipelined FF record on a SIMD with two resident wavefronts.
+// Every wave loops over 24 x { s_waitcnt lgkmcnt(7); v_mfma_f32_32x32x16_bf16; ds_read_b128 (in-place refill);
+// NV packed-fp16 VALU ops; NT fp16 transcendentals } and the table reports cycles per record (= 24 MFMAs per wave)
+// against the matrix-pipe floor 2 x 24 x 32 = 1536 cycles.
+// Build: hipcc --offload-arch=gfx950 -O3 swp_law.hip -o _build/swp_law
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define PK0 "v_pk_fma_f16 %[t0], %[g0], %[g1], %[t0]\n"
+#define PK1 "v_pk_mul_f16 %[t1], %[g0], %[t1]\n"
+#define PK2 "v_pk_fma_f16 %[t2], %[g1], %[g0], %[t2]\n"
+#define PK3 "v_pk_add_f16 %[t3], %[g1], %[t3]\n"
+#define TR0 "v_exp_f16_e32 %[t4], %[g0]\n"
+#define TR1 "v_rcp_f16_e32 %[t5], %[g1]\n"
+template <int NV> struct VS;
+#define DEFV(n, s) template <> struct VS<n> { static constexpr const char *x = s; };
+
+// the compiler's GELU sequence of one packed pair, split behind two MFMAs (copied from k_denoise_pipe -DDFX_SWP)
+#define GE0 "v_pk_mul_f16 %[t0], %[g0], %[g0]\n v_pk_fma_f16 %[t0], %[t0], %[g1], %[g1]\n v_pk_mul_f16 %[t1], %[g0], %[g1]\n v_pk_mul_f16 %[t0], %[g0], %[t0]\n s_nop 0\n" \
+            "v_exp_f16_e32 %[t2], %[t0]\n v_exp_f16_sdwa %[t0], %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n s_nop 0\n v_pack_b32_f16 %[t0], %[t2], %[t0]\n"
+#define GE1 "v_pk_add_f16 %[t0], %[t0], 1.0 op_sel_hi:[1,0]\n v_rcp_f16_e32 %[t2], %[t0]\n v_rcp_f16_sdwa %[t0], %[t0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n s_nop 0\n" \
+            "v_pack_b32_f16 %[t0], %[t2], %[t0]\n v_pk_mul_f16 %[t3], %[t1], %[t0]\n"
+// polynomial variant (no transcendentals): clamp, square, 4 fma, fma, mul, mul = 10 packed ops per pair
+#define GP0 "v_pk_max_f16 %[t0], %[g0], %[g1]\n v_pk_min_f16 %[t0], %[t0], %[g1]\n v_pk_mul_f16 %[t1], %[t0], %[t0]\n v_pk_fma_f16 %[t2], %[t1], %[g1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n"
+#define GP1 "v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t0], %[g1]\n v_pk_mul_f16 %[t3], %[g0], %[g1]\n v_pk_mul_f16 %[t3], %[t3], %[t2]\n"
+template <int NV, int NT, bool MFMA, bool LDS>
+__global__ void __launch_bounds__(512, 2) k(float *out, int iters, int rnd) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  for (int i = threadIdx.x; i < 32 * 1024 / 4; i += blockDim.x) {
+    unsigned hsh = (i * 2654435761u) ^ (i >> 3) * 40503u;   // random bf16 pairs in about (-2, 2): realistic operand toggling
+    unsigned w = rnd ? ((hsh & 0x807f807fu) | 0x3f003f00u | ((hsh >> 9) & 0x00800080u)) : 0u;
+    reinterpret_cast<unsigned *>(smem)[i] = w;
+  }
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63;
+  unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + lane * 16;
+  v16f a0 = {0}, a1 = a0, h0 = a0, h1 = a0;
+  v4f f0 = {0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0, f5 = f0, f6 = f0, f7 = f0, b = f0;
+  if (rnd) { b = reinterpret_cast<v4f *>(smem)[threadIdx.x & 63]; }
+  unsigned g0 = rnd ? (0x3c003c00u ^ (threadIdx.x * 0x01230123u & 0x03ff03ffu)) : 0x3c003c00u, g1 = rnd ? (0x38003800u ^ (threadIdx.x * 0x04560457u & 0x03ff03ffu)) : 0x38003800u, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#define OPS : [a0] "+v"(a0), [a1] "+v"(a1), [h0] "+v"(h0), [h1] "+v"(h1), [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3), \
+              [f4] "+v"(f4), [f5] "+v"(f5), [f6] "+v"(f6), [f7] "+v"(f7), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [t4] "+v"(t4), \
+              [t5] "+v"(t5) : [la] "v"(la), [b] "v"(b), [g0] "v"(g0), [g1] "v"(g1)
+  for (int it = 0; it < iters; ++it) {
+#define GRP(acc, fr, off)                                                                                          \
+    if (MFMA) asm volatile("s_waitcnt lgkmcnt(7)\n v_mfma_f32_32x32x16_bf16 %[" acc "], %[" fr "], %[b], %[" acc "]\n" OPS); \
+    if (LDS) asm volatile("ds_read_b128 %[" fr "], %[la] offset:" #off "\n" OPS);                                 \
+    if (NV >= 1) asm volatile(PK0 OPS); if (NV >= 2) asm volatile(PK1 OPS); if (NV >= 3) asm volatile(PK2 OPS);      \
+    if (NV >= 4) asm volatile(PK3 OPS); if (NV >= 5) asm volatile(PK0 OPS); if (NV >= 6) asm volatile(PK1 OPS);      \
+    if (NV >= 7) asm volatile(PK2 OPS); if (NV >= 8) asm volatile(PK3 OPS);                                         \
+    if (NT >= 1 && NT < 10) asm volatile(TR0 OPS); if (NT >= 2 && NT < 10) asm volatile(TR1 OPS);                 \
+    if (NT == 10) { if (((off) >> 10) & 1) asm volatile(GE1 OPS); else asm volatile(GE0 OPS); }                   \
+    if (NT == 11) { if (((off) >> 10) & 1) asm volatile(GP1 OPS); else asm volatile(GP0 OPS); }
+    GRP("a0", "f0", 0) GRP("a1", "f1", 1024) GRP("a0", "f2", 2048) GRP("a1", "f3", 3072) GRP("a0", "f4", 4096) GRP("a1", "f5", 5120) GRP("a0", "f6", 6144) GRP("a1", "f7", 7168)
+    GRP("a0", "f0", 8192) GRP("a1", "f1", 9216) GRP("a0", "f2", 10240) GRP("a1", "f3", 11264) GRP("a0", "f4", 12288) GRP("a1", "f5", 13312) GRP("a0", "f6", 14336) GRP("a1", "f7", 15360)
+    GRP("h0", "f0", 16384) GRP("h1", "f1", 17408) GRP("h0", "f2", 18432) GRP("h1", "f3", 19456) GRP("h0", "f4", 20480) GRP("h1", "f5", 21504) GRP("h0", "f6", 22528) GRP("h1", "f7", 23552)
+  }
+  v16f s = a0 + a1 + h0 + h1;
+  if (s[0] + f0[0] + f1[0] + f2[0] + f3[0] + f4[0] + f5[0] + f6[0] + f7[0] + (float)(t0 + t1 + t2 + t3 + t4 + t5) == 12345.678f) out[0] = s[0];
+}
+
+static double clk_ghz = 2.1;
+static int g_rnd = 0;
+template <int NV, int NT, bool MFMA = true, bool LDS = true>
+void run(float *d) {
+  const int iters = 4000;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  k<NV, NT, MFMA, LDS><<<256, 512, 32 * 1024>>>(d, 50, g_rnd);
+  (void)hipEventRecord(a);
+  k<NV, NT, MFMA, LDS><<<256, 512, 32 * 1024>>>(d, iters, g_rnd);
+  (void)hipEventRecord(b);
+  (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b);
+  const double ns = ms * 1e6 / iters;
+  printf("%s MFMA %d LDS %d  VALU/MFMA %d  TRANS/MFMA %d : %7.1f ns per record (2 waves/SIMD) = %5.0f cycles @%.1f GHz; per wave: %d VALU %d TRANS\n",
+         g_rnd ? "random" : "zeros ", (int)MFMA, (int)LDS, NV, NT, ns, ns * clk_ghz, clk_ghz, NV * 24, NT * 24);
+}
+
+int main(int argc, char **argv) {
+  float *d; (void)hipMalloc(&d, 64);
+  if (argc > 1) {   // power check: the same streams on zero operands and on random operands
+    for (g_rnd = 0; g_rnd < 2; ++g_rnd) { run<0, 0>(d); run<4, 0>(d); run<0, 11>(d); run<0, 10>(d); run<0, 11, false, true>(d); }
+    return 0;
+  }
+  run<0, 0>(d); run<2, 0>(d); run<3, 0>(d); run<4, 0>(d); run<5, 0>(d); run<6, 0>(d); run<8, 0>(d);
+  run<0, 1>(d); run<0, 2>(d); run<3, 1>(d); run<4, 1>(d); run<3, 2>(d);
+  run<4, 0, false, true>(d); run<8, 0, false, true>(d); run<0, 2, false, true>(d); run<3, 1, false, false>(d);
+  run<4, 0, true, false>(d);
+  printf("exact GELU sequence (12 instr + 3 s_nop per pair, 4 transcendentals), one pair per 2 MFMAs, 24 MFMAs:\n");
+  run<0, 10>(d); run<0, 10, false, true>(d); run<0, 10, true, false>(d);
+  printf("polynomial GELU (10 packed ops per pair, no transcendentals):\n");
+  run<0, 11>(d); run<0, 11, false, true>(d);
+  return 0;
+}
