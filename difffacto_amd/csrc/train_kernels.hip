@@ -1,0 +1,794 @@
+// Training-mode evaluation of the cross-diffusion denoiser and its backward:
+//   TransformerNet.forward / _forward_attn (attention.py:385-440, BasicTransformerBlock :296-306 with single_attn,
+//   CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94, timestep_embedding utils.py:7-24), dropout = 0,
+// in exact fp32 (v_mfma_f32_32x32x2_f32 through the shared row-batched linear kernels), every intermediate that the
+// backward needs kept in a caller-provided workspace (2.4 KB per point and block: 12.5 GB at B = 128, N = 2048 —
+// sized for 288 GB of HBM, nothing is recomputed).  The persistent bf16 chain kernel is the sampling path; this file is
+// the first correct training path: one launch per layer, parity with the reference's autograd is the bar
+// (tests/test_gpu_train.py against tests/golden/train_grads_*.npz generated from the reference's own model).
+//
+// Gradient of a linear layer Y = X W^T + b over R rows:
+//   dX = dY W          -> the shared forward kernel on a transposed copy of W (k_transpose, a few KB per call)
+//   dW = dY^T X, db    -> k_wgrad: one wavefront owns a 64 x 64 tile of dW and a slab of rows, two rows per
+//                         v_mfma_f32_32x32x2_f32 (lane (j, hf) feeds dY[r + hf][o0 + j] and X[r + hf][i0 + j]: 128-byte
+//                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
+#include "dfx_common.h"
+#include "mfma_linear.h"
+
+namespace {
+
+using dfx::lin::LinArgs;
+using dfx::lin::v16f;
+using dfx::lin::v4f;
+
+constexpr int C = 128, J = 4, HEADS = 8, HD = 16, FH = 512, CTX = 522, CTXP = 528, TE = 256, TEH = 1024, XIN = 16;
+constexpr float LN_EPS = 1e-5f;
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise / row kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+// xin (attention.py:398-405): [x | anchors | variances | one_hot(assignment)] per point, padded 13 -> 16
+__global__ void k_build_xin(const float *__restrict__ x, const float *__restrict__ anc, const float *__restrict__ var,
+                            const int32_t *__restrict__ asg, float *__restrict__ xin, int N, long long R) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const long long b = r / N;
+  const int n = (int)(r % N);
+  float v[XIN];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    v[c] = x[(b * 3 + c) * N + n];
+    v[3 + c] = anc[r * 3 + c];
+    v[6 + c] = var[r * 3 + c];
+  }
+  const int a = asg[r];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[9 + j] = a == j ? 1.f : 0.f;
+  v[13] = v[14] = v[15] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) reinterpret_cast<v4f *>(xin + r * XIN)[q] = v4f{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
+// LayerNorm over 128 channels, two-pass like torch (mean, then biased variance of the centred values); 32 lanes per row
+__global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, const float *__restrict__ g,
+                                                 const float *__restrict__ be, float *__restrict__ y,
+                                                 float *__restrict__ stats, long long R) {
+  const int l = threadIdx.x & 31;
+  const long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (r >= R) return;
+  const v4f v = reinterpret_cast<const v4f *>(x + r * C)[l];
+  float s = v[0] + v[1] + v[2] + v[3];
+  for (int o = 16; o; o >>= 1) s += __shfl_xor(s, o, 32);
+  const float mu = s * (1.0f / C);
+  const v4f d = {v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};
+  float q = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  for (int o = 16; o; o >>= 1) q += __shfl_xor(q, o, 32);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / C) + LN_EPS);
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l], bv = reinterpret_cast<const v4f *>(be)[l];
+  v4f o4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o4[e] = d[e] * rstd * gv[e] + bv[e];
+  reinterpret_cast<v4f *>(y + r * C)[l] = o4;
+  if (l == 0) stats[2 * r] = mu, stats[2 * r + 1] = rstd;
+}
+
+// LayerNorm backward: dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy gamma;  out = (resid ? resid : 0) + dx.
+// Column sums of dy xhat (d gamma) and dy (d beta) per block of rows -> part[blockIdx][2][128]
+constexpr int LNB_ROWS = 256;   // rows per block (8 row groups x 32 trips)
+__global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ dy, const float *__restrict__ x,
+                                                 const float *__restrict__ stats, const float *__restrict__ g,
+                                                 const float *__restrict__ resid, float *__restrict__ out,
+                                                 float *__restrict__ part, long long R) {
+  __shared__ float red[8][2][C];
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l];
+  v4f sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+  for (int it = 0; it < LNB_ROWS / 8; ++it) {
+    const long long r = (long long)blockIdx.x * LNB_ROWS + it * 8 + grp;
+    if (r >= R) break;
+    const v4f xv = reinterpret_cast<const v4f *>(x + r * C)[l], dv = reinterpret_cast<const v4f *>(dy + r * C)[l];
+    const float mu = stats[2 * r], rstd = stats[2 * r + 1];
+    v4f xh, dg;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = (xv[e] - mu) * rstd;
+      dg[e] = dv[e] * gv[e];
+      s1 += dg[e];
+      s2 += dg[e] * xh[e];
+      sg[e] += dv[e] * xh[e];
+      sb[e] += dv[e];
+    }
+    for (int o = 16; o; o >>= 1) s1 += __shfl_xor(s1, o, 32), s2 += __shfl_xor(s2, o, 32);
+    s1 *= (1.0f / C), s2 *= (1.0f / C);
+    v4f o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = rstd * (dg[e] - s1 - xh[e] * s2);
+    if (resid) {
+      const v4f rv = reinterpret_cast<const v4f *>(resid + r * C)[l];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] += rv[e];
+    }
+    reinterpret_cast<v4f *>(out + r * C)[l] = o4;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[grp][0][4 * l + e] = sg[e], red[grp][1][4 * l + e] = sb[e];
+  __syncthreads();
+  const int t = threadIdx.x;   // 256 = 2 x 128
+  float a = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a += red[q][t >> 7][t & 127];
+  part[(size_t)blockIdx.x * 2 * C + t] = a;
+}
+
+// out[c] = sum over nparts of part[p][c]  (second pass of every column reduction; fixed order)
+__global__ void k_sum_parts(const float *__restrict__ part, float *__restrict__ out, int nparts, int cols, int ld_part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int p = 0; p < nparts; ++p) a += part[(size_t)p * ld_part + c];
+  out[c] = a;
+}
+
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
+
+// GEGLU (attention.py:55-57): hid = a * gelu(g), ag = [a | g] (R, 2 H)
+__global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hid, int H, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / H;
+  const int c = (int)(i % H);
+  hid[i] = ag[r * 2 * H + c] * gelu_erf(ag[r * 2 * H + H + c]);
+}
+// d a = d hid gelu(g);  d g = d hid a (Phi(g) + g phi(g))
+__global__ void k_geglu_bwd(const float *__restrict__ ag, const float *__restrict__ dhid, float *__restrict__ dag, int H,
+                            long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / H;
+  const int c = (int)(i % H);
+  const float a = ag[r * 2 * H + c], g = ag[r * 2 * H + H + c], d = dhid[i];
+  const float Phi = 0.5f * (1.f + erff(g * 0.70710678118654752440f));
+  const float phi = 0.39894228040143267794f * expf(-0.5f * g * g);
+  dag[r * 2 * H + c] = d * g * Phi;
+  dag[r * 2 * H + H + c] = d * a * (Phi + g * phi);
+}
+
+// timestep_embedding (utils.py:7-24): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / 128)
+__global__ void k_timestep_embedding(const int32_t *__restrict__ t, float *__restrict__ out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * TE) return;
+  const int b = i / TE, k = i % TE, half = TE / 2;
+  const float f = expf(-9.21034037197618273607f * (float)(k % half) / (float)half);
+  const float a = (float)t[b] * f;
+  out[i] = k < half ? cosf(a) : sinf(a);
+}
+
+// ctx rows (attention.py:386-397): [(b, j)] = [part_code(b, :, j) | mean, var (b, :, j) | eye_j | t_emb(b) | 0 x 6]
+__global__ void k_build_ctx(const float *__restrict__ code, const float *__restrict__ mv, const float *__restrict__ temb,
+                            float *__restrict__ ctx, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * J * CTXP) return;
+  const int c = i % CTXP, bj = i / CTXP, j = bj % J, b = bj / J;
+  float v = 0.f;
+  if (c < 256) v = code[((size_t)b * 256 + c) * J + j];
+  else if (c < 262) v = mv[((size_t)b * 6 + (c - 256)) * J + j];
+  else if (c < 266) v = (c - 262) == j ? 1.f : 0.f;
+  else if (c < CTX) v = temb[(size_t)b * TE + (c - 266)];
+  ctx[i] = v;
+}
+// backward of the above: d code, d mv, d t_emb[b] = sum_j d ctx[(b, j)][266:522]
+__global__ void k_ctx_bwd(const float *__restrict__ dctx, float *__restrict__ dcode, float *__restrict__ dmv,
+                          float *__restrict__ dtemb, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * CTX) return;
+  const int c = i % CTX, b = i / CTX;
+  const float *row = dctx + (size_t)b * J * CTXP + c;
+  if (c < 256) {
+    if (dcode)
+      for (int j = 0; j < J; ++j) dcode[((size_t)b * 256 + c) * J + j] = row[(size_t)j * CTXP];
+  } else if (c < 262) {
+    if (dmv)
+      for (int j = 0; j < J; ++j) dmv[((size_t)b * 6 + (c - 256)) * J + j] = row[(size_t)j * CTXP];
+  } else if (c >= 266) {
+    float a = 0.f;
+    for (int j = 0; j < J; ++j) a += row[(size_t)j * CTXP];
+    dtemb[(size_t)b * TE + (c - 266)] = a;
+  }
+}
+
+// W (rows, cols) -> WT (cols_pad rows, ld = rows): the operand of the dX products; columns >= cols are not produced
+__global__ void k_transpose(const float *__restrict__ W, float *__restrict__ WT, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads
+  for (int k = ty; k < 32; k += 8)
+    tile[k][tx] = (r0 + k < rows && c0 + tx < cols) ? W[(size_t)(r0 + k) * cols + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < cols && r0 + tx < rows) WT[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+// W (rows, cols) -> Wp (rows, cols_pad) zero-padded (K of the shared linear kernel is consumed 8 at a time)
+__global__ void k_pad_cols(const float *__restrict__ W, float *__restrict__ Wp, int rows, int cols, int cols_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_pad) return;
+  const int c = i % cols_pad, r = i / cols_pad;
+  Wp[i] = c < cols ? W[(size_t)r * cols + c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cross attention to the 4 part tokens (attention.py:179-204), forward with saved probabilities, and backward
+// block = 32 points of one shape x 8 heads; k, v of the shape in LDS
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_fwd(const float *__restrict__ q, const float *__restrict__ k,
+                                                   const float *__restrict__ v, const float *__restrict__ valid,
+                                                   float *__restrict__ p, float *__restrict__ att, int N) {
+  __shared__ float ks[J][C], vs[J][C];
+  const int b = blockIdx.y, h = threadIdx.x >> 5, i = threadIdx.x & 31;
+  for (int e = threadIdx.x; e < J * C; e += 256) ks[e / C][e % C] = k[(size_t)b * J * C + e], vs[e / C][e % C] = v[(size_t)b * J * C + e];
+  __syncthreads();
+  const long long r = (long long)b * N + blockIdx.x * 32 + i;
+  float qv[HD];
+#pragma unroll
+  for (int e = 0; e < HD / 4; ++e) {
+    const v4f t = reinterpret_cast<const v4f *>(q + r * C + h * HD)[e];
+    qv[4 * e] = t[0], qv[4 * e + 1] = t[1], qv[4 * e + 2] = t[2], qv[4 * e + 3] = t[3];
+  }
+  float sim[J], mx = -3.402823466e38f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) s += qv[e] * ks[j][h * HD + e];
+    s *= 0.25f;   // dim_head ** -0.5
+    if (valid && valid[b * J + j] == 0.f) s = -3.402823466e38f;   // masked_fill_(~mask, -finfo.max)
+    sim[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) sim[j] = expf(sim[j] - mx), den += sim[j];
+  float o[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    sim[j] /= den;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) o[e] += sim[j] * vs[j][h * HD + e];
+  }
+  reinterpret_cast<v4f *>(p + r * (HEADS * J))[h] = v4f{sim[0], sim[1], sim[2], sim[3]};
+#pragma unroll
+  for (int e = 0; e < HD / 4; ++e) reinterpret_cast<v4f *>(att + r * C + h * HD)[e] = v4f{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]};
+}
+
+// d att -> d q (per point), d k / d v partial sums over the block's 32 points -> part[(b, blockIdx.x)][2][J][C]
+__global__ __launch_bounds__(256) void k_attn_bwd(const float *__restrict__ datt, const float *__restrict__ q,
+                                                   const float *__restrict__ k, const float *__restrict__ v,
+                                                   const float *__restrict__ p, float *__restrict__ dq,
+                                                   float *__restrict__ part, int N) {
+  __shared__ float ks[J][C], vs[J][C];
+  const int b = blockIdx.y, h = threadIdx.x >> 5, i = threadIdx.x & 31;
+  for (int e = threadIdx.x; e < J * C; e += 256) ks[e / C][e % C] = k[(size_t)b * J * C + e], vs[e / C][e % C] = v[(size_t)b * J * C + e];
+  __syncthreads();
+  const long long r = (long long)b * N + blockIdx.x * 32 + i;
+  float qv[HD], dv_[HD];
+#pragma unroll
+  for (int e = 0; e < HD / 4; ++e) {
+    const v4f t = reinterpret_cast<const v4f *>(q + r * C + h * HD)[e], u = reinterpret_cast<const v4f *>(datt + r * C + h * HD)[e];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qv[4 * e + s] = t[s], dv_[4 * e + s] = u[s];
+  }
+  const v4f pv = reinterpret_cast<const v4f *>(p + r * (HEADS * J))[h];
+  float dp[J], dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) s += dv_[e] * vs[j][h * HD + e];
+    dp[j] = s;
+    dot += pv[j] * s;
+  }
+  float dqv[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) dqv[e] = 0.f;
+  float *pk = part + ((size_t)(b * gridDim.x + blockIdx.x) * 2) * J * C;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const float ds = pv[j] * (dp[j] - dot) * 0.25f;   // d sim_j x scale (masked keys: p = 0 exactly)
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      dqv[e] += ds * ks[j][h * HD + e];
+      float a = ds * qv[e], c = pv[j] * dv_[e];   // d k[j][h, e], d v[j][h, e] of this point: sum over the 32 points
+      for (int o = 16; o; o >>= 1) a += __shfl_xor(a, o, 32), c += __shfl_xor(c, o, 32);
+      if (i == 0) pk[j * C + h * HD + e] = a, pk[(J + j) * C + h * HD + e] = c;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < HD / 4; ++e) reinterpret_cast<v4f *>(dq + r * C + h * HD)[e] = v4f{dqv[4 * e], dqv[4 * e + 1], dqv[4 * e + 2], dqv[4 * e + 3]};
+}
+// d k, d v (B J, C) = sum over the nb blocks of a shape
+__global__ void k_attn_bwd_finish(const float *__restrict__ part, float *__restrict__ dk, float *__restrict__ dv, int nb) {
+  const int b = blockIdx.x, t = threadIdx.x;   // 512 threads = J * C
+  float a = 0.f, c = 0.f;
+  for (int q = 0; q < nb; ++q) {
+    const float *pk = part + ((size_t)(b * nb + q) * 2) * J * C;
+    a += pk[t];
+    c += pk[J * C + t];
+  }
+  dk[(size_t)b * J * C + t] = a;
+  dv[(size_t)b * J * C + t] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// proj_out (3 x 128): eps (B, 3, N) = hn W^T + b; backward d hn, partial d W / d b
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eps_fwd(const float *__restrict__ hn, const float *__restrict__ W,
+                                                  const float *__restrict__ bias, float *__restrict__ eps, int N, long long R) {
+  const int l = threadIdx.x & 31;
+  const long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (r >= R) return;
+  const v4f v = reinterpret_cast<const v4f *>(hn + r * C)[l];
+  float s[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const v4f w = reinterpret_cast<const v4f *>(W + c * C)[l];
+    float a = v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+    for (int o = 16; o; o >>= 1) a += __shfl_xor(a, o, 32);
+    s[c] = a + bias[c];
+  }
+  if (l < 3) eps[((r / N) * 3 + l) * N + (r % N)] = s[l];
+}
+constexpr int EPSB_ROWS = 256;
+__global__ __launch_bounds__(128) void k_eps_bwd(const float *__restrict__ deps, const float *__restrict__ hn,
+                                                  const float *__restrict__ W, float *__restrict__ dhn,
+                                                  float *__restrict__ part /*[blk][4][128]*/, int N, long long R) {
+  const int kcol = threadIdx.x;
+  const float w0 = W[kcol], w1 = W[C + kcol], w2 = W[2 * C + kcol];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int it = 0; it < EPSB_ROWS; ++it) {
+    const long long r = (long long)blockIdx.x * EPSB_ROWS + it;
+    if (r >= R) break;
+    const long long b = r / N;
+    const int n = (int)(r % N);
+    const float d0 = deps[(b * 3 + 0) * N + n], d1 = deps[(b * 3 + 1) * N + n], d2 = deps[(b * 3 + 2) * N + n];
+    const float h = hn[r * C + kcol];
+    dhn[r * C + kcol] = d0 * w0 + d1 * w1 + d2 * w2;
+    a0 += d0 * h, a1 += d1 * h, a2 += d2 * h;
+    b0 += d0, b1 += d1, b2 += d2;
+  }
+  float *pp = part + (size_t)blockIdx.x * 4 * C;
+  pp[kcol] = a0, pp[C + kcol] = a1, pp[2 * C + kcol] = a2;
+  if (kcol < 3) pp[3 * C + kcol] = kcol == 0 ? b0 : kcol == 1 ? b1 : b2;
+}
+
+// d pred of the masked MSE (anchored_diffusion.py:840-847): gs 2 (pred - target) flag / (3 sum(flags)), or / (3 B N)
+__global__ void k_mse_bwd(const float *__restrict__ target, const float *__restrict__ pred, const float *__restrict__ flags,
+                          const double *__restrict__ acc, float gs, float *__restrict__ dpred, int N, long long total,
+                          double count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / N;
+  const int n = (int)(i % N);
+  const float fl = flags ? flags[i] : 1.f;
+  const float sc = flags ? (float)(2.0 * gs / (3.0 * acc[1])) : (float)(2.0 * gs / count);
+  for (int c = 0; c < 3; ++c) {
+    const long long o = (b * 3 + c) * N + n;
+    dpred[o] = sc * (pred[o] - target[o]) * fl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient: dW (O, I) = dY^T X over R rows, db = column sums of dY
+// grid (ceil(I/64), ceil(O/64), nslab); one wavefront per block; part[slab][O][I] (+ bpart[slab][O] from blockIdx.x == 0)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                               float *__restrict__ part, float *__restrict__ bpart, int O, int I,
+                                               long long R, int rows_per_slab) {
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+  const long long r0 = (long long)blockIdx.z * rows_per_slab;
+  const long long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+  const bool oa = o0 + j < O, ob = o0 + 32 + j < O, ia = i0 + j < I, ib = i0 + 32 + j < I;
+  const float *py = dY + o0 + j, *px = X + i0 + j;
+  v16f acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bs0 = 0.f, bs1 = 0.f;
+  long long r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float ya[4], yb[4], xa[4], xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long rr = r + 2 * u + hf;
+      ya[u] = oa ? py[rr * ldy] : 0.f;
+      yb[u] = ob ? py[rr * ldy + 32] : 0.f;
+      xa[u] = ia ? px[rr * ldx] : 0.f;
+      xb[u] = ib ? px[rr * ldx + 32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], xa[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], xb[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[u], xa[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[u], xb[u], acc[1][1], 0, 0, 0);
+      bs0 += ya[u], bs1 += yb[u];
+    }
+  }
+  for (; r < r1; r += 2) {
+    const long long rr = r + hf;
+    const bool in = rr < r1;
+    const float ya = (in && oa) ? py[rr * ldy] : 0.f, yb = (in && ob) ? py[rr * ldy + 32] : 0.f;
+    const float xa = (in && ia) ? px[rr * ldx] : 0.f, xb = (in && ib) ? px[rr * ldx + 32] : 0.f;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xa, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xb, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xa, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
+    bs0 += ya, bs1 += yb;
+  }
+  float *pp = part + (size_t)blockIdx.z * O * I;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + 32 * b + j;   // C/D layout: column = lane % 32 (the B operand's index), row = (r&3) + 8(r>>2) + 4 hf
+      if (i >= I) continue;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int o = o0 + 32 * a + (rg & 3) + 8 * (rg >> 2) + 4 * hf;
+        if (o < O) pp[(size_t)o * I + i] = acc[a][b][rg];
+      }
+    }
+  if (bpart && blockIdx.x == 0) {
+    bs0 += __shfl_xor(bs0, 32), bs1 += __shfl_xor(bs1, 32);
+    if (hf == 0) {
+      if (oa) bpart[(size_t)blockIdx.z * O + o0 + j] = bs0;
+      if (ob) bpart[(size_t)blockIdx.z * O + o0 + 32 + j] = bs1;
+    }
+  }
+}
+// dW[o][i < I_valid] = sum over slabs; ld of dW = I_valid
+__global__ void k_wgrad_finish(const float *__restrict__ part, float *__restrict__ dW, int nslab, int O, int I, int I_valid) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * I_valid) return;
+  const int o = idx / I_valid, i = idx % I_valid;
+  float a = 0.f;
+  for (int s = 0; s < nslab; ++s) a += part[((size_t)s * O + o) * I + i];
+  dW[idx] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// optimizer (Runner.train: clip_grad_norm_(10) -> Adam.step, torch.optim.Adam defaults of optimizers.py:4-16)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_sumsq(const float *__restrict__ g, long long n, double *__restrict__ acc_part) {
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += (double)g[i] * g[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) acc_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_sumsq_finish(const double *__restrict__ acc_part, int n, double *__restrict__ total /* += */) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += acc_part[i];
+  *total += s;
+}
+// p, m, v updated in place; grads scaled by clip = min(1, max_norm / (norm + 1e-6)) read from the device
+__global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                       long long n, const double *__restrict__ sumsq, float max_norm, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bc1, float bc2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float clip = 1.f;
+  if (max_norm > 0.f) {
+    const float norm = (float)sqrt(*sumsq);
+    clip = fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  float gi = g[i] * clip;
+  if (weight_decay != 0.f) gi += weight_decay * p[i];
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi, v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct Carver {
+  char *base;
+  size_t off = 0;
+  template <class T>
+  T *take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct BlockAct {
+  float *hin, *st2, *xn2, *q, *k, *v, *p, *att, *h1, *st3, *xn3, *ag, *hid;
+};
+struct TrainWs {
+  // saved by the forward
+  float *xin, *h0, *st_pre, *hfin, *st_post, *hn, *ctx, *te_in, *te_ag, *te_hid, *te_out;
+  BlockAct blk[DFX_MAX_DEPTH];
+  // backward scratch
+  float *dh, *dh2, *dwide, *dhid, *dq, *datt, *dk, *dv, *dctx, *dte_out, *dte_hid, *dte_ag, *wT, *wpad, *part, *bpart, *apart;
+  float *valid;
+  size_t part_floats;
+};
+
+constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab
+inline int nslabs(long long R) { return (int)((R + WG_SLAB - 1) / WG_SLAB); }
+
+size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
+  Carver c{static_cast<char *>(base)};
+  const size_t R = (size_t)B * N, BJ = (size_t)B * J;
+  w.xin = c.take<float>(R * XIN);
+  w.h0 = c.take<float>(R * C);
+  w.st_pre = c.take<float>(R * 2);
+  w.hfin = nullptr;   // = output buffer of the last block (blk[depth].hin slot below)
+  w.st_post = c.take<float>(R * 2);
+  w.hn = c.take<float>(R * C);
+  w.ctx = c.take<float>(BJ * CTXP);
+  w.te_in = c.take<float>((size_t)B * TE);
+  w.te_ag = c.take<float>((size_t)B * 2 * TEH);
+  w.te_hid = c.take<float>((size_t)B * TEH);
+  w.te_out = c.take<float>((size_t)B * TE);
+  w.valid = c.take<float>(BJ);
+  for (int i = 0; i < depth; ++i) {
+    BlockAct &a = w.blk[i];
+    a.hin = c.take<float>(R * C);
+    a.st2 = c.take<float>(R * 2);
+    a.xn2 = c.take<float>(R * C);
+    a.q = c.take<float>(R * C);
+    a.k = c.take<float>(BJ * C);
+    a.v = c.take<float>(BJ * C);
+    a.p = c.take<float>(R * HEADS * J);
+    a.att = c.take<float>(R * C);
+    a.h1 = c.take<float>(R * C);
+    a.st3 = c.take<float>(R * 2);
+    a.xn3 = c.take<float>(R * C);
+    a.ag = c.take<float>(R * 2 * FH);
+    a.hid = c.take<float>(R * FH);
+  }
+  w.hfin = c.take<float>(R * C);
+  w.dh = c.take<float>(R * C);
+  w.dh2 = c.take<float>(R * C);
+  w.dwide = c.take<float>(R * 2 * FH);
+  w.dhid = c.take<float>(R * FH);
+  w.dq = c.take<float>(R * C);
+  w.datt = c.take<float>(R * C);
+  w.dk = c.take<float>(BJ * C);
+  w.dv = c.take<float>(BJ * C);
+  w.dctx = c.take<float>(BJ * CTXP);
+  w.dte_out = c.take<float>((size_t)B * TE);
+  w.dte_hid = c.take<float>((size_t)B * TEH);
+  w.dte_ag = c.take<float>((size_t)B * 2 * TEH);
+  w.wT = c.take<float>((size_t)2 * TEH * TE + 64);      // largest transposed weight: time_embed.net.0.proj (2048 x 256)
+  w.wpad = c.take<float>((size_t)C * CTXP);
+  const size_t ns = nslabs((long long)R);
+  w.part_floats = ns * (size_t)(2 * FH) * C;               // largest weight-gradient partial: W1 (1024 x 128) per slab
+  const size_t ln_parts = ((R + LNB_ROWS - 1) / LNB_ROWS) * 2 * C, eps_parts = ((R + EPSB_ROWS - 1) / EPSB_ROWS) * 4 * C;
+  const size_t te_parts = (size_t)2 * TEH * TE;            // time-embed weight gradients: one slab
+  size_t pf = w.part_floats;
+  if (ln_parts > pf) pf = ln_parts;
+  if (eps_parts > pf) pf = eps_parts;
+  if (te_parts > pf) pf = te_parts;
+  w.part_floats = pf;
+  w.part = c.take<float>(pf);
+  w.bpart = c.take<float>(ns * (size_t)(2 * TEH));
+  w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
+  return c.off;
+}
+
+int lin(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M, int N_,
+        int K, const float *resid = nullptr, int ldr = 0) {
+  LinArgs a{};
+  a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = (int)M, a.N = N_, a.K = K;
+  a.R = resid, a.ldr = ldr, a.r_mod = 0;
+  if (resid) dfx::lin::launch<dfx::lin::EPI_RESID>(st, 1, a);
+  else dfx::lin::launch<dfx::lin::EPI_NONE>(st, 1, a);
+  return dfx::check_launch("train: linear");
+}
+
+// WT = W^T (cols rows of length rows) for dX = dY W
+void transpose(hipStream_t st, const float *W, float *WT, int rows, int cols) {
+  k_transpose<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, st>>>(W, WT, rows, cols);
+}
+
+// dW (O x I_valid), db (O) from dY (R x O, ld ldy) and X (R x I, ld ldx)
+int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
+          int I_valid, long long R) {
+  const int ns = nslabs(R);
+  k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, WG_SLAB);
+  k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
+  if (db) k_sum_parts<<<(O + 255) / 256, 256, 0, st>>>(w.bpart, db, ns, O, O);
+  return dfx::check_launch("train: wgrad");
+}
+
+int ln_bwd(hipStream_t st, TrainWs &w, const float *dy, const float *x, const float *stats, const float *g, const float *resid,
+           float *out, float *dg, float *db, long long R) {
+  const int nb = (int)((R + LNB_ROWS - 1) / LNB_ROWS);
+  k_ln_bwd<<<nb, 256, 0, st>>>(dy, x, stats, g, resid, out, w.part, R);
+  k_sum_parts<<<1, 128, 0, st>>>(w.part, dg, nb, C, 2 * C);
+  k_sum_parts<<<1, 128, 0, st>>>(w.part + C, db, nb, C, 2 * C);
+  return dfx::check_launch("train: ln_bwd");
+}
+
+inline float *mut(const float *p) { return const_cast<float *>(p); }
+
+int check_args(const dfx_denoiser_weights *wt, const void *ws, size_t ws_bytes, int B, int N, const char *what) {
+  DFX_REQUIRE(wt && ws, "%s: null argument", what);
+  DFX_REQUIRE(wt->depth >= 1 && wt->depth <= DFX_MAX_DEPTH, "%s: depth %d", what, wt->depth);
+  DFX_REQUIRE(B >= 1 && N >= 32 && N % 32 == 0, "%s: B >= 1 and N a multiple of 32 required (B=%d N=%d)", what, B, N);
+  DFX_REQUIRE((long long)B * N < (1ll << 31), "%s: B*N too large", what);
+  TrainWs t;
+  const size_t need = carve(t, nullptr, B, N, wt->depth);
+  DFX_REQUIRE(ws_bytes >= need, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+  DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
+  return DFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth) {
+  if (B < 1 || N < 32 || depth < 1 || depth > DFX_MAX_DEPTH) return 0;
+  TrainWs t;
+  return carve(t, nullptr, B, N, depth);
+}
+
+int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes, const float *x,
+                               const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
+                               const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
+                               int N, dfx_stream_t stream) {
+  int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_forward");
+  if (rc) return rc;
+  DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");
+  hipStream_t st = dfx::as_stream(stream);
+  TrainWs w;
+  carve(w, workspace, B, N, wt->depth);
+  const long long R = (long long)B * N;
+  const int BJ = B * J;
+  // time embedding -> context rows
+  k_timestep_embedding<<<(B * TE + 255) / 256, 256, 0, st>>>(t, w.te_in, B);
+  if ((rc = lin(st, w.te_in, TE, wt->te0_w, wt->te0_b, w.te_ag, 2 * TEH, B, 2 * TEH, TE))) return rc;
+  k_geglu_fwd<<<(int)(((long long)B * TEH + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH);
+  if ((rc = lin(st, w.te_hid, TEH, wt->te2_w, wt->te2_b, w.te_out, TE, B, TE, TEH))) return rc;
+  k_build_ctx<<<(BJ * CTXP + 255) / 256, 256, 0, st>>>(ctx_code, ctx_mv, w.te_out, w.ctx, B);
+  if (valid) DFX_HIP_TRY(hipMemcpyAsync(w.valid, valid, sizeof(float) * BJ, hipMemcpyDeviceToDevice, st));
+  else DFX_HIP_TRY(hipMemsetAsync(w.valid, 0x3f, sizeof(float) * BJ, st));   // any non-zero value = keep
+  // proj_in + pre_norm
+  k_build_xin<<<(int)((R + 255) / 256), 256, 0, st>>>(x, anchors, variances, assignment, w.xin, N, R);
+  k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
+  if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
+  k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
+  for (int i = 0; i < wt->depth; ++i) {
+    const dfx_block_weights &bw = wt->blk[i];
+    BlockAct &a = w.blk[i];
+    float *hout = i + 1 < wt->depth ? w.blk[i + 1].hin : w.hfin;
+    k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+    if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C))) return rc;
+    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_k, w.wpad, C, CTX, CTXP);
+    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.k, C, BJ, C, CTXP))) return rc;
+    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_v, w.wpad, C, CTX, CTXP);
+    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
+    k_attn_fwd<<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
+    if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C))) return rc;
+    k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
+    if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C))) return rc;
+    k_geglu_fwd<<<(int)((R * FH + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
+    if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C))) return rc;
+  }
+  k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
+  k_eps_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hn, wt->proj_out_w, wt->proj_out_b, eps, N, R);
+  return dfx::check_launch("denoiser_train_forward");
+}
+
+int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes,
+                                const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
+                                int B, int N, dfx_stream_t stream) {
+  int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_backward");
+  if (rc) return rc;
+  DFX_REQUIRE(d_eps && grads, "denoiser_train_backward: null tensor");
+  hipStream_t st = dfx::as_stream(stream);
+  TrainWs w;
+  carve(w, workspace, B, N, wt->depth);
+  const long long R = (long long)B * N;
+  const int BJ = B * J;
+  // proj_out, post_norm
+  {
+    const int nb = (int)((R + EPSB_ROWS - 1) / EPSB_ROWS);
+    k_eps_bwd<<<nb, 128, 0, st>>>(d_eps, w.hn, wt->proj_out_w, w.dh2, w.part, N, R);
+    k_sum_parts<<<2, 256, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
+    k_sum_parts<<<1, 64, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
+  }
+  if ((rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
+  DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));
+  for (int i = wt->depth - 1; i >= 0; --i) {
+    const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
+    BlockAct &a = w.blk[i];
+    // feed-forward: h2 = h1 + W2 hid + b2, hid = a gelu(g), [a | g] = W1 xn3 + b1
+    if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R))) return rc;
+    transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
+    if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.dhid, FH, R, FH, C))) return rc;
+    k_geglu_bwd<<<(int)((R * FH + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
+    if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R))) return rc;
+    transpose(st, bw.ff0_w, w.wT, 2 * FH, C);                                // (128, 1024)
+    if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH))) return rc;
+    if ((rc = ln_bwd(st, w, w.dh2, a.h1, a.st3, bw.norm3_w, w.dh, w.dh, mut(gw.norm3_w), mut(gw.norm3_b), R))) return rc;
+    // attention: h1 = hin + Wo att + bo
+    if ((rc = wgrad(st, w, w.dh, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R))) return rc;
+    transpose(st, bw.to_out_w, w.wT, C, C);
+    if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.datt, C, R, C, C))) return rc;
+    k_attn_bwd<<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
+    k_attn_bwd_finish<<<B, J * C, 0, st>>>(w.apart, w.dk, w.dv, N / 32);
+    if ((rc = wgrad(st, w, w.dq, C, a.xn2, C, mut(gw.to_q), nullptr, C, C, C, R))) return rc;
+    transpose(st, bw.to_q, w.wT, C, C);
+    if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C))) return rc;
+    if ((rc = ln_bwd(st, w, w.dh2, a.hin, a.st2, bw.norm2_w, w.dh, w.dh, mut(gw.norm2_w), mut(gw.norm2_b), R))) return rc;
+    // keys / values of the 4 context tokens
+    if ((rc = wgrad(st, w, w.dk, C, w.ctx, CTXP, mut(gw.to_k), nullptr, C, CTXP, CTX, BJ))) return rc;
+    if ((rc = wgrad(st, w, w.dv, C, w.ctx, CTXP, mut(gw.to_v), nullptr, C, CTXP, CTX, BJ))) return rc;
+    DFX_HIP_TRY(hipMemsetAsync(w.wT, 0, sizeof(float) * (size_t)CTXP * C, st));
+    transpose(st, bw.to_k, w.wT, C, CTX);                                    // (522 -> 528 rows of 128)
+    if ((rc = lin(st, w.dk, C, w.wT, nullptr, w.dctx, CTXP, BJ, CTXP, C, w.dctx, CTXP))) return rc;
+    transpose(st, bw.to_v, w.wT, C, CTX);
+    if ((rc = lin(st, w.dv, C, w.wT, nullptr, w.dctx, CTXP, BJ, CTXP, C, w.dctx, CTXP))) return rc;
+  }
+  // pre_norm, proj_in
+  if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
+  if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
+  // context -> part codes, (mean, var), time embedding MLP
+  k_ctx_bwd<<<(B * CTX + 255) / 256, 256, 0, st>>>(w.dctx, d_ctx_code, d_ctx_mv, w.dte_out, B);
+  if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;
+  transpose(st, wt->te2_w, w.wT, TE, TEH);                                   // (1024, 256)
+  if ((rc = lin(st, w.dte_out, TE, w.wT, nullptr, w.dte_hid, TEH, B, TEH, TE))) return rc;
+  k_geglu_bwd<<<(int)(((long long)B * TEH + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH);
+  if ((rc = wgrad(st, w, w.dte_ag, 2 * TEH, w.te_in, TE, mut(grads->te0_w), mut(grads->te0_b), 2 * TEH, TE, TE, B))) return rc;
+  return dfx::check_launch("denoiser_train_backward");
+}
+
+int dfx_masked_mse_backward_f32(const float *target, const float *pred, const float *flags, const double *workspace2,
+                                float grad_scale, float *d_pred, int B, int N, dfx_stream_t stream) {
+  DFX_REQUIRE(target && pred && workspace2 && d_pred && B >= 1 && N >= 1, "masked_mse_backward: bad argument");
+  const long long total = (long long)B * N;
+  k_mse_bwd<<<(int)((total + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(target, pred, flags, workspace2, grad_scale, d_pred, N,
+                                                                               total, 3.0 * (double)B * N);
+  return dfx::check_launch("masked_mse_backward");
+}
+
+// Global gradient norm^2 accumulated over tensors (clip_grad_norm_): *sumsq += sum g^2.  workspace: 1024 doubles.
+int dfx_grad_sumsq_accumulate(const float *g, long long n, double *workspace1024, double *sumsq, dfx_stream_t stream) {
+  DFX_REQUIRE(g && workspace1024 && sumsq && n >= 1, "grad_sumsq: bad argument");
+  long long nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  k_sumsq<<<(int)nb, 256, 0, dfx::as_stream(stream)>>>(g, n, workspace1024);
+  k_sumsq_finish<<<1, 1, 0, dfx::as_stream(stream)>>>(workspace1024, (int)nb, sumsq);
+  return dfx::check_launch("grad_sumsq");
+}
+
+// One Adam step on one tensor (torch.optim.Adam, amsgrad off), gradient clipped by min(1, max_norm / (sqrt(*sumsq) + 1e-6))
+// when max_norm > 0 (torch.nn.utils.clip_grad_norm_); step = 1-based step count for the bias corrections.
+int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const double *sumsq,
+                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      dfx_stream_t stream) {
+  DFX_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 1 && step >= 1, "adam_step: bad argument");
+  DFX_REQUIRE(max_norm <= 0.f || sumsq, "adam_step: clipping needs the gradient norm");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  k_adam<<<(int)((n + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, sumsq, max_norm, lr, beta1,
+                                                                    beta2, eps, weight_decay, bc1, bc2);
+  return dfx::check_launch("adam_step");
+}
+
+}  // extern "C"

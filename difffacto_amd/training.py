@@ -1,0 +1,202 @@
+"""Training-mode denoiser on the HIP path: autograd functions over libdfx's forward / backward kernels,
+and the reference's optimiser step.
+
+Mirrors what ``loss.backward()`` + ``clip_grad_norm_`` + ``Adam.step`` do to ``TransformerNet`` in the reference
+(python/difffacto/models/networks/attention.py:385-440 forward; python/difffacto/runner/runner.py:312-316 step;
+anchored_diffusion.py:840-847 loss) with dropout = 0.  PyTorch provides the tensors, the autograd graph and the
+stream; every number is produced by the kernels of ``csrc/train_kernels.hip``.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES
+
+__all__ = ["param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam"]
+
+
+def param_names(depth):
+    """state_dict keys of TransformerNet in the order the autograd function takes them."""
+    names = list(_TOP_FIELDS.values())
+    for b in range(depth):
+        names += [f"transformer_blocks.{b}.{k}" for k in _BLOCK_FIELDS.values()]
+    return names
+
+
+def _struct(tensors, depth):
+    """dfx_denoiser_weights over `tensors` (dict name -> contiguous fp32 cuda tensor)."""
+    w = _ffi.DenoiserWeights()
+    w.depth = depth
+    for field, key in _TOP_FIELDS.items():
+        setattr(w, field, tensors[key].data_ptr())
+    for b in range(depth):
+        for field, key in _BLOCK_FIELDS.items():
+            setattr(w.blk[b], field, tensors[f"transformer_blocks.{b}.{key}"].data_ptr())
+    return w
+
+
+def _need(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: contiguous fp32 tensor on the GPU required (got {t.dtype}, {t.device})")
+    return t
+
+
+class DenoiserTrainFn(torch.autograd.Function):
+    """eps = TransformerNet(x, t, [ctx_code, ctx_mv], anchors, variances, valid_id, anchor_assignment), differentiable in
+    the parameters and in the two context tensors (x_t, anchors and variances are data: anchored_diffusion.py detaches
+    them, agent :1011-1014)."""
+
+    @staticmethod
+    def forward(ctx, depth, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
+        names = param_names(depth)
+        if len(params) != len(names):
+            raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
+        B, _, N = x.shape
+        tensors = {}
+        for n, p in zip(names, params):
+            base = n.split(".", 2)[2] if n.startswith("transformer_blocks.") else n
+            if base in EXPECTED_SHAPES and tuple(p.shape) != EXPECTED_SHAPES[base]:
+                raise ValueError(f"{n}: shape {tuple(p.shape)} != {EXPECTED_SHAPES[base]}")
+            tensors[n] = _need(p.detach(), n)
+        x = _need(x.detach().contiguous(), "x")
+        ctx_code = _need(ctx_code.detach().contiguous(), "ctx_code")
+        ctx_mv = _need(ctx_mv.detach().contiguous(), "ctx_mv")
+        anchors = _need(anchors.detach().contiguous(), "anchors")
+        variances = _need(variances.detach().contiguous(), "variances")
+        t32 = t.to(device=x.device, dtype=torch.int32).contiguous()
+        asg = assignment.to(device=x.device, dtype=torch.int32).contiguous()
+        vld = None if valid is None else valid.to(device=x.device, dtype=torch.float32).contiguous()
+        if ctx_code.shape != (B, 256, 4) or ctx_mv.shape != (B, 6, 4) or anchors.shape != (B, N, 3) or variances.shape != (B, N, 3):
+            raise ValueError("ctx_code (B,256,4), ctx_mv (B,6,4), anchors / variances (B,N,3) expected")
+        lib = _ffi.lib()
+        nbytes = lib.dfx_denoiser_train_workspace_bytes(B, N, depth)
+        if nbytes == 0:
+            raise ValueError(f"unsupported training shape B={B} N={N} depth={depth}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        eps = torch.empty(B, 3, N, dtype=torch.float32, device=x.device)
+        w = _struct(tensors, depth)
+        with torch.cuda.device(x.device):
+            _ffi.check(lib.dfx_denoiser_train_forward(ctypes.byref(w), ws_ptr, nbytes, x.data_ptr(), t32.data_ptr(),
+                                                      ctx_code.data_ptr(), ctx_mv.data_ptr(), anchors.data_ptr(),
+                                                      variances.data_ptr(), None if vld is None else vld.data_ptr(),
+                                                      asg.data_ptr(), eps.data_ptr(), B, N, _ffi.current_stream()),
+                       "dfx_denoiser_train_forward")
+        ctx.depth, ctx.shape, ctx.ws, ctx.ws_ptr, ctx.nbytes = depth, (B, N), ws, ws_ptr, nbytes
+        ctx.tensors = tensors
+        ctx.need_ctx = (ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        return eps
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        B, N = ctx.shape
+        depth = ctx.depth
+        names = param_names(depth)
+        d_eps = _need(d_eps.contiguous(), "d_eps")
+        grads = {n: torch.empty_like(ctx.tensors[n]) for n in names}
+        dev = d_eps.device
+        d_code = torch.empty(B, 256, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[0] else None
+        d_mv = torch.empty(B, 6, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[1] else None
+        w, g = _struct(ctx.tensors, depth), _struct(grads, depth)
+        with torch.cuda.device(dev):
+            _ffi.check(_ffi.lib().dfx_denoiser_train_backward(ctypes.byref(w), ctx.ws_ptr, ctx.nbytes, d_eps.data_ptr(),
+                                                              ctypes.byref(g), None if d_code is None else d_code.data_ptr(),
+                                                              None if d_mv is None else d_mv.data_ptr(), B, N,
+                                                              _ffi.current_stream()),
+                       "dfx_denoiser_train_backward")
+        ctx.ws = None
+        return (None, None, None, d_code, d_mv, None, None, None, None) + tuple(grads[n] for n in names)
+
+
+def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment):
+    """`params`: dict state_dict-key -> fp32 cuda tensor (requires_grad as the caller wishes) of a TransformerNet."""
+    depth = 0
+    while f"transformer_blocks.{depth}.norm2.weight" in params:
+        depth += 1
+    return DenoiserTrainFn.apply(depth, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
+                                 *[params[n] for n in param_names(depth)])
+
+
+class MaskedMSEFn(torch.autograd.Function):
+    """((target - pred)^2 * flags).mean(1).sum() / flags.sum()  (anchored_diffusion.py:840-847); differentiable in pred."""
+
+    @staticmethod
+    def forward(ctx, target, pred, flags):
+        target = _need(target.detach().contiguous(), "target")
+        predc = _need(pred.detach().contiguous(), "pred")
+        B, _, N = predc.shape
+        fl = None if flags is None else _need(flags.detach().reshape(B, N).to(torch.float32).contiguous(), "flags")
+        ws2 = torch.zeros(2, dtype=torch.float64, device=predc.device)
+        loss = torch.empty((), dtype=torch.float32, device=predc.device)
+        with torch.cuda.device(predc.device):
+            _ffi.check(_ffi.lib().dfx_masked_mse_f32(target.data_ptr(), predc.data_ptr(), None if fl is None else fl.data_ptr(),
+                                                     ws2.data_ptr(), loss.data_ptr(), B, N, _ffi.current_stream()),
+                       "dfx_masked_mse_f32")
+        ctx.saved = (target, predc, fl, ws2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        target, pred, fl, ws2 = ctx.saved
+        B, _, N = pred.shape
+        d = torch.empty_like(pred)
+        with torch.cuda.device(pred.device):
+            _ffi.check(_ffi.lib().dfx_masked_mse_backward_f32(target.data_ptr(), pred.data_ptr(),
+                                                              None if fl is None else fl.data_ptr(), ws2.data_ptr(), float(g),
+                                                              d.data_ptr(), B, N, _ffi.current_stream()),
+                       "dfx_masked_mse_backward_f32")
+        return None, d, None
+
+
+def masked_mse(target, pred, flags=None):
+    return MaskedMSEFn.apply(target, pred, flags)
+
+
+class Adam:
+    """torch.optim.Adam (amsgrad off) with Runner.train's clip_grad_norm_(max_norm) in front of it (runner.py:312-316),
+    one kernel per tensor.  `params`: iterable of fp32 cuda tensors with .grad set by backward()."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=10.0):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.step_count = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        dev = self.params[0].device
+        self._ws = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def grad_norm(self):
+        """Global L2 norm of the gradients (what clip_grad_norm_ returns), as a 0-dim float64 cuda tensor."""
+        lib = _ffi.lib()
+        self._sumsq.zero_()
+        for p in self.params:
+            if p.grad is None:
+                continue
+            g = _need(p.grad.contiguous(), "grad")
+            with torch.cuda.device(g.device):
+                _ffi.check(lib.dfx_grad_sumsq_accumulate(g.data_ptr(), g.numel(), self._ws.data_ptr(), self._sumsq.data_ptr(),
+                                                         _ffi.current_stream()), "dfx_grad_sumsq_accumulate")
+        return self._sumsq.sqrt()[0]
+
+    @torch.no_grad()
+    def step(self):
+        lib = _ffi.lib()
+        norm = self.grad_norm() if self.max_norm and self.max_norm > 0 else None
+        self.step_count += 1
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = _need(p.grad.contiguous(), "grad")
+            with torch.cuda.device(p.device):
+                _ffi.check(lib.dfx_adam_step_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                                 self._sumsq.data_ptr() if norm is not None else None,
+                                                 float(self.max_norm or 0.0), float(self.lr), float(self.betas[0]),
+                                                 float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                                 self.step_count, _ffi.current_stream()), "dfx_adam_step_f32")
+        return norm

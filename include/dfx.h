@@ -347,6 +347,38 @@ int dfx_emd_forward_f32(const float *xyz1, const float *xyz2, float *dist, int32
 int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad_dist, const int32_t *assignment,
                          float *grad_xyz1, int B, int n, dfx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-mode denoiser: forward with saved activations, backward, loss gradient, optimizer.
+ * Replaces autograd through TransformerNet.forward / _forward_attn (python/difffacto/models/networks/attention.py:385-440;
+ * BasicTransformerBlock :296-306, CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94; dropout = 0), the
+ * mse_loss of AnchoredDiffusion.training_losses (anchored_diffusion.py:840-847), and Runner.train's
+ * clip_grad_norm_ + Adam.step (runner.py:312-316, optimizers.py:4-16).  Exact fp32 throughout.
+ *   x (B,3,N); t (B,) int32; ctx_code (B,256,4) and ctx_mv (B,6,4) = the two tensors of the reference's ctx list;
+ *   anchors, variances (B,N,3) per point (the caller's gather, as at anchored_diffusion.py:261); valid (B,4) 0/1 or
+ *   NULL; assignment (B,N) int32; eps (B,3,N).
+ *   workspace: dfx_denoiser_train_workspace_bytes(B, N, depth) device bytes, 256-byte aligned; the backward reads what
+ *   the forward of the SAME (B, N) call left in it.
+ *   grads: a dfx_denoiser_weights whose pointers name WRITABLE device buffers of the parameters' shapes; every one of
+ *   them is overwritten (not accumulated).  d_ctx_code / d_ctx_mv: (B,256,4) / (B,6,4) or NULL.
+ * ------------------------------------------------------------------------------------------ */
+size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth);
+int dfx_denoiser_train_forward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes, const float *x,
+                               const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
+                               const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
+                               int N, dfx_stream_t stream);
+int dfx_denoiser_train_backward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes,
+                                const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
+                                int B, int N, dfx_stream_t stream);
+/* d loss / d pred of dfx_masked_mse_f32, times grad_scale; workspace2 = the two doubles its forward left behind */
+int dfx_masked_mse_backward_f32(const float *target, const float *pred, const float *flags, const double *workspace2,
+                                float grad_scale, float *d_pred, int B, int N, dfx_stream_t stream);
+/* *sumsq += sum(g^2) (zero it before the first tensor); workspace1024 = 1024 doubles on the device */
+int dfx_grad_sumsq_accumulate(const float *g, long long n, double *workspace1024, double *sumsq, dfx_stream_t stream);
+/* torch.optim.Adam step on one tensor, gradient scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) if max_norm > 0 */
+int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const double *sumsq,
+                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      dfx_stream_t stream);
+
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

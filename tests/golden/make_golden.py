@@ -21,6 +21,10 @@ latents_*.npz        PartEncoder.sample_latents (part_encoders.py:1052-1110: flo
                      one flow / the aligner called on their own
 train_fwd_*.npz      AnchoredDiffusion.training_losses / q_sample (anchored_diffusion.py:760-853, :148-173) in eval mode
                      (dropout off), per-shape timesteps, with and without flags
+train_grads_*.npz    autograd through TransformerNet in TRAIN mode with every Dropout set to p = 0 (the parity setting of
+                     SURVEY.md §7 config 5): eps, the masked mse_loss of training_losses, and d loss / d (every parameter,
+                     both ctx tensors).  Gradients of tensors with more than 4096 elements are stored as
+                     (sum, L2 norm, 1024 elements at seeded positions) to keep the fixture small
 pointnet_v2_*.npz    PointNetV2.forward (pointnet.py:187-213, eval-mode BatchNorm), the encode-side part encoder
 pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
                      (models/encoders/pointnet2_utils.py:84-104,41-57)
@@ -222,6 +226,52 @@ def gen_training_losses(model, tag, B, N, seed, T):
     print("wrote train_fwd_" + tag, out)
 
 
+def gen_train_grads(model, tag, B, N, seed, T):
+    """loss.backward() through the reference's TransformerNet (attention.py:385-440) and mse_loss (anchored_diffusion.py:840-847)."""
+    case = make_case(B, N, seed, False)
+    anchors, variance, ctx, va, sg = to_ref_inputs(*case)
+    rng = np.random.Generator(np.random.PCG64(seed + 300))
+    x0 = (np.sqrt(variance.numpy()) * rng.standard_normal((B, 3, N)).astype(F32) * 0.5 + anchors.numpy()).astype(F32)
+    noise = rng.standard_normal((B, 3, N)).astype(F32)
+    t = rng.integers(0, T, size=(B,)).astype(np.int64)
+    flags = (rng.uniform(size=(B, 1, N)) > 0.2).astype(F32)
+    net = model.diffusion.model
+    model.train()
+    ndrop = 0
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+            ndrop += 1
+    for p in net.parameters():
+        p.grad = None
+    ctx = [c.clone().requires_grad_(True) for c in ctx]
+    r = model.diffusion.training_losses(torch.from_numpy(x0), torch.from_numpy(t), anchors=anchors, variance=variance, ctx=ctx,
+                                        anchor_assignment=sg.to(torch.int32), valid_id=va, flags=torch.from_numpy(flags),
+                                        noise=torch.from_numpy(noise))
+    loss = r["mse_loss"]
+    loss.backward()
+    with torch.no_grad():
+        x_t = model.diffusion.q_sample(torch.from_numpy(x0), torch.from_numpy(t), anchors, noise=torch.from_numpy(noise), variance=variance)
+        eps = net(x_t, torch.from_numpy(t), [c.detach() for c in ctx], anchors=anchors.transpose(1, 2), variances=variance.transpose(1, 2),
+                  valid_id=va, anchor_assignment=sg)
+    out = {"loss": np.array(float(loss), F32), "eps": eps.numpy().astype(F32), "x_t": x_t.numpy().astype(F32),
+           "d_ctx_code": ctx[0].grad.numpy().astype(F32), "d_ctx_mv": ctx[1].grad.numpy().astype(F32)}
+    srng = np.random.Generator(np.random.PCG64(4242))
+    for name, p in net.named_parameters():
+        g = p.grad.numpy().astype(F32).ravel()
+        if g.size <= 4096:
+            out["g/" + name] = g
+        else:
+            idx = np.sort(srng.choice(g.size, size=1024, replace=False)).astype(np.int64)
+            out["gi/" + name] = idx
+            out["gs/" + name] = g[idx]
+            out["gn/" + name] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+    model.eval()
+    np.savez_compressed(os.path.join(HERE, f"train_grads_{tag}.npz"), part_code=case[0], mean=case[1], logvar=case[2], valid=case[3],
+                        seg=case[4], x_start=x0, noise=noise, t=t, flags=flags, weight_seed=np.array(0), **out)
+    print("wrote train_grads_" + tag, float(loss), ndrop, "dropouts zeroed;", len(out), "arrays")
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -265,6 +315,9 @@ def main():
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
     gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
     gen_training_losses(model, "B3_N64_T10", B=3, N=64, seed=71, T=10)
+    gen_train_grads(model, "B3_N64_T10", B=3, N=64, seed=81, T=10)
+    if "--only-train" in sys.argv:
+        return
     if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:
         from difffacto.config.config import get_cfg
         from difffacto.utils.registry import build_from_cfg, MODELS

@@ -1,0 +1,136 @@
+"""Training-mode denoiser on the HIP path: forward with saved activations, backward, loss gradient, Adam.
+
+Tolerances (fp32 everywhere; the reductions over B*N rows run in a different order than torch's):
+  gradients     5e-4 of the tensor's max-abs + 1e-7   (measured ~1e-5)
+  eps / loss    2e-5 / 5e-6
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _train_case import check_against_golden, load_case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(case, with_flags=True):
+    from difffacto_amd import training
+    dev = "cuda"
+    P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in case["W"].items()}
+    cc = torch.from_numpy(case["ctx_code"]).to(dev).requires_grad_(True)
+    cm = torch.from_numpy(case["ctx_mv"]).to(dev).requires_grad_(True)
+    eps = training.denoiser_train_forward(P, torch.from_numpy(case["x_t"]).to(dev), torch.from_numpy(case["t"]).to(dev), cc, cm,
+                                          torch.from_numpy(case["anchors_pt"]).to(dev), torch.from_numpy(case["variances_pt"]).to(dev),
+                                          None if case["valid"] is None else torch.from_numpy(case["valid"]).to(dev),
+                                          torch.from_numpy(case["assignment"]).to(dev))
+    flags = torch.from_numpy(case["flags"]).to(dev) if with_flags and case["flags"] is not None else None
+    loss = training.masked_mse(torch.from_numpy(case["noise"]).to(dev), eps, flags)
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(loss=float(loss.detach()), eps=eps.detach().cpu().numpy(), grads={k: v.grad.cpu().numpy() for k, v in P.items()},
+                d_ctx_code=cc.grad.cpu().numpy(), d_ctx_mv=cm.grad.cpu().numpy(), params=P)
+
+
+def test_forward_backward_vs_reference_autograd_golden():
+    g, c = load_case("B3_N64_T10")
+    r = _run(c)
+    assert abs(r["loss"] - float(g["loss"])) < 5e-6, (r["loss"], float(g["loss"]))
+    assert np.abs(r["eps"] - g["eps"]).max() < 2e-5
+    n, worst = check_against_golden(g, r["grads"], rtol=5e-4, atol=1e-7)
+    assert n == 77
+    print(f"77 parameter gradients vs the reference's autograd: worst max-abs error / max-abs = {worst:.2e}")
+    for k in ("d_ctx_code", "d_ctx_mv"):
+        err = np.abs(r[k] - g[k]).max()
+        assert err <= 5e-4 * np.abs(g[k]).max() + 1e-8, (k, err)
+
+
+@pytest.mark.parametrize("B,N,all_valid,with_flags", [(2, 96, True, False), (5, 32, False, True), (1, 2048, False, True)])
+def test_forward_backward_vs_oracle_full_gradients(B, N, all_valid, with_flags):
+    """Every element of every gradient against oracle/train.py (pinned to the reference by the golden above) on seeded
+    inputs of other shapes: ragged part validity, no flags, N = 2048."""
+    from difffacto_amd import synth
+    from oracle import train
+    rng = np.random.Generator(np.random.PCG64(100 + B + N))
+    W = synth.make_denoiser_weights(3)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=7 + B, all_valid=all_valid)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32) if with_flags else None)
+    ref = train.loss_and_grads(**c)
+    r = _run(c, with_flags)
+    assert abs(r["loss"] - ref["loss"]) < 5e-6 * max(1.0, abs(ref["loss"]))
+    assert np.abs(r["eps"] - ref["eps"]).max() < 2e-5
+    worst = 0.0
+    for k, gr in ref["grads"].items():
+        scale = max(np.abs(gr).max(), 1e-30)
+        err = np.abs(r["grads"][k] - gr).max()
+        assert err <= 5e-4 * scale + 1e-7, (k, err, scale)
+        worst = max(worst, err / scale)
+    for k in ("d_ctx_code", "d_ctx_mv"):
+        assert np.abs(r[k] - ref[k]).max() <= 5e-4 * np.abs(ref[k]).max() + 1e-8, k
+    print(f"B={B} N={N}: worst gradient error / max-abs = {worst:.2e}")
+
+
+def test_adam_with_clipping_matches_torch():
+    """Three steps of dfx Adam + clip_grad_norm_(max_norm) against torch.optim.Adam + torch.nn.utils.clip_grad_norm_ on
+    the CPU (what Runner.train does, runner.py:312-316), on tensors of awkward sizes."""
+    from difffacto_amd import training
+    rng = np.random.Generator(np.random.PCG64(5))
+    shapes = [(1024, 128), (3,), (128, 522), (77,)]
+    p0 = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    ref = [torch.from_numpy(a.copy()).requires_grad_(True) for a in p0]
+    mine = [torch.from_numpy(a.copy()).cuda() for a in p0]
+    opt_ref = torch.optim.Adam(ref, lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt = training.Adam(mine, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0)
+    for step in range(3):
+        gs = [(rng.standard_normal(s) * (30.0 if step == 0 else 0.01)).astype(np.float32) for s in shapes]   # step 0 clips
+        for p, g in zip(ref, gs):
+            p.grad = torch.from_numpy(g.copy())
+        for p, g in zip(mine, gs):
+            p.grad = torch.from_numpy(g.copy()).cuda()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        opt_ref.step()
+        n = opt.step()
+        assert abs(float(n) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for a, b in zip(mine, ref):
+            assert np.abs(a.cpu().numpy() - b.detach().numpy()).max() < 2e-6
+
+
+def test_training_steps_reduce_the_loss():
+    """Five optimiser steps on one fixed batch through the autograd functions: the masked MSE goes down."""
+    from difffacto_amd import training
+    g, c = load_case("B3_N64_T10")
+    dev = "cuda"
+    P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in c["W"].items()}
+    opt = training.Adam(list(P.values()), lr=1e-3, max_norm=10.0)
+    args = [torch.from_numpy(c[k]).to(dev) for k in ("x_t", "t", "ctx_code", "ctx_mv", "anchors_pt", "variances_pt", "valid", "assignment")]
+    noise, flags = torch.from_numpy(c["noise"]).to(dev), torch.from_numpy(c["flags"]).to(dev)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args), flags)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] and all(np.isfinite(losses)), losses
+
+
+def test_train_entry_points_reject_bad_arguments():
+    from difffacto_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.dfx_denoiser_train_workspace_bytes(0, 64, 5) == 0
+    assert lib.dfx_denoiser_train_workspace_bytes(2, 64, 5) > 0
+    w = _ffi.DenoiserWeights()
+    w.depth = 5
+    rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, None)
+    assert rc != 0 and b"null" in lib.dfx_last_error()

@@ -166,3 +166,20 @@ def test_torch_cpu_oracle_matches_reference(W):
     for i, t in enumerate(range(9, -1, -1)):
         x, _ = tc.p_sample(tb, Wt, x, t, t_(anchors), [t_(v) for v in _ctx(c)], t_(variance), t_(c["seg"]), t_(c["valid"]), t_(c["step_noise"][i]))
         assert np.abs(x.numpy() - c["traj"][i + 1]).max() < TOL_CHAIN
+
+
+def test_training_gradient_oracle_matches_reference_autograd():
+    """oracle/train.py (torch-CPU autograd over the restated forward) against loss.backward() through the reference's own
+    TransformerNet in train mode with dropout 0 (tests/golden/train_grads_*.npz): loss, eps, 77 parameter gradients, ctx grads."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _train_case import check_against_golden, load_case
+    from oracle import train
+    g, c = load_case("B3_N64_T10")
+    r = train.loss_and_grads(**c)
+    assert abs(r["loss"] - float(g["loss"])) < 2e-6
+    assert np.abs(r["eps"] - g["eps"]).max() < 5e-6
+    n, worst = check_against_golden(g, r["grads"], rtol=1e-4, atol=1e-8)
+    assert n == 77
+    for k in ("d_ctx_code", "d_ctx_mv"):
+        assert np.abs(r[k] - g[k]).max() <= 1e-4 * np.abs(g[k]).max() + 1e-9
