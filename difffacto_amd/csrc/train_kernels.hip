@@ -122,13 +122,23 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ dy, co
   part[(size_t)blockIdx.x * 2 * C + t] = a;
 }
 
-// out[c] = sum over nparts of part[p][c]  (second pass of every column reduction; fixed order)
-__global__ void k_sum_parts(const float *__restrict__ part, float *__restrict__ out, int nparts, int cols, int ld_part) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] = sum over nparts of part[p][c]  (second pass of every column reduction).  Block = 32 columns x 8 part groups;
+// group q adds parts q, q+8, ... in order, the eight group sums are added in order: a fixed summation tree.
+__global__ __launch_bounds__(256) void k_sum_parts(const float *__restrict__ part, float *__restrict__ out, int nparts, int cols,
+                                                    int ld_part) {
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
   float a = 0.f;
-  for (int p = 0; p < nparts; ++p) a += part[(size_t)p * ld_part + c];
-  out[c] = a;
+  if (c < cols)
+    for (int p = q; p < nparts; p += 8) a += part[(size_t)p * ld_part + c];
+  red[q][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (q == 0 && c < cols) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    out[c] = t;
+  }
 }
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
@@ -611,7 +621,7 @@ int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, 
   const int ns = nslabs(R);
   k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, WG_SLAB);
   k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
-  if (db) k_sum_parts<<<(O + 255) / 256, 256, 0, st>>>(w.bpart, db, ns, O, O);
+  if (db) k_sum_parts<<<(O + 31) / 32, 256, 0, st>>>(w.bpart, db, ns, O, O);
   return dfx::check_launch("train: wgrad");
 }
 
@@ -619,8 +629,8 @@ int ln_bwd(hipStream_t st, TrainWs &w, const float *dy, const float *x, const fl
            float *out, float *dg, float *db, long long R) {
   const int nb = (int)((R + LNB_ROWS - 1) / LNB_ROWS);
   k_ln_bwd<<<nb, 256, 0, st>>>(dy, x, stats, g, resid, out, w.part, R);
-  k_sum_parts<<<1, 128, 0, st>>>(w.part, dg, nb, C, 2 * C);
-  k_sum_parts<<<1, 128, 0, st>>>(w.part + C, db, nb, C, 2 * C);
+  k_sum_parts<<<C / 32, 256, 0, st>>>(w.part, dg, nb, C, 2 * C);
+  k_sum_parts<<<C / 32, 256, 0, st>>>(w.part + C, db, nb, C, 2 * C);
   return dfx::check_launch("train: ln_bwd");
 }
 
@@ -710,8 +720,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   {
     const int nb = (int)((R + EPSB_ROWS - 1) / EPSB_ROWS);
     k_eps_bwd<<<nb, 128, 0, st>>>(d_eps, w.hn, wt->proj_out_w, w.dh2, w.part, N, R);
-    k_sum_parts<<<2, 256, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
-    k_sum_parts<<<1, 64, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
+    k_sum_parts<<<3 * C / 32, 256, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
+    k_sum_parts<<<1, 256, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
   }
   if ((rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
   DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));

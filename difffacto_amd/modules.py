@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import training as _training
 from .engine import DenoiserEngine
 
 
@@ -145,11 +146,28 @@ class TransformerNet(nn.Module):
         ``anchor_assignment``, which the kernel performs itself."""
         if anchor_assignment is None:
             _unsupported("anchor_assignment is required (cat_class_to_x)")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())
+                                        or any(c.requires_grad for c in ctx)):
+            return self._forward_train(x, t, ctx, anchors, variances, valid_id, anchor_assignment)
         tt = t if isinstance(t, int) else int(t.reshape(-1)[0].item())
         if not isinstance(t, int) and t.numel() > 1 and not bool((t == t.reshape(-1)[0]).all()):
             _unsupported("per-sample timesteps (the sampling loop uses one t for the batch, anchored_diffusion.py:576)")
         sc = self.shape_context(ctx, valid_id)
         return self.engine().eps(sc, x, anchor_assignment, tt)
+
+    def _forward_train(self, x, t, ctx, anchors, variances, valid_id, anchor_assignment):
+        """Differentiable evaluation (per-shape t, saved activations, exact fp32): libdfx's training kernels behind
+        torch.autograd (difffacto_amd/training.py).  Dropout must be 0 (the parity setting)."""
+        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()):
+            _unsupported("dropout > 0 in train() mode: the native training path has no dropout (build the net with dropout=0)")
+        if anchors is None or variances is None:
+            _unsupported("anchors / variances (B,N,3) are required on the training path")
+        if not isinstance(ctx, (list, tuple)) or len(ctx) != 2:
+            _unsupported("ctx must be the [part_code, params] list of PartEncoderForTransformerDecoder.prepare_ctx")
+        B = x.shape[0]
+        tt = torch.full((B,), int(t), device=x.device) if isinstance(t, int) else t.reshape(-1).expand(B) if t.numel() == 1 else t
+        return _training.denoiser_train_forward(dict(self.named_parameters()), x, tt, ctx[0], ctx[1], anchors, variances,
+                                                valid_id, anchor_assignment)
 
 
 class AnchoredDiffusion(nn.Module):
@@ -259,15 +277,23 @@ class AnchoredDiffusion(nn.Module):
 
     def training_losses(self, x_start, t, anchors=None, variance=None, ctx=None, reduce=True, anchor_assignment=None,
                         valid_id=None, flags=None, noise=None):
-        """anchored_diffusion.py:760-853, forward value only: {'mse_loss'} of the epsilon objective at per-shape
-        timesteps ``t`` (B,), evaluated natively (q_sample -> denoiser -> masked MSE).  Available in inference
-        (``eval()`` + ``no_grad``): gradients / dropout are training and not libdfx's path."""
-        if self.training or torch.is_grad_enabled():
-            _unsupported("training_losses with gradients or in train() mode (dropout, autograd)")
+        """anchored_diffusion.py:760-853: {'mse_loss'} of the epsilon objective at per-shape timesteps ``t`` (B,)
+        (q_sample -> denoiser -> masked MSE).  Under ``no_grad`` in ``eval()`` the value comes from the inference
+        engine; with gradients enabled it is differentiable in the denoiser's parameters and in ``ctx`` through libdfx's
+        training kernels (dropout must be 0; anchors / variance are data, as the reference detaches them,
+        anchor_gen.py:1011-1014)."""
         if not reduce:
             _unsupported("training_losses(reduce=False)")
         if noise is None:
             noise = torch.randn_like(x_start)
+        if self.training or torch.is_grad_enabled():
+            if anchors is None or variance is None:
+                _unsupported("anchors / variance (B,3,N) are required on the training path")
+            x_t = self.q_sample(x_start, t, anchors.detach(), noise=noise, variance=variance.detach())
+            eps = self.model(x_t, t, ctx, anchors=anchors.detach().transpose(1, 2).contiguous(),
+                             variances=variance.detach().transpose(1, 2).contiguous(), valid_id=valid_id,
+                             anchor_assignment=anchor_assignment)
+            return {"mse_loss": _training.masked_mse(noise, eps, flags)}
         eng = self.model.engine()
         sc = self._sc(ctx, valid_id)
         x_t = eng.q_sample(sc, anchor_assignment, x_start, t, noise)

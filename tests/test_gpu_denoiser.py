@@ -284,7 +284,7 @@ def test_training_losses_forward_vs_reference_golden(W, prec, tol):
             ref = float(g["mse_loss_" + name])
             assert abs(float(r["mse_loss"]) - ref) < tol * max(1.0, ref), (name, float(r["mse_loss"]), ref)
     with pytest.raises(NotImplementedError):
-        d.training_losses(c(g["x_start"]), c(g["t"]), ctx=ctx, anchor_assignment=seg, valid_id=valid, noise=c(g["noise"]))   # grad mode
+        d.training_losses(c(g["x_start"]), c(g["t"]), ctx=ctx, anchor_assignment=seg, valid_id=valid, noise=c(g["noise"]))   # grad mode without anchors / variance
     # the pipelined kernel (N % 256 == 0) with per-shape t agrees with the direct kernel
     B, N = 4, 256
     pc, mean, logvar, va = synth.make_latents(B, seed=3)

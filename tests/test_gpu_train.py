@@ -134,3 +134,37 @@ def test_train_entry_points_reject_bad_arguments():
     w.depth = 5
     rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, None)
     assert rc != 0 and b"null" in lib.dfx_last_error()
+
+
+def test_module_api_training_losses_backward_like_the_reference():
+    """The reference's call sequence (anchor_gen.py:1020, runner.py:312-316) through the drop-in modules: train() mode,
+    diffusion.training_losses(...)['mse_loss'].backward(), clip + Adam — parameter gradients against the golden."""
+    from difffacto_amd import training
+    from difffacto_amd.modules import AnchoredDiffusion
+    from test_modules_cpu import DIFF_CFG
+    g, c = load_case("B3_N64_T10")
+    net = dict(DIFF_CFG["net"], dropout=0.0)
+    d = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": net})
+    d.model.load_state_dict({k: torch.from_numpy(v) for k, v in c["W"].items()})
+    d = d.cuda().train()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ctx = [cu(c["ctx_code"]).requires_grad_(True), cu(c["ctx_mv"]).requires_grad_(True)]
+    anchors, variance = cu(c["anchors_pt"].transpose(0, 2, 1)), cu(c["variances_pt"].transpose(0, 2, 1))     # (B,3,N)
+    r = d.training_losses(cu(g["x_start"]), cu(g["t"]), anchors=anchors, variance=variance, ctx=ctx, anchor_assignment=cu(c["assignment"]),
+                          valid_id=cu(c["valid"]), flags=cu(c["flags"]), noise=cu(c["noise"]))
+    loss = r["mse_loss"]
+    assert abs(float(loss.detach()) - float(g["loss"])) < 5e-6
+    loss.backward()
+    grads = {k: p.grad.cpu().numpy() for k, p in d.model.named_parameters()}
+    n, worst = check_against_golden(g, grads, rtol=5e-4, atol=1e-7)
+    assert n == 77
+    assert np.abs(ctx[0].grad.cpu().numpy() - g["d_ctx_code"]).max() <= 5e-4 * np.abs(g["d_ctx_code"]).max() + 1e-8
+    opt = training.Adam(list(d.model.parameters()), lr=1e-3, max_norm=10.0)
+    before = d.model.proj_out.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, d.model.proj_out.weight.detach())
+    # dropout > 0 in train mode is refused (no native dropout)
+    d2 = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.2)}).cuda().train()
+    with pytest.raises(NotImplementedError):
+        d2.training_losses(cu(g["x_start"]), cu(g["t"]), anchors=anchors, variance=variance, ctx=ctx, anchor_assignment=cu(c["assignment"]),
+                           valid_id=cu(c["valid"]), flags=cu(c["flags"]), noise=cu(c["noise"]))

@@ -1,0 +1,54 @@
+"""Forward + backward time of the training-mode denoiser at BASELINE config 4's size (B=128 x 2048 pts, fp32):
+python tools/bench_train.py [B] [N].  Prints ms per iteration and the achieved fp32 matrix throughput
+(3 x 4.734 GFLOP per shape: forward + dX + dW products)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from difffacto_amd import synth, training
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+dev = "cuda"
+W = synth.make_denoiser_weights(0)
+P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in W.items()}
+pc, mean, logvar, valid = synth.make_latents(B, seed=1)
+seg = synth.make_seg_mask(valid, N)
+var = np.exp(logvar).astype(np.float32)
+idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+rng = np.random.default_rng(0)
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+x_t = cu((anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32))
+t = cu(rng.integers(0, 1000, size=(B,)).astype(np.int64))
+args = [x_t, t, cu(pc), cu(np.concatenate([mean, var], 1).astype(np.float32)), cu(anc.transpose(0, 2, 1)), cu(vr.transpose(0, 2, 1)),
+        cu(valid), cu(seg.astype(np.int32))]
+noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
+opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
+
+
+def it():
+    opt.zero_grad()
+    loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args), None)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    it()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 5
+for _ in range(K):
+    loss = it()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / K * 1e3
+flops = 3 * 4.734e9 * B * (N / 2048)
+print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, fp32: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
+      f"{flops / ms / 1e9:.1f} TFLOP/s of the 157.3 TFLOP/s fp32 matrix peak ({flops / ms / 1e9 / 157.3 * 100:.1f} %), loss {float(loss.detach()):.4f}, "
+      f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak")
