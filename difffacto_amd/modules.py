@@ -158,6 +158,8 @@ class TransformerNet(nn.Module):
     def _forward_train(self, x, t, ctx, anchors, variances, valid_id, anchor_assignment):
         """Differentiable evaluation (per-shape t, saved activations, exact fp32): libdfx's training kernels behind
         torch.autograd (difffacto_amd/training.py).  Dropout must be 0 (the parity setting)."""
+        if next(self.parameters()).device.type != "cuda" or x.device.type != "cuda":
+            raise RuntimeError("TransformerNet (libdfx) needs its parameters and inputs on a HIP device: CPU not supported")
         if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()):
             _unsupported("dropout > 0 in train() mode: the native training path has no dropout (build the net with dropout=0)")
         if anchors is None or variances is None:
