@@ -162,10 +162,15 @@ class TransformerNet(nn.Module):
             raise RuntimeError("TransformerNet (libdfx) needs its parameters and inputs on a HIP device: CPU not supported")
         if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()):
             _unsupported("dropout > 0 in train() mode: the native training path has no dropout (build the net with dropout=0)")
-        if anchors is None or variances is None:
-            _unsupported("anchors / variances (B,N,3) are required on the training path")
         if not isinstance(ctx, (list, tuple)) or len(ctx) != 2:
             _unsupported("ctx must be the [part_code, params] list of PartEncoderForTransformerDecoder.prepare_ctx")
+        if anchors is None or variances is None:
+            # the caller's per-point anchors / variances are the gather of ctx[1] by anchor_assignment
+            # (anchored_diffusion.py:261, part_encoders.py:417-428); they are data, not differentiated
+            idx = anchor_assignment.long()[:, None, :].expand(-1, 3, -1)
+            par = ctx[1].detach()
+            anchors = torch.gather(par[:, :3], 2, idx).transpose(1, 2).contiguous()
+            variances = torch.gather(par[:, 3:], 2, idx).transpose(1, 2).contiguous()
         B = x.shape[0]
         tt = torch.full((B,), int(t), device=x.device) if isinstance(t, int) else t.reshape(-1).expand(B) if t.numel() == 1 else t
         return _training.denoiser_train_forward(dict(self.named_parameters()), x, tt, ctx[0], ctx[1], anchors, variances,

@@ -42,9 +42,14 @@ def test_transformer_net_forward_signature(diffusion):
     x = torch.from_numpy(g["x"]).cuda()
     for t in g["ts"]:
         tt = torch.tensor([int(t)] * x.shape[0], device="cuda")
-        eps = diffusion.model(x, tt, ctx, anchors=anchors.transpose(1, 2), variances=variance.transpose(1, 2),
-                              valid_id=valid, anchor_assignment=seg)
+        with torch.no_grad():   # the sampling path (inference engine)
+            eps = diffusion.model(x, tt, ctx, anchors=anchors.transpose(1, 2), variances=variance.transpose(1, 2),
+                                  valid_id=valid, anchor_assignment=seg)
         assert np.abs(eps.cpu().numpy() - g[f"eps_t{int(t)}"]).max() < 1e-4
+        # with autograd enabled the same call is the differentiable training-mode evaluation (as in the reference)
+        eps_g = diffusion.model(x, tt, ctx, anchors=anchors.transpose(1, 2).contiguous(), variances=variance.transpose(1, 2).contiguous(),
+                                valid_id=valid, anchor_assignment=seg)
+        assert eps_g.requires_grad and np.abs(eps_g.detach().cpu().numpy() - g[f"eps_t{int(t)}"]).max() < 1e-4
 
 
 def test_generator_protocol_and_decode(diffusion):

@@ -121,7 +121,7 @@ def test_training_steps_reduce_the_loss():
         loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args), flags)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and all(np.isfinite(losses)), losses
 
 
