@@ -1,0 +1,195 @@
+// LDS-tiled GEMMs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate) over fp32 operands in HBM, for the
+// training path (train_kernels.hip): operands are rounded to bf16 (RNE) on their way into LDS, results stay fp32.
+//
+//   NT   C (M, N) = X (M, K) W (N, K)^T + bias + residual       linear forward and dX (W = transposed weight copy)
+//   TN   C (O, I) = dY (R, O)^T X (R, I), column sums of dY     weight / bias gradient, one partial tile per slab of rows
+//
+// Workgroup = 256 threads, 128 x 128 output tile, K consumed 32 at a time through two LDS buffers (one barrier per
+// K tile, the next tile's global loads in flight during the MFMAs).  Evaluated transposed like every linear layer of
+// NT puts the rows on the MFMA M axis (accumulator registers) and the output channels on the lanes, so that one store
+// instruction writes 128-byte row segments; TN puts dY's columns (o) on the M axis and X's columns (i) on the lanes.  Each wavefront owns a
+// 64 x 64 quadrant: two fragments of either operand per 16-deep step feed four MFMAs.  LDS rows are 32 bf16 + 8 padding
+// (80 bytes: the 16-byte fragment reads of 32 consecutive rows fall on distinct bank groups).
+// The TN variant transposes while staging: a thread loads an 8-row x 4-column block (rows = the reduction index) and
+// writes, per column, the eight values as one 16-byte bf16 fragment.
+#pragma once
+#include "dfx_common.h"
+
+namespace dfx {
+namespace gemm {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = 128, TK = 32, LROW = 40;   // LDS row: 32 bf16 + 8 pad
+
+struct GemmArgs {
+  const float *A; int lda;   // NT: X (M, K)          TN: dY (R, O)
+  const float *B; int ldb;   // NT: W (N, K)          TN: X (R, I)
+  const float *bias;         // NT: (N) or nullptr
+  const float *R; int ldr;   // NT: residual (M, N) or nullptr (may alias C)
+  float *C; int ldc;         // NT: (M, N)            TN: partial tiles [slab][O][I], ldc = I
+  float *bpart;              // TN: [slab][O] column sums of dY (exact fp32) or nullptr
+  int M, N, K;               // NT: rows, outputs, inputs      TN: M = O, N = I, K = R (all rows)
+  int rows_per_slab;         // TN: multiple of 32
+};
+
+template <bool TN>
+__global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[2][TILE * LROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][TILE * LROW];
+  __shared__ float bsum[4][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, kq = lane >> 5;
+  // tile origins: w0 on the M axis of the MFMA (NT: output channel n; TN: o), x0 on the N axis (NT: row m; TN: i)
+  const int w0 = (TN ? blockIdx.y : blockIdx.x) * TILE, x0 = (TN ? blockIdx.x : blockIdx.y) * TILE;
+  long long kbeg = 0, kend = a.K;
+  if (TN) {
+    kbeg = (long long)blockIdx.z * a.rows_per_slab;
+    kend = kbeg + a.rows_per_slab < a.K ? kbeg + a.rows_per_slab : a.K;
+  }
+  const int nk = (int)((kend - kbeg + TK - 1) / TK);
+
+  v4f gw[TN ? 8 : 4], gx[TN ? 8 : 4];   // staging registers (TN: a thread stages ONE operand, 8 x float4; NT: both, 4 + 4)
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_tile = [&](int kt) {
+    const long long k0 = kbeg + (long long)kt * TK;
+    if (!TN) {
+      const int row = tid >> 1, ks = (tid & 1) * 16;
+      const int xr = x0 + row < a.M ? x0 + row : a.M - 1;
+      const float *px = a.A + (size_t)xr * a.lda + k0 + ks, *pw = a.B + (size_t)(w0 + row) * a.ldb + k0 + ks;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gx[e] = reinterpret_cast<const v4f *>(px)[e], gw[e] = reinterpret_cast<const v4f *>(pw)[e];
+    } else {
+      const int tt = tid & 127, cg = tt & 31, rg = tt >> 5;
+      const bool isw = tid < 128;
+      const float *p = (isw ? a.A + w0 : a.B + x0) + 4 * cg;
+      const int ld = isw ? a.lda : a.ldb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const long long r = k0 + 8 * rg + e;
+        gw[e] = r < kend ? *reinterpret_cast<const v4f *>(p + (size_t)r * ld) : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (!TN) {
+      const int row = tid >> 1, ks = (tid & 1) * 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const v8f fx = {gx[2 * h][0], gx[2 * h][1], gx[2 * h][2], gx[2 * h][3], gx[2 * h + 1][0], gx[2 * h + 1][1], gx[2 * h + 1][2], gx[2 * h + 1][3]};
+        const v8f fw = {gw[2 * h][0], gw[2 * h][1], gw[2 * h][2], gw[2 * h][3], gw[2 * h + 1][0], gw[2 * h + 1][1], gw[2 * h + 1][2], gw[2 * h + 1][3]};
+        *reinterpret_cast<v8bf *>(&Xs[buf][row * LROW + ks + 8 * h]) = __builtin_convertvector(fx, v8bf);
+        *reinterpret_cast<v8bf *>(&Ws[buf][row * LROW + ks + 8 * h]) = __builtin_convertvector(fw, v8bf);
+      }
+    } else {
+      const int tt = tid & 127, cg = tt & 31, rg = tt >> 5;
+      __bf16 *S = tid < 128 ? Ws[buf] : Xs[buf];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const v8f f = {gw[0][c], gw[1][c], gw[2][c], gw[3][c], gw[4][c], gw[5][c], gw[6][c], gw[7][c]};
+        *reinterpret_cast<v8bf *>(&S[(4 * cg + c) * LROW + 8 * rg]) = __builtin_convertvector(f, v8bf);
+        if (tid < 128) colsum[c] += (f[0] + f[1]) + (f[2] + f[3]) + ((f[4] + f[5]) + (f[6] + f[7]));
+      }
+    }
+  };
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v8bf wf[2], xf[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        wf[p] = *reinterpret_cast<const v8bf *>(&Ws[buf][(64 * wc + 32 * p + li) * LROW + 16 * s + 8 * kq]);
+        xf[p] = *reinterpret_cast<const v8bf *>(&Xs[buf][(64 * wr + 32 * p + li) * LROW + 16 * s + 8 * kq]);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[p][q] = TN ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p], xf[q], acc[p][q], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[q], wf[p], acc[p][q], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!TN) {
+    // NT: rows on the MFMA M axis (registers), output channels on the lanes: one store instruction writes two rows x 32
+    // consecutive channels (128-byte segments)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int n = w0 + 64 * wc + 32 * p + li;
+      const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int m = x0 + 64 * wr + 32 * q + (rg & 3) + 8 * (rg >> 2) + 4 * kq;
+          if (m >= a.M) continue;
+          float y = acc[p][q][rg] + bv;
+          if (a.R) y += a.R[(size_t)m * a.ldr + n];
+          a.C[(size_t)m * a.ldc + n] = y;
+        }
+    }
+  } else {
+    float *pp = a.C + (size_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = x0 + 64 * wr + 32 * q + li;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int o = w0 + 64 * wc + 32 * p + (rg & 3) + 8 * (rg >> 2) + 4 * kq;
+          pp[(size_t)o * a.N + i] = acc[p][q][rg];
+        }
+      }
+    if (a.bpart && blockIdx.x == 0) {   // column sums of dY over this slab: 4 row groups x 32 column groups of 4
+      if (tid < 128) {
+        const int tt = tid, cg = tt & 31, rg = tt >> 5;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bsum[rg][4 * cg + c] = colsum[c];
+      }
+      __syncthreads();
+      if (tid < TILE) a.bpart[(size_t)blockIdx.z * a.M + w0 + tid] = (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
+    }
+  }
+}
+
+// NT usable: N % 128 == 0, K % 32 == 0, 16-byte aligned rows; TN usable: O % 128 == 0, I % 128 == 0, rows_per_slab % 32 == 0
+inline bool nt_ok(const GemmArgs &a) {
+  return a.N % TILE == 0 && a.K % TK == 0 && a.M >= 256 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B) | reinterpret_cast<uintptr_t>(a.C)) & 15) == 0 &&
+         (!a.R || (a.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0));
+}
+inline bool tn_ok(const GemmArgs &a) {
+  return a.M % TILE == 0 && a.N % TILE == 0 && a.rows_per_slab % TK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
+}
+inline void launch_nt(hipStream_t st, const GemmArgs &a) {
+  k_gemm_bf16<false><<<dim3(a.N / TILE, (a.M + TILE - 1) / TILE), 256, 0, st>>>(a);
+}
+inline void launch_tn(hipStream_t st, const GemmArgs &a, int nslab) {
+  k_gemm_bf16<true><<<dim3(a.N / TILE, a.M / TILE, nslab), 256, 0, st>>>(a);
+}
+
+}  // namespace gemm
+}  // namespace dfx

@@ -13,6 +13,7 @@
 //                         v_mfma_f32_32x32x2_f32 (lane (j, hf) feeds dY[r + hf][o0 + j] and X[r + hf][i0 + j]: 128-byte
 //                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
 #include "dfx_common.h"
+#include "gemm_bf16.h"
 #include "mfma_linear.h"
 
 namespace {
@@ -536,8 +537,9 @@ struct TrainWs {
   size_t part_floats;
 };
 
-constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab
-inline int nslabs(long long R) { return (int)((R + WG_SLAB - 1) / WG_SLAB); }
+constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab (64 for the few-row products over the context tokens / the batch)
+inline int slab_rows(long long R) { return R <= 8192 ? 64 : WG_SLAB; }
+inline int nslabs(long long R) { return (int)((R + slab_rows(R) - 1) / slab_rows(R)); }
 
 size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   Carver c{static_cast<char *>(base)};
@@ -585,23 +587,36 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.dte_ag = c.take<float>((size_t)B * 2 * TEH);
   w.wT = c.take<float>((size_t)2 * TEH * TE + 64);      // largest transposed weight: time_embed.net.0.proj (2048 x 256)
   w.wpad = c.take<float>((size_t)C * CTXP);
-  const size_t ns = nslabs((long long)R);
-  w.part_floats = ns * (size_t)(2 * FH) * C;               // largest weight-gradient partial: W1 (1024 x 128) per slab
-  const size_t ln_parts = ((R + LNB_ROWS - 1) / LNB_ROWS) * 2 * C, eps_parts = ((R + EPSB_ROWS - 1) / EPSB_ROWS) * 4 * C;
-  const size_t te_parts = (size_t)2 * TEH * TE;            // time-embed weight gradients: one slab
-  size_t pf = w.part_floats;
-  if (ln_parts > pf) pf = ln_parts;
-  if (eps_parts > pf) pf = eps_parts;
-  if (te_parts > pf) pf = te_parts;
+  // partial buffers of the two-pass reductions: the largest weight-gradient partial of each row count (points, context
+  // tokens, batch rows), the LayerNorm / proj_out column sums
+  const size_t ns_r = nslabs((long long)R), ns_bj = nslabs((long long)BJ), ns_b = nslabs(B);
+  size_t pf = ns_r * (size_t)(2 * FH) * C;                                  // W1 (1024 x 128) over the points
+  const size_t cands[] = {ns_bj * (size_t)C * CTXP, ns_b * (size_t)2 * TEH * TE, ((R + LNB_ROWS - 1) / LNB_ROWS) * 2 * C,
+                          ((R + EPSB_ROWS - 1) / EPSB_ROWS) * 4 * C};
+  for (size_t v : cands)
+    if (v > pf) pf = v;
   w.part_floats = pf;
   w.part = c.take<float>(pf);
-  w.bpart = c.take<float>(ns * (size_t)(2 * TEH));
+  size_t ns_max = ns_r > ns_bj ? ns_r : ns_bj;
+  if (ns_b > ns_max) ns_max = ns_b;
+  w.bpart = c.take<float>(ns_max * (size_t)(2 * TEH));
   w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
   return c.off;
 }
 
+// bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
+thread_local int g_prec = DFX_PREC_F32;
+
 int lin(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M, int N_,
         int K, const float *resid = nullptr, int ldr = 0) {
+  if (g_prec == DFX_PREC_BF16) {
+    dfx::gemm::GemmArgs g{};
+    g.A = X, g.lda = ldx, g.B = W, g.ldb = K, g.bias = b, g.R = resid, g.ldr = ldr, g.C = Y, g.ldc = ldy, g.M = (int)M, g.N = N_, g.K = K;
+    if (dfx::gemm::nt_ok(g)) {
+      dfx::gemm::launch_nt(st, g);
+      return dfx::check_launch("train: gemm_nt_bf16");
+    }
+  }
   LinArgs a{};
   a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = (int)M, a.N = N_, a.K = K;
   a.R = resid, a.ldr = ldr, a.r_mod = 0;
@@ -619,7 +634,18 @@ void transpose(hipStream_t st, const float *W, float *WT, int rows, int cols) {
 int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
           int I_valid, long long R) {
   const int ns = nslabs(R);
-  k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, WG_SLAB);
+  bool done = false;
+  if (g_prec == DFX_PREC_BF16) {
+    dfx::gemm::GemmArgs g{};
+    g.A = dY, g.lda = ldy, g.B = X, g.ldb = ldx, g.C = w.part, g.ldc = I, g.bpart = db ? w.bpart : nullptr, g.M = O, g.N = I, g.K = (int)R;
+    g.rows_per_slab = slab_rows(R);
+    if (R >= 256 && dfx::gemm::tn_ok(g)) {
+      dfx::gemm::launch_tn(st, g, ns);
+      done = true;
+    }
+  }
+  if (!done)
+    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab_rows(R));
   k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
   if (db) k_sum_parts<<<(O + 31) / 32, 256, 0, st>>>(w.bpart, db, ns, O, O);
   return dfx::check_launch("train: wgrad");
@@ -661,9 +687,11 @@ size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth) {
 int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes, const float *x,
                                const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
                                const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
-                               int N, dfx_stream_t stream) {
+                               int N, int precision, dfx_stream_t stream) {
   int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_forward");
   if (rc) return rc;
+  DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_forward: precision %d", precision);
+  g_prec = precision;
   DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
   TrainWs w;
@@ -707,9 +735,11 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
 
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, dfx_stream_t stream) {
+                                int B, int N, int precision, dfx_stream_t stream) {
   int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_backward");
   if (rc) return rc;
+  DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_backward: precision %d", precision);
+  g_prec = precision;
   DFX_REQUIRE(d_eps && grads, "denoiser_train_backward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
   TrainWs w;

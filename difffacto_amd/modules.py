@@ -174,7 +174,7 @@ class TransformerNet(nn.Module):
         B = x.shape[0]
         tt = torch.full((B,), int(t), device=x.device) if isinstance(t, int) else t.reshape(-1).expand(B) if t.numel() == 1 else t
         return _training.denoiser_train_forward(dict(self.named_parameters()), x, tt, ctx[0], ctx[1], anchors, variances,
-                                                valid_id, anchor_assignment)
+                                                valid_id, anchor_assignment, precision=self._dfx_precision)
 
 
 class AnchoredDiffusion(nn.Module):

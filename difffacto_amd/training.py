@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _ffi
-from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES
+from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
 __all__ = ["param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam"]
 
@@ -48,8 +48,11 @@ class DenoiserTrainFn(torch.autograd.Function):
     them, agent :1011-1014)."""
 
     @staticmethod
-    def forward(ctx, depth, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
+    def forward(ctx, depth, precision, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
         names = param_names(depth)
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r}: one of {sorted(PRECISIONS)}")
+        prec = PRECISIONS[precision]
         if len(params) != len(names):
             raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
         B, _, N = x.shape
@@ -81,11 +84,11 @@ class DenoiserTrainFn(torch.autograd.Function):
             _ffi.check(lib.dfx_denoiser_train_forward(ctypes.byref(w), ws_ptr, nbytes, x.data_ptr(), t32.data_ptr(),
                                                       ctx_code.data_ptr(), ctx_mv.data_ptr(), anchors.data_ptr(),
                                                       variances.data_ptr(), None if vld is None else vld.data_ptr(),
-                                                      asg.data_ptr(), eps.data_ptr(), B, N, _ffi.current_stream()),
+                                                      asg.data_ptr(), eps.data_ptr(), B, N, prec, _ffi.current_stream()),
                        "dfx_denoiser_train_forward")
-        ctx.depth, ctx.shape, ctx.ws, ctx.ws_ptr, ctx.nbytes = depth, (B, N), ws, ws_ptr, nbytes
+        ctx.depth, ctx.shape, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.prec = depth, (B, N), ws, ws_ptr, nbytes, prec
         ctx.tensors = tensors
-        ctx.need_ctx = (ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        ctx.need_ctx = (ctx.needs_input_grad[4], ctx.needs_input_grad[5])
         return eps
 
     @staticmethod
@@ -103,18 +106,19 @@ class DenoiserTrainFn(torch.autograd.Function):
             _ffi.check(_ffi.lib().dfx_denoiser_train_backward(ctypes.byref(w), ctx.ws_ptr, ctx.nbytes, d_eps.data_ptr(),
                                                               ctypes.byref(g), None if d_code is None else d_code.data_ptr(),
                                                               None if d_mv is None else d_mv.data_ptr(), B, N,
-                                                              _ffi.current_stream()),
+                                                              ctx.prec, _ffi.current_stream()),
                        "dfx_denoiser_train_backward")
         ctx.ws = None
-        return (None, None, None, d_code, d_mv, None, None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(grads[n] for n in names)
 
 
-def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment):
-    """`params`: dict state_dict-key -> fp32 cuda tensor (requires_grad as the caller wishes) of a TransformerNet."""
+def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, precision="f32"):
+    """`params`: dict state_dict-key -> fp32 cuda tensor (requires_grad as the caller wishes) of a TransformerNet.
+    precision "f32": exact fp32 (parity gate); "bf16": bf16 operands / fp32 accumulate for the matrix products."""
     depth = 0
     while f"transformer_blocks.{depth}.norm2.weight" in params:
         depth += 1
-    return DenoiserTrainFn.apply(depth, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
+    return DenoiserTrainFn.apply(depth, precision, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
                                  *[params[n] for n in param_names(depth)])
 
 

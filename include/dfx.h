@@ -352,7 +352,11 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
  * Replaces autograd through TransformerNet.forward / _forward_attn (python/difffacto/models/networks/attention.py:385-440;
  * BasicTransformerBlock :296-306, CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94; dropout = 0), the
  * mse_loss of AnchoredDiffusion.training_losses (anchored_diffusion.py:840-847), and Runner.train's
- * clip_grad_norm_ + Adam.step (runner.py:312-316, optimizers.py:4-16).  Exact fp32 throughout.
+ * clip_grad_norm_ + Adam.step (runner.py:312-316, optimizers.py:4-16).
+ *   precision DFX_PREC_F32: exact fp32 throughout (the parity gate).  DFX_PREC_BF16: the large matrix products (every
+ *   linear layer over the B*N points: forward, dX, dW) round their operands to bf16 on the way into LDS and accumulate
+ *   in fp32 (v_mfma_f32_32x32x16_bf16); activations, gradients, LayerNorm / softmax / GELU and the optimiser stay fp32.
+ *   The same value must be passed to the forward and the backward of one step.
  *   x (B,3,N); t (B,) int32; ctx_code (B,256,4) and ctx_mv (B,6,4) = the two tensors of the reference's ctx list;
  *   anchors, variances (B,N,3) per point (the caller's gather, as at anchored_diffusion.py:261); valid (B,4) 0/1 or
  *   NULL; assignment (B,N) int32; eps (B,3,N).
@@ -365,10 +369,10 @@ size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth);
 int dfx_denoiser_train_forward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes, const float *x,
                                const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
                                const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
-                               int N, dfx_stream_t stream);
+                               int N, int precision, dfx_stream_t stream);
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, dfx_stream_t stream);
+                                int B, int N, int precision, dfx_stream_t stream);
 /* d loss / d pred of dfx_masked_mse_f32, times grad_scale; workspace2 = the two doubles its forward left behind */
 int dfx_masked_mse_backward_f32(const float *target, const float *pred, const float *flags, const double *workspace2,
                                 float grad_scale, float *d_pred, int B, int N, dfx_stream_t stream);

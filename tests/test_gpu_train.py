@@ -17,7 +17,7 @@ from _train_case import check_against_golden, load_case  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _run(case, with_flags=True):
+def _run(case, with_flags=True, precision="f32"):
     from difffacto_amd import training
     dev = "cuda"
     P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in case["W"].items()}
@@ -26,7 +26,7 @@ def _run(case, with_flags=True):
     eps = training.denoiser_train_forward(P, torch.from_numpy(case["x_t"]).to(dev), torch.from_numpy(case["t"]).to(dev), cc, cm,
                                           torch.from_numpy(case["anchors_pt"]).to(dev), torch.from_numpy(case["variances_pt"]).to(dev),
                                           None if case["valid"] is None else torch.from_numpy(case["valid"]).to(dev),
-                                          torch.from_numpy(case["assignment"]).to(dev))
+                                          torch.from_numpy(case["assignment"]).to(dev), precision=precision)
     flags = torch.from_numpy(case["flags"]).to(dev) if with_flags and case["flags"] is not None else None
     loss = training.masked_mse(torch.from_numpy(case["noise"]).to(dev), eps, flags)
     loss.backward()
@@ -81,6 +81,42 @@ def test_forward_backward_vs_oracle_full_gradients(B, N, all_valid, with_flags):
     print(f"B={B} N={N}: worst gradient error / max-abs = {worst:.2e}")
 
 
+def test_bf16_matrix_products_within_stated_tolerance():
+    """precision="bf16": the linear layers over the B*N points run on the bf16 matrix pipe (operands rounded to bf16, fp32
+    accumulate).  Tolerance: loss 2e-3 relative, eps 3e-2 max-abs (|eps| ~ 1), every gradient 4e-2 of its max-abs in
+    max norm and 1.5e-2 in relative L2 (measured: 4e-4, 8e-3, <1.5e-2, <5e-3)."""
+    from difffacto_amd import synth
+    from oracle import train
+    B, N = 2, 1024
+    rng = np.random.Generator(np.random.PCG64(77))
+    W = synth.make_denoiser_weights(3)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=9, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    ref = train.loss_and_grads(**c)
+    r = _run(c, True, precision="bf16")
+    f = _run(c, True, precision="f32")
+    assert any(not np.array_equal(r["grads"][k], f["grads"][k]) for k in f["grads"]), "bf16 path not taken"
+    assert abs(r["loss"] - ref["loss"]) < 2e-3 * abs(ref["loss"])
+    assert np.abs(r["eps"] - ref["eps"]).max() < 3e-2
+    worst_max = worst_l2 = 0.0
+    for k, gr in ref["grads"].items():
+        scale = max(np.abs(gr).max(), 1e-30)
+        e_max = np.abs(r["grads"][k] - gr).max() / scale
+        e_l2 = np.linalg.norm((r["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
+        assert e_max < 4e-2 and e_l2 < 1.5e-2, (k, e_max, e_l2)
+        worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
+    print(f"bf16 products: loss rel err {abs(r['loss'] - ref['loss']) / abs(ref['loss']):.1e}, eps max-abs {np.abs(r['eps'] - ref['eps']).max():.1e}, "
+          f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
+
+
 def test_adam_with_clipping_matches_torch():
     """Three steps of dfx Adam + clip_grad_norm_(max_norm) against torch.optim.Adam + torch.nn.utils.clip_grad_norm_ on
     the CPU (what Runner.train does, runner.py:312-316), on tensors of awkward sizes."""
@@ -132,7 +168,7 @@ def test_train_entry_points_reject_bad_arguments():
     assert lib.dfx_denoiser_train_workspace_bytes(2, 64, 5) > 0
     w = _ffi.DenoiserWeights()
     w.depth = 5
-    rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, None)
+    rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, 0, None)
     assert rc != 0 and b"null" in lib.dfx_last_error()
 
 

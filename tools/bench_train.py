@@ -1,5 +1,5 @@
 """Forward + backward time of the training-mode denoiser at BASELINE config 4's size (B=128 x 2048 pts, fp32):
-python tools/bench_train.py [B] [N].  Prints ms per iteration and the achieved fp32 matrix throughput
+python tools/bench_train.py [B] [N] [f32|bf16].  Prints ms per iteration and the achieved fp32 matrix throughput
 (3 x 4.734 GFLOP per shape: forward + dX + dW products)."""
 import os
 import sys
@@ -13,6 +13,7 @@ from difffacto_amd import synth, training
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+PREC = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 dev = "cuda"
 W = synth.make_denoiser_weights(0)
 P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in W.items()}
@@ -33,7 +34,7 @@ opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
 
 def it():
     opt.zero_grad()
-    loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args), None)
+    loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args, precision=PREC), None)
     loss.backward()
     opt.step()
     return loss
@@ -49,6 +50,7 @@ for _ in range(K):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
 flops = 3 * 4.734e9 * B * (N / 2048)
-print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, fp32: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
-      f"{flops / ms / 1e9:.1f} TFLOP/s of the 157.3 TFLOP/s fp32 matrix peak ({flops / ms / 1e9 / 157.3 * 100:.1f} %), loss {float(loss.detach()):.4f}, "
+peak = 157.3 if PREC == "f32" else 2500.0
+print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
+      f"{flops / ms / 1e9:.1f} TFLOP/s of the {peak} TFLOP/s {PREC} matrix peak ({flops / ms / 1e9 / peak * 100:.1f} %), loss {float(loss.detach()):.4f}, "
       f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak")
