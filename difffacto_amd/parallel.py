@@ -68,3 +68,41 @@ def gather_clouds(pred, dst=0):
         return torch.cat([b[:n] for b, n in zip(bufs, sizes)]).to(out_device)
     dist.gather(pad, gather_list=None, dst=dst)
     return None
+
+
+def allreduce_gradients(params, average=True, bucket=None):
+    """Data-parallel training step exchange (the one real collective of the training path): the gradients of all `params`
+    are packed into ONE flat fp32 bucket (10.5 MB for the denoiser: a single ring all-reduce over xGMI, per-link bound,
+    instead of 77 small ones), summed across ranks with `all_reduce` (RCCL on GPUs, gloo on CPU) and scattered back.
+    Parameters without a gradient contribute zeros, so every rank reduces the same layout.  Returns the bucket for reuse.
+    No-op when torch.distributed is not initialised or the world has one rank."""
+    import torch
+    import torch.distributed as dist
+    params = [p for p in params]
+    if not params or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bucket
+    n = sum(p.numel() for p in params)
+    dev = params[0].device
+    if bucket is None or bucket.numel() != n or bucket.device != dev:
+        bucket = torch.empty(n, dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        k = p.numel()
+        if p.grad is None:
+            bucket[off:off + k].zero_()
+        else:
+            bucket[off:off + k].copy_(p.grad.reshape(-1))
+        off += k
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    if average:
+        bucket.div_(dist.get_world_size())
+    off = 0
+    for p in params:
+        k = p.numel()
+        g = bucket[off:off + k].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += k
+    return bucket

@@ -13,7 +13,7 @@ import torch
 from . import _ffi
 from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
-__all__ = ["param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam"]
+__all__ = ["param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
 
 
 def param_names(depth):
@@ -204,3 +204,16 @@ class Adam:
                                                  float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                                  self.step_count, _ffi.current_stream()), "dfx_adam_step_f32")
         return norm
+
+
+def linear_lr(epoch, start_epoch, end_epoch, start_lr, end_lr):
+    """The reference's `LinearLR` schedule (optimizers/schedulers.py:8-19, a LambdaLR factor on the optimiser's base lr =
+    start_lr): constant up to start_epoch, linear to end_lr at end_epoch, constant after.  Returns the learning rate."""
+    if epoch <= start_epoch:
+        f = 1.0
+    elif epoch <= end_epoch:
+        frac = (epoch - start_epoch) / (end_epoch - start_epoch)
+        f = (1 - frac) * 1.0 + frac * (end_lr / start_lr)
+    else:
+        f = end_lr / start_lr
+    return start_lr * f

@@ -68,3 +68,57 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = [(5, 3), (7,), (2, 2, 2)]
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        for i, p in enumerate(params):
+            if not (rank == 1 and i == 1):                      # rank 1 has no gradient for tensor 1: counts as zeros
+                p.grad = torch.full(p.shape, float(rank + 1) * (i + 1))
+        bucket = parallel.allreduce_gradients(params, average=True)
+        exp = [torch.full(shapes[0], (1 + 2) * 1 / 2), torch.full(shapes[1], (1 * 2 + 0) / 2), torch.full(shapes[2], (1 + 2) * 3 / 2)]
+        ok = all(torch.equal(p.grad, e) for p, e in zip(params, exp)) and bucket.numel() == 15 + 7 + 8
+        bucket2 = parallel.allreduce_gradients(params, average=False, bucket=bucket)   # reuse, sum
+        ok = ok and bucket2 is bucket and torch.equal(params[0].grad, exp[0] * 2)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """The training path's collective: one flat bucket, summed / averaged across two ranks (gloo here, RCCL on GPUs)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_linear_lr_matches_the_reference_schedule():
+    """training.linear_lr against torch's LambdaLR driven by the reference's lr_func (optimizers/schedulers.py:8-19),
+    with train_chair_stage1.py's values (2e-3 -> 1e-4 between epochs 4000 and 8000)."""
+    from difffacto_amd.training import linear_lr
+    start_epoch, end_epoch, start_lr, end_lr = 4000, 8000, 2e-3, 1e-4
+
+    def lr_func(epoch):
+        if epoch <= start_epoch:
+            return 1.0
+        if epoch <= end_epoch:
+            frac = (epoch - start_epoch) / (end_epoch - start_epoch)
+            return (1 - frac) * 1.0 + frac * (end_lr / start_lr)
+        return end_lr / start_lr
+
+    for e in (0, 1, 3999, 4000, 4001, 6000, 7999, 8000, 8001, 20000):
+        assert abs(linear_lr(e, start_epoch, end_epoch, start_lr, end_lr) - start_lr * lr_func(e)) < 1e-15
+    assert linear_lr(6000, start_epoch, end_epoch, start_lr, end_lr) == pytest.approx(1.05e-3)
