@@ -21,6 +21,9 @@ namespace gemm {
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TILE = 128, TK = 32, LROW = 40;   // LDS row: 32 bf16 + 8 pad
@@ -34,6 +37,7 @@ struct GemmArgs {
   float *bpart;              // TN: [slab][O] column sums of dY (exact fp32) or nullptr
   int M, N, K;               // NT: rows, outputs, inputs      TN: M = O, N = I, K = R (all rows)
   int rows_per_slab;         // TN: multiple of 32
+  int a_bf16, b_bf16;        // the operand is already stored as bf16 (lda / ldb in elements): NT: A only; TN: A and / or B
 };
 
 // (A GEGLU-backward epilogue on the dX product was tried and dropped: 664 us fused against 244 + 388 us for the product and
@@ -55,24 +59,42 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
   const int nk = (int)((kend - kbeg + TK - 1) / TK);
 
   v4f gw[TN ? 8 : 4], gx[TN ? 8 : 4];   // staging registers (TN: a thread stages ONE operand, 8 x float4; NT: both, 4 + 4)
+  v2u gb[8];                            // TN, bf16-stored operand: 8 rows x 4 columns = 8 x 8 bytes
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
   auto load_tile = [&](int kt) {
     const long long k0 = kbeg + (long long)kt * TK;
     if (!TN) {
       const int row = tid >> 1, ks = (tid & 1) * 16;
       const int xr = x0 + row < a.M ? x0 + row : a.M - 1;
-      const float *px = a.A + (size_t)xr * a.lda + k0 + ks, *pw = a.B + (size_t)(w0 + row) * a.ldb + k0 + ks;
+      const float *pw = a.B + (size_t)(w0 + row) * a.ldb + k0 + ks;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gx[e] = reinterpret_cast<const v4f *>(px)[e], gw[e] = reinterpret_cast<const v4f *>(pw)[e];
+      for (int e = 0; e < 4; ++e) gw[e] = reinterpret_cast<const v4f *>(pw)[e];
+      if (a.a_bf16) {   // 16 bf16 = 32 bytes, copied to LDS as they are
+        const __bf16 *px = reinterpret_cast<const __bf16 *>(a.A) + (size_t)xr * a.lda + k0 + ks;
+        gx[0] = reinterpret_cast<const v4f *>(px)[0], gx[1] = reinterpret_cast<const v4f *>(px)[1];
+      } else {
+        const float *px = a.A + (size_t)xr * a.lda + k0 + ks;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gx[e] = reinterpret_cast<const v4f *>(px)[e];
+      }
     } else {
       const int tt = tid & 127, cg = tt & 31, rg = tt >> 5;
       const bool isw = tid < 128;
-      const float *p = (isw ? a.A + w0 : a.B + x0) + 4 * cg;
-      const int ld = isw ? a.lda : a.ldb;
+      const int ld = isw ? a.lda : a.ldb, c0 = (isw ? w0 : x0) + 4 * cg;
+      if (isw ? a.a_bf16 : a.b_bf16) {   // four bf16 columns = 8 bytes per row
+        const __bf16 *p = reinterpret_cast<const __bf16 *>(isw ? a.A : a.B) + c0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const long long r = k0 + 8 * rg + e;
-        gw[e] = r < kend ? *reinterpret_cast<const v4f *>(p + (size_t)r * ld) : v4f{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 8; ++e) {
+          const long long r = k0 + 8 * rg + e;
+          gb[e] = r < kend ? *reinterpret_cast<const v2u *>(p + (size_t)r * ld) : v2u{0u, 0u};
+        }
+      } else {
+        const float *p = (isw ? a.A : a.B) + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const long long r = k0 + 8 * rg + e;
+          gw[e] = r < kend ? *reinterpret_cast<const v4f *>(p + (size_t)r * ld) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
@@ -81,19 +103,42 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
       const int row = tid >> 1, ks = (tid & 1) * 16;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const v8f fx = {gx[2 * h][0], gx[2 * h][1], gx[2 * h][2], gx[2 * h][3], gx[2 * h + 1][0], gx[2 * h + 1][1], gx[2 * h + 1][2], gx[2 * h + 1][3]};
         const v8f fw = {gw[2 * h][0], gw[2 * h][1], gw[2 * h][2], gw[2 * h][3], gw[2 * h + 1][0], gw[2 * h + 1][1], gw[2 * h + 1][2], gw[2 * h + 1][3]};
-        *reinterpret_cast<v8bf *>(&Xs[buf][row * LROW + ks + 8 * h]) = __builtin_convertvector(fx, v8bf);
         *reinterpret_cast<v8bf *>(&Ws[buf][row * LROW + ks + 8 * h]) = __builtin_convertvector(fw, v8bf);
+        if (a.a_bf16) {
+          *reinterpret_cast<v4f *>(&Xs[buf][row * LROW + ks + 8 * h]) = gx[h];
+        } else {
+          const v8f fx = {gx[2 * h][0], gx[2 * h][1], gx[2 * h][2], gx[2 * h][3], gx[2 * h + 1][0], gx[2 * h + 1][1], gx[2 * h + 1][2], gx[2 * h + 1][3]};
+          *reinterpret_cast<v8bf *>(&Xs[buf][row * LROW + ks + 8 * h]) = __builtin_convertvector(fx, v8bf);
+        }
       }
     } else {
       const int tt = tid & 127, cg = tt & 31, rg = tt >> 5;
       __bf16 *S = tid < 128 ? Ws[buf] : Xs[buf];
+      if (tid < 128 ? a.a_bf16 : a.b_bf16) {
+        // rows e hold columns (0, 1) in word 0 and (2, 3) in word 1: gather column c of the eight rows with byte permutes
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const v8f f = {gw[0][c], gw[1][c], gw[2][c], gw[3][c], gw[4][c], gw[5][c], gw[6][c], gw[7][c]};
-        *reinterpret_cast<v8bf *>(&S[(4 * cg + c) * LROW + 8 * rg]) = __builtin_convertvector(f, v8bf);
-        if (tid < 128) colsum[c] += (f[0] + f[1]) + (f[2] + f[3]) + ((f[4] + f[5]) + (f[6] + f[7]));
+        for (int c = 0; c < 4; ++c) {
+          const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+          v4u o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = __builtin_amdgcn_perm(c < 2 ? gb[2 * k + 1][0] : gb[2 * k + 1][1], c < 2 ? gb[2 * k][0] : gb[2 * k][1], sel);
+          *reinterpret_cast<v4u *>(&S[(4 * cg + c) * LROW + 8 * rg]) = o;
+          if (tid < 128 && a.bpart) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t += __builtin_bit_cast(float, o[k] << 16) + __builtin_bit_cast(float, o[k] & 0xffff0000u);
+            colsum[c] += t;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const v8f f = {gw[0][c], gw[1][c], gw[2][c], gw[3][c], gw[4][c], gw[5][c], gw[6][c], gw[7][c]};
+          *reinterpret_cast<v8bf *>(&S[(4 * cg + c) * LROW + 8 * rg]) = __builtin_convertvector(f, v8bf);
+          if (tid < 128) colsum[c] += (f[0] + f[1]) + (f[2] + f[3]) + ((f[4] + f[5]) + (f[6] + f[7]));
+        }
       }
     }
   };
@@ -188,12 +233,12 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 
 // NT usable: N % 128 == 0, K % 32 == 0, 16-byte aligned rows; TN usable: O % 128 == 0, I % 128 == 0, rows_per_slab % 32 == 0
 inline bool nt_ok(const GemmArgs &a) {
-  return a.N % TILE == 0 && a.K % TK == 0 && a.M >= 256 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 &&
+  return a.N % TILE == 0 && a.K % TK == 0 && a.M >= 256 && a.lda % (a.a_bf16 ? 8 : 4) == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 &&
          ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B) | reinterpret_cast<uintptr_t>(a.C)) & 15) == 0 &&
          (!a.R || (a.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0));
 }
 inline bool tn_ok(const GemmArgs &a) {
-  return a.M % TILE == 0 && a.N % TILE == 0 && a.rows_per_slab % TK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+  return a.M % TILE == 0 && a.N % TILE == 0 && a.rows_per_slab % TK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&   // (8-byte rows of 4 bf16 need ld % 4 too)
          ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
 }
 inline void launch_nt(hipStream_t st, const GemmArgs &a) {

@@ -29,6 +29,21 @@ constexpr float LN_EPS = 1e-5f;
 // elementwise / row kernels
 // ---------------------------------------------------------------------------------------------------------------
 
+// Tensors that only matrix products consume (xn2, xn3, att, hid, d[a|g], dq) are STORED as bf16 when the products run in
+// bf16 (template parameter BF of their producers): the product kernels would round them to bf16 anyway, so the values
+// entering the MFMAs are the same and the HBM traffic of these tensors halves.
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ void store4(float *base, size_t idx, v4f v) {   // idx in elements, multiple of 4
+  if (BF) *reinterpret_cast<v4bf *>(reinterpret_cast<__bf16 *>(base) + idx) = __builtin_convertvector(v, v4bf);
+  else *reinterpret_cast<v4f *>(base + idx) = v;
+}
+template <bool BF>
+__device__ __forceinline__ void store1(float *base, size_t idx, float v) {
+  if (BF) reinterpret_cast<__bf16 *>(base)[idx] = (__bf16)v;
+  else base[idx] = v;
+}
+
 // xin (attention.py:398-405): [x | anchors | variances | one_hot(assignment)] per point, padded 13 -> 16
 __global__ void k_build_xin(const float *__restrict__ x, const float *__restrict__ anc, const float *__restrict__ var,
                             const int32_t *__restrict__ asg, float *__restrict__ xin, int N, long long R) {
@@ -52,6 +67,7 @@ __global__ void k_build_xin(const float *__restrict__ x, const float *__restrict
 }
 
 // LayerNorm over 128 channels, two-pass like torch (mean, then biased variance of the centred values); 32 lanes per row
+template <bool BF>
 __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, const float *__restrict__ g,
                                                  const float *__restrict__ be, float *__restrict__ y,
                                                  float *__restrict__ stats, long long R) {
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, con
   v4f o4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o4[e] = d[e] * rstd * gv[e] + bv[e];
-  reinterpret_cast<v4f *>(y + r * C)[l] = o4;
+  store4<BF>(y, (size_t)r * C + 4 * l, o4);
   if (l == 0) stats[2 * r] = mu, stats[2 * r + 1] = rstd;
 }
 
@@ -144,26 +160,36 @@ __global__ __launch_bounds__(256) void k_sum_parts(const float *__restrict__ par
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
 
-// GEGLU (attention.py:55-57): hid = a * gelu(g), ag = [a | g] (R, 2 H)
+// GEGLU (attention.py:55-57): hid = a * gelu(g), ag = [a | g] (R, 2 H); four consecutive units per thread (16-byte loads)
+template <bool BF>
 __global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hid, int H, long long total) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
-  hid[i] = ag[r * 2 * H + c] * gelu_erf(ag[r * 2 * H + H + c]);
+  const v4f a = *reinterpret_cast<const v4f *>(ag + r * 2 * H + c), g = *reinterpret_cast<const v4f *>(ag + r * 2 * H + H + c);
+  store4<BF>(hid, (size_t)i, v4f{a[0] * gelu_erf(g[0]), a[1] * gelu_erf(g[1]), a[2] * gelu_erf(g[2]), a[3] * gelu_erf(g[3])});
 }
 // d a = d hid gelu(g);  d g = d hid a (Phi(g) + g phi(g))
+template <bool BF>
 __global__ void k_geglu_bwd(const float *__restrict__ ag, const float *__restrict__ dhid, float *__restrict__ dag, int H,
                             long long total) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
-  const float a = ag[r * 2 * H + c], g = ag[r * 2 * H + H + c], d = dhid[i];
-  const float Phi = 0.5f * (1.f + erff(g * 0.70710678118654752440f));
-  const float phi = 0.39894228040143267794f * expf(-0.5f * g * g);
-  dag[r * 2 * H + c] = d * g * Phi;
-  dag[r * 2 * H + H + c] = d * a * (Phi + g * phi);
+  const v4f a = *reinterpret_cast<const v4f *>(ag + r * 2 * H + c), g = *reinterpret_cast<const v4f *>(ag + r * 2 * H + H + c);
+  const v4f d = *reinterpret_cast<const v4f *>(dhid + i);
+  v4f da, dg;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float Phi = 0.5f * (1.f + erff(g[e] * 0.70710678118654752440f));
+    const float phi = 0.39894228040143267794f * expf(-0.5f * g[e] * g[e]);
+    da[e] = d[e] * g[e] * Phi;
+    dg[e] = d[e] * a[e] * (Phi + g[e] * phi);
+  }
+  store4<BF>(dag, (size_t)(r * 2 * H + c), da);
+  store4<BF>(dag, (size_t)(r * 2 * H + H + c), dg);
 }
 
 // timestep_embedding (utils.py:7-24): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / 128)
@@ -231,6 +257,7 @@ __global__ void k_pad_cols(const float *__restrict__ W, float *__restrict__ Wp, 
 // cross attention to the 4 part tokens (attention.py:179-204), forward with saved probabilities, and backward
 // block = 32 points of one shape x 8 heads; k, v of the shape in LDS
 // ---------------------------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(256) void k_attn_fwd(const float *__restrict__ q, const float *__restrict__ k,
                                                    const float *__restrict__ v, const float *__restrict__ valid,
                                                    float *__restrict__ p, float *__restrict__ att, int N) {
@@ -270,10 +297,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float *__restrict__ q, c
   }
   reinterpret_cast<v4f *>(p + r * (HEADS * J))[h] = v4f{sim[0], sim[1], sim[2], sim[3]};
 #pragma unroll
-  for (int e = 0; e < HD / 4; ++e) reinterpret_cast<v4f *>(att + r * C + h * HD)[e] = v4f{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]};
+  for (int e = 0; e < HD / 4; ++e) store4<BF>(att, (size_t)r * C + h * HD + 4 * e, v4f{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]});
 }
 
 // d att -> d q (per point), d k / d v partial sums over the block's 32 points -> part[(b, blockIdx.x)][2][J][C]
+template <bool BF>
 __global__ __launch_bounds__(256) void k_attn_bwd(const float *__restrict__ datt, const float *__restrict__ q,
                                                    const float *__restrict__ k, const float *__restrict__ v,
                                                    const float *__restrict__ p, float *__restrict__ dq,
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float *__restrict__ datt
     }
   }
 #pragma unroll
-  for (int e = 0; e < HD / 4; ++e) reinterpret_cast<v4f *>(dq + r * C + h * HD)[e] = v4f{dqv[4 * e], dqv[4 * e + 1], dqv[4 * e + 2], dqv[4 * e + 3]};
+  for (int e = 0; e < HD / 4; ++e) store4<BF>(dq, (size_t)r * C + h * HD + 4 * e, v4f{dqv[4 * e], dqv[4 * e + 1], dqv[4 * e + 2], dqv[4 * e + 3]});
 }
 // d k, d v (B J, C) = sum over the nb blocks of a shape
 __global__ void k_attn_bwd_finish(const float *__restrict__ part, float *__restrict__ dk, float *__restrict__ dv, int nb) {
@@ -606,17 +634,22 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
 thread_local int g_prec = DFX_PREC_F32;
+// product-only tensors are stored as bf16 when every product over the points takes the bf16 kernel (see store4 above)
+inline bool bf_store(long long R) { return g_prec == DFX_PREC_BF16 && R >= 256; }
 
+// x_bf: X is one of the bf16-stored tensors (only when bf_store(R): the bf16 product kernel is then guaranteed to apply)
 int lin(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M, int N_,
-        int K, const float *resid = nullptr, int ldr = 0) {
+        int K, const float *resid = nullptr, int ldr = 0, bool x_bf = false) {
   if (g_prec == DFX_PREC_BF16) {
     dfx::gemm::GemmArgs g{};
     g.A = X, g.lda = ldx, g.B = W, g.ldb = K, g.bias = b, g.R = resid, g.ldr = ldr, g.C = Y, g.ldc = ldy, g.M = (int)M, g.N = N_, g.K = K;
+    g.a_bf16 = x_bf;
     if (dfx::gemm::nt_ok(g)) {
       dfx::gemm::launch_nt(st, g);
       return dfx::check_launch("train: gemm_nt_bf16");
     }
   }
+  if (x_bf) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (M=%lld N=%d K=%d)", M, N_, K);
   LinArgs a{};
   a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = (int)M, a.N = N_, a.K = K;
   a.R = resid, a.ldr = ldr, a.r_mod = 0;
@@ -632,18 +665,20 @@ void transpose(hipStream_t st, const float *W, float *WT, int rows, int cols) {
 
 // dW (O x I_valid), db (O) from dY (R x O, ld ldy) and X (R x I, ld ldx)
 int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
-          int I_valid, long long R) {
+          int I_valid, long long R, bool dy_bf = false, bool x_bf = false) {
   const int ns = nslabs(R);
   bool done = false;
   if (g_prec == DFX_PREC_BF16) {
     dfx::gemm::GemmArgs g{};
     g.A = dY, g.lda = ldy, g.B = X, g.ldb = ldx, g.C = w.part, g.ldc = I, g.bpart = db ? w.bpart : nullptr, g.M = O, g.N = I, g.K = (int)R;
     g.rows_per_slab = slab_rows(R);
+    g.a_bf16 = dy_bf, g.b_bf16 = x_bf;
     if (R >= 256 && dfx::gemm::tn_ok(g)) {
       dfx::gemm::launch_tn(st, g, ns);
       done = true;
     }
   }
+  if (!done && (dy_bf || x_bf)) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (O=%d I=%d)", O, I);
   if (!done)
     k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab_rows(R));
   k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
@@ -692,6 +727,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   if (rc) return rc;
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_forward: precision %d", precision);
   g_prec = precision;
+  const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
   TrainWs w;
@@ -701,7 +737,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   // time embedding -> context rows
   k_timestep_embedding<<<(B * TE + 255) / 256, 256, 0, st>>>(t, w.te_in, B);
   if ((rc = lin(st, w.te_in, TE, wt->te0_w, wt->te0_b, w.te_ag, 2 * TEH, B, 2 * TEH, TE))) return rc;
-  k_geglu_fwd<<<(int)(((long long)B * TEH + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH);
+  k_geglu_fwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH);
   if ((rc = lin(st, w.te_hid, TEH, wt->te2_w, wt->te2_b, w.te_out, TE, B, TE, TEH))) return rc;
   k_build_ctx<<<(BJ * CTXP + 255) / 256, 256, 0, st>>>(ctx_code, ctx_mv, w.te_out, w.ctx, B);
   if (valid) DFX_HIP_TRY(hipMemcpyAsync(w.valid, valid, sizeof(float) * BJ, hipMemcpyDeviceToDevice, st));
@@ -710,25 +746,29 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   k_build_xin<<<(int)((R + 255) / 256), 256, 0, st>>>(x, anchors, variances, assignment, w.xin, N, R);
   k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
   if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
-  k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
+  k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
   for (int i = 0; i < wt->depth; ++i) {
     const dfx_block_weights &bw = wt->blk[i];
     BlockAct &a = w.blk[i];
     float *hout = i + 1 < wt->depth ? w.blk[i + 1].hin : w.hfin;
-    k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
-    if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C))) return rc;
+    if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+    else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+    if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C, nullptr, 0, bf))) return rc;
     k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_k, w.wpad, C, CTX, CTXP);
     if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.k, C, BJ, C, CTXP))) return rc;
     k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_v, w.wpad, C, CTX, CTXP);
     if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
-    k_attn_fwd<<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
-    if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C))) return rc;
-    k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
-    if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C))) return rc;
-    k_geglu_fwd<<<(int)((R * FH + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
-    if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C))) return rc;
+    if (bf) k_attn_fwd<true><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
+    else k_attn_fwd<false><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
+    if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
+    if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
+    else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
+    if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf))) return rc;
+    if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
+    else k_geglu_fwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
+    if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C, bf))) return rc;
   }
-  k_ln_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
+  k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
   k_eps_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hn, wt->proj_out_w, wt->proj_out_b, eps, N, R);
   return dfx::check_launch("denoiser_train_forward");
 }
@@ -740,6 +780,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   if (rc) return rc;
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_backward: precision %d", precision);
   g_prec = precision;
+  const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(d_eps && grads, "denoiser_train_backward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
   TrainWs w;
@@ -759,23 +800,25 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
     BlockAct &a = w.blk[i];
     // feed-forward: h2 = h1 + W2 hid + b2, hid = a gelu(g), [a | g] = W1 xn3 + b1
-    if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R))) return rc;
+    if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
     if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.dhid, FH, R, FH, C))) return rc;
-    k_geglu_bwd<<<(int)((R * FH + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
-    if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R))) return rc;
+    if (bf) k_geglu_bwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
+    else k_geglu_bwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
+    if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, bf, bf))) return rc;
     transpose(st, bw.ff0_w, w.wT, 2 * FH, C);                                // (128, 1024)
-    if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH))) return rc;
+    if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH, nullptr, 0, bf))) return rc;
     if ((rc = ln_bwd(st, w, w.dh2, a.h1, a.st3, bw.norm3_w, w.dh, w.dh, mut(gw.norm3_w), mut(gw.norm3_b), R))) return rc;
     // attention: h1 = hin + Wo att + bo
-    if ((rc = wgrad(st, w, w.dh, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R))) return rc;
+    if ((rc = wgrad(st, w, w.dh, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R, false, bf))) return rc;
     transpose(st, bw.to_out_w, w.wT, C, C);
     if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.datt, C, R, C, C))) return rc;
-    k_attn_bwd<<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
+    if (bf) k_attn_bwd<true><<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
+    else k_attn_bwd<false><<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
     k_attn_bwd_finish<<<B, J * C, 0, st>>>(w.apart, w.dk, w.dv, N / 32);
-    if ((rc = wgrad(st, w, w.dq, C, a.xn2, C, mut(gw.to_q), nullptr, C, C, C, R))) return rc;
+    if ((rc = wgrad(st, w, w.dq, C, a.xn2, C, mut(gw.to_q), nullptr, C, C, C, R, bf, bf))) return rc;
     transpose(st, bw.to_q, w.wT, C, C);
-    if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C))) return rc;
+    if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C, nullptr, 0, bf))) return rc;
     if ((rc = ln_bwd(st, w, w.dh2, a.hin, a.st2, bw.norm2_w, w.dh, w.dh, mut(gw.norm2_w), mut(gw.norm2_b), R))) return rc;
     // keys / values of the 4 context tokens
     if ((rc = wgrad(st, w, w.dk, C, w.ctx, CTXP, mut(gw.to_k), nullptr, C, CTXP, CTX, BJ))) return rc;
@@ -794,7 +837,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;
   transpose(st, wt->te2_w, w.wT, TE, TEH);                                   // (1024, 256)
   if ((rc = lin(st, w.dte_out, TE, w.wT, nullptr, w.dte_hid, TEH, B, TEH, TE))) return rc;
-  k_geglu_bwd<<<(int)(((long long)B * TEH + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH);
+  k_geglu_bwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH);
   if ((rc = wgrad(st, w, w.dte_ag, 2 * TEH, w.te_in, TE, mut(grads->te0_w), mut(grads->te0_b), 2 * TEH, TE, TE, B))) return rc;
   return dfx::check_launch("denoiser_train_backward");
 }
@@ -806,6 +849,34 @@ int dfx_masked_mse_backward_f32(const float *target, const float *pred, const fl
   k_mse_bwd<<<(int)((total + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(target, pred, flags, workspace2, grad_scale, d_pred, N,
                                                                                total, 3.0 * (double)B * N);
   return dfx::check_launch("masked_mse_backward");
+}
+
+// Test hook for the bf16 product kernels of gemm_bf16.h (tests/test_gpu_train.py):
+//   tn = 0:  C (M, N) = A (M, K) B (N, K)^T + bias + resid                      (A fp32 or bf16-stored, B fp32)
+//   tn = 1:  C (M, N) = A (K, M)^T B (K, N), db (M) = column sums of A          (A, B fp32 or bf16-stored); workspace for the
+//            per-slab partials: (K / 64 + 1) * (M * N + M) floats
+int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *B, int ldb, int b_bf16, const float *bias,
+                        const float *resid, float *Cout, float *db, float *workspace, size_t workspace_floats, int M, int N, int K,
+                        dfx_stream_t stream) {
+  DFX_REQUIRE(A && B && Cout, "debug_gemm_bf16: null argument");
+  hipStream_t st = dfx::as_stream(stream);
+  dfx::gemm::GemmArgs g{};
+  g.A = static_cast<const float *>(A), g.lda = lda, g.B = static_cast<const float *>(B), g.ldb = ldb, g.M = M, g.N = N, g.K = K;
+  g.a_bf16 = a_bf16, g.b_bf16 = b_bf16;
+  if (!tn) {
+    g.bias = bias, g.R = resid, g.ldr = N, g.C = Cout, g.ldc = N;
+    DFX_REQUIRE(dfx::gemm::nt_ok(g), "debug_gemm_bf16: shape not supported by the NT kernel");
+    dfx::gemm::launch_nt(st, g);
+    return dfx::check_launch("debug_gemm_bf16 nt");
+  }
+  const int slab = K <= 8192 ? 64 : 2048, ns = (K + slab - 1) / slab;
+  DFX_REQUIRE(workspace && workspace_floats >= (size_t)ns * ((size_t)M * N + M), "debug_gemm_bf16: workspace too small");
+  g.C = workspace, g.ldc = N, g.bpart = db ? workspace + (size_t)ns * M * N : nullptr, g.rows_per_slab = slab;
+  DFX_REQUIRE(dfx::gemm::tn_ok(g), "debug_gemm_bf16: shape not supported by the TN kernel");
+  dfx::gemm::launch_tn(st, g, ns);
+  k_wgrad_finish<<<(M * N + 255) / 256, 256, 0, st>>>(workspace, Cout, ns, M, N, N);
+  if (db) k_sum_parts<<<(M + 31) / 32, 256, 0, st>>>(g.bpart, db, ns, M, M);
+  return dfx::check_launch("debug_gemm_bf16 tn");
 }
 
 // Global gradient norm^2 accumulated over tensors (clip_grad_norm_): *sumsq += sum g^2.  workspace: 1024 doubles.

@@ -383,6 +383,12 @@ int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       dfx_stream_t stream);
 
+/* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
+ * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
+ * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */
+int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *B, int ldb, int b_bf16, const float *bias,
+                        const float *resid, float *C, float *db, float *workspace, size_t workspace_floats, int M, int N, int K,
+                        dfx_stream_t stream);
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */

@@ -81,6 +81,43 @@ def test_forward_backward_vs_oracle_full_gradients(B, N, all_valid, with_flags):
     print(f"B={B} N={N}: worst gradient error / max-abs = {worst:.2e}")
 
 
+@pytest.mark.parametrize("tn,M,N,K,a_bf,b_bf", [(0, 300, 128, 128, 0, 0), (0, 1000, 1024, 128, 1, 0), (0, 512, 128, 1024, 1, 0),
+                                               (1, 128, 128, 4100, 0, 0), (1, 1024, 128, 4100, 1, 1), (1, 128, 512, 9000, 0, 1),
+                                               (1, 256, 256, 70, 1, 0), (1, 128, 128, 4100, 1, 1), (1, 128, 128, 64, 1, 0), (1, 128, 128, 64, 0, 1),
+                                               (1, 256, 128, 64, 1, 0)])
+def test_bf16_product_kernels_against_torch(tn, M, N, K, a_bf, b_bf):
+    """gemm_bf16.h through its test hook: fp32 or bf16-stored operands, ragged row counts, several tiles per axis; the
+    reference is a float64 product of the bf16-rounded operands (fp32 accumulation order differs: 2e-5 of the max-abs)."""
+    from difffacto_amd import _ffi
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    if tn == 0:
+        A, B = rnd(M, K), rnd(N, K)
+        bias, resid = rnd(N), rnd(M, N)
+    else:
+        A, B = rnd(K, M), rnd(K, N)
+        bias = resid = None
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()
+    ref = Ar @ Br.T + bias.double() + resid.double() if tn == 0 else Ar.T @ Br
+    Ad = (A.bfloat16() if a_bf else A).cuda().contiguous()
+    Bd = (B.bfloat16() if b_bf else B).cuda().contiguous()
+    C = torch.empty(M, N, device="cuda")
+    db = torch.empty(M, device="cuda") if tn else None
+    ws = torch.empty((K // 64 + 1) * (M * N + M), device="cuda") if tn else None
+    p = lambda t: None if t is None else t.data_ptr()
+    bias_d = None if bias is None else bias.cuda()
+    resid_d = None if resid is None else resid.cuda()
+    rc = _ffi.lib().dfx_debug_gemm_bf16(tn, Ad.data_ptr(), Ad.shape[1], a_bf, Bd.data_ptr(), Bd.shape[1], b_bf, p(bias_d), p(resid_d),
+                                       C.data_ptr(), p(db), p(ws), 0 if ws is None else ws.numel(), M, N, K, _ffi.current_stream())
+    _ffi.check(rc, "dfx_debug_gemm_bf16")
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item() + 1e-6, err
+    if tn:
+        col = (Ar if a_bf else A.double()).sum(0)     # column sums use the stored values (exact fp32 sums of fp32 inputs)
+        assert (db.cpu().double() - col).abs().max().item() < 1e-4 * col.abs().max().item() + 1e-5
+
+
 def test_bf16_matrix_products_within_stated_tolerance():
     """precision="bf16": the linear layers over the B*N points run on the bf16 matrix pipe (operands rounded to bf16, fp32
     accumulate).  Tolerance: loss 2e-3 relative, eps 3e-2 max-abs (|eps| ~ 1), every gradient 4e-2 of its max-abs in
