@@ -38,6 +38,7 @@ struct GemmArgs {
   int M, N, K;               // NT: rows, outputs, inputs      TN: M = O, N = I, K = R (all rows)
   int rows_per_slab;         // TN: multiple of 32
   int a_bf16, b_bf16;        // the operand is already stored as bf16 (lda / ldb in elements): NT: A only; TN: A and / or B
+  int c_bf16;                // NT: store the result as bf16 (ldc in elements)
 };
 
 // (A GEGLU-backward epilogue on the dX product was tried and dropped: 664 us fused against 244 + 388 us for the product and
@@ -201,7 +202,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
           for (int rg = 0; rg < 16; ++rg) {
             const int m = mb + (rg & 3) + 8 * (rg >> 2);
             // streaming output (0.1 - 1 GB per call, read next by another kernel): non-temporal stores, +4 % per iteration
-            if (m < a.M) __builtin_nontemporal_store(acc[p][q][rg] + bv + rv[rg], &a.C[(size_t)m * a.ldc + n]);
+            if (m < a.M) {
+              if (a.c_bf16) __builtin_nontemporal_store((__bf16)(acc[p][q][rg] + bv + rv[rg]), &reinterpret_cast<__bf16 *>(a.C)[(size_t)m * a.ldc + n]);
+              else __builtin_nontemporal_store(acc[p][q][rg] + bv + rv[rg], &a.C[(size_t)m * a.ldc + n]);
+            }
           }
         }
       }

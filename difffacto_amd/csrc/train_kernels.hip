@@ -160,6 +160,19 @@ __global__ __launch_bounds__(256) void k_sum_parts(const float *__restrict__ par
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
 
+// [a | g] itself is stored as bf16 in bf16 mode (-DDFX_TRAIN_AG_F32 keeps it fp32): written once and read twice per block, it
+// is the largest saved tensor (1 GB at B = 128 x 2048).  Unlike the product-only tensors this IS lossy for the backward:
+// gelu'(g) and a are taken from the rounded values (the tolerance test covers it).
+#ifdef DFX_TRAIN_AG_F32
+constexpr bool AG_BF16 = false;
+#else
+constexpr bool AG_BF16 = true;
+#endif
+template <bool BF>
+__device__ __forceinline__ v4f load4(const float *base, size_t idx) {
+  if (BF) return __builtin_convertvector(*reinterpret_cast<const v4bf *>(reinterpret_cast<const __bf16 *>(base) + idx), v4f);
+  return *reinterpret_cast<const v4f *>(base + idx);
+}
 // GEGLU (attention.py:55-57): hid = a * gelu(g), ag = [a | g] (R, 2 H); four consecutive units per thread (16-byte loads)
 template <bool BF>
 __global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hid, int H, long long total) {
@@ -167,7 +180,7 @@ __global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hi
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
-  const v4f a = *reinterpret_cast<const v4f *>(ag + r * 2 * H + c), g = *reinterpret_cast<const v4f *>(ag + r * 2 * H + H + c);
+  const v4f a = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + c)), g = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + H + c));
   store4<BF>(hid, (size_t)i, v4f{a[0] * gelu_erf(g[0]), a[1] * gelu_erf(g[1]), a[2] * gelu_erf(g[2]), a[3] * gelu_erf(g[3])});
 }
 // d a = d hid gelu(g);  d g = d hid a (Phi(g) + g phi(g))
@@ -178,7 +191,7 @@ __global__ void k_geglu_bwd(const float *__restrict__ ag, const float *__restric
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
-  const v4f a = *reinterpret_cast<const v4f *>(ag + r * 2 * H + c), g = *reinterpret_cast<const v4f *>(ag + r * 2 * H + H + c);
+  const v4f a = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + c)), g = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + H + c));
   const v4f d = *reinterpret_cast<const v4f *>(dhid + i);
   v4f da, dg;
 #pragma unroll
@@ -639,17 +652,17 @@ inline bool bf_store(long long R) { return g_prec == DFX_PREC_BF16 && R >= 256; 
 
 // x_bf: X is one of the bf16-stored tensors (only when bf_store(R): the bf16 product kernel is then guaranteed to apply)
 int lin(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, long long M, int N_,
-        int K, const float *resid = nullptr, int ldr = 0, bool x_bf = false) {
+        int K, const float *resid = nullptr, int ldr = 0, bool x_bf = false, bool y_bf = false) {
   if (g_prec == DFX_PREC_BF16) {
     dfx::gemm::GemmArgs g{};
     g.A = X, g.lda = ldx, g.B = W, g.ldb = K, g.bias = b, g.R = resid, g.ldr = ldr, g.C = Y, g.ldc = ldy, g.M = (int)M, g.N = N_, g.K = K;
-    g.a_bf16 = x_bf;
+    g.a_bf16 = x_bf, g.c_bf16 = y_bf;
     if (dfx::gemm::nt_ok(g)) {
       dfx::gemm::launch_nt(st, g);
       return dfx::check_launch("train: gemm_nt_bf16");
     }
   }
-  if (x_bf) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (M=%lld N=%d K=%d)", M, N_, K);
+  if (x_bf || y_bf) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (M=%lld N=%d K=%d)", M, N_, K);
   LinArgs a{};
   a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = (int)M, a.N = N_, a.K = K;
   a.R = resid, a.ldr = ldr, a.r_mod = 0;
@@ -763,7 +776,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
     if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
     else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
-    if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf))) return rc;
+    if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf, bf && AG_BF16))) return rc;
     if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
     else k_geglu_fwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
     if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C, bf))) return rc;

@@ -88,6 +88,7 @@ class DenoiserTrainFn(torch.autograd.Function):
                        "dfx_denoiser_train_forward")
         ctx.depth, ctx.shape, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.prec = depth, (B, N), ws, ws_ptr, nbytes, prec
         ctx.tensors = tensors
+        ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
         ctx.need_ctx = (ctx.needs_input_grad[4], ctx.needs_input_grad[5])
         return eps
 
@@ -97,8 +98,18 @@ class DenoiserTrainFn(torch.autograd.Function):
         depth = ctx.depth
         names = param_names(depth)
         d_eps = _need(d_eps.contiguous(), "d_eps")
-        grads = {n: torch.empty_like(ctx.tensors[n]) for n in names}
         dev = d_eps.device
+        # one flat buffer, handed out as views in parameter order: clip + Adam can then run as ONE launch each over the
+        # whole parameter set (training.Adam), and a data-parallel all-reduce needs no packing copy
+        # (every slice starts on a 256-byte boundary: the product kernels want 16-byte aligned weights once the optimiser
+        # has re-pointed the parameters into a buffer of the same layout; the gaps stay zero)
+        sizes = [ctx.tensors[n].numel() for n in names]
+        starts, off = [], 0
+        for k in sizes:
+            starts.append(off)
+            off += (k + 63) // 64 * 64
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        grads = {n: flat[o:o + k].view(ctx.tensors[n].shape) for n, o, k in zip(names, starts, sizes)}
         d_code = torch.empty(B, 256, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[0] else None
         d_mv = torch.empty(B, 6, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[1] else None
         w, g = _struct(ctx.tensors, depth), _struct(grads, depth)
@@ -109,7 +120,21 @@ class DenoiserTrainFn(torch.autograd.Function):
                                                               ctx.prec, _ffi.current_stream()),
                        "dfx_denoiser_train_backward")
         ctx.ws = None
-        return (None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(grads[n] for n in names)
+        # Leaf parameters get their slice of the flat buffer assigned to .grad directly (accumulating if one is already
+        # there): returned through autograd, AccumulateGrad would clone every tensor out of the flat buffer, because the
+        # Python wrappers of the returned views still hold references when it runs.
+        out = []
+        for n, leaf in zip(names, ctx.leaves):
+            if leaf is None:
+                out.append(grads[n])
+            else:
+                if leaf.grad is None:
+                    leaf.grad = grads[n]
+                else:
+                    leaf.grad.add_(grads[n])
+                out.append(None)
+        ctx.leaves = None
+        return (None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(out)
 
 
 def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, precision="f32"):
@@ -158,15 +183,21 @@ def masked_mse(target, pred, flags=None):
 
 
 class Adam:
-    """torch.optim.Adam (amsgrad off) with Runner.train's clip_grad_norm_(max_norm) in front of it (runner.py:312-316),
-    one kernel per tensor.  `params`: iterable of fp32 cuda tensors with .grad set by backward()."""
+    """torch.optim.Adam (amsgrad off) with Runner.train's clip_grad_norm_(max_norm) in front of it (runner.py:312-316).
+    `params`: iterable of fp32 cuda tensors with .grad set by backward().  When the gradients sit back to back in one
+    buffer — as DenoiserTrainFn.backward leaves them — the parameters are re-pointed (once, at the first step; values
+    unchanged, p.data becomes a view) into ONE flat buffer in the same order, next to flat moment buffers, and the
+    gradient norm and the update are one kernel launch each instead of three per tensor (flatten=False: never)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=10.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=10.0, flatten=True):
         self.params = [p for p in params]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.step_count = 0
+        self.flatten = flatten
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
+        self._flat = None            # (order, offsets, flat_p, flat_m, flat_v) once the layout of the gradients is known
+        self.last_step_was_flat = False
         dev = self.params[0].device
         self._ws = torch.zeros(1024, dtype=torch.float64, device=dev)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -175,14 +206,60 @@ class Adam:
         for p in self.params:
             p.grad = None
 
+    def _grad_layout(self):
+        """(order, offsets, total) if the gradients are disjoint slices of ONE fp32 buffer (gaps allowed: they must hold
+        zeros, as DenoiserTrainFn.backward leaves them), else None."""
+        if any(p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda for p in self.params):
+            return None
+        order = sorted(range(len(self.params)), key=lambda i: self.params[i].grad.data_ptr())
+        g0 = self.params[order[0]].grad
+        base, store = g0.data_ptr(), g0.untyped_storage()
+        if base != store.data_ptr():
+            return None
+        offsets, end = [], 0
+        for i in order:
+            g = self.params[i].grad
+            off = (g.data_ptr() - base) // 4
+            if g.untyped_storage().data_ptr() != store.data_ptr() or (g.data_ptr() - base) % 4 or off < end:
+                return None
+            offsets.append(off)
+            end = off + g.numel()
+        if end * 4 > store.nbytes():
+            return None
+        return order, offsets, end
+
+    def _flat_grad(self):
+        """The gradients as one flat tensor matching the flat parameter buffer, or None."""
+        if not self.flatten:
+            return None
+        lay = self._grad_layout()
+        if lay is None:
+            return None
+        order, offsets, total = lay
+        if self._flat is None or self._flat[0] != order or self._flat[1] != offsets:
+            dev = self.params[0].device
+            fp, fm, fv = (torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
+            with torch.no_grad():
+                for i, o in zip(order, offsets):
+                    p, k = self.params[i], self.params[i].numel()
+                    fp[o:o + k].copy_(p.detach().reshape(-1))
+                    fm[o:o + k].copy_(self.m[i].reshape(-1))
+                    fv[o:o + k].copy_(self.v[i].reshape(-1))
+                    p.data = fp[o:o + k].view_as(p)
+                    self.m[i] = fm[o:o + k].view_as(p)
+                    self.v[i] = fv[o:o + k].view_as(p)
+            self._flat = (order, offsets, fp, fm, fv)
+        g0 = self.params[order[0]].grad
+        return torch.as_strided(g0, (total,), (1,))   # same storage, layout checked above
+
     def grad_norm(self):
         """Global L2 norm of the gradients (what clip_grad_norm_ returns), as a 0-dim float64 cuda tensor."""
         lib = _ffi.lib()
         self._sumsq.zero_()
-        for p in self.params:
-            if p.grad is None:
-                continue
-            g = _need(p.grad.contiguous(), "grad")
+        flat = self._flat_grad()
+        todo = [flat] if flat is not None else [p.grad for p in self.params if p.grad is not None]
+        for g in todo:
+            g = _need(g.contiguous(), "grad")
             with torch.cuda.device(g.device):
                 _ffi.check(lib.dfx_grad_sumsq_accumulate(g.data_ptr(), g.numel(), self._ws.data_ptr(), self._sumsq.data_ptr(),
                                                          _ffi.current_stream()), "dfx_grad_sumsq_accumulate")
@@ -193,10 +270,13 @@ class Adam:
         lib = _ffi.lib()
         norm = self.grad_norm() if self.max_norm and self.max_norm > 0 else None
         self.step_count += 1
-        for p, m, v in zip(self.params, self.m, self.v):
-            if p.grad is None:
-                continue
-            g = _need(p.grad.contiguous(), "grad")
+        flat = self._flat_grad()
+        self.last_step_was_flat = flat is not None
+        if flat is not None:
+            work = [(self._flat[2], flat, self._flat[3], self._flat[4])]
+        else:
+            work = [(p, _need(p.grad.contiguous(), "grad"), m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        for p, g, m, v in work:
             with torch.cuda.device(p.device):
                 _ffi.check(lib.dfx_adam_step_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                                  self._sumsq.data_ptr() if norm is not None else None,

@@ -196,6 +196,7 @@ def test_training_steps_reduce_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and all(np.isfinite(losses)), losses
+    assert opt.last_step_was_flat   # the backward leaves the gradients in one buffer: clip + Adam are one launch each
 
 
 def test_train_entry_points_reject_bad_arguments():

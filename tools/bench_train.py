@@ -53,4 +53,4 @@ flops = 3 * 4.734e9 * B * (N / 2048)
 peak = 157.3 if PREC == "f32" else 2500.0
 print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
       f"{flops / ms / 1e9:.1f} TFLOP/s of the {peak} TFLOP/s {PREC} matrix peak ({flops / ms / 1e9 / peak * 100:.1f} %), loss {float(loss.detach()):.4f}, "
-      f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak")
+      f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak, optimiser in {'one launch' if opt.last_step_was_flat else 'one launch per tensor'}")
