@@ -45,8 +45,9 @@ struct GemmArgs {
 // the element-wise kernel, which streams at 5 TB/s; the dword-per-lane epilogue accesses do not.)
 template <bool TN>
 __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ws[2][TILE * LROW];
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][TILE * LROW];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[4 * TILE * LROW];   // 40 KiB: W and X tiles x 2 buffers; NT epilogue staging
+  __bf16(*Ws)[TILE * LROW] = reinterpret_cast<__bf16(*)[TILE * LROW]>(smem);
+  __bf16(*Xs)[TILE * LROW] = reinterpret_cast<__bf16(*)[TILE * LROW]>(smem + 2 * TILE * LROW);
   __shared__ float bsum[4][TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, kq = lane >> 5;
@@ -180,35 +181,59 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
   }
 
   if (!TN) {
-    // NT: rows on the MFMA M axis (registers), output channels on the lanes: one store instruction writes two rows x 32
-    // consecutive channels (128-byte segments)
+    // NT epilogue through LDS: rows sit on the MFMA M axis (registers) and output channels on the lanes, so a wavefront
+    // writes its quadrant into a staging tile two rows x 32 consecutive floats per instruction (conflict-free); the
+    // workgroup then streams the tile out with 16-byte non-temporal stores, a full 512-byte (fp32) / 256-byte (bf16) row
+    // segment per 32 / 16 threads, bias and residual added on the way.  64 rows per pass (the staging tile is the 40 KiB
+    // of the operand buffers: 64 x 132 floats).
+    constexpr int SROW = TILE + 4;
+    float *stage = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int n = w0 + 64 * wc + 32 * p + li;
-      const float bv = a.bias ? a.bias[n] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      if (wr == h) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int mb = x0 + 64 * wr + 32 * q + 4 * kq;   // row of register rg: mb + (rg & 3) + 8 (rg >> 2)
-        {
-          // the residual may be the output buffer itself (element-wise in place): read the sixteen values first, so the
-          // loads do not queue behind the stores
-          float rv[16];
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int rg = 0; rg < 16; ++rg) {
-            const int m = mb + (rg & 3) + 8 * (rg >> 2);
-            rv[rg] = (a.R && m < a.M) ? a.R[(size_t)m * a.ldr + n] : 0.f;
-          }
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int rg = 0; rg < 16; ++rg) {
-            const int m = mb + (rg & 3) + 8 * (rg >> 2);
-            // streaming output (0.1 - 1 GB per call, read next by another kernel): non-temporal stores, +4 % per iteration
-            if (m < a.M) {
-              if (a.c_bf16) __builtin_nontemporal_store((__bf16)(acc[p][q][rg] + bv + rv[rg]), &reinterpret_cast<__bf16 *>(a.C)[(size_t)m * a.ldc + n]);
-              else __builtin_nontemporal_store(acc[p][q][rg] + bv + rv[rg], &a.C[(size_t)m * a.ldc + n]);
+            for (int rg = 0; rg < 16; ++rg)
+              stage[(32 * q + (rg & 3) + 8 * (rg >> 2) + 4 * kq) * SROW + 64 * wc + 32 * p + li] = acc[p][q][rg];
+      }
+      __syncthreads();
+      const int mrow0 = x0 + 64 * h;
+      if (a.c_bf16) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 256 + tid, row = idx >> 4, c8 = (idx & 15) * 8, m = mrow0 + row;
+          if (m < a.M) {
+            v8f v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = stage[row * SROW + c8 + e] + (a.bias ? a.bias[w0 + c8 + e] : 0.f);
+            if (a.R) {
+              const v4f r0 = *reinterpret_cast<const v4f *>(a.R + (size_t)m * a.ldr + w0 + c8), r1 = *reinterpret_cast<const v4f *>(a.R + (size_t)m * a.ldr + w0 + c8 + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += r0[e], v[4 + e] += r1[e];
             }
+            __builtin_nontemporal_store(__builtin_bit_cast(v4f, __builtin_convertvector(v, v8bf)),
+                                        reinterpret_cast<v4f *>(reinterpret_cast<__bf16 *>(a.C) + (size_t)m * a.ldc + w0 + c8));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int idx = it * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4, m = mrow0 + row;
+          if (m < a.M) {
+            v4f v = *reinterpret_cast<const v4f *>(&stage[row * SROW + c4]);
+            if (a.bias) {
+              const v4f bv = *reinterpret_cast<const v4f *>(a.bias + w0 + c4);
+              v += bv;
+            }
+            if (a.R) v += *reinterpret_cast<const v4f *>(a.R + (size_t)m * a.ldr + w0 + c4);   // may be C itself: same thread, read before write
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(a.C + (size_t)m * a.ldc + w0 + c4));
           }
         }
       }
+      __syncthreads();
     }
   } else {
     float *pp = a.C + (size_t)blockIdx.z * a.M * a.N;
@@ -239,7 +264,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 inline bool nt_ok(const GemmArgs &a) {
   return a.N % TILE == 0 && a.K % TK == 0 && a.M >= 256 && a.lda % (a.a_bf16 ? 8 : 4) == 0 && a.ldb % 4 == 0 && a.ldc % 4 == 0 &&
          ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B) | reinterpret_cast<uintptr_t>(a.C)) & 15) == 0 &&
-         (!a.R || (a.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0));
+         (!a.R || (a.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0)) &&
+         (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && (!a.c_bf16 || a.ldc % 8 == 0);
 }
 inline bool tn_ok(const GemmArgs &a) {
   return a.M % TILE == 0 && a.N % TILE == 0 && a.rows_per_slab % TK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&   // (8-byte rows of 4 bf16 need ld % 4 too)
