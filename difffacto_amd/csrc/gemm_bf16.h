@@ -206,9 +206,13 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 256 + tid, row = idx >> 4, c8 = (idx & 15) * 8, m = mrow0 + row;
           if (m < a.M) {
-            v8f v;
+            const v4f s0 = *reinterpret_cast<const v4f *>(&stage[row * SROW + c8]), s1 = *reinterpret_cast<const v4f *>(&stage[row * SROW + c8 + 4]);
+            v8f v = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (a.bias) {
+              const v4f b0 = *reinterpret_cast<const v4f *>(a.bias + w0 + c8), b1 = *reinterpret_cast<const v4f *>(a.bias + w0 + c8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = stage[row * SROW + c8 + e] + (a.bias ? a.bias[w0 + c8 + e] : 0.f);
+              for (int e = 0; e < 4; ++e) v[e] += b0[e], v[4 + e] += b1[e];
+            }
             if (a.R) {
               const v4f r0 = *reinterpret_cast<const v4f *>(a.R + (size_t)m * a.ldr + w0 + c8), r1 = *reinterpret_cast<const v4f *>(a.R + (size_t)m * a.ldr + w0 + c8 + 4);
 #pragma unroll

@@ -666,6 +666,12 @@ int lin(hipStream_t st, const float *X, int ldx, const float *W, const float *b,
   LinArgs a{};
   a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = (int)M, a.N = N_, a.K = K;
   a.R = resid, a.ldr = ldr, a.r_mod = 0;
+  if (M <= 4096) {   // few rows (context tokens, batch rows): 32 x 32 tiles, one wavefront each, fill more CUs than the wide kernel's 128 x 128
+    const dim3 grid((N_ + 31) / 32, (unsigned)((M + 31) / 32), 1);
+    if (resid) dfx::lin::k_lin<dfx::lin::EPI_RESID><<<grid, 64, 0, st>>>(a);
+    else dfx::lin::k_lin<dfx::lin::EPI_NONE><<<grid, 64, 0, st>>>(a);
+    return dfx::check_launch("train: linear");
+  }
   if (resid) dfx::lin::launch<dfx::lin::EPI_RESID>(st, 1, a);
   else dfx::lin::launch<dfx::lin::EPI_NONE>(st, 1, a);
   return dfx::check_launch("train: linear");
