@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, con
 
 // LayerNorm backward: dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy gamma;  out = (resid ? resid : 0) + dx.
 // Column sums of dy xhat (d gamma) and dy (d beta) per block of rows -> part[blockIdx][2][128]
-constexpr int LNB_ROWS = 256;   // rows per block (8 row groups x 32 trips)
+constexpr int LNB_ROWS = 512;   // rows per block (8 row groups x 64 trips)
 __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ dy, const float *__restrict__ x,
                                                  const float *__restrict__ stats, const float *__restrict__ g,
                                                  const float *__restrict__ resid, float *__restrict__ out,
@@ -575,7 +575,7 @@ struct TrainWs {
   // backward scratch
   float *dh, *dh2, *dwide, *dhid, *dq, *datt, *dk, *dv, *dctx, *dte_out, *dte_hid, *dte_ag, *wT, *wpad, *part, *bpart, *apart;
   float *valid;
-  size_t part_floats;
+  size_t part_floats, bpart_floats;
 };
 
 constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab (64 for the few-row products over the context tokens / the batch)
@@ -640,7 +640,8 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.part = c.take<float>(pf);
   size_t ns_max = ns_r > ns_bj ? ns_r : ns_bj;
   if (ns_b > ns_max) ns_max = ns_b;
-  w.bpart = c.take<float>(ns_max * (size_t)(2 * TEH));
+  w.bpart_floats = (ns_max > 2048 ? ns_max : 2048) * (size_t)(2 * TEH);   // room for 2048 slabs of the widest bias
+  w.bpart = c.take<float>(w.bpart_floats);
   w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
   return c.off;
 }
@@ -683,24 +684,47 @@ void transpose(hipStream_t st, const float *W, float *WT, int rows, int cols) {
 }
 
 // dW (O x I_valid), db (O) from dY (R x O, ld ldy) and X (R x I, ld ldx)
+// Slab size of a weight-gradient product: enough slabs to fill the chip (small outputs have few tiles per slab), few enough
+// to keep the partial tiles within the workspace and the second pass short; a multiple of 64 rows.
+inline int pick_slab(long long R, long long tiles, long long target_blocks, size_t part_floats, size_t out_floats) {
+  long long ns = target_blocks / (tiles > 0 ? tiles : 1);
+  if (ns < 1) ns = 1;
+  const long long ns_cap = (long long)(part_floats / (out_floats ? out_floats : 1));
+  if (ns > ns_cap) ns = ns_cap;
+  if (ns < 1) ns = 1;
+  long long slab = ((R + ns - 1) / ns + 63) / 64 * 64;
+  if (slab < 64) slab = 64;
+  return (int)slab;
+}
+
 int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
           int I_valid, long long R, bool dy_bf = false, bool x_bf = false) {
-  const int ns = nslabs(R);
   bool done = false;
+  int ns = 1;
+  const size_t bcap = w.bpart_floats / (size_t)O;   // slabs the bias partials have room for
   if (g_prec == DFX_PREC_BF16) {
     dfx::gemm::GemmArgs g{};
     g.A = dY, g.lda = ldy, g.B = X, g.ldb = ldx, g.C = w.part, g.ldc = I, g.bpart = db ? w.bpart : nullptr, g.M = O, g.N = I, g.K = (int)R;
-    g.rows_per_slab = slab_rows(R);
+    g.rows_per_slab = pick_slab(R, (long long)(O / 128) * (I / 128), 512, w.part_floats, (size_t)O * I);
+    ns = (int)((R + g.rows_per_slab - 1) / g.rows_per_slab);
     g.a_bf16 = dy_bf, g.b_bf16 = x_bf;
-    if (R >= 256 && dfx::gemm::tn_ok(g)) {
+    if (R >= 256 && (size_t)ns <= bcap && dfx::gemm::tn_ok(g)) {
       dfx::gemm::launch_tn(st, g, ns);
       done = true;
     }
   }
   if (!done && (dy_bf || x_bf)) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (O=%d I=%d)", O, I);
-  if (!done)
-    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab_rows(R));
-  k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
+  if (!done) {
+    int slab = pick_slab(R, (long long)((O + 63) / 64) * ((I + 63) / 64), 2048, w.part_floats, (size_t)O * I);
+    ns = (int)((R + slab - 1) / slab);
+    if ((size_t)ns > bcap) {
+      slab = (int)(((R + (long long)bcap - 1) / (long long)bcap + 63) / 64 * 64);
+      ns = (int)((R + slab - 1) / slab);
+    }
+    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
+  }
+  if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
+  else k_wgrad_finish<<<(O * I_valid + 255) / 256, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
   if (db) k_sum_parts<<<(O + 31) / 32, 256, 0, st>>>(w.bpart, db, ns, O, O);
   return dfx::check_launch("train: wgrad");
 }
