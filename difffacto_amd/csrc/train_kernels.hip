@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float *__restrict__ q, c
   for (int e = 0; e < HD / 4; ++e) store4<BF>(att, (size_t)r * C + h * HD + 4 * e, v4f{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]});
 }
 
-// d att -> d q (per point), d k / d v partial sums over the block's 32 points -> part[(b, blockIdx.x)][2][J][C]
+// d att -> d q (per point), d k / d v partial sums over the block's points -> part[(b, blockIdx.x)][2][J][C].
+// A block covers ATT_BP = 128 points of one shape: every lane walks four points, keeping its 2 x 4 x 16 d k / d v
+// contributions in registers, and the cross-lane reduction over the 32 lanes of a head runs once per block, not per point.
+constexpr int ATT_BP = 128;
 template <bool BF>
 __global__ __launch_bounds__(256) void k_attn_bwd(const float *__restrict__ datt, const float *__restrict__ q,
                                                    const float *__restrict__ k, const float *__restrict__ v,
@@ -323,41 +326,57 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float *__restrict__ datt
   const int b = blockIdx.y, h = threadIdx.x >> 5, i = threadIdx.x & 31;
   for (int e = threadIdx.x; e < J * C; e += 256) ks[e / C][e % C] = k[(size_t)b * J * C + e], vs[e / C][e % C] = v[(size_t)b * J * C + e];
   __syncthreads();
-  const long long r = (long long)b * N + blockIdx.x * 32 + i;
-  float qv[HD], dv_[HD];
+  float ak[J][HD], av[J][HD];
 #pragma unroll
-  for (int e = 0; e < HD / 4; ++e) {
-    const v4f t = reinterpret_cast<const v4f *>(q + r * C + h * HD)[e], u = reinterpret_cast<const v4f *>(datt + r * C + h * HD)[e];
+  for (int j = 0; j < J; ++j)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qv[4 * e + s] = t[s], dv_[4 * e + s] = u[s];
+    for (int e = 0; e < HD; ++e) ak[j][e] = 0.f, av[j][e] = 0.f;
+  for (int pt = 0; pt < ATT_BP / 32; ++pt) {
+    const int n = blockIdx.x * ATT_BP + pt * 32 + i;
+    if (n >= N) break;   // N is a multiple of 32: whole groups of 32 lanes drop out together
+    const long long r = (long long)b * N + n;
+    float qv[HD], dv_[HD];
+#pragma unroll
+    for (int e = 0; e < HD / 4; ++e) {
+      const v4f t = reinterpret_cast<const v4f *>(q + r * C + h * HD)[e], u = reinterpret_cast<const v4f *>(datt + r * C + h * HD)[e];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qv[4 * e + s] = t[s], dv_[4 * e + s] = u[s];
+    }
+    const v4f pv = reinterpret_cast<const v4f *>(p + r * (HEADS * J))[h];
+    float dp[J], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) s += dv_[e] * vs[j][h * HD + e];
+      dp[j] = s;
+      dot += pv[j] * s;
+    }
+    float dqv[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dqv[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float ds = pv[j] * (dp[j] - dot) * 0.25f;   // d sim_j x scale (masked keys: p = 0 exactly)
+#pragma unroll
+      for (int e = 0; e < HD; ++e) {
+        dqv[e] += ds * ks[j][h * HD + e];
+        ak[j][e] += ds * qv[e];
+        av[j][e] += pv[j] * dv_[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < HD / 4; ++e) store4<BF>(dq, (size_t)r * C + h * HD + 4 * e, v4f{dqv[4 * e], dqv[4 * e + 1], dqv[4 * e + 2], dqv[4 * e + 3]});
   }
-  const v4f pv = reinterpret_cast<const v4f *>(p + r * (HEADS * J))[h];
-  float dp[J], dot = 0.f;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) s += dv_[e] * vs[j][h * HD + e];
-    dp[j] = s;
-    dot += pv[j] * s;
-  }
-  float dqv[HD];
-#pragma unroll
-  for (int e = 0; e < HD; ++e) dqv[e] = 0.f;
   float *pk = part + ((size_t)(b * gridDim.x + blockIdx.x) * 2) * J * C;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const float ds = pv[j] * (dp[j] - dot) * 0.25f;   // d sim_j x scale (masked keys: p = 0 exactly)
+  for (int j = 0; j < J; ++j)
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      dqv[e] += ds * ks[j][h * HD + e];
-      float a = ds * qv[e], c = pv[j] * dv_[e];   // d k[j][h, e], d v[j][h, e] of this point: sum over the 32 points
+      float a = ak[j][e], c = av[j][e];
       for (int o = 16; o; o >>= 1) a += __shfl_xor(a, o, 32), c += __shfl_xor(c, o, 32);
       if (i == 0) pk[j * C + h * HD + e] = a, pk[(J + j) * C + h * HD + e] = c;
     }
-  }
-#pragma unroll
-  for (int e = 0; e < HD / 4; ++e) store4<BF>(dq, (size_t)r * C + h * HD + 4 * e, v4f{dqv[4 * e], dqv[4 * e + 1], dqv[4 * e + 2], dqv[4 * e + 3]});
 }
 // d k, d v (B J, C) = sum over the nb blocks of a shape
 __global__ void k_attn_bwd_finish(const float *__restrict__ part, float *__restrict__ dk, float *__restrict__ dv, int nb) {
@@ -856,9 +875,10 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = wgrad(st, w, w.dh, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R, false, bf))) return rc;
     transpose(st, bw.to_out_w, w.wT, C, C);
     if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.datt, C, R, C, C))) return rc;
-    if (bf) k_attn_bwd<true><<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
-    else k_attn_bwd<false><<<dim3(N / 32, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
-    k_attn_bwd_finish<<<B, J * C, 0, st>>>(w.apart, w.dk, w.dv, N / 32);
+    const int nab = (N + ATT_BP - 1) / ATT_BP;
+    if (bf) k_attn_bwd<true><<<dim3(nab, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
+    else k_attn_bwd<false><<<dim3(nab, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
+    k_attn_bwd_finish<<<B, J * C, 0, st>>>(w.apart, w.dk, w.dv, nab);
     if ((rc = wgrad(st, w, w.dq, C, a.xn2, C, mut(gw.to_q), nullptr, C, C, C, R, bf, bf))) return rc;
     transpose(st, bw.to_q, w.wT, C, C);
     if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C, nullptr, 0, bf))) return rc;
