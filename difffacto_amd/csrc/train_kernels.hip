@@ -1,7 +1,7 @@
 // Training-mode evaluation of the cross-diffusion denoiser and its backward:
 //   TransformerNet.forward / _forward_attn (attention.py:385-440, BasicTransformerBlock :296-306 with single_attn,
-//   CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94, timestep_embedding utils.py:7-24), dropout = 0,
-// in exact fp32 (v_mfma_f32_32x32x2_f32 through the shared row-batched linear kernels), every intermediate that the
+//   CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94, timestep_embedding utils.py:7-24), optional dropout,
+// in exact fp32 or with bf16 matrix products (gemm_bf16.h) (v_mfma_f32_32x32x2_f32 through the shared row-batched linear kernels), every intermediate that the
 // backward needs kept in a caller-provided workspace (2.4 KB per point and block: 12.5 GB at B = 128, N = 2048 —
 // sized for 288 GB of HBM, nothing is recomputed).  The persistent bf16 chain kernel is the sampling path; this file is
 // the first correct training path: one launch per layer, parity with the reference's autograd is the bar
@@ -33,6 +33,32 @@ constexpr float LN_EPS = 1e-5f;
 // bf16 (template parameter BF of their producers): the product kernels would round them to bf16 anyway, so the values
 // entering the MFMAs are the same and the HBM traffic of these tensors halves.
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+
+// Dropout (nn.Dropout in train mode: attention.py:84 after the GEGLU, :177 after to_out): Philox4x32-10 keyed by the step's
+// seed, counter = (group of four consecutive elements, site), one 32-bit draw per element; factor = keep ? 1 / (1 - p) : 0.
+// The backward regenerates the factors from the same (seed, site, index): no mask is stored.  torch's own CUDA dropout
+// stream depends on its launch geometry and cannot be reproduced; the contract here is (seed, site, element index).
+__device__ __forceinline__ v4f dropout4(unsigned long long seed, unsigned site, unsigned long long idx4, float p) {
+  uint4 c = make_uint4((unsigned)idx4, (unsigned)(idx4 >> 32), site, 0xD20F0u);
+  uint2 k = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  const float keep = 1.0f / (1.0f - p);
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);   // drop when the draw is below p * 2^32
+  return v4f{c.x < thr ? 0.f : keep, c.y < thr ? 0.f : keep, c.z < thr ? 0.f : keep, c.w < thr ? 0.f : keep};
+}
+struct Drop {
+  float p;                  // 0 = off
+  unsigned long long seed;
+  unsigned site;
+};
+enum { SITE_TE = 1000 };    // sites: 2 i = attention output of block i, 2 i + 1 = feed-forward of block i, SITE_TE = time_embed
 template <bool BF>
 __device__ __forceinline__ void store4(float *base, size_t idx, v4f v) {   // idx in elements, multiple of 4
   if (BF) *reinterpret_cast<v4bf *>(reinterpret_cast<__bf16 *>(base) + idx) = __builtin_convertvector(v, v4bf);
@@ -175,24 +201,27 @@ __device__ __forceinline__ v4f load4(const float *base, size_t idx) {
 }
 // GEGLU (attention.py:55-57): hid = a * gelu(g), ag = [a | g] (R, 2 H); four consecutive units per thread (16-byte loads)
 template <bool BF>
-__global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hid, int H, long long total) {
+__global__ void k_geglu_fwd(const float *__restrict__ ag, float *__restrict__ hid, int H, long long total, Drop dr) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
   const v4f a = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + c)), g = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + H + c));
-  store4<BF>(hid, (size_t)i, v4f{a[0] * gelu_erf(g[0]), a[1] * gelu_erf(g[1]), a[2] * gelu_erf(g[2]), a[3] * gelu_erf(g[3])});
+  v4f h = {a[0] * gelu_erf(g[0]), a[1] * gelu_erf(g[1]), a[2] * gelu_erf(g[2]), a[3] * gelu_erf(g[3])};
+  if (dr.p > 0.f) h *= dropout4(dr.seed, dr.site, (unsigned long long)(i >> 2), dr.p);
+  store4<BF>(hid, (size_t)i, h);
 }
 // d a = d hid gelu(g);  d g = d hid a (Phi(g) + g phi(g))
 template <bool BF>
 __global__ void k_geglu_bwd(const float *__restrict__ ag, const float *__restrict__ dhid, float *__restrict__ dag, int H,
-                            long long total) {
+                            long long total, Drop dr) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const long long r = i / H;
   const int c = (int)(i % H);
   const v4f a = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + c)), g = load4<BF && AG_BF16>(ag, (size_t)(r * 2 * H + H + c));
-  const v4f d = *reinterpret_cast<const v4f *>(dhid + i);
+  v4f d = *reinterpret_cast<const v4f *>(dhid + i);
+  if (dr.p > 0.f) d *= dropout4(dr.seed, dr.site, (unsigned long long)(i >> 2), dr.p);
   v4f da, dg;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -203,6 +232,20 @@ __global__ void k_geglu_bwd(const float *__restrict__ ag, const float *__restric
   }
   store4<BF>(dag, (size_t)(r * 2 * H + c), da);
   store4<BF>(dag, (size_t)(r * 2 * H + H + c), dg);
+}
+
+// out = x * factor (+ resid): the dropout behind to_out (forward: + block input; backward: the masked gradient)
+__global__ void k_dropout(const float *__restrict__ x, const float *__restrict__ resid, float *__restrict__ out, long long total, Drop dr) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= total) return;
+  v4f v = *reinterpret_cast<const v4f *>(x + i) * dropout4(dr.seed, dr.site, (unsigned long long)(i >> 2), dr.p);
+  if (resid) v += *reinterpret_cast<const v4f *>(resid + i);
+  *reinterpret_cast<v4f *>(out + i) = v;
+}
+__global__ void k_dropout_factors(float *__restrict__ out, long long total, Drop dr) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= total) return;
+  *reinterpret_cast<v4f *>(out + i) = dropout4(dr.seed, dr.site, (unsigned long long)(i >> 2), dr.p);
 }
 
 // timestep_embedding (utils.py:7-24): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / 128)
@@ -784,10 +827,11 @@ size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth) {
 int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes, const float *x,
                                const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
                                const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
-                               int N, int precision, dfx_stream_t stream) {
+                               int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream) {
   int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_forward");
   if (rc) return rc;
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_forward: precision %d", precision);
+  DFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "denoiser_train_forward: dropout_p %g", (double)dropout_p);
   g_prec = precision;
   const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");
@@ -799,7 +843,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   // time embedding -> context rows
   k_timestep_embedding<<<(B * TE + 255) / 256, 256, 0, st>>>(t, w.te_in, B);
   if ((rc = lin(st, w.te_in, TE, wt->te0_w, wt->te0_b, w.te_ag, 2 * TEH, B, 2 * TEH, TE))) return rc;
-  k_geglu_fwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH);
+  k_geglu_fwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH, Drop{dropout_p, dropout_seed, SITE_TE});
   if ((rc = lin(st, w.te_hid, TEH, wt->te2_w, wt->te2_b, w.te_out, TE, B, TE, TEH))) return rc;
   k_build_ctx<<<(BJ * CTXP + 255) / 256, 256, 0, st>>>(ctx_code, ctx_mv, w.te_out, w.ctx, B);
   if (valid) DFX_HIP_TRY(hipMemcpyAsync(w.valid, valid, sizeof(float) * BJ, hipMemcpyDeviceToDevice, st));
@@ -822,12 +866,16 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
     if (bf) k_attn_fwd<true><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
     else k_attn_fwd<false><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
-    if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
+    if (dropout_p > 0.f) {   // h1 = dropout(att Wo^T + bo) + hin   (attention.py:177: to_out = Sequential(Linear, Dropout))
+      if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, nullptr, 0, bf))) return rc;
+      k_dropout<<<(int)((R * C / 4 + 255) / 256), 256, 0, st>>>(a.h1, a.hin, a.h1, R * C, Drop{dropout_p, dropout_seed, (unsigned)(2 * i)});
+    } else if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
     if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
     else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
     if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf, bf && AG_BF16))) return rc;
-    if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
-    else k_geglu_fwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH);
+    const Drop dff{dropout_p, dropout_seed, (unsigned)(2 * i + 1)};
+    if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH, dff);
+    else k_geglu_fwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH, dff);
     if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C, bf))) return rc;
   }
   k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
@@ -837,10 +885,11 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
 
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, int precision, dfx_stream_t stream) {
+                                int B, int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream) {
   int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_backward");
   if (rc) return rc;
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_backward: precision %d", precision);
+  DFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "denoiser_train_backward: dropout_p %g", (double)dropout_p);
   g_prec = precision;
   const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(d_eps && grads, "denoiser_train_backward: null tensor");
@@ -865,16 +914,22 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
     if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.dhid, FH, R, FH, C))) return rc;
-    if (bf) k_geglu_bwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
-    else k_geglu_bwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH);
+    const Drop dff{dropout_p, dropout_seed, (unsigned)(2 * i + 1)};
+    if (bf) k_geglu_bwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH, dff);
+    else k_geglu_bwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, w.dhid, w.dwide, FH, R * FH, dff);
     if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, bf, bf))) return rc;
     transpose(st, bw.ff0_w, w.wT, 2 * FH, C);                                // (128, 1024)
     if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH, nullptr, 0, bf))) return rc;
     if ((rc = ln_bwd(st, w, w.dh2, a.h1, a.st3, bw.norm3_w, w.dh, w.dh, mut(gw.norm3_w), mut(gw.norm3_b), R))) return rc;
     // attention: h1 = hin + Wo att + bo
-    if ((rc = wgrad(st, w, w.dh, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R, false, bf))) return rc;
+    const float *dho = w.dh;   // gradient at the output of to_out: dh behind the dropout
+    if (dropout_p > 0.f) {
+      k_dropout<<<(int)((R * C / 4 + 255) / 256), 256, 0, st>>>(w.dh, nullptr, w.dh2, R * C, Drop{dropout_p, dropout_seed, (unsigned)(2 * i)});
+      dho = w.dh2;
+    }
+    if ((rc = wgrad(st, w, dho, C, a.att, C, mut(gw.to_out_w), mut(gw.to_out_b), C, C, C, R, false, bf))) return rc;
     transpose(st, bw.to_out_w, w.wT, C, C);
-    if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.datt, C, R, C, C))) return rc;
+    if ((rc = lin(st, dho, C, w.wT, nullptr, w.datt, C, R, C, C))) return rc;
     const int nab = (N + ATT_BP - 1) / ATT_BP;
     if (bf) k_attn_bwd<true><<<dim3(nab, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
     else k_attn_bwd<false><<<dim3(nab, B), 256, 0, st>>>(w.datt, a.q, a.k, a.v, a.p, w.dq, w.apart, N);
@@ -900,7 +955,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;
   transpose(st, wt->te2_w, w.wT, TE, TEH);                                   // (1024, 256)
   if ((rc = lin(st, w.dte_out, TE, w.wT, nullptr, w.dte_hid, TEH, B, TEH, TE))) return rc;
-  k_geglu_bwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH);
+  k_geglu_bwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH, Drop{dropout_p, dropout_seed, SITE_TE});
   if ((rc = wgrad(st, w, w.dte_ag, 2 * TEH, w.te_in, TE, mut(grads->te0_w), mut(grads->te0_b), 2 * TEH, TE, TE, B))) return rc;
   return dfx::check_launch("denoiser_train_backward");
 }
@@ -912,6 +967,14 @@ int dfx_masked_mse_backward_f32(const float *target, const float *pred, const fl
   k_mse_bwd<<<(int)((total + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(target, pred, flags, workspace2, grad_scale, d_pred, N,
                                                                                total, 3.0 * (double)B * N);
   return dfx::check_launch("masked_mse_backward");
+}
+
+// The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
+// (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
+int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream) {
+  DFX_REQUIRE(out && n >= 4 && n % 4 == 0 && p > 0.f && p < 1.f, "debug_dropout_factors: bad argument");
+  k_dropout_factors<<<(int)((n / 4 + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(out, n, Drop{p, seed, (unsigned)site});
+  return dfx::check_launch("debug_dropout_factors");
 }
 
 // Test hook for the bf16 product kernels of gemm_bf16.h (tests/test_gpu_train.py):

@@ -157,11 +157,19 @@ class TransformerNet(nn.Module):
 
     def _forward_train(self, x, t, ctx, anchors, variances, valid_id, anchor_assignment):
         """Differentiable evaluation (per-shape t, saved activations, exact fp32): libdfx's training kernels behind
-        torch.autograd (difffacto_amd/training.py).  Dropout must be 0 (the parity setting)."""
+        torch.autograd (difffacto_amd/training.py).  In train() mode the modules' Dropout(p) is applied with libdfx's Philox
+        factors (p = 0 is the parity setting of SURVEY.md §7 config 5)."""
         if next(self.parameters()).device.type != "cuda" or x.device.type != "cuda":
             raise RuntimeError("TransformerNet (libdfx) needs its parameters and inputs on a HIP device: CPU not supported")
-        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()):
-            _unsupported("dropout > 0 in train() mode: the native training path has no dropout (build the net with dropout=0)")
+        dropout = None
+        if self.training:
+            ps = {float(m.p) for m in self.modules() if isinstance(m, nn.Dropout)}
+            if len(ps) > 1:
+                _unsupported("different dropout probabilities inside one TransformerNet")
+            if ps and max(ps) > 0:
+                # one seed per step from torch's CPU generator (reproducible under torch.manual_seed); libdfx's own Philox
+                # contract: torch's CUDA dropout stream depends on its launch geometry and cannot be reproduced
+                dropout = (max(ps), int(torch.randint(0, 2 ** 62, ()).item()))
         if not isinstance(ctx, (list, tuple)) or len(ctx) != 2:
             _unsupported("ctx must be the [part_code, params] list of PartEncoderForTransformerDecoder.prepare_ctx")
         if anchors is None or variances is None:
@@ -174,7 +182,7 @@ class TransformerNet(nn.Module):
         B = x.shape[0]
         tt = torch.full((B,), int(t), device=x.device) if isinstance(t, int) else t.reshape(-1).expand(B) if t.numel() == 1 else t
         return _training.denoiser_train_forward(dict(self.named_parameters()), x, tt, ctx[0], ctx[1], anchors, variances,
-                                                valid_id, anchor_assignment, precision=self._dfx_precision)
+                                                valid_id, anchor_assignment, precision=self._dfx_precision, dropout=dropout)
 
 
 class AnchoredDiffusion(nn.Module):
@@ -287,7 +295,7 @@ class AnchoredDiffusion(nn.Module):
         """anchored_diffusion.py:760-853: {'mse_loss'} of the epsilon objective at per-shape timesteps ``t`` (B,)
         (q_sample -> denoiser -> masked MSE).  Under ``no_grad`` in ``eval()`` the value comes from the inference
         engine; with gradients enabled it is differentiable in the denoiser's parameters and in ``ctx`` through libdfx's
-        training kernels (dropout must be 0; anchors / variance are data, as the reference detaches them,
+        training kernels (Dropout(p) of train() mode included; anchors / variance are data, as the reference detaches them,
         anchor_gen.py:1011-1014)."""
         if not reduce:
             _unsupported("training_losses(reduce=False)")

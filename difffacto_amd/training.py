@@ -3,7 +3,7 @@ and the reference's optimiser step.
 
 Mirrors what ``loss.backward()`` + ``clip_grad_norm_`` + ``Adam.step`` do to ``TransformerNet`` in the reference
 (python/difffacto/models/networks/attention.py:385-440 forward; python/difffacto/runner/runner.py:312-316 step;
-anchored_diffusion.py:840-847 loss) with dropout = 0.  PyTorch provides the tensors, the autograd graph and the
+anchored_diffusion.py:840-847 loss), dropout included.  PyTorch provides the tensors, the autograd graph and the
 stream; every number is produced by the kernels of ``csrc/train_kernels.hip``.
 """
 import ctypes
@@ -13,7 +13,7 @@ import torch
 from . import _ffi
 from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
-__all__ = ["param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
+__all__ = ["dropout_factors", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
 
 
 def param_names(depth):
@@ -48,11 +48,14 @@ class DenoiserTrainFn(torch.autograd.Function):
     them, agent :1011-1014)."""
 
     @staticmethod
-    def forward(ctx, depth, precision, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
+    def forward(ctx, depth, precision, dropout, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
         names = param_names(depth)
         if precision not in PRECISIONS:
             raise ValueError(f"precision {precision!r}: one of {sorted(PRECISIONS)}")
         prec = PRECISIONS[precision]
+        drop_p, drop_seed = (0.0, 0) if not dropout else (float(dropout[0]), int(dropout[1]) & (2 ** 64 - 1))
+        if not 0.0 <= drop_p < 1.0:
+            raise ValueError(f"dropout probability {drop_p}")
         if len(params) != len(names):
             raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
         B, _, N = x.shape
@@ -84,12 +87,13 @@ class DenoiserTrainFn(torch.autograd.Function):
             _ffi.check(lib.dfx_denoiser_train_forward(ctypes.byref(w), ws_ptr, nbytes, x.data_ptr(), t32.data_ptr(),
                                                       ctx_code.data_ptr(), ctx_mv.data_ptr(), anchors.data_ptr(),
                                                       variances.data_ptr(), None if vld is None else vld.data_ptr(),
-                                                      asg.data_ptr(), eps.data_ptr(), B, N, prec, _ffi.current_stream()),
+                                                      asg.data_ptr(), eps.data_ptr(), B, N, prec, drop_p, drop_seed, _ffi.current_stream()),
                        "dfx_denoiser_train_forward")
         ctx.depth, ctx.shape, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.prec = depth, (B, N), ws, ws_ptr, nbytes, prec
+        ctx.drop = (drop_p, drop_seed)
         ctx.tensors = tensors
         ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
-        ctx.need_ctx = (ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        ctx.need_ctx = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
         return eps
 
     @staticmethod
@@ -117,7 +121,7 @@ class DenoiserTrainFn(torch.autograd.Function):
             _ffi.check(_ffi.lib().dfx_denoiser_train_backward(ctypes.byref(w), ctx.ws_ptr, ctx.nbytes, d_eps.data_ptr(),
                                                               ctypes.byref(g), None if d_code is None else d_code.data_ptr(),
                                                               None if d_mv is None else d_mv.data_ptr(), B, N,
-                                                              ctx.prec, _ffi.current_stream()),
+                                                              ctx.prec, ctx.drop[0], ctx.drop[1], _ffi.current_stream()),
                        "dfx_denoiser_train_backward")
         ctx.ws = None
         # Leaf parameters get their slice of the flat buffer assigned to .grad directly (accumulating if one is already
@@ -134,17 +138,30 @@ class DenoiserTrainFn(torch.autograd.Function):
                     leaf.grad.add_(grads[n])
                 out.append(None)
         ctx.leaves = None
-        return (None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(out)
 
 
-def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, precision="f32"):
+def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, precision="f32", dropout=None):
     """`params`: dict state_dict-key -> fp32 cuda tensor (requires_grad as the caller wishes) of a TransformerNet.
-    precision "f32": exact fp32 (parity gate); "bf16": bf16 operands / fp32 accumulate for the matrix products."""
+    precision "f32": exact fp32 (parity gate); "bf16": bf16 operands / fp32 accumulate for the matrix products.
+    dropout: None, or (p, seed): nn.Dropout(p) of train() mode behind every to_out and GEGLU, Philox factors keyed by
+    `seed` (a fresh integer per step; the backward of this call regenerates the same factors)."""
     depth = 0
     while f"transformer_blocks.{depth}.norm2.weight" in params:
         depth += 1
-    return DenoiserTrainFn.apply(depth, precision, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
+    return DenoiserTrainFn.apply(depth, precision, dropout, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
                                  *[params[n] for n in param_names(depth)])
+
+
+def dropout_factors(seed, site, p, n, device="cuda"):
+    """The factors (0 or 1/(1-p)) the training kernels apply to `n` consecutive elements of a dropout site (tests / debugging):
+    site 2 i = behind to_out of block i over (B N, 128); 2 i + 1 = behind the GEGLU of block i over (B N, 512); 1000 =
+    time_embed over (B, 1024)."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _ffi.check(_ffi.lib().dfx_debug_dropout_factors(int(seed) & (2 ** 64 - 1), int(site), float(p), out.data_ptr(), n,
+                                                        _ffi.current_stream()), "dfx_debug_dropout_factors")
+    return out
 
 
 class MaskedMSEFn(torch.autograd.Function):

@@ -350,13 +350,18 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
 /* ------------------------------------------------------------------------------------------
  * Training-mode denoiser: forward with saved activations, backward, loss gradient, optimizer.
  * Replaces autograd through TransformerNet.forward / _forward_attn (python/difffacto/models/networks/attention.py:385-440;
- * BasicTransformerBlock :296-306, CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94; dropout = 0), the
+ * BasicTransformerBlock :296-306, CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94; nn.Dropout optional, see below), the
  * mse_loss of AnchoredDiffusion.training_losses (anchored_diffusion.py:840-847), and Runner.train's
  * clip_grad_norm_ + Adam.step (runner.py:312-316, optimizers.py:4-16).
  *   precision DFX_PREC_F32: exact fp32 throughout (the parity gate).  DFX_PREC_BF16: the large matrix products (every
  *   linear layer over the B*N points: forward, dX, dW) round their operands to bf16 on the way into LDS and accumulate
  *   in fp32 (v_mfma_f32_32x32x16_bf16); activations, gradients, LayerNorm / softmax / GELU and the optimiser stay fp32.
  *   The same value must be passed to the forward and the backward of one step.
+ *   dropout_p in [0, 1): nn.Dropout of train() mode behind every to_out (attention.py:177) and GEGLU (:84, time_embed
+ *   included); factors come from Philox4x32-10 keyed by dropout_seed with counter (element group, site) and are
+ *   regenerated by the backward (pass the same p and seed); torch's own CUDA dropout stream is launch-geometry dependent
+ *   and not reproducible, so this is libdfx's contract, checked against torch autograd by replaying the factors
+ *   (dfx_debug_dropout_factors).
  *   x (B,3,N); t (B,) int32; ctx_code (B,256,4) and ctx_mv (B,6,4) = the two tensors of the reference's ctx list;
  *   anchors, variances (B,N,3) per point (the caller's gather, as at anchored_diffusion.py:261); valid (B,4) 0/1 or
  *   NULL; assignment (B,N) int32; eps (B,3,N).
@@ -369,10 +374,10 @@ size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth);
 int dfx_denoiser_train_forward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes, const float *x,
                                const int32_t *t, const float *ctx_code, const float *ctx_mv, const float *anchors,
                                const float *variances, const float *valid, const int32_t *assignment, float *eps, int B,
-                               int N, int precision, dfx_stream_t stream);
+                               int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream);
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, int precision, dfx_stream_t stream);
+                                int B, int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream);
 /* d loss / d pred of dfx_masked_mse_f32, times grad_scale; workspace2 = the two doubles its forward left behind */
 int dfx_masked_mse_backward_f32(const float *target, const float *pred, const float *flags, const double *workspace2,
                                 float grad_scale, float *d_pred, int B, int N, dfx_stream_t stream);
@@ -383,6 +388,9 @@ int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       dfx_stream_t stream);
 
+/* Dropout factors (0 or 1/(1-p)) of n consecutive elements of a site: 2 i = behind to_out of block i over (B N, 128),
+ * 2 i + 1 = behind the GEGLU of block i over (B N, 512), 1000 = time_embed over (B, 1024).  n % 4 == 0. */
+int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream);
 /* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
  * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
  * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */

@@ -25,12 +25,16 @@ def timestep_embedding(t, dim=256, max_period=10000):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
-def feed_forward(x, W, p):
+def feed_forward(x, W, p, drop=None):
+    """drop: explicit dropout factors (0 or 1/(1-p)) behind the GEGLU (attention.py:84), or None (eval mode)."""
     a, g = F.linear(x, W[p + "net.0.proj.weight"], W[p + "net.0.proj.bias"]).chunk(2, dim=-1)
-    return F.linear(a * F.gelu(g), W[p + "net.2.weight"], W[p + "net.2.bias"])
+    h = a * F.gelu(g)
+    if drop is not None:
+        h = h * drop
+    return F.linear(h, W[p + "net.2.weight"], W[p + "net.2.bias"])
 
 
-def cross_attention(x, context, mask, W, p, heads=8):
+def cross_attention(x, context, mask, W, p, heads=8, drop=None):
     B, N, _ = x.shape
     J = context.shape[1]
     q, k, v = F.linear(x, W[p + "to_q.weight"]), F.linear(context, W[p + "to_k.weight"]), F.linear(context, W[p + "to_v.weight"])
@@ -40,23 +44,26 @@ def cross_attention(x, context, mask, W, p, heads=8):
     if mask is not None:
         sim = sim.masked_fill(~mask.bool()[:, None, None, :], -torch.finfo(sim.dtype).max)
     out = torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v).transpose(1, 2).reshape(B, N, heads * d)
-    return F.linear(out, W[p + "to_out.0.weight"], W[p + "to_out.0.bias"])
+    out = F.linear(out, W[p + "to_out.0.weight"], W[p + "to_out.0.bias"])
+    return out if drop is None else out * drop   # to_out = Sequential(Linear, Dropout)  (attention.py:177)
 
 
-def transformer_net_forward(W, x, t, ctx_list, anchors, variances, valid_id, anchor_assignment, n_class=4, depth=5):
+def transformer_net_forward(W, x, t, ctx_list, anchors, variances, valid_id, anchor_assignment, n_class=4, depth=5, drops=None):
     """Arguments as oracle.denoiser.transformer_net_forward, torch CPU tensors; returns eps (B,3,N)."""
     B = x.shape[0]
     ctx = torch.cat(ctx_list, dim=1).transpose(1, 2)
     ctx = torch.cat([ctx, torch.eye(n_class)[None].expand(B, -1, -1)], dim=-1)
-    t_emb = feed_forward(timestep_embedding(t), W, "time_embed.")
+    drops = drops or {}   # explicit dropout factors: {"te": (B,1024), ("attn", i): (B,N,128), ("ff", i): (B,N,512)}
+    t_emb = feed_forward(timestep_embedding(t), W, "time_embed.", drops.get("te"))
     ctx = torch.cat([ctx, t_emb[:, None, :].expand(-1, ctx.shape[1], -1)], dim=-1)
     onehot = F.one_hot(anchor_assignment.long(), n_class).float()
     h = torch.cat([x.transpose(1, 2), anchors, variances, onehot], dim=-1)
     h = F.layer_norm(F.linear(h, W["proj_in.weight"], W["proj_in.bias"]), (128,), W["pre_norm.weight"], W["pre_norm.bias"])
     for i in range(depth):
         p = f"transformer_blocks.{i}."
-        h = cross_attention(F.layer_norm(h, (128,), W[p + "norm2.weight"], W[p + "norm2.bias"]), ctx, valid_id, W, p + "attn2.") + h
-        h = feed_forward(F.layer_norm(h, (128,), W[p + "norm3.weight"], W[p + "norm3.bias"]), W, p + "ff.") + h
+        h = cross_attention(F.layer_norm(h, (128,), W[p + "norm2.weight"], W[p + "norm2.bias"]), ctx, valid_id, W, p + "attn2.",
+                            drop=drops.get(("attn", i))) + h
+        h = feed_forward(F.layer_norm(h, (128,), W[p + "norm3.weight"], W[p + "norm3.bias"]), W, p + "ff.", drops.get(("ff", i))) + h
     h = F.layer_norm(h, (128,), W["post_norm.weight"], W["post_norm.bias"])
     return F.linear(h, W["proj_out.weight"], W["proj_out.bias"]).transpose(1, 2)
 

@@ -18,8 +18,9 @@ def masked_mse(target, pred, flags):
     return (d * flags).mean(dim=1).sum() / flags.sum()
 
 
-def loss_and_grads(W, x_t, t, ctx_code, ctx_mv, anchors_pt, variances_pt, valid, assignment, noise, flags):
+def loss_and_grads(W, x_t, t, ctx_code, ctx_mv, anchors_pt, variances_pt, valid, assignment, noise, flags, drops=None):
     """W: dict name -> float32 numpy array.  x_t, noise (B,3,N); anchors_pt, variances_pt (B,N,3); flags (B,1,N) or None.
+    drops: explicit dropout factors as numpy arrays, keys as in oracle.torch_cpu.transformer_net_forward, or None.
     Returns dict(loss, eps, grads{name: array}, d_ctx_code, d_ctx_mv) as numpy."""
     Wt = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in W.items()}
     cc = torch.from_numpy(np.ascontiguousarray(ctx_code)).clone().requires_grad_(True)
@@ -30,7 +31,7 @@ def loss_and_grads(W, x_t, t, ctx_code, ctx_mv, anchors_pt, variances_pt, valid,
     eps = torch_cpu.transformer_net_forward(Wt, torch.from_numpy(x_t), torch.from_numpy(np.asarray(t, dtype=np.int64)), [cc, cm],
                                             torch.from_numpy(anchors_pt), torch.from_numpy(variances_pt),
                                             None if valid is None else torch.from_numpy(valid), torch.from_numpy(np.asarray(assignment)),
-                                            depth=depth)
+                                            depth=depth, drops=None if drops is None else {k: torch.from_numpy(v) for k, v in drops.items()})
     loss = masked_mse(torch.from_numpy(noise), eps, None if flags is None else torch.from_numpy(flags))
     loss.backward()
     return dict(loss=float(loss.detach()), eps=eps.detach().numpy(), grads={k: v.grad.numpy() for k, v in Wt.items() if v.grad is not None},

@@ -17,7 +17,7 @@ from _train_case import check_against_golden, load_case  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _run(case, with_flags=True, precision="f32"):
+def _run(case, with_flags=True, precision="f32", dropout=None):
     from difffacto_amd import training
     dev = "cuda"
     P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in case["W"].items()}
@@ -26,7 +26,7 @@ def _run(case, with_flags=True, precision="f32"):
     eps = training.denoiser_train_forward(P, torch.from_numpy(case["x_t"]).to(dev), torch.from_numpy(case["t"]).to(dev), cc, cm,
                                           torch.from_numpy(case["anchors_pt"]).to(dev), torch.from_numpy(case["variances_pt"]).to(dev),
                                           None if case["valid"] is None else torch.from_numpy(case["valid"]).to(dev),
-                                          torch.from_numpy(case["assignment"]).to(dev), precision=precision)
+                                          torch.from_numpy(case["assignment"]).to(dev), precision=precision, dropout=dropout)
     flags = torch.from_numpy(case["flags"]).to(dev) if with_flags and case["flags"] is not None else None
     loss = training.masked_mse(torch.from_numpy(case["noise"]).to(dev), eps, flags)
     loss.backward()
@@ -154,6 +154,48 @@ def test_bf16_matrix_products_within_stated_tolerance():
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
 
 
+def test_dropout_factors_and_replayed_mask_parity():
+    """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
+    seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the
+    torch-CPU oracle at the reference's dropout sites (behind to_out, behind the GEGLU, time_embed included)."""
+    from difffacto_amd import synth, training
+    from oracle import train
+    p, seed = 0.2, 123456789
+    f = training.dropout_factors(seed, 3, p, 1 << 20).cpu().numpy()
+    assert set(np.unique(f)) == {0.0, np.float32(1.0 / (1.0 - p))}
+    assert abs((f == 0).mean() - p) < 3e-3
+    assert not np.array_equal(f, training.dropout_factors(seed, 5, p, 1 << 20).cpu().numpy())
+    assert not np.array_equal(f, training.dropout_factors(seed + 1, 3, p, 1 << 20).cpu().numpy())
+    B, N = 2, 96
+    rng = np.random.Generator(np.random.PCG64(5))
+    W = synth.make_denoiser_weights(3)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=4, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    drops = {"te": training.dropout_factors(seed, 1000, p, B * 1024).cpu().numpy().reshape(B, 1024)}
+    for i in range(5):
+        drops[("attn", i)] = training.dropout_factors(seed, 2 * i, p, B * N * 128).cpu().numpy().reshape(B, N, 128)
+        drops[("ff", i)] = training.dropout_factors(seed, 2 * i + 1, p, B * N * 512).cpu().numpy().reshape(B, N, 512)
+    ref = train.loss_and_grads(**c, drops=drops)
+    r = _run(c, True, dropout=(p, seed))
+    r0 = _run(c, True)
+    assert abs(r["loss"] - r0["loss"]) > 1e-3                      # dropout did something
+    assert abs(r["loss"] - ref["loss"]) < 5e-6 * max(1.0, abs(ref["loss"]))
+    assert np.abs(r["eps"] - ref["eps"]).max() < 3e-5
+    for k, gr in ref["grads"].items():
+        scale = max(np.abs(gr).max(), 1e-30)
+        assert np.abs(r["grads"][k] - gr).max() <= 5e-4 * scale + 1e-7, k
+    for k in ("d_ctx_code", "d_ctx_mv"):
+        assert np.abs(r[k] - ref[k]).max() <= 5e-4 * np.abs(ref[k]).max() + 1e-8, k
+
+
 def test_adam_with_clipping_matches_torch():
     """Three steps of dfx Adam + clip_grad_norm_(max_norm) against torch.optim.Adam + torch.nn.utils.clip_grad_norm_ on
     the CPU (what Runner.train does, runner.py:312-316), on tensors of awkward sizes."""
@@ -206,7 +248,7 @@ def test_train_entry_points_reject_bad_arguments():
     assert lib.dfx_denoiser_train_workspace_bytes(2, 64, 5) > 0
     w = _ffi.DenoiserWeights()
     w.depth = 5
-    rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, 0, None)
+    rc = lib.dfx_denoiser_train_forward(w, None, 0, None, None, None, None, None, None, None, None, None, 2, 64, 0, 0.0, 0, None)
     assert rc != 0 and b"null" in lib.dfx_last_error()
 
 
@@ -237,8 +279,16 @@ def test_module_api_training_losses_backward_like_the_reference():
     before = d.model.proj_out.weight.detach().clone()
     opt.step()
     assert not torch.equal(before, d.model.proj_out.weight.detach())
-    # dropout > 0 in train mode is refused (no native dropout)
-    d2 = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.2)}).cuda().train()
-    with pytest.raises(NotImplementedError):
-        d2.training_losses(cu(g["x_start"]), cu(g["t"]), anchors=anchors, variance=variance, ctx=ctx, anchor_assignment=cu(c["assignment"]),
-                           valid_id=cu(c["valid"]), flags=cu(c["flags"]), noise=cu(c["noise"]))
+    # dropout > 0 in train() mode: libdfx's Philox dropout; the loss differs from the p = 0 value and from step to step,
+    # and is reproducible under torch.manual_seed
+    d2 = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.2)})
+    d2.model.load_state_dict({k: torch.from_numpy(v) for k, v in c["W"].items()})
+    d2 = d2.cuda().train()
+    args = dict(anchors=anchors, variance=variance, ctx=ctx, anchor_assignment=cu(c["assignment"]), valid_id=cu(c["valid"]),
+                flags=cu(c["flags"]), noise=cu(c["noise"]))
+    torch.manual_seed(7)
+    l1 = float(d2.training_losses(cu(g["x_start"]), cu(g["t"]), **args)["mse_loss"].detach())
+    l2 = float(d2.training_losses(cu(g["x_start"]), cu(g["t"]), **args)["mse_loss"].detach())
+    torch.manual_seed(7)
+    l1b = float(d2.training_losses(cu(g["x_start"]), cu(g["t"]), **args)["mse_loss"].detach())
+    assert l1 == l1b and l1 != l2 and abs(l1 - float(g["loss"])) > 1e-4 and np.isfinite([l1, l2]).all()
