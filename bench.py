@@ -39,6 +39,48 @@ def flops_per_step(N, depth=5):
 SUSTAINED_BF16_TFLOPS = 1630.0   # 24 x 8 x 256 MFMAs of 32768 FLOP per 988 ns record (profiles/r01_ubench_power.txt)
 
 
+def train_iteration(Wnp, B, N, iters=4):
+    """Secondary figure (BASELINE configs[4]), outside the timed region of the headline metric: one training
+    iteration of the denoiser (forward with saved activations + backward + clip + Adam, bf16 matrix products) on the
+    same batch shape, wall-clock over `iters` iterations after two warm-ups."""
+    import numpy as np
+    import torch
+    from difffacto_amd import synth, training
+    try:
+        dev = "cuda"
+        P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in Wnp.items()}
+        pc, mean, logvar, valid = synth.make_latents(B, seed=1)
+        seg = synth.make_seg_mask(valid, N)
+        var = np.exp(logvar).astype(np.float32)
+        idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+        anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+        rng = np.random.default_rng(0)
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        a = [cu((anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32)), cu(rng.integers(0, 1000, size=(B,)).astype(np.int64)),
+             cu(pc), cu(np.concatenate([mean, var], 1).astype(np.float32)), cu(anc.transpose(0, 2, 1)), cu(vr.transpose(0, 2, 1)), cu(valid),
+             cu(seg.astype(np.int32))]
+        noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
+        opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
+
+        def it():
+            opt.zero_grad()
+            training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16"), None).backward()
+            opt.step()
+
+        for _ in range(2):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            it()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        return {"what": "denoiser forward + backward + clip + Adam, bf16 matrix products, fp32 master weights (tools/bench_train.py)",
+                "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters}
+    except Exception as e:   # secondary line: never fail the headline measurement
+        return {"error": repr(e)[:200]}
+
+
 def measured_traffic(T, B, N):
     """Fabric-side bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes, see
     profiles/README.md), which scales linearly with the number of diffusion steps; None if not applicable."""
@@ -117,6 +159,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-line", action="store_true", help="skip the secondary training-iteration measurement")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing ablations (invalid results)")
     ap.add_argument("--force-direct", action="store_true")
     args = ap.parse_args()
@@ -239,6 +282,8 @@ def main():
             res["roofline"]["frac_of_sustained"] = achieved / SUSTAINED_BF16_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(Wnp, N)
+        if world == 1 and not args.no_train_line and args.precision == "bf16":
+            res["train_iteration"] = train_iteration(Wnp, B, N)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

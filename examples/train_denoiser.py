@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--dropout", type=float, default=0.0, help="nn.Dropout p of the denoiser (train_chair_stage1.py: 0.2)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -40,7 +41,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl")   # RCCL on ROCm
-    net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=0.0, context_dim=256 + 6,
+    net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=a.dropout, context_dim=256 + 6,
                n_class=4, class_cond=True, use_linear=True, cat_params_to_x=True, use_checkpoint=False, single_attn=True,
                cat_class_to_x=True)
     diff = AnchoredDiffusion(net=net, num_timesteps=a.timesteps, beta_1=1e-4, beta_T=.02, k=1.0, res=False, mode='linear',
