@@ -114,6 +114,9 @@ SIGNATURES = {
     "dfx_denoiser_train_forward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P]),
     "dfx_denoiser_train_backward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, ctypes.POINTER(DenoiserWeights), _P, _P, _I, _I, _I, _F, _U64, _P]),
     "dfx_debug_dropout_factors": (_I, [_U64, _I, _F, _P, ctypes.c_longlong, _P]),
+    "dfx_pointnet_v2_train_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "dfx_pointnet_v2_train_forward": (_I, [ctypes.POINTER(PointNetV2Weights), _P, _SZ, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    "dfx_pointnet_v2_train_backward": (_I, [ctypes.POINTER(PointNetV2Weights), _P, _SZ, _P, _P, _P, ctypes.POINTER(PointNetV2Weights), _I, _I, _I, _P]),
     "dfx_debug_gemm_bf16": (_I, [_I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "dfx_masked_mse_backward_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "dfx_grad_sumsq_accumulate": (_I, [_P, ctypes.c_longlong, _P, _P, _P]),

@@ -613,6 +613,149 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// PointNetV2 part encoder in train mode (pointnet.py:187-213): BatchNorm with batch statistics over the rows, masked max-pool
+// ---------------------------------------------------------------------------------------------------------------
+// Column sums over a slab of rows: MODE 0: sum x;  MODE 1: sum (x - mean)^2  (the second pass of the two-pass variance).
+// grid (ceil(Cc / 64), nslab), 256 threads = 64 columns x 4 row groups; part[slab][Cc]
+constexpr int BN_SLAB = 512;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_col_stats(const float *__restrict__ x, const float *__restrict__ mean, float *__restrict__ part,
+                                                    long long R, int Cc) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float a = 0.f;
+  if (c < Cc) {
+    const float mu = MODE ? mean[c] : 0.f;
+    const long long r1 = ((long long)blockIdx.y + 1) * BN_SLAB < R ? ((long long)blockIdx.y + 1) * BN_SLAB : R;
+    for (long long r = (long long)blockIdx.y * BN_SLAB + rgp; r < r1; r += 4) {
+      const float v = x[r * Cc + c] - mu;
+      a += MODE ? v * v : v;
+    }
+  }
+  red[rgp][cl] = a;
+  __syncthreads();
+  if (rgp == 0 && c < Cc) part[(size_t)blockIdx.y * Cc + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+// sums -> mean;  centred sums of squares -> rstd (+ running statistics, nn.BatchNorm1d: unbiased variance, momentum)
+__global__ void k_bn_mean(const float *__restrict__ sum, float *__restrict__ mean, float invR, int Cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < Cc) mean[c] = sum[c] * invR;
+}
+__global__ void k_bn_rstd(const float *__restrict__ ssq, const float *__restrict__ mean, float *__restrict__ rstd, float *run_mean,
+                          float *run_var, float invR, float unbias, float eps, float momentum, int Cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cc) return;
+  const float var = ssq[c] * invR;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (momentum >= 0.f && run_mean && run_var) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
+  }
+}
+template <bool RELU>
+__global__ void k_bn_apply(const float *__restrict__ z, const float *__restrict__ mean, const float *__restrict__ rstd,
+                           const float *__restrict__ g, const float *__restrict__ b, float *__restrict__ y, long long total, int Cc) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= total) return;
+  const int c = (int)(i % Cc);
+  const v4f zv = *reinterpret_cast<const v4f *>(z + i), mu = *reinterpret_cast<const v4f *>(mean + c), rs = *reinterpret_cast<const v4f *>(rstd + c);
+  const v4f gv = *reinterpret_cast<const v4f *>(g + c), bv = *reinterpret_cast<const v4f *>(b + c);
+  v4f o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = (zv[e] - mu[e]) * rs[e] * gv[e] + bv[e];
+    if (RELU) o[e] = fmaxf(o[e], 0.f);
+  }
+  *reinterpret_cast<v4f *>(y + i) = o;
+}
+// backward, pass 1: gm = RELU ? dy (y > 0) : dy;  column sums of gm (d beta) and gm xhat (d gamma) -> part[slab][2][Cc]
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ z,
+                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                      float *__restrict__ part, long long R, int Cc) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float sb = 0.f, sg = 0.f;
+  if (c < Cc) {
+    const float mu = mean[c], rs = rstd[c];
+    const long long r1 = ((long long)blockIdx.y + 1) * BN_SLAB < R ? ((long long)blockIdx.y + 1) * BN_SLAB : R;
+    for (long long r = (long long)blockIdx.y * BN_SLAB + rgp; r < r1; r += 4) {
+      float gm = dy[r * Cc + c];
+      if (RELU && !(y[r * Cc + c] > 0.f)) gm = 0.f;
+      sb += gm;
+      sg += gm * (z[r * Cc + c] - mu) * rs;
+    }
+  }
+  red[0][rgp][cl] = sb, red[1][rgp][cl] = sg;
+  __syncthreads();
+  if (rgp == 0 && c < Cc) {
+    part[((size_t)blockIdx.y * 2) * Cc + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    part[((size_t)blockIdx.y * 2 + 1) * Cc + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  }
+}
+// pass 2: dz = gamma rstd (gm - d beta / R - xhat d gamma / R)
+template <bool RELU>
+__global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ z,
+                               const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
+                               const float *__restrict__ dbeta, const float *__restrict__ dgamma, float *__restrict__ dz, float invR,
+                               long long total, int Cc) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= total) return;
+  const int c = (int)(i % Cc);
+  const v4f dv = *reinterpret_cast<const v4f *>(dy + i), zv = *reinterpret_cast<const v4f *>(z + i);
+  v4f yv = {1.f, 1.f, 1.f, 1.f};
+  if (RELU) yv = *reinterpret_cast<const v4f *>(y + i);
+  v4f o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gm = (RELU && !(yv[e] > 0.f)) ? 0.f : dv[e];
+    const float xh = (zv[e] - mean[c + e]) * rstd[c + e];
+    o[e] = g[c + e] * rstd[c + e] * (gm - dbeta[c + e] * invR - xh * dgamma[c + e] * invR);
+  }
+  *reinterpret_cast<v4f *>(dz + i) = o;
+}
+// x (B,N,3) -> rows of 8 (zero padded)
+__global__ void k_pn_rows(const float *__restrict__ x, float *__restrict__ X8, long long R) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  reinterpret_cast<v4f *>(X8 + r * 8)[0] = v4f{x[r * 3], x[r * 3 + 1], x[r * 3 + 2], 0.f};
+  reinterpret_cast<v4f *>(X8 + r * 8)[1] = v4f{0.f, 0.f, 0.f, 0.f};
+}
+// pooled[b][a][c] = max_n y[b, n, c] attn[b, n, a] scale  (pointnet.py:194-198), with the arg max for the backward
+template <int A>
+__global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ y, const float *__restrict__ attn, float *__restrict__ pooled,
+                                                   int32_t *__restrict__ arg, int N, int Cc, float scale) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cc) return;
+  float best[A];
+  int bi[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) best[a] = -3.402823466e38f, bi[a] = 0;
+  for (int n = 0; n < N; ++n) {
+    const float v = y[((size_t)b * N + n) * Cc + c];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
+      if (w > best[a]) best[a] = w, bi[a] = n;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) pooled[((size_t)b * A + a) * Cc + c] = best[a], arg[((size_t)b * A + a) * Cc + c] = bi[a];
+}
+// dy (zero-initialised) [b, arg, c] += d pooled[b][a][c] attn[b, arg, a] scale; one thread per (b, c): no atomics
+template <int A>
+__global__ __launch_bounds__(256) void k_pool_bwd(const float *__restrict__ dpooled, const int32_t *__restrict__ arg,
+                                                   const float *__restrict__ attn, float *__restrict__ dy, int N, int Cc, float scale) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cc) return;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    const int n = arg[((size_t)b * A + a) * Cc + c];
+    dy[((size_t)b * N + n) * Cc + c] += dpooled[((size_t)b * A + a) * Cc + c] * attn[((size_t)b * N + n) * A + a] * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct Carver {
@@ -759,7 +902,13 @@ inline int pick_slab(long long R, long long tiles, long long target_blocks, size
   return (int)slab;
 }
 
-int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
+struct PartBufs {   // scratch of the two-pass reductions
+  float *part;
+  size_t part_floats;
+  float *bpart;
+  size_t bpart_floats;
+};
+int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
           int I_valid, long long R, bool dy_bf = false, bool x_bf = false) {
   bool done = false;
   int ns = 1;
@@ -791,6 +940,11 @@ int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, 
   return dfx::check_launch("train: wgrad");
 }
 
+inline int wgrad(hipStream_t st, TrainWs &w, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, int O, int I,
+                 int I_valid, long long R, bool dy_bf = false, bool x_bf = false) {
+  return wgrad(st, PartBufs{w.part, w.part_floats, w.bpart, w.bpart_floats}, dY, ldy, X, ldx, dW, db, O, I, I_valid, R, dy_bf, x_bf);
+}
+
 int ln_bwd(hipStream_t st, TrainWs &w, const float *dy, const float *x, const float *stats, const float *g, const float *resid,
            float *out, float *dg, float *db, long long R) {
   const int nb = (int)((R + LNB_ROWS - 1) / LNB_ROWS);
@@ -812,6 +966,110 @@ int check_args(const dfx_denoiser_weights *wt, const void *ws, size_t ws_bytes, 
   DFX_REQUIRE(ws_bytes >= need, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
   DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
   return DFX_OK;
+}
+
+// ---- PointNetV2 train mode: workspace and BatchNorm helpers ----
+struct PnWs {
+  float *X8, *z[4], *y[4], *mean[4], *rstd[4];
+  float *pooled;
+  int32_t *arg;
+  float *hz[2][2], *hy[2][2], *hmean[2][2], *hrstd[2][2];
+  // backward scratch
+  float *dA, *dB, *dpooled, *dh[2], *wpad, *wT, *sums;
+  PartBufs pb;
+};
+constexpr int PN_C[5] = {8, 128, 128, 256, 512};   // trunk widths (input padded 3 -> 8)
+size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int zdim) {
+  Carver c{static_cast<char *>(base)};
+  const size_t R = (size_t)B * N;
+  w.X8 = c.take<float>(R * 8);
+  for (int l = 0; l < 4; ++l) {
+    w.z[l] = c.take<float>(R * PN_C[l + 1]);
+    w.y[l] = c.take<float>(R * PN_C[l + 1]);
+    w.mean[l] = c.take<float>(PN_C[l + 1]);
+    w.rstd[l] = c.take<float>(PN_C[l + 1]);
+  }
+  w.pooled = c.take<float>((size_t)B * A * 512);
+  w.arg = c.take<int32_t>((size_t)B * A * 512);
+  const int hc[2] = {256, 128};
+  for (int k = 0; k < 2; ++k)
+    for (int l = 0; l < 2; ++l) {
+      w.hz[k][l] = c.take<float>((size_t)B * A * hc[l]);
+      w.hy[k][l] = c.take<float>((size_t)B * A * hc[l]);
+      w.hmean[k][l] = c.take<float>((size_t)A * hc[l]);
+      w.hrstd[k][l] = c.take<float>((size_t)A * hc[l]);
+    }
+  w.dA = c.take<float>(R * 512);
+  w.dB = c.take<float>(R * 512);
+  w.dpooled = c.take<float>((size_t)B * A * 512);
+  w.dh[0] = c.take<float>((size_t)B * A * 256);
+  w.dh[1] = c.take<float>((size_t)B * A * 256);
+  w.wpad = c.take<float>(128 * 8);
+  w.wT = c.take<float>((size_t)512 * 512);
+  w.sums = c.take<float>(4 * 1024);
+  const size_t nslab = (R + BN_SLAB - 1) / BN_SLAB;
+  size_t pf = nslab * 2 * 1024;                            // BatchNorm column-sum partials (up to A * 256 channels)
+  const size_t wg = (size_t)nslabs((long long)R) * 512 * 256;   // weight-gradient partials (conv4: 512 x 256)
+  if (wg > pf) pf = wg;
+  w.pb.part_floats = pf;
+  w.pb.part = c.take<float>(pf);
+  w.pb.bpart_floats = (size_t)2048 * 1024;
+  w.pb.bpart = c.take<float>(w.pb.bpart_floats);
+  return c.off;
+}
+
+// y = [relu] BN_train(z) over R rows; leaves mean / rstd behind and updates the running statistics when momentum >= 0
+int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, const float *g, const float *b, float *run_mean,
+           float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu) {
+  const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
+  const dim3 grid((Cc + 63) / 64, ns);
+  k_col_stats<0><<<grid, 256, 0, st>>>(z, nullptr, w.pb.part, R, Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
+  k_bn_mean<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, 1.0f / (float)R, Cc);
+  k_col_stats<1><<<grid, 256, 0, st>>>(z, mean, w.pb.part, R, Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
+  k_bn_rstd<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, rstd, run_mean, run_var, 1.0f / (float)R,
+                                              R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
+  const long long total = R * Cc;
+  if (relu) k_bn_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(z, mean, rstd, g, b, y, total, Cc);
+  else k_bn_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(z, mean, rstd, g, b, y, total, Cc);
+  return dfx::check_launch("train: bn_fwd");
+}
+// dz from dy (gradient at the output of [relu] BN); d gamma, d beta written
+int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *y, const float *z, long long R, int Cc, const float *g,
+           const float *mean, const float *rstd, float *dz, float *dgamma, float *dbeta, bool relu) {
+  const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
+  const dim3 grid((Cc + 63) / 64, ns);
+  if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
+  else k_bn_bwd_part<false><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part + Cc, dgamma, ns, Cc, 2 * Cc);
+  const long long total = R * Cc;
+  if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
+  else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
+  return dfx::check_launch("train: bn_bwd");
+}
+int check_pn(const dfx_pointnet_v2_weights *wt, const void *ws, size_t ws_bytes, int B, int N, const char *what) {
+  DFX_REQUIRE(wt && ws, "%s: null argument", what);
+  DFX_REQUIRE(wt->num_anchors == 4 && wt->zdim >= 4 && wt->zdim % 4 == 0, "%s: num_anchors 4 and zdim %% 4 == 0 required", what);
+  DFX_REQUIRE(B >= 2 && N >= 1, "%s: B >= 2 (BatchNorm over the batch in the heads) and N >= 1 required", what);
+  DFX_REQUIRE((long long)B * N < (1ll << 31), "%s: B*N too large", what);
+  PnWs t;
+  const size_t need = carve_pn(t, nullptr, B, N, wt->num_anchors, wt->zdim);
+  DFX_REQUIRE(ws_bytes >= need, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+  DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
+  return DFX_OK;
+}
+// grouped 1x1 convolution over B rows: group a reads columns a*cin.., writes a*cout..  (one launch, blockIdx.z = group)
+int glin(hipStream_t st, const float *X, const float *W, const float *b, float *Y, int B, int A, int cin, int cout) {
+  LinArgs a{};
+  a.M = B, a.N = cout, a.K = cin;
+  a.X = X, a.ldx = A * cin, a.x_gs = cin;
+  a.W = W, a.w_gs = (long long)cout * cin;
+  a.b = b, a.b_gs = cout;
+  a.Y = Y, a.ldy = A * cout, a.y_gs = cout;
+  dfx::lin::k_lin<dfx::lin::EPI_NONE><<<dim3((cout + 31) / 32, (B + 31) / 32, A), 64, 0, st>>>(a);
+  return dfx::check_launch("train: grouped linear");
 }
 
 }  // namespace
@@ -967,6 +1225,104 @@ int dfx_masked_mse_backward_f32(const float *target, const float *pred, const fl
   k_mse_bwd<<<(int)((total + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(target, pred, flags, workspace2, grad_scale, d_pred, N,
                                                                                total, 3.0 * (double)B * N);
   return dfx::check_launch("masked_mse_backward");
+}
+
+// ---- PointNetV2 part encoder, train mode (pointnet.py:187-213 with nn.BatchNorm1d in training: batch statistics) ----
+size_t dfx_pointnet_v2_train_workspace_bytes(int B, int N, int num_anchors, int zdim) {
+  if (B < 2 || N < 1 || num_anchors != 4 || zdim < 4) return 0;
+  PnWs t;
+  return carve_pn(t, nullptr, B, N, num_anchors, zdim);
+}
+
+int dfx_pointnet_v2_train_forward(const dfx_pointnet_v2_weights *wt, void *workspace, size_t workspace_bytes, const float *x,
+                                  const float *attn, float *m, float *v, float momentum, int B, int N, int precision,
+                                  dfx_stream_t stream) {
+  int rc = check_pn(wt, workspace, workspace_bytes, B, N, "pointnet_v2_train_forward");
+  if (rc) return rc;
+  DFX_REQUIRE(x && attn && m && v, "pointnet_v2_train_forward: null tensor");
+  DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "pointnet_v2_train_forward: precision %d", precision);
+  g_prec = precision;
+  hipStream_t st = dfx::as_stream(stream);
+  const int A = wt->num_anchors, zd = wt->zdim;
+  PnWs w;
+  carve_pn(w, workspace, B, N, A, zd);
+  const long long R = (long long)B * N;
+  k_pn_rows<<<(int)((R + 255) / 256), 256, 0, st>>>(x, w.X8, R);
+  k_pad_cols<<<(128 * 8 + 255) / 256, 256, 0, st>>>(wt->conv_w[0], w.wpad, 128, 3, 8);
+  for (int l = 0; l < 4; ++l) {
+    const float *in = l == 0 ? w.X8 : w.y[l - 1];
+    const int K = PN_C[l], Co = PN_C[l + 1];
+    if ((rc = lin(st, in, K, l == 0 ? w.wpad : wt->conv_w[l], wt->conv_b[l], w.z[l], Co, R, Co, K))) return rc;
+    if ((rc = bn_fwd(st, w, w.z[l], R, Co, wt->bn_w[l], wt->bn_b[l], mut(wt->bn_mean[l]), mut(wt->bn_var[l]), momentum, wt->bn_eps,
+                     w.mean[l], w.rstd[l], w.y[l], l < 3))) return rc;
+  }
+  const float scale = wt->reweight_by_anchor ? (float)A : 1.0f;
+  k_pool_fwd<4><<<dim3(2, B), 256, 0, st>>>(w.y[3], attn, w.pooled, w.arg, N, 512, scale);
+  const int hc[3] = {512, 256, 128};
+  for (int k = 0; k < 2; ++k) {
+    const float *in = w.pooled;
+    for (int l = 0; l < 2; ++l) {
+      if ((rc = glin(st, in, wt->head_w[k][l], wt->head_b[k][l], w.hz[k][l], B, A, hc[l], hc[l + 1]))) return rc;
+      if ((rc = bn_fwd(st, w, w.hz[k][l], B, A * hc[l + 1], wt->head_bn_w[k][l], wt->head_bn_b[k][l], mut(wt->head_bn_mean[k][l]),
+                       mut(wt->head_bn_var[k][l]), momentum, wt->bn_eps, w.hmean[k][l], w.hrstd[k][l], w.hy[k][l], true))) return rc;
+      in = w.hy[k][l];
+    }
+    if ((rc = glin(st, in, wt->head_w[k][2], wt->head_b[k][2], k == 0 ? m : v, B, A, 128, zd))) return rc;
+  }
+  return dfx::check_launch("pointnet_v2_train_forward");
+}
+
+int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *workspace, size_t workspace_bytes, const float *attn,
+                                   const float *dm, const float *dv, const dfx_pointnet_v2_weights *grads, int B, int N,
+                                   int precision, dfx_stream_t stream) {
+  int rc = check_pn(wt, workspace, workspace_bytes, B, N, "pointnet_v2_train_backward");
+  if (rc) return rc;
+  DFX_REQUIRE(attn && dm && dv && grads, "pointnet_v2_train_backward: null tensor");
+  DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "pointnet_v2_train_backward: precision %d", precision);
+  g_prec = precision;
+  hipStream_t st = dfx::as_stream(stream);
+  const int A = wt->num_anchors, zd = wt->zdim;
+  PnWs w;
+  carve_pn(w, workspace, B, N, A, zd);
+  const long long R = (long long)B * N;
+  DFX_HIP_TRY(hipMemsetAsync(w.dpooled, 0, sizeof(float) * (size_t)B * A * 512, st));
+  const int hc[4] = {512, 256, 128, zd};
+  for (int k = 0; k < 2; ++k) {
+    const float *dcur = k == 0 ? dm : dv;   // gradient at the output of head layer l (before its BatchNorm for l < 2)
+    for (int l = 2; l >= 0; --l) {
+      const int cin = hc[l], cout = hc[l + 1];
+      const float *in = l == 0 ? w.pooled : w.hy[k][l - 1];
+      const float *dz = dcur;
+      if (l < 2) {   // through relu + BatchNorm over the B rows
+        if ((rc = bn_bwd(st, w, dcur, w.hy[k][l], w.hz[k][l], B, A * cout, wt->head_bn_w[k][l], w.hmean[k][l], w.hrstd[k][l], w.dh[1],
+                         mut(grads->head_bn_w[k][l]), mut(grads->head_bn_b[k][l]), true))) return rc;
+        dz = w.dh[1];
+      }
+      for (int a = 0; a < A; ++a) {   // per-part weights: group a of the grouped 1x1 convolution
+        if ((rc = wgrad(st, w.pb, dz + a * cout, A * cout, in + a * cin, A * cin, mut(grads->head_w[k][l]) + (size_t)a * cout * cin,
+                        mut(grads->head_b[k][l]) + a * cout, cout, cin, cin, B))) return rc;
+        transpose(st, wt->head_w[k][l] + (size_t)a * cout * cin, w.wT, cout, cin);   // (cin, cout)
+        if (l == 0) {   // d pooled accumulates over the two heads
+          if ((rc = lin(st, dz + a * cout, A * cout, w.wT, nullptr, w.dpooled + a * cin, A * cin, B, cin, cout, w.dpooled + a * cin, A * cin))) return rc;
+        } else if ((rc = lin(st, dz + a * cout, A * cout, w.wT, nullptr, w.dh[0] + a * cin, A * cin, B, cin, cout))) return rc;
+      }
+      dcur = w.dh[0];
+    }
+  }
+  // max-pool: the gradient goes to the arg-max point of every (shape, part, channel)
+  DFX_HIP_TRY(hipMemsetAsync(w.dA, 0, sizeof(float) * (size_t)R * 512, st));
+  k_pool_bwd<4><<<dim3(2, B), 256, 0, st>>>(w.dpooled, w.arg, attn, w.dA, N, 512, wt->reweight_by_anchor ? (float)A : 1.0f);
+  float *dy = w.dA, *dz = w.dB;
+  for (int l = 3; l >= 0; --l) {
+    const int K = PN_C[l], Co = PN_C[l + 1];
+    if ((rc = bn_bwd(st, w, dy, w.y[l], w.z[l], R, Co, wt->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), l < 3))) return rc;
+    if ((rc = wgrad(st, w.pb, dz, Co, l == 0 ? w.X8 : w.y[l - 1], K, mut(grads->conv_w[l]), mut(grads->conv_b[l]), Co, K, l == 0 ? 3 : K, R))) return rc;
+    if (l > 0) {
+      transpose(st, wt->conv_w[l], w.wT, Co, K);   // (K, Co)
+      if ((rc = lin(st, dz, Co, w.wT, nullptr, dy, K, R, K, Co))) return rc;
+    }
+  }
+  return dfx::check_launch("pointnet_v2_train_backward");
 }
 
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them

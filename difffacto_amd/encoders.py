@@ -35,8 +35,9 @@ def _unsupported(what):
 class PointNetV2(nn.Module):
     """``ENCODERS['PointNetV2']`` (python/difffacto/models/encoders/pointnet.py:124-213): per-point MLP, attention-weighted
     max-pool per part, per-part heads -> (m, v) of shape (B, num_anchors, zdim).  Same constructor arguments and parameter
-    names.  In inference (eval + no_grad) the whole forward is ``dfx_pointnet_v2_forward_f32``; with gradients / batch
-    statistics it runs on the module's own torch layers."""
+    names.  In inference (eval + no_grad) the whole forward is ``dfx_pointnet_v2_forward_f32``; in train() mode forward and
+    backward are ``dfx_pointnet_v2_train_forward / _backward`` (batch-statistics BatchNorm); only eval-mode statistics WITH
+    autograd fall back to the module's own torch layers."""
 
     def __init__(self, point_dim=3, zdim=1024, num_anchors=4, reweight_by_anchor=True, use_ln=False, per_part_mlp=False):
         super().__init__()
@@ -117,7 +118,22 @@ class PointNetV2(nn.Module):
                                                             B, N, _ffi.current_stream())
             _ffi.check(rc, "dfx_pointnet_v2_forward_f32")
             return m, v
-        # autograd / batch-statistics path on the module's own layers
+        if self.training and x.is_cuda and B >= 2 and A == 4 and self.zdim % 4 == 0:
+            # train() mode: batch-statistics BatchNorm forward (running statistics updated in place like nn.BatchNorm1d) and
+            # the backward on libdfx's training kernels (exact fp32; difffacto_amd/training.py)
+            from . import training as _training
+            sd_p, sd_b = dict(self.named_parameters()), dict(self.named_buffers())
+            momentum = self.bn1.momentum if self.bn1.momentum is not None else 0.1
+            m, v = _training.pointnet_v2_train_forward(sd_p, sd_b, x, attn_weight, num_anchors=A, zdim=self.zdim,
+                                                       reweight_by_anchor=self.reweight_by_anchor, eps=self.bn1.eps, momentum=momentum,
+                                                       precision="f32")
+            with torch.no_grad():
+                for mod in self.modules():
+                    if isinstance(mod, nn.BatchNorm1d) and mod.num_batches_tracked is not None:
+                        mod.num_batches_tracked += 1
+            self.__dict__["_ver"] = None      # the running statistics changed under the eval handle's feet
+            return m, v
+        # eval-mode statistics with autograd, CPU tensors, B = 1: the module's own torch layers
         h = x.transpose(1, 2)
         for i in (1, 2, 3):
             h = F.relu(getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h)))

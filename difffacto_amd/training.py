@@ -13,7 +13,7 @@ import torch
 from . import _ffi
 from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
-__all__ = ["dropout_factors", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
+__all__ = ["dropout_factors", "pointnet_v2_train_forward", "PointNetV2TrainFn", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
 
 
 def param_names(depth):
@@ -151,6 +151,116 @@ def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, v
         depth += 1
     return DenoiserTrainFn.apply(depth, precision, dropout, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
                                  *[params[n] for n in param_names(depth)])
+
+
+def _flat_slices(shapes, device):
+    """One zero-initialised flat fp32 buffer and a view per shape, every view starting on a 256-byte boundary (see
+    DenoiserTrainFn.backward)."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    starts, off = [], 0
+    for k in sizes:
+        starts.append(off)
+        off += (k + 63) // 64 * 64
+    flat = torch.zeros(off, dtype=torch.float32, device=device)
+    return [flat[o:o + k].view(s) for o, k, s in zip(starts, sizes, shapes)]
+
+
+def _assign_or_return(leaves, grads):
+    """Leaf parameters get `.grad` assigned (accumulated) directly and None is returned for them; others get the gradient back."""
+    out = []
+    for leaf, g in zip(leaves, grads):
+        if leaf is None:
+            out.append(g)
+        else:
+            if leaf.grad is None:
+                leaf.grad = g
+            else:
+                leaf.grad.add_(g)
+            out.append(None)
+    return out
+
+
+PNV2_PARAMS = [f"conv{i}.{k}" for i in (1, 2, 3, 4) for k in ("weight", "bias")] + [f"bn{i}.{k}" for i in (1, 2, 3, 4) for k in ("weight", "bias")] + \
+              [f"{h}.{i}.{k}" for h in ("mlp_m", "mlp_v") for i in (0, 1, 3, 4, 6) for k in ("weight", "bias")]
+PNV2_BUFFERS = [f"bn{i}.{k}" for i in (1, 2, 3, 4) for k in ("running_mean", "running_var")] + \
+               [f"{h}.{i}.{k}" for h in ("mlp_m", "mlp_v") for i in (1, 4) for k in ("running_mean", "running_var")]
+
+
+def _pnv2_struct(t, num_anchors, zdim, reweight, eps):
+    """dfx_pointnet_v2_weights over the dict `t` (state_dict names -> contiguous fp32 cuda tensors; missing names stay NULL)."""
+    w = _ffi.PointNetV2Weights()
+    w.num_anchors, w.zdim, w.reweight_by_anchor, w.bn_eps = num_anchors, zdim, int(reweight), float(eps)
+    ptr = lambda n: t[n].data_ptr() if n in t else None
+    for i in range(4):
+        w.conv_w[i], w.conv_b[i] = ptr(f"conv{i + 1}.weight"), ptr(f"conv{i + 1}.bias")
+        w.bn_w[i], w.bn_b[i] = ptr(f"bn{i + 1}.weight"), ptr(f"bn{i + 1}.bias")
+        w.bn_mean[i], w.bn_var[i] = ptr(f"bn{i + 1}.running_mean"), ptr(f"bn{i + 1}.running_var")
+    for k, h in enumerate(("mlp_m", "mlp_v")):
+        for l, ci in enumerate((0, 3, 6)):
+            w.head_w[k][l], w.head_b[k][l] = ptr(f"{h}.{ci}.weight"), ptr(f"{h}.{ci}.bias")
+        for l, bi in enumerate((1, 4)):
+            w.head_bn_w[k][l], w.head_bn_b[k][l] = ptr(f"{h}.{bi}.weight"), ptr(f"{h}.{bi}.bias")
+            w.head_bn_mean[k][l], w.head_bn_var[k][l] = ptr(f"{h}.{bi}.running_mean"), ptr(f"{h}.{bi}.running_var")
+    return w
+
+
+class PointNetV2TrainFn(torch.autograd.Function):
+    """(m, v) = PointNetV2(x, attn) in train mode (pointnet.py:187-213, BatchNorm with batch statistics), differentiable in
+    the parameters; the running statistics in `buffers` are updated in place when momentum >= 0."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, attn, buffers, *params):
+        num_anchors, zdim, reweight, eps, momentum, precision = cfg
+        if len(params) != len(PNV2_PARAMS):
+            raise ValueError(f"expected {len(PNV2_PARAMS)} parameter tensors")
+        t = {n: _need(p.detach(), n) for n, p in zip(PNV2_PARAMS, params)}
+        for n, b in zip(PNV2_BUFFERS, buffers):
+            t[n] = _need(b.detach(), n)
+        x = _need(x.detach().to(torch.float32).contiguous(), "x")
+        attn = _need(attn.detach().to(device=x.device, dtype=torch.float32).contiguous(), "attn_weight")
+        B, N, _ = x.shape
+        prec = PRECISIONS[precision]
+        lib = _ffi.lib()
+        nbytes = lib.dfx_pointnet_v2_train_workspace_bytes(B, N, num_anchors, zdim)
+        if nbytes == 0:
+            raise ValueError(f"unsupported PointNetV2 training shape B={B} N={N} num_anchors={num_anchors}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        m = torch.empty(B, num_anchors, zdim, dtype=torch.float32, device=x.device)
+        v = torch.empty_like(m)
+        w = _pnv2_struct(t, num_anchors, zdim, reweight, eps)
+        with torch.cuda.device(x.device):
+            _ffi.check(lib.dfx_pointnet_v2_train_forward(ctypes.byref(w), ws_ptr, nbytes, x.data_ptr(), attn.data_ptr(), m.data_ptr(),
+                                                         v.data_ptr(), float(momentum), B, N, prec, _ffi.current_stream()),
+                       "dfx_pointnet_v2_train_forward")
+        ctx.cfg, ctx.t, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.attn, ctx.shape, ctx.prec = cfg, t, ws, ws_ptr, nbytes, attn, (B, N), prec
+        ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
+        return m, v
+
+    @staticmethod
+    def backward(ctx, dm, dv):
+        num_anchors, zdim, reweight, eps, momentum, precision = ctx.cfg
+        B, N = ctx.shape
+        dm = _need(dm.contiguous(), "dm")
+        dv = _need(dv.contiguous(), "dv")
+        views = _flat_slices([ctx.t[n].shape for n in PNV2_PARAMS], dm.device)
+        g = dict(zip(PNV2_PARAMS, views))
+        w, gw = _pnv2_struct(ctx.t, num_anchors, zdim, reweight, eps), _pnv2_struct(g, num_anchors, zdim, reweight, eps)
+        with torch.cuda.device(dm.device):
+            _ffi.check(_ffi.lib().dfx_pointnet_v2_train_backward(ctypes.byref(w), ctx.ws_ptr, ctx.nbytes, ctx.attn.data_ptr(),
+                                                                 dm.data_ptr(), dv.data_ptr(), ctypes.byref(gw), B, N, ctx.prec,
+                                                                 _ffi.current_stream()), "dfx_pointnet_v2_train_backward")
+        ctx.ws = None
+        out = _assign_or_return(ctx.leaves, views)
+        ctx.leaves = None
+        return (None, None, None, None) + tuple(out)
+
+
+def pointnet_v2_train_forward(params, buffers, x, attn, num_anchors=4, zdim=256, reweight_by_anchor=True, eps=1e-5, momentum=0.1,
+                              precision="f32"):
+    """`params` / `buffers`: dicts with the state_dict names of PointNetV2 (fp32 cuda tensors).  Returns (m, v)."""
+    return PointNetV2TrainFn.apply((num_anchors, zdim, reweight_by_anchor, eps, momentum, precision), x, attn,
+                                   [buffers[n] for n in PNV2_BUFFERS], *[params[n] for n in PNV2_PARAMS])
 
 
 def dropout_factors(seed, site, p, n, device="cuda"):

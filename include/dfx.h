@@ -334,6 +334,20 @@ void dfx_pointnet_v2_destroy(dfx_pointnet_v2 *h);
 int dfx_pointnet_v2_forward_f32(dfx_pointnet_v2 *h, const float *x, const float *attn, float *m, float *v, int B, int N,
                                 dfx_stream_t stream);
 
+/* The same encoder in TRAIN mode (nn.BatchNorm1d with batch statistics over the B N points / over the B shapes in the heads) and
+ * its backward (encoder side): m, v as above; the backward takes d m, d v (B,num_anchors,zdim) and writes the
+ * gradients of conv / BatchNorm / head weights and biases into `grads` (same struct, writable pointers; its running-statistics
+ * pointers are ignored).  momentum >= 0 updates the running statistics in place like nn.BatchNorm1d (unbiased variance),
+ * momentum < 0 leaves them alone.  workspace: dfx_pointnet_v2_train_workspace_bytes(B, N, 4, zdim), 256-byte aligned, shared
+ * by the forward and the backward of one step.  num_anchors = 4, B >= 2.  precision as for the denoiser. */
+size_t dfx_pointnet_v2_train_workspace_bytes(int B, int N, int num_anchors, int zdim);
+int dfx_pointnet_v2_train_forward(const dfx_pointnet_v2_weights *w, void *workspace, size_t workspace_bytes, const float *x,
+                                  const float *attn, float *m, float *v, float momentum, int B, int N, int precision,
+                                  dfx_stream_t stream);
+int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *w, void *workspace, size_t workspace_bytes, const float *attn,
+                                   const float *dm, const float *dv, const dfx_pointnet_v2_weights *grads, int B, int N,
+                                   int precision, dfx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Approximate EMD by auction — replaces the `emd` extension
  * (python/difffacto/metrics/emd/emd_cuda.cu: forward :236-284, backward :286-316; bound in emd_module.py:17-51).

@@ -25,6 +25,8 @@ train_grads_*.npz    autograd through TransformerNet in TRAIN mode with every Dr
                      SURVEY.md §7 config 5): eps, the masked mse_loss of training_losses, and d loss / d (every parameter,
                      both ctx tensors).  Gradients of tensors with more than 4096 elements are stored as
                      (sum, L2 norm, 1024 elements at seeded positions) to keep the fixture small
+pointnet_v2_train_*.npz  the same class in TRAIN mode (batch-statistics BatchNorm): m, v, the running statistics it leaves behind, and
+                     autograd gradients of sum(m dm) + sum(v dv) for every parameter (large tensors as sum / L2 norm / 1024 samples)
 pointnet_v2_*.npz    PointNetV2.forward (pointnet.py:187-213, eval-mode BatchNorm), the encode-side part encoder
 pn2_torch_*.npz      ball-query / grouping semantics from the reference's pure-torch PointNet++
                      (models/encoders/pointnet2_utils.py:84-104,41-57)
@@ -272,6 +274,44 @@ def gen_train_grads(model, tag, B, N, seed, T):
     print("wrote train_grads_" + tag, float(loss), ndrop, "dropouts zeroed;", len(out), "arrays")
 
 
+def gen_pointnet_v2_train(model, tag, B, N, seed):
+    """PointNetV2 (pointnet.py:187-213) in train() mode + loss.backward(), from the reference class itself."""
+    enc = model.encoder.encoder
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = synth.make_pointnet_v2_weights(seed=0)
+    sd = enc.state_dict()
+    for k, a in W.items():
+        sd[k] = torch.from_numpy(a.copy())
+    enc.load_state_dict(sd)
+    enc.train()
+    for p in enc.parameters():
+        p.grad = None
+    x = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    seg = rng.integers(0, 4, size=(B, N))
+    seg[0][seg[0] == 3] = 0
+    attn = np.eye(4, dtype=F32)[seg]
+    dm = rng.standard_normal((B, 4, 256)).astype(F32)
+    dv = rng.standard_normal((B, 4, 256)).astype(F32)
+    m, v = enc(torch.from_numpy(x), torch.from_numpy(attn))
+    ((m * torch.from_numpy(dm)).sum() + (v * torch.from_numpy(dv)).sum()).backward()
+    out = {"m": m.detach().numpy().astype(F32), "v": v.detach().numpy().astype(F32)}
+    for k, t in enc.state_dict().items():
+        if "running" in k:
+            out["r/" + k] = t.numpy().astype(F32)
+    srng = np.random.Generator(np.random.PCG64(4243))
+    for name, p in enc.named_parameters():
+        g = p.grad.numpy().astype(F32).ravel()
+        if g.size <= 4096:
+            out["g/" + name] = g
+        else:
+            idx = np.sort(srng.choice(g.size, size=1024, replace=False)).astype(np.int64)
+            out["gi/" + name], out["gs/" + name] = idx, g[idx]
+            out["gn/" + name] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+    enc.eval()
+    np.savez_compressed(os.path.join(HERE, f"pointnet_v2_train_{tag}.npz"), x=x, attn=attn, dm=dm, dv=dv, weight_seed=np.array(0), **out)
+    print("wrote pointnet_v2_train_" + tag, len(out), "arrays", float(np.abs(out["m"]).max()))
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -315,7 +355,11 @@ def main():
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
     gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
     gen_training_losses(model, "B3_N64_T10", B=3, N=64, seed=71, T=10)
+    if "--only-pnv2-train" in sys.argv:
+        gen_pointnet_v2_train(model, "B5_N160", B=5, N=160, seed=91)
+        return
     gen_train_grads(model, "B3_N64_T10", B=3, N=64, seed=81, T=10)
+    gen_pointnet_v2_train(model, "B5_N160", B=5, N=160, seed=91)
     if "--only-train" in sys.argv:
         return
     if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:

@@ -1,0 +1,141 @@
+"""PointNetV2 part encoder in train mode on the HIP path (encoder side): batch-statistics BatchNorm forward,
+running-statistics update, and the backward, against the reference class's own autograd (golden) and the torch-CPU oracle.
+
+Tolerances (fp32; the batch statistics and the column reductions sum in a different order than torch): outputs 2e-5 max-abs,
+running statistics 1e-5, gradients 1e-3 of each tensor's max-abs (BatchNorm over B = 5 samples in the heads amplifies
+rounding: 1 / sqrt(var + eps) of five numbers).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+# a bias in front of a train-mode BatchNorm has a mathematically ZERO gradient (the batch mean removes it): what torch and the
+# kernels return for these is rounding noise of the reductions (1e-4), compared in absolute terms only
+ZERO_GRAD = {f"conv{i}.bias" for i in (1, 2, 3, 4)} | {f"{h}.{i}.bias" for h in ("mlp_m", "mlp_v") for i in (0, 3)}
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(W, x, attn, dm, dv, precision="f32", momentum=0.1):
+    from difffacto_amd import training
+    P = {n: torch.from_numpy(W[n].copy()).cuda().requires_grad_(True) for n in training.PNV2_PARAMS}
+    Bf = {n: torch.from_numpy(W[n].copy()).cuda() for n in training.PNV2_BUFFERS}
+    m, v = training.pointnet_v2_train_forward(P, Bf, torch.from_numpy(x).cuda(), torch.from_numpy(attn).cuda(), momentum=momentum,
+                                              precision=precision)
+    ((m * torch.from_numpy(dm).cuda()).sum() + (v * torch.from_numpy(dv).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    return dict(m=m.detach().cpu().numpy(), v=v.detach().cpu().numpy(), running={n: b.cpu().numpy() for n, b in Bf.items()},
+                grads={n: p.grad.cpu().numpy() for n, p in P.items()})
+
+
+def test_train_mode_vs_reference_autograd_golden():
+    from difffacto_amd import synth
+    g = dict(np.load(os.path.join(GOLD, "pointnet_v2_train_B5_N160.npz")))
+    W = synth.make_pointnet_v2_weights(int(g["weight_seed"]))
+    r = _run(W, g["x"], g["attn"], g["dm"], g["dv"])
+    assert np.abs(r["m"] - g["m"]).max() < 2e-5 and np.abs(r["v"] - g["v"]).max() < 2e-5
+    n = 0
+    worst = 0.0
+    for key in g:
+        if key.startswith("r/"):
+            assert np.abs(r["running"][key[2:]] - g[key]).max() < 1e-5, key
+        elif key.startswith("g/") or key.startswith("gs/"):
+            name = key.split("/", 1)[1]
+            got = r["grads"][name].astype(np.float64).ravel()
+            ref = g[key].astype(np.float64)
+            if key.startswith("gs/"):
+                l2 = g["gn/" + name][1]
+                assert abs(np.sqrt((got ** 2).sum()) - l2) <= 1e-3 * l2 + 1e-7, (name, "L2")
+                got = got[g["gi/" + name]]
+            n += 1
+            if name in ZERO_GRAD:
+                assert np.abs(got).max() < 5e-3 and np.abs(ref).max() < 5e-3, name
+                continue
+            scale = max(np.abs(ref).max(), 1e-30)
+            err = np.abs(got - ref).max()
+            assert err <= 1e-3 * scale + 1e-7, (name, err, scale)
+            worst = max(worst, err / scale)
+    assert n == 36
+    print(f"36 parameter gradients vs the reference's autograd: worst max-abs error / max-abs = {worst:.2e}")
+
+
+@pytest.mark.parametrize("B,N,precision,tol", [(4, 333, "f32", 1e-3), (8, 1024, "f32", 1e-3)])
+def test_train_mode_vs_oracle_full_gradients(B, N, precision, tol):
+    from difffacto_amd import synth
+    from oracle import pointnet_v2_train as pt
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + N))
+    W = synth.make_pointnet_v2_weights(2)
+    x = rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    seg = rng.integers(0, 4, size=(B, N))
+    seg[0][seg[0] == 2] = 1                                    # shape 0 lacks part 2
+    attn = np.eye(4, dtype=np.float32)[seg]
+    dm, dv = rng.standard_normal((B, 4, 256)).astype(np.float32), rng.standard_normal((B, 4, 256)).astype(np.float32)
+    ref = pt.outputs_and_grads(W, x, attn, dm, dv)
+    r = _run(W, x, attn, dm, dv, precision=precision)
+    otol = 2e-5 if precision == "f32" else 5e-2
+    assert np.abs(r["m"] - ref["m"]).max() < otol * max(1.0, np.abs(ref["m"]).max())
+    assert np.abs(r["v"] - ref["v"]).max() < otol * max(1.0, np.abs(ref["v"]).max())
+    for k, a in ref["running"].items():
+        assert np.abs(r["running"][k] - a).max() < (1e-5 if precision == "f32" else 3e-2), k
+    worst = 0.0
+    for k, gr in ref["grads"].items():
+        if k in ZERO_GRAD:
+            assert np.abs(r["grads"][k]).max() < (5e-3 if precision == "f32" else 5e-2), k
+            continue
+        scale = max(np.abs(gr).max(), 1e-30)
+        err = np.abs(r["grads"][k] - gr).max()
+        assert err <= tol * scale + 1e-7, (k, err, scale)
+        worst = max(worst, err / scale)
+    print(f"B={B} N={N} {precision}: worst gradient error / max-abs = {worst:.2e}")
+
+
+def test_bf16_products_run_and_stay_close():
+    """precision="bf16" rounds the trunk's matrix-product operands to bf16.  Through four BatchNorm layers, a max-pool whose
+    arg-max can flip under that noise, and BatchNorm over only B samples in the heads, outputs move by a few percent and
+    gradients discontinuously: the drop-in module trains this encoder in fp32; here only closeness of the outputs and
+    finiteness / rough agreement (cosine > 0.7 on the trunk weights) of the gradients are required."""
+    from difffacto_amd import synth
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, N = 16, 1024
+    W = synth.make_pointnet_v2_weights(2)
+    x = rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    attn = np.eye(4, dtype=np.float32)[rng.integers(0, 4, size=(B, N))]
+    dm, dv = rng.standard_normal((B, 4, 256)).astype(np.float32), rng.standard_normal((B, 4, 256)).astype(np.float32)
+    f, b = _run(W, x, attn, dm, dv, precision="f32"), _run(W, x, attn, dm, dv, precision="bf16")
+    assert np.abs(b["m"] - f["m"]).max() < 0.15 * np.abs(f["m"]).max() and np.abs(b["v"] - f["v"]).max() < 0.15 * np.abs(f["v"]).max()
+    assert not np.array_equal(b["m"], f["m"])
+    for k in ("conv2.weight", "conv3.weight", "conv4.weight"):
+        gb, gf = b["grads"][k].ravel().astype(np.float64), f["grads"][k].ravel().astype(np.float64)
+        assert np.isfinite(gb).all()
+        assert gb @ gf / (np.linalg.norm(gb) * np.linalg.norm(gf)) > 0.7, k
+
+
+def test_module_train_mode_is_native_and_matches_the_golden():
+    """encoders.PointNetV2 in train(): forward / backward through libdfx, running statistics and num_batches_tracked updated."""
+    from difffacto_amd import synth
+    from difffacto_amd.encoders import PointNetV2
+    g = dict(np.load(os.path.join(GOLD, "pointnet_v2_train_B5_N160.npz")))
+    W = synth.make_pointnet_v2_weights(int(g["weight_seed"]))
+    enc = PointNetV2(zdim=256, num_anchors=4, per_part_mlp=True)
+    sd = enc.state_dict()
+    for k, a in W.items():
+        sd[k] = torch.from_numpy(a.copy())
+    enc.load_state_dict(sd)
+    enc = enc.cuda().train()
+    m, v = enc(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["attn"]).cuda())
+    assert m.grad_fn is not None and type(m.grad_fn).__name__.startswith("PointNetV2TrainFn")
+    ((m * torch.from_numpy(g["dm"]).cuda()).sum() + (v * torch.from_numpy(g["dv"]).cuda()).sum()).backward()
+    assert np.abs(m.detach().cpu().numpy() - g["m"]).max() < 2e-5
+    assert int(enc.bn1.num_batches_tracked) == 1
+    assert np.abs(enc.bn3.running_var.cpu().numpy() - g["r/bn3.running_var"]).max() < 1e-5
+    gw = enc.conv4.weight.grad.cpu().numpy().ravel()
+    ref = g["gs/conv4.weight"]
+    assert np.abs(gw[g["gi/conv4.weight"]] - ref).max() <= 1e-3 * np.abs(ref).max()
+    enc.eval()
+    with torch.no_grad():      # the eval handle is rebuilt with the updated running statistics
+        m2, _ = enc(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["attn"]).cuda())
+    assert torch.isfinite(m2).all() and not torch.equal(m2, m.detach())

@@ -183,3 +183,25 @@ def test_training_gradient_oracle_matches_reference_autograd():
     assert n == 77
     for k in ("d_ctx_code", "d_ctx_mv"):
         assert np.abs(r[k] - g[k]).max() <= 1e-4 * np.abs(g[k]).max() + 1e-9
+
+
+def test_pointnet_v2_train_oracle_matches_reference_autograd():
+    """oracle/pointnet_v2_train.py (F.batch_norm(training=True) restatement) against the reference class in train() mode:
+    outputs, running statistics and parameter gradients (tests/golden/pointnet_v2_train_*.npz)."""
+    from oracle import pointnet_v2_train as pt
+    g = dict(np.load(os.path.join(GOLDEN, "pointnet_v2_train_B5_N160.npz")))
+    W = synth.make_pointnet_v2_weights(int(g["weight_seed"]))
+    r = pt.outputs_and_grads(W, g["x"], g["attn"], g["dm"], g["dv"])
+    assert np.abs(r["m"] - g["m"]).max() < 1e-6 and np.abs(r["v"] - g["v"]).max() < 1e-6
+    n = 0
+    for key in g:
+        if key.startswith("r/"):
+            assert np.abs(r["running"][key[2:]] - g[key]).max() < 1e-6
+        elif key.startswith("g/"):
+            assert np.abs(r["grads"][key[2:]].ravel() - g[key]).max() <= 1e-5 * max(np.abs(g[key]).max(), 1e-3)
+            n += 1
+        elif key.startswith("gs/"):
+            name = key[3:]
+            assert np.abs(r["grads"][name].ravel()[g["gi/" + name]] - g[key]).max() <= 1e-5 * np.abs(g[key]).max()
+            n += 1
+    assert n == 36
