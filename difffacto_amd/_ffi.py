@@ -117,6 +117,9 @@ SIGNATURES = {
     "dfx_pointnet_v2_train_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "dfx_pointnet_v2_train_forward": (_I, [ctypes.POINTER(PointNetV2Weights), _P, _SZ, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     "dfx_pointnet_v2_train_backward": (_I, [ctypes.POINTER(PointNetV2Weights), _P, _SZ, _P, _P, _P, ctypes.POINTER(PointNetV2Weights), _I, _I, _I, _P]),
+    "dfx_prior_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "dfx_prior_loss_forward": (_I, [ctypes.POINTER(c_fp), _I, _I, _P, _SZ, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
+    "dfx_prior_loss_backward": (_I, [ctypes.POINTER(c_fp), _I, _I, _P, _SZ, _P, _F, _F, ctypes.POINTER(c_fp), _P, _P, _I, _P]),
     "dfx_debug_gemm_bf16": (_I, [_I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "dfx_masked_mse_backward_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "dfx_grad_sumsq_accumulate": (_I, [_P, ctypes.c_longlong, _P, _P, _P]),

@@ -756,6 +756,100 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float *__restrict__ dpoo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// prior loss of the part encoder (part_encoders.py:1143-1182): coupling flows forward + log-det, log-likelihood, entropy
+// rows are part-major: row = i * B + b, 256 latent channels, the conditioning half is [0,128) (swap: [128,256))
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ZD = 256, ZH = 128, NPART = 4;
+__global__ void k_flow_gather(const float *__restrict__ z, float *__restrict__ x, int B) {   // z (B, 256, 4) -> x[i][b][c]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NPART * B * ZD) return;
+  const int c = idx % ZD, b = (idx / ZD) % B, i = idx / (ZD * B);
+  x[idx] = z[((size_t)b * ZD + c) * NPART + i];
+}
+__global__ void k_flow_scatter(const float *__restrict__ x, float *__restrict__ z, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NPART * B * ZD) return;
+  const int c = idx % ZD, b = (idx / ZD) % B, i = idx / (ZD * B);
+  z[((size_t)b * ZD + c) * NPART + i] = x[idx];
+}
+// flow.py:21-41 forward: y1 = x1 sigmoid(s + 2) + t, logdet += sum log sigmoid(s + 2); one block of 128 threads per row
+__global__ __launch_bounds__(128) void k_coupling_fwd(const float *__restrict__ xin, const float *__restrict__ st, float *__restrict__ xout,
+                                                       float *__restrict__ logdet, int swap) {
+  __shared__ float red[2];
+  const size_t row = blockIdx.x;
+  const int c = threadIdx.x, xc = swap ? ZH : 0, xt = swap ? 0 : ZH;
+  const float scale = 1.0f / (1.0f + expf(-(st[row * ZD + c] + 2.0f)));
+  xout[row * ZD + xt + c] = xin[row * ZD + xt + c] * scale + st[row * ZD + ZH + c];
+  xout[row * ZD + xc + c] = xin[row * ZD + xc + c];
+  float l = logf(scale);
+  for (int o = 32; o; o >>= 1) l += __shfl_xor(l, o);
+  if ((c & 63) == 0) red[c >> 6] = l;
+  __syncthreads();
+  if (c == 0) logdet[row] += red[0] + red[1];
+}
+// backward: d st = [dy1 x1 s (1 - s) + dlogdet (1 - s) | dy1], dx1 = dy1 s, dx (conditioning half) = dy (the net's share is added later)
+__global__ __launch_bounds__(128) void k_coupling_bwd(const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ st,
+                                                       const float *__restrict__ dlogdet, float *__restrict__ dst, float *__restrict__ dx,
+                                                       int swap) {
+  const size_t row = blockIdx.x;
+  const int c = threadIdx.x, xc = swap ? ZH : 0, xt = swap ? 0 : ZH;
+  const float scale = 1.0f / (1.0f + expf(-(st[row * ZD + c] + 2.0f)));
+  const float dy1 = dy[row * ZD + xt + c];
+  dst[row * ZD + c] = dy1 * xin[row * ZD + xt + c] * scale * (1.0f - scale) + dlogdet[row] * (1.0f - scale);
+  dst[row * ZD + ZH + c] = dy1;
+  dx[row * ZD + xt + c] = dy1 * scale;
+  dx[row * ZD + xc + c] = dy[row * ZD + xc + c];
+}
+__global__ void k_relu_mask(float *__restrict__ d, const float *__restrict__ h, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(h[i] > 0.f)) d[i] = 0.f;
+}
+// per (part, shape): log p(w) + log det (0 for absent parts), posterior entropy, and the loss coefficient a = kl valid / (B n_valid)
+__global__ __launch_bounds__(256) void k_prior_terms(const float *__restrict__ w, const float *__restrict__ logdet, const float *__restrict__ logvar,
+                                                      const float *__restrict__ valid, float prior_var, float kl, int B, float *__restrict__ logp,
+                                                      float *__restrict__ ent, float *__restrict__ acoef) {
+  __shared__ float red[2][4];
+  const int row = blockIdx.x, i = row / B, b = row % B, c = threadIdx.x;
+  const float wv = w[(size_t)row * ZD + c];
+  float s2 = wv * wv, sl = logvar[((size_t)b * NPART + i) * ZD + c];
+  for (int o = 32; o; o >>= 1) s2 += __shfl_xor(s2, o), sl += __shfl_xor(sl, o);
+  if ((c & 63) == 0) red[0][c >> 6] = s2, red[1][c >> 6] = sl;
+  __syncthreads();
+  if (c == 0) {
+    const float sw = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), slv = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float v = valid[b * NPART + i];
+    float nv = 0.f;
+    for (int j = 0; j < NPART; ++j) nv += valid[b * NPART + j];
+    // misc.py:301-317 with dim = 256, summed over the 256 elements: the constant -0.5 log(2 pi) * 256 enters 256 times
+    const float lp = (float)ZD * (-logf(prior_var) - 0.91893853320467274178f * (float)ZD) - sw / (2.0f * prior_var) + logdet[row];
+    logp[row] = v == 1.f ? lp : 0.f;
+    ent[row] = 0.5f * slv + 0.5f * (float)ZD * 2.83787706640934548356f;   // 1 + log(2 pi)
+    acoef[row] = kl * v / ((float)B * nv);
+  }
+}
+__global__ __launch_bounds__(256) void k_prior_loss(const float *__restrict__ logp, const float *__restrict__ ent, const float *__restrict__ acoef,
+                                                     int rows, float *__restrict__ loss) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) s += (double)acoef[r] * (double)(-logp[r] - ent[r]);
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+// d loss / d w = gs a w / prior_var (present parts), d loss / d logdet = -gs a, d loss / d logvar = -gs a / 2
+__global__ void k_prior_bwd_init(const float *__restrict__ w, const float *__restrict__ acoef, const float *__restrict__ valid, float gs,
+                                 float prior_var, int B, float *__restrict__ dy, float *__restrict__ dlogdet, float *__restrict__ dlogvar) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NPART * B * ZD) return;
+  const int c = idx % ZD, row = idx / ZD, i = row / B, b = row % B;
+  const float a = gs * acoef[row], present = valid[b * NPART + i] == 1.f ? 1.f : 0.f;
+  dy[idx] = present * a * w[idx] / prior_var;
+  if (c == 0) dlogdet[row] = -present * a;
+  if (dlogvar) dlogvar[((size_t)b * NPART + i) * ZD + c] = -0.5f * a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct Carver {
@@ -932,6 +1026,10 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
       slab = (int)(((R + (long long)bcap - 1) / (long long)bcap + 63) / 64 * 64);
       ns = (int)((R + slab - 1) / slab);
     }
+    if (ns == 1 && I_valid == I) {   // one slab: the "partial" tile is the result (few-row products: heads, flows, time embedding)
+      k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, 1), 64, 0, st>>>(dY, ldy, X, ldx, dW, db, O, I, R, slab);
+      return dfx::check_launch("train: wgrad");
+    }
     k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
   }
   if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
@@ -1070,6 +1168,57 @@ int glin(hipStream_t st, const float *X, const float *W, const float *b, float *
   a.Y = Y, a.ldy = A * cout, a.y_gs = cout;
   dfx::lin::k_lin<dfx::lin::EPI_NONE><<<dim3((cout + 31) / 32, (B + 31) / 32, A), 64, 0, st>>>(a);
   return dfx::check_launch("train: grouped linear");
+}
+
+// ---- prior loss: workspace ----
+struct FlowWs {
+  float *xs[DFX_MAX_FLOW_DEPTH + 1], *h1[DFX_MAX_FLOW_DEPTH], *h2[DFX_MAX_FLOW_DEPTH], *st[DFX_MAX_FLOW_DEPTH];
+  float *logdet, *acoef, *logp, *ent, *dlogdet;
+  float *dy, *dy2, *dst, *dh1, *dh2, *wT;
+  PartBufs pb;
+};
+size_t carve_flow(FlowWs &w, void *base, int B, int depth, int H) {
+  Carver c{static_cast<char *>(base)};
+  const size_t Rf = (size_t)NPART * B;
+  for (int l = 0; l <= depth; ++l) w.xs[l] = c.take<float>(Rf * ZD);
+  for (int l = 0; l < depth; ++l) {
+    w.h1[l] = c.take<float>(Rf * H);
+    w.h2[l] = c.take<float>(Rf * H);
+    w.st[l] = c.take<float>(Rf * ZD);
+  }
+  w.logdet = c.take<float>(Rf);
+  w.acoef = c.take<float>(Rf);
+  w.logp = c.take<float>(Rf);
+  w.ent = c.take<float>(Rf);
+  w.dlogdet = c.take<float>(Rf);
+  w.dy = c.take<float>(Rf * ZD);
+  w.dy2 = c.take<float>(Rf * ZD);
+  w.dst = c.take<float>(Rf * ZD);
+  w.dh1 = c.take<float>(Rf * H);
+  w.dh2 = c.take<float>(Rf * H);
+  const size_t hm = (size_t)(H > ZD ? H : ZD);
+  w.wT = c.take<float>(hm * hm);
+  const size_t ns = (size_t)(B + 63) / 64 + 1;
+  w.pb.part_floats = ns * hm * hm;
+  w.pb.part = c.take<float>(w.pb.part_floats);
+  w.pb.bpart_floats = ns * hm;
+  w.pb.bpart = c.take<float>(w.pb.bpart_floats);
+  return c.off;
+}
+int check_flow(const float *const *flow, int depth, int H, const void *ws, size_t ws_bytes, int B, const char *what) {
+  DFX_REQUIRE(flow && ws, "%s: null argument", what);
+  DFX_REQUIRE(depth >= 1 && depth <= DFX_MAX_FLOW_DEPTH && H >= 8 && H % 8 == 0 && B >= 1, "%s: depth %d hidden %d B %d", what, depth, H, B);
+  FlowWs t;
+  DFX_REQUIRE(ws_bytes >= carve_flow(t, nullptr, B, depth, H), "%s: workspace too small", what);
+  DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
+  for (int k = 0; k < NPART * depth * 6; ++k) DFX_REQUIRE(flow[k], "%s: null flow parameter %d", what, k);
+  return DFX_OK;
+}
+int lin_relu(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N_, int K) {
+  LinArgs a{};
+  a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = M, a.N = N_, a.K = K;
+  dfx::lin::k_lin<dfx::lin::EPI_RELU><<<dim3((N_ + 31) / 32, (M + 31) / 32, 1), 64, 0, st>>>(a);
+  return dfx::check_launch("train: linear + relu");
 }
 
 }  // namespace
@@ -1323,6 +1472,97 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *work
     }
   }
   return dfx::check_launch("pointnet_v2_train_backward");
+}
+
+// ---- prior loss (PartEncoder.get_prior_loss, part_encoders.py:1143-1182, use_flow = True) ----
+size_t dfx_prior_loss_workspace_bytes(int B, int flow_depth, int flow_hidden) {
+  if (B < 1 || flow_depth < 1 || flow_depth > DFX_MAX_FLOW_DEPTH || flow_hidden < 8) return 0;
+  FlowWs t;
+  return carve_flow(t, nullptr, B, flow_depth, flow_hidden);
+}
+
+int dfx_prior_loss_forward(const float *const *flow, int flow_depth, int flow_hidden, void *workspace, size_t workspace_bytes,
+                           const float *part_code, const float *logvar, const float *valid, float prior_var, float kl_weight,
+                           float *loss, float *log_p_part, float *entropy, int B, dfx_stream_t stream) {
+  int rc = check_flow(flow, flow_depth, flow_hidden, workspace, workspace_bytes, B, "prior_loss_forward");
+  if (rc) return rc;
+  DFX_REQUIRE(part_code && logvar && valid && loss && prior_var > 0.f, "prior_loss_forward: bad argument");
+  hipStream_t st = dfx::as_stream(stream);
+  const int H = flow_hidden, Rf = NPART * B;
+  const int prec_saved = g_prec;
+  g_prec = DFX_PREC_F32;   // few-row products: exact fp32
+  FlowWs w;
+  carve_flow(w, workspace, B, flow_depth, H);
+  k_flow_gather<<<(Rf * ZD + 255) / 256, 256, 0, st>>>(part_code, w.xs[0], B);
+  DFX_HIP_TRY(hipMemsetAsync(w.logdet, 0, sizeof(float) * Rf, st));
+  for (int l = 0; l < flow_depth; ++l) {
+    const int swap = (l % 2 == 0), xc = swap ? ZH : 0;
+    for (int i = 0; i < NPART; ++i) {
+      const float *const *p = flow + ((size_t)i * flow_depth + l) * 6;
+      const size_t r0 = (size_t)i * B;
+      if ((rc = lin_relu(st, w.xs[l] + r0 * ZD + xc, ZD, p[0], p[1], w.h1[l] + r0 * H, H, B, H, ZH))) return rc;
+      if ((rc = lin_relu(st, w.h1[l] + r0 * H, H, p[2], p[3], w.h2[l] + r0 * H, H, B, H, H))) return rc;
+      if ((rc = lin(st, w.h2[l] + r0 * H, H, p[4], p[5], w.st[l] + r0 * ZD, ZD, B, ZD, H))) return rc;
+    }
+    k_coupling_fwd<<<Rf, 128, 0, st>>>(w.xs[l], w.st[l], w.xs[l + 1], w.logdet, swap);
+  }
+  k_prior_terms<<<Rf, 256, 0, st>>>(w.xs[flow_depth], w.logdet, logvar, valid, prior_var, kl_weight, B, w.logp, w.ent, w.acoef);
+  k_prior_loss<<<1, 256, 0, st>>>(w.logp, w.ent, w.acoef, Rf, loss);
+  if (log_p_part || entropy) {   // (B, 4) views of the part-major rows
+    for (int i = 0; i < NPART; ++i) {
+      if (log_p_part) DFX_HIP_TRY(hipMemcpy2DAsync(log_p_part + i, NPART * sizeof(float), w.logp + (size_t)i * B, sizeof(float), sizeof(float), B, hipMemcpyDeviceToDevice, st));
+      if (entropy) DFX_HIP_TRY(hipMemcpy2DAsync(entropy + i, NPART * sizeof(float), w.ent + (size_t)i * B, sizeof(float), sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  g_prec = prec_saved;
+  return dfx::check_launch("prior_loss_forward");
+}
+
+int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_hidden, void *workspace, size_t workspace_bytes,
+                            const float *valid, float prior_var, float grad_scale, float *const *flow_grads, float *d_part_code,
+                            float *d_logvar, int B, dfx_stream_t stream) {
+  int rc = check_flow(flow, flow_depth, flow_hidden, workspace, workspace_bytes, B, "prior_loss_backward");
+  if (rc) return rc;
+  DFX_REQUIRE(valid && flow_grads && prior_var > 0.f, "prior_loss_backward: bad argument");
+  for (int k = 0; k < NPART * flow_depth * 6; ++k) DFX_REQUIRE(flow_grads[k], "prior_loss_backward: null gradient buffer %d", k);
+  hipStream_t st = dfx::as_stream(stream);
+  const int H = flow_hidden, Rf = NPART * B;
+  const int prec_saved = g_prec;
+  g_prec = DFX_PREC_F32;
+  FlowWs w;
+  carve_flow(w, workspace, B, flow_depth, H);
+  k_prior_bwd_init<<<(Rf * ZD + 255) / 256, 256, 0, st>>>(w.xs[flow_depth], w.acoef, valid, grad_scale, prior_var, B, w.dy, w.dlogdet, d_logvar);
+  float *dy = w.dy, *dx = w.dy2;
+  for (int l = flow_depth - 1; l >= 0; --l) {
+    const int swap = (l % 2 == 0), xc = swap ? ZH : 0;
+    k_coupling_bwd<<<Rf, 128, 0, st>>>(dy, w.xs[l], w.st[l], w.dlogdet, w.dst, dx, swap);
+    for (int i = 0; i < NPART; ++i) {
+      const float *const *p = flow + ((size_t)i * flow_depth + l) * 6;
+      float *const *g = flow_grads + ((size_t)i * flow_depth + l) * 6;
+      const size_t r0 = (size_t)i * B;
+      const float *dst = w.dst + r0 * ZD;
+      float *dh2 = w.dh2 + r0 * H, *dh1 = w.dh1 + r0 * H;
+      // net_s_t.4: s_t = h2 W3^T + b3
+      if ((rc = wgrad(st, w.pb, dst, ZD, w.h2[l] + r0 * H, H, g[4], g[5], ZD, H, H, B))) return rc;
+      transpose(st, p[4], w.wT, ZD, H);
+      if ((rc = lin(st, dst, ZD, w.wT, nullptr, dh2, H, B, H, ZD))) return rc;
+      k_relu_mask<<<(int)(((long long)B * H + 255) / 256), 256, 0, st>>>(dh2, w.h2[l] + r0 * H, (long long)B * H);
+      // net_s_t.2
+      if ((rc = wgrad(st, w.pb, dh2, H, w.h1[l] + r0 * H, H, g[2], g[3], H, H, H, B))) return rc;
+      transpose(st, p[2], w.wT, H, H);
+      if ((rc = lin(st, dh2, H, w.wT, nullptr, dh1, H, B, H, H))) return rc;
+      k_relu_mask<<<(int)(((long long)B * H + 255) / 256), 256, 0, st>>>(dh1, w.h1[l] + r0 * H, (long long)B * H);
+      // net_s_t.0: input = the conditioning half of x
+      if ((rc = wgrad(st, w.pb, dh1, H, w.xs[l] + r0 * ZD + xc, ZD, g[0], g[1], H, ZH, ZH, B))) return rc;
+      transpose(st, p[0], w.wT, H, ZH);
+      if ((rc = lin(st, dh1, H, w.wT, nullptr, dx + r0 * ZD + xc, ZD, B, ZH, H, dx + r0 * ZD + xc, ZD))) return rc;
+    }
+    float *t = dy;
+    dy = dx, dx = t;
+  }
+  if (d_part_code) k_flow_scatter<<<(Rf * ZD + 255) / 256, 256, 0, st>>>(dy, d_part_code, B);
+  g_prec = prec_saved;
+  return dfx::check_launch("prior_loss_backward");
 }
 
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them

@@ -13,7 +13,7 @@ import torch
 from . import _ffi
 from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
-__all__ = ["dropout_factors", "pointnet_v2_train_forward", "PointNetV2TrainFn", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
+__all__ = ["dropout_factors", "prior_loss", "PriorLossFn", "pointnet_v2_train_forward", "PointNetV2TrainFn", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
 
 
 def param_names(depth):
@@ -261,6 +261,77 @@ def pointnet_v2_train_forward(params, buffers, x, attn, num_anchors=4, zdim=256,
     """`params` / `buffers`: dicts with the state_dict names of PointNetV2 (fp32 cuda tensors).  Returns (m, v)."""
     return PointNetV2TrainFn.apply((num_anchors, zdim, reweight_by_anchor, eps, momentum, precision), x, attn,
                                    [buffers[n] for n in PNV2_BUFFERS], *[params[n] for n in PNV2_PARAMS])
+
+
+def flow_param_names(depth, n_class=4):
+    """state_dict names (relative to the encoder) of the coupling flows, in libdfx's [part][layer][w0,b0,w1,b1,w2,b2] order."""
+    return [f"flow.{i}.chain.{l}.net_s_t.{k}.{wb}" for i in range(n_class) for l in range(depth) for k in (0, 2, 4) for wb in ("weight", "bias")]
+
+
+def _ptr_array(tensors):
+    arr = (_ffi.c_fp * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = t.data_ptr()
+    return arr
+
+
+class PriorLossFn(torch.autograd.Function):
+    """prior_loss = PartEncoder.get_prior_loss(part_code, ., logvar, valid)['prior_loss'] (part_encoders.py:1143-1182, use_flow),
+    differentiable in part_code, logvar and the flow parameters."""
+
+    @staticmethod
+    def forward(ctx, cfg, part_code, logvar, valid, *params):
+        depth, hidden, prior_var, kl_weight = cfg
+        if len(params) != 4 * depth * 6:
+            raise ValueError(f"expected {4 * depth * 6} flow parameter tensors")
+        ps = [_need(p.detach(), "flow parameter") for p in params]
+        z = _need(part_code.detach().contiguous(), "part_code")
+        lv = _need(logvar.detach().contiguous(), "logvar")
+        B = z.shape[0]
+        if z.shape != (B, 256, 4) or lv.shape != (B, 4, 256):
+            raise ValueError("part_code (B,256,4) and logvar (B,4,256) expected")
+        vd = valid.detach().to(device=z.device, dtype=torch.float32).contiguous()
+        lib = _ffi.lib()
+        nbytes = lib.dfx_prior_loss_workspace_bytes(B, depth, hidden)
+        if nbytes == 0:
+            raise ValueError(f"unsupported prior-loss configuration B={B} depth={depth} hidden={hidden}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=z.device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        log_p = torch.empty(B, 4, dtype=torch.float32, device=z.device)
+        ent = torch.empty(B, 4, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _ffi.check(lib.dfx_prior_loss_forward(_ptr_array(ps), depth, hidden, ws_ptr, nbytes, z.data_ptr(), lv.data_ptr(), vd.data_ptr(),
+                                                  float(prior_var), float(kl_weight), loss.data_ptr(), log_p.data_ptr(), ent.data_ptr(), B,
+                                                  _ffi.current_stream()), "dfx_prior_loss_forward")
+        ctx.cfg, ctx.ps, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.vd, ctx.B = cfg, ps, ws, ws_ptr, nbytes, vd, B
+        ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
+        ctx.mark_non_differentiable(log_p, ent)
+        return loss, log_p, ent
+
+    @staticmethod
+    def backward(ctx, g, _glp, _gent):
+        depth, hidden, prior_var, kl_weight = ctx.cfg
+        B = ctx.B
+        dev = ctx.vd.device
+        views = _flat_slices([p.shape for p in ctx.ps], dev)
+        dz = torch.empty(B, 256, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dlv = torch.empty(B, 4, 256, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            _ffi.check(_ffi.lib().dfx_prior_loss_backward(_ptr_array(ctx.ps), depth, hidden, ctx.ws_ptr, ctx.nbytes, ctx.vd.data_ptr(),
+                                                          float(prior_var), float(g), _ptr_array(views), None if dz is None else dz.data_ptr(),
+                                                          None if dlv is None else dlv.data_ptr(), B, _ffi.current_stream()),
+                       "dfx_prior_loss_backward")
+        ctx.ws = None
+        out = _assign_or_return(ctx.leaves, views)
+        ctx.leaves = None
+        return (None, dz, dlv, None) + tuple(out)
+
+
+def prior_loss(flow_params, part_code, logvar, valid, depth=14, hidden=256, prior_var=1.0, kl_weight=5e-4):
+    """`flow_params`: dict with the encoder's state_dict names 'flow.{i}.chain.{l}.net_s_t.{0,2,4}.{weight,bias}'.
+    Returns (prior_loss, log_p_part (B,4), entropy (B,4))."""
+    return PriorLossFn.apply((depth, hidden, prior_var, kl_weight), part_code, logvar, valid, *[flow_params[n] for n in flow_param_names(depth)])
 
 
 def dropout_factors(seed, site, p, n, device="cuda"):

@@ -348,6 +348,24 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *w, void *works
                                    const float *dm, const float *dv, const dfx_pointnet_v2_weights *grads, int B, int N,
                                    int precision, dfx_stream_t stream);
 
+/* Prior loss of the part encoder with use_flow (PartEncoder.get_prior_loss, part_encoders.py:1143-1182) and its backward
+ * (encoder side): per part, the latents go FORWARD through that part's coupling layers (flow.py:21-41,
+ * logpx - log det), log N(w; 0, prior_var) with the reference's normalisation (misc.py:301-317 called with dim = zdim and summed
+ * over the zdim elements), minus the posterior's Gaussian entropy (misc.py:292-295), averaged over the valid parts of a shape
+ * and over the batch, times kl_weight.  n_class = 4, zdim = 256.
+ *   flow / flow_grads: HOST arrays of 4 * flow_depth * 6 device pointers, [part][layer][w0,b0,w1,b1,w2,b2] = net_s_t.{0,2,4}
+ *   (as in dfx_latent_weights); flow_grads buffers are overwritten.  part_code (B,256,4), logvar (B,4,256), valid (B,4) 0/1.
+ *   loss: one float on the device; log_p_part / entropy (B,4) or NULL.  d_part_code (B,256,4) / d_logvar (B,4,256) or NULL.
+ *   workspace: dfx_prior_loss_workspace_bytes(B, flow_depth, flow_hidden), shared by the forward and the backward of a step. */
+#define DFX_MAX_FLOW_DEPTH 16
+size_t dfx_prior_loss_workspace_bytes(int B, int flow_depth, int flow_hidden);
+int dfx_prior_loss_forward(const float *const *flow, int flow_depth, int flow_hidden, void *workspace, size_t workspace_bytes,
+                           const float *part_code, const float *logvar, const float *valid, float prior_var, float kl_weight,
+                           float *loss, float *log_p_part, float *entropy, int B, dfx_stream_t stream);
+int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_hidden, void *workspace, size_t workspace_bytes,
+                            const float *valid, float prior_var, float grad_scale, float *const *flow_grads, float *d_part_code,
+                            float *d_logvar, int B, dfx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Approximate EMD by auction — replaces the `emd` extension
  * (python/difffacto/metrics/emd/emd_cuda.cu: forward :236-284, backward :286-316; bound in emd_module.py:17-51).

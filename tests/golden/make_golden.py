@@ -25,6 +25,8 @@ train_grads_*.npz    autograd through TransformerNet in TRAIN mode with every Dr
                      SURVEY.md §7 config 5): eps, the masked mse_loss of training_losses, and d loss / d (every parameter,
                      both ctx tensors).  Gradients of tensors with more than 4096 elements are stored as
                      (sum, L2 norm, 1024 elements at seeded positions) to keep the fixture small
+prior_loss_*.npz     PartEncoder.get_prior_loss (part_encoders.py:1143-1182: flows forward + log-det, N(0, prior_var) log-likelihood,
+                     posterior entropy, kl_weight) with autograd gradients for part_code, logvar and the 336 flow parameters
 pointnet_v2_train_*.npz  the same class in TRAIN mode (batch-statistics BatchNorm): m, v, the running statistics it leaves behind, and
                      autograd gradients of sum(m dm) + sum(v dv) for every parameter (large tensors as sum / L2 norm / 1024 samples)
 pointnet_v2_*.npz    PointNetV2.forward (pointnet.py:187-213, eval-mode BatchNorm), the encode-side part encoder
@@ -312,6 +314,48 @@ def gen_pointnet_v2_train(model, tag, B, N, seed):
     print("wrote pointnet_v2_train_" + tag, len(out), "arrays", float(np.abs(out["m"]).max()))
 
 
+def gen_prior_loss(model, tag, B, seed):
+    """get_prior_loss + backward from the reference encoder itself (kl_weight / prior_var as built by ref_import)."""
+    enc = model.encoder
+    rng = np.random.Generator(np.random.PCG64(seed))
+    part_code = rng.standard_normal((B, 256, 4)).astype(F32)
+    mean = rng.standard_normal((B, 4, 256)).astype(F32)
+    logvar = (-1.0 + 0.3 * rng.standard_normal((B, 4, 256))).astype(F32)
+    pats = np.array([[1, 1, 1, 1], [1, 1, 1, 0], [0, 1, 1, 0], [1, 1, 0, 0], [0, 1, 1, 1]], dtype=F32)
+    valid = pats[np.arange(B) % len(pats)]
+    for p in enc.parameters():
+        p.grad = None
+    z = torch.from_numpy(part_code).requires_grad_(True)
+    lv = torch.from_numpy(logvar).requires_grad_(True)
+    old_kl, enc.kl_weight = enc.kl_weight, 5e-4        # configs/train_chair_stage1.py:13 (the gen config carries 0)
+    # loss_dict['kl_weight'] = torch.ones(1).cuda() * kl_weight: no CUDA here
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        d = enc.get_prior_loss(z, torch.from_numpy(mean), lv, torch.from_numpy(valid), epoch=0)
+    finally:
+        del torch.Tensor.cuda
+        enc.kl_weight = old_kl
+    d["prior_loss"].backward()
+    out = {"loss": np.array(float(d["prior_loss"]), F32), "kl_weight": np.array(float(d["kl_weight"]), F32), "prior_var": np.array(float(enc.prior_var), F32),
+           "d_part_code": z.grad.numpy().astype(F32), "d_logvar": lv.grad.numpy().astype(F32),
+           "log_p_mean": np.array([float(d[f"log_p_part_{i}"]) for i in range(4)], F32),
+           "entropy_mean": np.array([float(d[f"entropy_{i}"]) for i in range(4)], F32)}
+    srng = np.random.Generator(np.random.PCG64(4244))
+    for name, p in enc.named_parameters():
+        if not name.startswith("flow.") or p.grad is None:
+            continue
+        g = p.grad.numpy().astype(F32).ravel()
+        if g.size <= 512:
+            out["g/" + name] = g
+        else:
+            idx = np.sort(srng.choice(g.size, size=64, replace=False)).astype(np.int64)
+            out["gi/" + name], out["gs/" + name] = idx, g[idx]
+            out["gn/" + name] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+    np.savez_compressed(os.path.join(HERE, f"prior_loss_{tag}.npz"), part_code=part_code, mean=mean, logvar=logvar, valid=valid,
+                        weight_seed=np.array(0), **out)
+    print("wrote prior_loss_" + tag, float(d["prior_loss"]), float(d["kl_weight"]), len(out), "arrays")
+
+
 def gen_tables():
     from difffacto.models.diffusions.diffusion_utils import extract_into_tensor
     from difffacto.utils.registry import DIFFUSIONS
@@ -355,11 +399,15 @@ def main():
     gen_latents(model, "S4_K3_fixed", S=4, K=3, npoints=32, seed=32, fixed_id=[0, 1, 0, 0], all_valid=False)
     gen_pointnet_v2(model, "B3_N200", B=3, N=200, seed=51)
     gen_training_losses(model, "B3_N64_T10", B=3, N=64, seed=71, T=10)
+    if "--only-prior" in sys.argv:
+        gen_prior_loss(model, "B6", B=6, seed=95)
+        return
     if "--only-pnv2-train" in sys.argv:
         gen_pointnet_v2_train(model, "B5_N160", B=5, N=160, seed=91)
         return
     gen_train_grads(model, "B3_N64_T10", B=3, N=64, seed=81, T=10)
     gen_pointnet_v2_train(model, "B5_N160", B=5, N=160, seed=91)
+    gen_prior_loss(model, "B6", B=6, seed=95)
     if "--only-train" in sys.argv:
         return
     if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:

@@ -205,3 +205,25 @@ def test_pointnet_v2_train_oracle_matches_reference_autograd():
             assert np.abs(r["grads"][name].ravel()[g["gi/" + name]] - g[key]).max() <= 1e-5 * np.abs(g[key]).max()
             n += 1
     assert n == 36
+
+
+def test_prior_loss_oracle_matches_reference_autograd():
+    """oracle/prior_loss.py against PartEncoder.get_prior_loss + autograd of the reference encoder (tests/golden/prior_loss_*.npz):
+    loss value (with the reference's normalisation constant), d part_code, d logvar, 336 flow-parameter gradients."""
+    from oracle import prior_loss as pl
+    g = dict(np.load(os.path.join(GOLDEN, "prior_loss_B6.npz")))
+    W = synth.make_latent_weights(int(g["weight_seed"]))
+    r = pl.loss_and_grads(W, g["part_code"], g["logvar"], g["valid"], prior_var=float(g["prior_var"]), kl_weight=float(g["kl_weight"]))
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    assert np.abs(r["d_part_code"] - g["d_part_code"]).max() <= 1e-5 * np.abs(g["d_part_code"]).max()
+    assert np.abs(r["d_logvar"] - g["d_logvar"]).max() <= 1e-6 * np.abs(g["d_logvar"]).max()
+    n = 0
+    for key in g:
+        if key.startswith("g/"):
+            assert np.abs(r["grads"][key[2:]].ravel() - g[key]).max() <= 1e-4 * max(np.abs(g[key]).max(), 1e-30)
+            n += 1
+        elif key.startswith("gs/"):
+            name = key[3:]
+            assert np.abs(r["grads"][name].ravel()[g["gi/" + name]] - g[key]).max() <= 1e-4 * max(np.abs(g[key]).max(), 1e-30)
+            n += 1
+    assert n == 336
