@@ -241,11 +241,24 @@ class PartEncoderForTransformerDecoder(nn.Module):
                  latent_flow_hidden_dim=256, gen=False, prior_var=1.0, selective_noise_sampling=False,
                  selective_noise_sampling_global=False, per_part_encoder=False, **kwargs):
         super().__init__()
-        if not (gen and include_part_code and include_params) or include_z or use_gt_params or encode_ref or per_part_encoder:
-            _unsupported("PartEncoder needs gen, include_part_code, include_params and no include_z / use_gt_params / "
-                         "encode_ref / per_part_encoder")
+        if not (gen and include_part_code and include_params) or include_z or encode_ref or per_part_encoder:
+            _unsupported("PartEncoder needs gen, include_part_code, include_params and no include_z / encode_ref / per_part_encoder")
         if selective_noise_sampling or selective_noise_sampling_global:
             _unsupported("selective_noise_sampling")
+        if use_gt_params and part_aligner is not None:
+            _unsupported("use_gt_params together with a part_aligner (stage 1 trains without one, train_chair_stage1.py)")
+        if not use_gt_params and part_aligner is None:
+            _unsupported("a PartEncoder without part_aligner needs use_gt_params=True")
+        for flag in ("gt_param_annealing", "normalize_part_code", "use_gt_params_in_training"):
+            if kwargs.get(flag, False):
+                _unsupported(flag)
+        # training-side settings (part_encoders.py:320-390)
+        self.use_gt_params, self.origin_scale, self.kl_weight = use_gt_params, origin_scale, kl_weight
+        self.kl_weight_annealing = kwargs.get("kl_weight_annealing", False)
+        self.min_kl_weight = kwargs.get("min_kl_weight", 1e-7)
+        self.kl_weight_annealing_end_epoch = kwargs.get("kl_weight_annealing_end_epoch", 3000)
+        self.detach_params_in_ctx = kwargs.get("detach_params_in_ctx", False)
+        self.latent_flow_depth, self.latent_flow_hidden_dim = latent_flow_depth, latent_flow_hidden_dim
         self.encoder_cfg = dict(encoder or {})
         self.zdim = int(self.encoder_cfg.get("zdim", 1024))
         if self.encoder_cfg.get("type", None) == "PointNetV2":   # encode side (get_part_code); not on the generation path
@@ -258,7 +271,8 @@ class PartEncoderForTransformerDecoder(nn.Module):
             cfg.pop("type", None)
             part_aligner = PartAlignerTransformer(**cfg)
         self.part_aligner = part_aligner
-        self.part_aligner._owner = weakref.ref(self)
+        if part_aligner is not None:
+            self.part_aligner._owner = weakref.ref(self)
         if use_flow:
             self.flow = nn.ModuleList([build_latent_flow(latent_flow_depth, latent_flow_hidden_dim, self.zdim)
                                        for _ in range(n_class)])                          # part_encoders.py:388-390
@@ -283,8 +297,78 @@ class PartEncoderForTransformerDecoder(nn.Module):
         """part_encoders.py:429-445 (per_part_encoder=False): (means, logvars) of the part codes, each (B, n_class, zdim)."""
         return self.encoder(input, seg_flag)
 
-    def get_params_from_part_code(self, part_code, valid_id, noise=None, **kwargs):
-        return self.part_aligner(part_code, valid_id, noise=noise)                        # part_encoders.py:447-459
+    def get_params_from_part_code(self, part_code, valid_id, noise=None, gt_mean=None, gt_var=None, **kwargs):
+        if self.use_gt_params:                                                            # part_encoders.py:456-458
+            return gt_mean, torch.log(gt_var)
+        return self.part_aligner(part_code, valid_id, noise=noise)                        # part_encoders.py:447-455
+
+    def gather_all(self, anchor_assignments, anchors=None, variances=None, valid_id=None):
+        """part_encoders.py:417-428: per-point (B,3,N) anchors / variances and (B,1,N) flags by part id (index plumbing)."""
+        B, N = anchor_assignments.shape
+        idx = anchor_assignments.long()[:, None, :]
+        dev = anchor_assignments.device
+        a = torch.gather(anchors, 2, idx.expand(-1, 3, -1)) if anchors is not None else torch.zeros(B, 3, N, device=dev)
+        v = torch.gather(variances, 2, idx.expand(-1, 3, -1)) if variances is not None else torch.zeros(B, 3, N, device=dev)
+        f = torch.gather(valid_id[:, None, :].to(torch.float32), 2, idx) if valid_id is not None else torch.ones(B, 1, N, device=dev)
+        return a, v, f
+
+    def prepare_ctx(self, part_code, mean, logvar, **kwargs):
+        params = torch.cat([mean, torch.exp(logvar + self.log_scale_var)], dim=1)          # part_encoders.py:1317-1326
+        return [part_code, params.detach() if self.detach_params_in_ctx else params]
+
+    def get_prior_loss(self, part_code, mean, logvar, valid_id, epoch=-1):
+        """part_encoders.py:1143-1182 (use_flow): {'prior_loss', 'kl_weight', per-part log p / entropy / mean / logvar averages}.
+        The loss (flows forward + log-det, log-likelihood, entropy) and its backward are libdfx kernels (training.prior_loss)."""
+        if not self.use_flow:
+            _unsupported("get_prior_loss without use_flow")
+        from . import training as _training
+        if self.kl_weight_annealing and self.kl_weight_annealing_end_epoch > epoch:
+            kl = self.min_kl_weight + (self.kl_weight - self.min_kl_weight) * epoch / self.kl_weight_annealing_end_epoch
+        else:
+            kl = self.kl_weight
+        params = {n: p for n, p in self.named_parameters() if n.startswith("flow.")}
+        loss, log_p, ent = _training.prior_loss(params, part_code, logvar, valid_id, depth=self.latent_flow_depth,
+                                                hidden=self.latent_flow_hidden_dim, prior_var=self.prior_var, kl_weight=kl)
+        d = {"prior_loss": loss, "kl_weight": torch.ones(1, device=part_code.device) * kl}
+        with torch.no_grad():                                                             # logging values only
+            nv = valid_id.sum(0)
+            mlp, ment = (log_p * valid_id).sum(0) / nv, (ent * valid_id).sum(0) / nv
+            mmean, mlv = mean.mean(2).sum(0) / nv, logvar.mean(2).sum(0) / nv
+        for i in range(self.n_class):
+            d[f"log_p_part_{i}"], d[f"entropy_{i}"] = mlp[i], ment[i]
+            d[f"part_{i}_mean"], d[f"part_{i}_logvar"] = mmean[i], mlv[i]
+        return d
+
+    def forward(self, pcds, device, noise=None, epoch=-1):
+        """Training forward of the encoder (part_encoders.py:1185-1260) for the stage-1 configuration (gen, use_flow,
+        use_gt_params, no part_aligner): part codes from PointNetV2 (train-mode kernels), reparameterisation, prior loss,
+        ground-truth anchors / variances gathered per point, ctx for the denoiser.
+        Returns (ctx, mean_per_point, logvar_per_point, flag_per_point, loss_dict, [part_code, mean, logvar, noise])."""
+        if not self.use_gt_params:
+            _unsupported("encoder training forward with a part_aligner (stage 2)")
+        inp = pcds["input"].to(device)
+        valid_id = pcds["present"].to(device).to(torch.float32)
+        ref = pcds["ref"].to(device).transpose(1, 2)
+        seg_mask = pcds["ref_seg_mask"].to(device).to(torch.int32)
+        seg_flag = pcds["ref_attn_map"].to(device)
+        B = ref.shape[0]
+        gt_shift = pcds.get("part_shift", torch.zeros(B, 3, self.n_class)).to(device)
+        gt_var = pcds.get("part_scale", torch.ones(B, 3, self.n_class)).to(device)
+        if noise is None:
+            noise = pcds["noise"].to(device).unsqueeze(1)
+        if noise.shape[1] != 1:
+            _unsupported("more than one noise sample per shape in the encoder's training forward")
+        if not self.origin_scale:
+            gt_var = gt_var ** 2
+        m, lv = self.get_part_code(inp, seg_flag)
+        eps = torch.randn(lv.size(), device=lv.device)                                     # reparameterize_gaussian, misc.py:282-285
+        part_code = (m + torch.exp(0.5 * lv) * eps).transpose(1, 2)                         # (B, zdim, n_class)
+        loss_dict = dict(self.get_prior_loss(part_code, m, lv, valid_id, epoch=epoch))
+        mean, logvar = self.get_params_from_part_code(part_code, valid_id, gt_mean=gt_shift, gt_var=gt_var, ref=ref, noise=noise.reshape(B, -1))
+        mean_pp, logvar_pp, flag_pp = self.gather_all(seg_mask, anchors=mean, variances=logvar, valid_id=valid_id)
+        loss_dict["fit_loss"] = torch.zeros(1, device=ref.device)                          # no part_aligner: part_encoders.py:489,521
+        ctx = self.prepare_ctx(part_code, mean, logvar, anchor_assignments=seg_mask)
+        return ctx, mean_pp, logvar_pp + self.log_scale_var, flag_pp, loss_dict, [part_code, mean, logvar, noise.reshape(B, -1)]
 
     @torch.no_grad()
     def sample_latents(self, sample_num, sample_points, device, fixed_id=None, valid_id=None, epoch=0, K=None,

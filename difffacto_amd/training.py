@@ -13,7 +13,7 @@ import torch
 from . import _ffi
 from .engine import _BLOCK_FIELDS, _TOP_FIELDS, EXPECTED_SHAPES, PRECISIONS
 
-__all__ = ["dropout_factors", "prior_loss", "PriorLossFn", "pointnet_v2_train_forward", "PointNetV2TrainFn", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
+__all__ = ["dropout_factors", "stage1_losses", "prior_loss", "PriorLossFn", "pointnet_v2_train_forward", "PointNetV2TrainFn", "param_names", "DenoiserTrainFn", "denoiser_train_forward", "MaskedMSEFn", "masked_mse", "Adam", "linear_lr"]
 
 
 def param_names(depth):
@@ -495,3 +495,29 @@ def linear_lr(epoch, start_epoch, end_epoch, start_lr, end_lr):
     else:
         f = end_lr / start_lr
     return start_lr * f
+
+
+def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None):
+    """The training forward of the reference's agent for stage 1 (AnchorDiffAE.forward, anchor_gen.py:970-1020): the encoder's
+    training forward (part codes, prior loss, ground-truth anchors per point, ctx), one timestep per shape, and the denoiser's
+    masked MSE.  `encoder` / `diffusion`: difffacto_amd.encoders.PartEncoderForTransformerDecoder / modules.AnchoredDiffusion in
+    train() mode; `t`: (B,) timesteps (the reference draws them with its Uniform sampler, samplers/sampler.py:25-40); `noise`: the
+    diffusion noise (B,3,N) or None.  Returns the loss dict; sum the entries whose key contains 'loss' and call backward()."""
+    import numpy as np
+    ref = pcds["ref"].to(device)
+    seg = pcds["ref_seg_mask"].to(device).to(torch.int32)
+    B = ref.shape[0]
+    ctx, mean_pp, logvar_pp, _flag_pp, losses, _ = encoder(pcds, device, epoch=epoch)
+    variance_pp = torch.exp(logvar_pp)
+    if t is None:
+        t = torch.from_numpy(np.random.choice(diffusion.num_timesteps, size=(B,))).to(device)
+    dp = pcds.get("dp_present", None)
+    flags = None
+    if dp is not None:
+        dp = dp.to(device).to(torch.float32)
+        flags = torch.gather(dp[:, None, :], 2, seg.long()[:, None, :])
+    d = diffusion.training_losses(ref.transpose(1, 2).contiguous(), t, anchors=mean_pp, variance=variance_pp, ctx=ctx,
+                                  anchor_assignment=seg, valid_id=dp, flags=flags, noise=noise)
+    losses = dict(losses)
+    losses["mse_loss"] = diffusion_loss_weight * d["mse_loss"]
+    return losses

@@ -208,3 +208,87 @@ def test_prior_loss_vs_oracle_other_batch(B, strict):
             assert np.abs(a - b).max() <= 1e-3 * max(np.abs(b).max(), 1e-30) + 1e-12, name
         else:
             assert np.linalg.norm((a - b).ravel()) <= 5e-2 * max(np.linalg.norm(b.ravel()), 1e-30), name
+
+
+def test_stage1_training_step_against_composed_oracles():
+    """The whole stage-1 training forward + backward through the drop-in modules (encoder.forward -> training_losses, as
+    anchor_gen.py:970-1020 strings them together) against the same composition of the torch-CPU oracles with the
+    reparameterisation noise replayed: loss values and gradients of PointNetV2, the flows and the denoiser."""
+    from difffacto_amd import synth, training
+    from difffacto_amd.encoders import PartEncoderForTransformerDecoder
+    from difffacto_amd.modules import AnchoredDiffusion
+    from oracle import pointnet_v2_train as pt, prior_loss as pl, torch_cpu, train as otrain
+    from test_modules_cpu import DIFF_CFG
+    B, N, T = 6, 256, 100
+    rng = np.random.Generator(np.random.PCG64(21))
+    W_pn, W_lat, W_dn = synth.make_pointnet_v2_weights(0), synth.make_latent_weights(0), synth.make_denoiser_weights(0)
+    _, gt_shift, lvv, valid = synth.make_latents(B, seed=2)
+    gt_std = np.exp(0.5 * lvv).astype(np.float32)                       # 'part_scale' is a std: squared by the encoder
+    seg = synth.make_seg_mask(valid, N)
+    ref = rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    attn = np.eye(4, dtype=np.float32)[seg]
+    eps = rng.standard_normal((B, 4, 256)).astype(np.float32)
+    noise = rng.standard_normal((B, 3, N)).astype(np.float32)
+    t = rng.integers(0, T, size=(B,)).astype(np.int64)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    enc = PartEncoderForTransformerDecoder(encoder=dict(type="PointNetV2", zdim=256, per_part_mlp=True), n_class=4, part_aligner=None,
+                                           include_z=False, include_part_code=True, include_params=True, use_gt_params=True, kl_weight=5e-4,
+                                           use_flow=True, gen=True, prior_var=1.0)
+    sd = enc.state_dict()
+    for k, a in W_pn.items():
+        sd["encoder." + k] = torch.from_numpy(a.copy())
+    for k, a in W_lat.items():
+        if k.startswith("flow."):
+            sd[k] = torch.from_numpy(a.copy())
+    enc.load_state_dict(sd)
+    diff = AnchoredDiffusion(num_timesteps=T, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)})
+    diff.model.load_state_dict({k: torch.from_numpy(v) for k, v in W_dn.items()})
+    enc, diff = enc.cuda().train(), diff.cuda().train()
+    pcds = {"input": cu(ref), "ref": cu(ref), "present": cu(valid), "dp_present": cu(valid), "ref_seg_mask": cu(seg.astype(np.int64)),
+            "ref_attn_map": cu(attn), "part_shift": cu(gt_shift), "part_scale": cu(gt_std), "noise": torch.zeros(B, 32).cuda()}
+    real_randn = torch.randn
+    try:
+        torch.randn = lambda *a, **k: cu(eps)                     # the reparameterisation draw (misc.py:282-285)
+        losses = training.stage1_losses(enc, diff, pcds, t=cu(t), noise=cu(noise))
+    finally:
+        torch.randn = real_randn
+    total = losses["prior_loss"] + losses["fit_loss"].sum() + losses["mse_loss"]
+    total.backward()
+    torch.cuda.synchronize()
+    # ---- the same composition on the CPU oracles ----
+    Wp = {k: torch.from_numpy(a.copy()) for k, a in W_pn.items()}
+    for k, v in Wp.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    Wf = {k: torch.from_numpy(a.copy()).requires_grad_(True) for k, a in W_lat.items() if k.startswith("flow.")}
+    Wd = {k: torch.from_numpy(a.copy()).requires_grad_(True) for k, a in W_dn.items()}
+    m, lv = pt.forward(Wp, torch.from_numpy(ref), torch.from_numpy(attn))
+    part_code = (m + torch.exp(0.5 * lv) * torch.from_numpy(eps)).transpose(1, 2)
+    prior, _, _ = pl.prior_loss(Wf, part_code, lv, torch.from_numpy(valid), prior_var=1.0, kl_weight=5e-4)
+    mean_t, gt_var = torch.from_numpy(gt_shift), torch.from_numpy(gt_std) ** 2
+    idx = torch.from_numpy(seg.astype(np.int64))[:, None, :].expand(-1, 3, -1)
+    anc_pp, var_pp = torch.gather(mean_t, 2, idx), torch.gather(gt_var, 2, idx)
+    flags = torch.gather(torch.from_numpy(valid)[:, None, :], 2, torch.from_numpy(seg.astype(np.int64))[:, None, :])
+    sa = torch.from_numpy(diff.sqrt_alphas_cumprod).float()[torch.from_numpy(t)].view(-1, 1, 1)
+    s1 = torch.from_numpy(diff.sqrt_one_minus_alphas_cumprod).float()[torch.from_numpy(t)].view(-1, 1, 1)
+    x0 = torch.from_numpy(ref).transpose(1, 2)
+    x_t = sa * (x0 - anc_pp) + anc_pp + s1 * torch.sqrt(var_pp) * torch.from_numpy(noise)
+    eps_hat = torch_cpu.transformer_net_forward(Wd, x_t, torch.from_numpy(t), [part_code, torch.cat([mean_t, gt_var], 1)],
+                                                anc_pp.transpose(1, 2), var_pp.transpose(1, 2), torch.from_numpy(valid), torch.from_numpy(seg))
+    mse = otrain.masked_mse(torch.from_numpy(noise), eps_hat, flags)
+    (prior + mse).backward()
+    assert abs(float(losses["prior_loss"].detach()) - float(prior.detach())) < 1e-5 * abs(float(prior.detach()))
+    assert abs(float(losses["mse_loss"].detach()) - float(mse.detach())) < 2e-5 * abs(float(mse.detach()))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+    worst = {}
+    for name, p in enc.encoder.named_parameters():
+        if name in ZERO_GRAD:
+            continue
+        worst["pn"] = max(worst.get("pn", 0.0), rel(p.grad.cpu().numpy(), Wp[name].grad.numpy()))
+    for name, p in enc.named_parameters():
+        if name.startswith("flow."):
+            worst["flow"] = max(worst.get("flow", 0.0), rel(p.grad.cpu().numpy(), Wf[name].grad.numpy()))
+    for name, p in diff.model.named_parameters():
+        worst["denoiser"] = max(worst.get("denoiser", 0.0), rel(p.grad.cpu().numpy(), Wd[name].grad.numpy()))
+    print("stage-1 step, worst relative L2 gradient error per group:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert worst["pn"] < 2e-3 and worst["flow"] < 2e-3 and worst["denoiser"] < 2e-3, worst
