@@ -404,58 +404,82 @@ class Adam:
         for p in self.params:
             p.grad = None
 
-    def _grad_layout(self):
-        """(order, offsets, total) if the gradients are disjoint slices of ONE fp32 buffer (gaps allowed: they must hold
-        zeros, as DenoiserTrainFn.backward leaves them), else None."""
-        if any(p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda for p in self.params):
+    def _grad_groups(self):
+        """Partition the parameters by the storage their gradient lives in.  A group whose gradients are disjoint fp32
+        slices of ONE buffer (gaps allowed: they hold zeros, as the libdfx backward functions leave them) is returned as
+        (order, offsets, total); parameters whose gradient stands alone come back in `loose`.  None if a gradient is missing."""
+        if any(p.grad is None for p in self.params):
             return None
-        order = sorted(range(len(self.params)), key=lambda i: self.params[i].grad.data_ptr())
-        g0 = self.params[order[0]].grad
-        base, store = g0.data_ptr(), g0.untyped_storage()
-        if base != store.data_ptr():
-            return None
-        offsets, end = [], 0
-        for i in order:
-            g = self.params[i].grad
-            off = (g.data_ptr() - base) // 4
-            if g.untyped_storage().data_ptr() != store.data_ptr() or (g.data_ptr() - base) % 4 or off < end:
-                return None
-            offsets.append(off)
-            end = off + g.numel()
-        if end * 4 > store.nbytes():
-            return None
-        return order, offsets, end
+        by_store = {}
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+                by_store.setdefault(("loose", i), []).append(i)
+            else:
+                by_store.setdefault(g.untyped_storage().data_ptr(), []).append(i)
+        groups, loose = [], []
+        for key, idxs in by_store.items():
+            if isinstance(key, tuple) or len(idxs) == 1:
+                loose += idxs
+                continue
+            order = sorted(idxs, key=lambda i: self.params[i].grad.data_ptr())
+            g0 = self.params[order[0]].grad
+            base, store = g0.data_ptr(), g0.untyped_storage()
+            offsets, end, ok = [], 0, base == store.data_ptr()
+            for i in order:
+                g = self.params[i].grad
+                off = (g.data_ptr() - base) // 4
+                if (g.data_ptr() - base) % 4 or off < end:
+                    ok = False
+                    break
+                offsets.append(off)
+                end = off + g.numel()
+            if ok and end * 4 <= store.nbytes():
+                groups.append((order, offsets, end))
+            else:
+                loose += idxs
+        return groups, loose
 
-    def _flat_grad(self):
-        """The gradients as one flat tensor matching the flat parameter buffer, or None."""
+    def _flat_work(self):
+        """[(flat_param, flat_grad, flat_m, flat_v)] for the grouped parameters + [(p, g, m, v)] for the loose ones, or None."""
         if not self.flatten:
             return None
-        lay = self._grad_layout()
+        lay = self._grad_groups()
         if lay is None:
             return None
-        order, offsets, total = lay
-        if self._flat is None or self._flat[0] != order or self._flat[1] != offsets:
-            dev = self.params[0].device
-            fp, fm, fv = (torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
-            with torch.no_grad():
-                for i, o in zip(order, offsets):
-                    p, k = self.params[i], self.params[i].numel()
-                    fp[o:o + k].copy_(p.detach().reshape(-1))
-                    fm[o:o + k].copy_(self.m[i].reshape(-1))
-                    fv[o:o + k].copy_(self.v[i].reshape(-1))
-                    p.data = fp[o:o + k].view_as(p)
-                    self.m[i] = fm[o:o + k].view_as(p)
-                    self.v[i] = fv[o:o + k].view_as(p)
-            self._flat = (order, offsets, fp, fm, fv)
-        g0 = self.params[order[0]].grad
-        return torch.as_strided(g0, (total,), (1,))   # same storage, layout checked above
+        groups, loose = lay
+        if self._flat is None:
+            self._flat = {}
+        work = []
+        dev = self.params[0].device
+        for order, offsets, total in groups:
+            key = (tuple(order), tuple(offsets), total)
+            if key not in self._flat:
+                fp, fm, fv = (torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
+                with torch.no_grad():
+                    for i, o in zip(order, offsets):
+                        p, k = self.params[i], self.params[i].numel()
+                        fp[o:o + k].copy_(p.detach().reshape(-1))
+                        fm[o:o + k].copy_(self.m[i].reshape(-1))
+                        fv[o:o + k].copy_(self.v[i].reshape(-1))
+                        p.data = fp[o:o + k].view_as(p)
+                        self.m[i] = fm[o:o + k].view_as(p)
+                        self.v[i] = fv[o:o + k].view_as(p)
+                self._flat[key] = (fp, fm, fv)
+            fp, fm, fv = self._flat[key]
+            g0 = self.params[order[0]].grad
+            work.append((fp, torch.as_strided(g0, (total,), (1,)), fm, fv))   # same storage, layout checked above
+        self.last_step_was_flat = len(groups) > 0 and not loose
+        for i in loose:
+            work.append((self.params[i], _need(self.params[i].grad.contiguous(), "grad"), self.m[i], self.v[i]))
+        return work
 
     def grad_norm(self):
         """Global L2 norm of the gradients (what clip_grad_norm_ returns), as a 0-dim float64 cuda tensor."""
         lib = _ffi.lib()
         self._sumsq.zero_()
-        flat = self._flat_grad()
-        todo = [flat] if flat is not None else [p.grad for p in self.params if p.grad is not None]
+        work = self._flat_work()
+        todo = [w[1] for w in work] if work is not None else [p.grad for p in self.params if p.grad is not None]
         for g in todo:
             g = _need(g.contiguous(), "grad")
             with torch.cuda.device(g.device):
@@ -468,11 +492,9 @@ class Adam:
         lib = _ffi.lib()
         norm = self.grad_norm() if self.max_norm and self.max_norm > 0 else None
         self.step_count += 1
-        flat = self._flat_grad()
-        self.last_step_was_flat = flat is not None
-        if flat is not None:
-            work = [(self._flat[2], flat, self._flat[3], self._flat[4])]
-        else:
+        work = self._flat_work()
+        if work is None:
+            self.last_step_was_flat = False
             work = [(p, _need(p.grad.contiguous(), "grad"), m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
         for p, g, m, v in work:
             with torch.cuda.device(p.device):
