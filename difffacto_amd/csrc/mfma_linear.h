@@ -19,8 +19,11 @@ struct LinArgs {
   const float *X; long long x_gs; int ldx;   // activations (M, K) rows, leading dimension ldx, group stride
   const float *W; long long w_gs;            // weights (N or 2N, K) row-major (nn.Linear layout)
   const float *b; long long b_gs;            // bias (N or 2N) or nullptr
+  const float *Wtab[4], *btab[4];            // k_lin only: per-group weight / bias pointers (groups <= 4) when Wtab[0] != nullptr,
+                                             // for groups whose parameters are separate tensors (the per-part flows)
   float *Y; long long y_gs; int ldy;         // output (M, N); COUPLING: the half of x updated in place
   const float *R; int ldr; int r_mod;        // RESID: Y = acc + b + R[(r_mod ? m % r_mod : m)][n]
+  long long r_gs;                            // k_lin only: group stride of R
   int M, N, K;                               // N = output columns (dual epilogues read 2N weight rows)
 };
 
@@ -31,7 +34,7 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, g = blockIdx.z;
   const int mrow = min(m0 + j, a.M - 1), nrow = min(n0 + j, a.N - 1);   // clamped rows are never stored
   const float *xp = a.X + g * a.x_gs + (size_t)mrow * a.ldx + 4 * hf;
-  const float *wp = a.W + g * a.w_gs + (size_t)nrow * a.K + 4 * hf;
+  const float *wp = (a.Wtab[0] ? a.Wtab[g] : a.W + g * a.w_gs) + (size_t)nrow * a.K + 4 * hf;
   const float *wq = wp + (size_t)a.N * a.K;
   v16f acc0, acc1;
 #pragma unroll
@@ -59,7 +62,7 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
   for (; k < a.K; k += 8) block(ld(xp + k), ld(wp + k), DUAL ? ld(wq + k) : v4f{0.f, 0.f, 0.f, 0.f});
   const int m = m0 + j;
   if (m >= a.M) return;
-  const float *bp = a.b ? a.b + g * a.b_gs : nullptr;
+  const float *bp = a.Wtab[0] ? a.btab[g] : (a.b ? a.b + g * a.b_gs : nullptr);
   float *yp = a.Y + g * a.y_gs + (size_t)m * a.ldy;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -67,7 +70,7 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
     if (n >= a.N) continue;
     float v = acc0[r] + (bp ? bp[n] : 0.f);
     if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-    if (EPI == EPI_RESID) v += a.R[(size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr + n];
+    if (EPI == EPI_RESID) v += a.R[g * a.r_gs + (size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr + n];
     if (EPI == EPI_COUPLING) {   // flow.py:30-31,40: y1 = (x2 - shift) / sigmoid(s + 2)
       const float shift = acc1[r] + (bp ? bp[a.N + n] : 0.f);
       const float scale = 1.f / (1.f + expf(-(v + 2.f)));

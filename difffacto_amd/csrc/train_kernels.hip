@@ -496,13 +496,10 @@ __global__ void k_mse_bwd(const float *__restrict__ target, const float *__restr
 // weight gradient: dW (O, I) = dY^T X over R rows, db = column sums of dY
 // grid (ceil(I/64), ceil(O/64), nslab); one wavefront per block; part[slab][O][I] (+ bpart[slab][O] from blockIdx.x == 0)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
-                                               float *__restrict__ part, float *__restrict__ bpart, int O, int I,
-                                               long long R, int rows_per_slab) {
+__device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                           float *__restrict__ pp, float *__restrict__ bp, int O, int I, long long r0, long long r1) {
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
   const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
-  const long long r0 = (long long)blockIdx.z * rows_per_slab;
-  const long long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
   const bool oa = o0 + j < O, ob = o0 + 32 + j < O, ia = i0 + j < I, ib = i0 + 32 + j < I;
   const float *py = dY + o0 + j, *px = X + i0 + j;
   v16f acc[2][2];
@@ -544,7 +541,6 @@ __global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int 
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
     bs0 += ya, bs1 += yb;
   }
-  float *pp = part + (size_t)blockIdx.z * O * I;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -557,13 +553,44 @@ __global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int 
         if (o < O) pp[(size_t)o * I + i] = acc[a][b][rg];
       }
     }
-  if (bpart && blockIdx.x == 0) {
+  if (bp && blockIdx.x == 0) {
     bs0 += __shfl_xor(bs0, 32), bs1 += __shfl_xor(bs1, 32);
     if (hf == 0) {
-      if (oa) bpart[(size_t)blockIdx.z * O + o0 + j] = bs0;
-      if (ob) bpart[(size_t)blockIdx.z * O + o0 + 32 + j] = bs1;
+      if (oa) bp[o0 + j] = bs0;
+      if (ob) bp[o0 + 32 + j] = bs1;
     }
   }
+}
+__global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                               float *__restrict__ part, float *__restrict__ bpart, int O, int I,
+                                               long long R, int rows_per_slab) {
+  const long long r0 = (long long)blockIdx.z * rows_per_slab;
+  const long long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+  wgrad_tile(dY, ldy, X, ldx, part + (size_t)blockIdx.z * O * I, bpart ? bpart + (size_t)blockIdx.z * O : nullptr, O, I, r0, r1);
+}
+// Up to four independent few-row products in one launch (blockIdx.z = group): operands at uniform group strides, results
+// through pointer tables (the per-part flows' parameters are separate tensors); all R rows in one slab, written directly
+struct Ptr4 {
+  float *p[4];
+};
+__global__ __launch_bounds__(64) void k_wgrad_g4(const float *__restrict__ dY, int ldy, long long dy_gs, const float *__restrict__ X,
+                                                  int ldx, long long x_gs, Ptr4 dW, Ptr4 db, int O, int I, long long R) {
+  const int g = blockIdx.z;
+  wgrad_tile(dY + g * dy_gs, ldy, X + g * x_gs, ldx, dW.p[g], db.p[g], O, I, 0, R);
+}
+struct CPtr4 {
+  const float *p[4];
+};
+// W_g (rows, cols) -> WT + g * wt_gs (cols, rows) for up to four groups
+__global__ void k_transpose_g4(CPtr4 W, float *__restrict__ WT, long long wt_gs, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const float *Wg = W.p[blockIdx.z];
+  float *T = WT + blockIdx.z * wt_gs;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) tile[k][tx] = (r0 + k < rows && c0 + tx < cols) ? Wg[(size_t)(r0 + k) * cols + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < cols && r0 + tx < rows) T[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 // dW[o][i < I_valid] = sum over slabs; ld of dW = I_valid
 __global__ void k_wgrad_finish(const float *__restrict__ part, float *__restrict__ dW, int nslab, int O, int I, int I_valid) {
@@ -721,26 +748,45 @@ __global__ void k_pn_rows(const float *__restrict__ x, float *__restrict__ X8, l
   reinterpret_cast<v4f *>(X8 + r * 8)[0] = v4f{x[r * 3], x[r * 3 + 1], x[r * 3 + 2], 0.f};
   reinterpret_cast<v4f *>(X8 + r * 8)[1] = v4f{0.f, 0.f, 0.f, 0.f};
 }
-// pooled[b][a][c] = max_n y[b, n, c] attn[b, n, a] scale  (pointnet.py:194-198), with the arg max for the backward
+// pooled[b][a][c] = max_n y[b, n, c] attn[b, n, a] scale  (pointnet.py:194-198), with the arg max for the backward.
+// Block = 64 channels x 4 point phases (thread (c, ph) walks n = ph, ph + 4, ...), grid (Cc / 64, B); the four phases are
+// merged through LDS keeping the FIRST maximum (lowest n) like the serial scan.
 template <int A>
 __global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ y, const float *__restrict__ attn, float *__restrict__ pooled,
                                                    int32_t *__restrict__ arg, int N, int Cc, float scale) {
-  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= Cc) return;
+  __shared__ float sb[4][A][64];
+  __shared__ int si[4][A][64];
+  const int b = blockIdx.y, cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float best[A];
   int bi[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) best[a] = -3.402823466e38f, bi[a] = 0;
-  for (int n = 0; n < N; ++n) {
-    const float v = y[((size_t)b * N + n) * Cc + c];
+  if (c < Cc)
+    for (int n = ph; n < N; n += 4) {
+      const float v = y[((size_t)b * N + n) * Cc + c];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
+        if (w > best[a]) best[a] = w, bi[a] = n;
+      }
+    }
+#pragma unroll
+  for (int a = 0; a < A; ++a) sb[ph][a][cl] = best[a], si[ph][a][cl] = bi[a];
+  __syncthreads();
+  if (ph == 0 && c < Cc) {
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
-      if (w > best[a]) best[a] = w, bi[a] = n;
+      float m = sb[0][a][cl];
+      int mi = si[0][a][cl];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const float v = sb[q][a][cl];
+        const int vi = si[q][a][cl];
+        if (v > m || (v == m && vi < mi)) m = v, mi = vi;
+      }
+      pooled[((size_t)b * A + a) * Cc + c] = m, arg[((size_t)b * A + a) * Cc + c] = mi;
     }
   }
-#pragma unroll
-  for (int a = 0; a < A; ++a) pooled[((size_t)b * A + a) * Cc + c] = best[a], arg[((size_t)b * A + a) * Cc + c] = bi[a];
 }
 // dy (zero-initialised) [b, arg, c] += d pooled[b][a][c] attn[b, arg, a] scale; one thread per (b, c): no atomics
 template <int A>
@@ -1021,6 +1067,7 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
   if (!done && (dy_bf || x_bf)) return dfx::set_error(DFX_ERR_UNSUPPORTED, "train: bf16-stored operand without the bf16 product kernel (O=%d I=%d)", O, I);
   if (!done) {
     int slab = pick_slab(R, (long long)((O + 63) / 64) * ((I + 63) / 64), 2048, w.part_floats, (size_t)O * I);
+    if (R <= 512) slab = (int)((R + 63) / 64 * 64);   // a handful of rows: one slab, the tile is written straight into dW / db
     ns = (int)((R + slab - 1) / slab);
     if ((size_t)ns > bcap) {
       slab = (int)(((R + (long long)bcap - 1) / (long long)bcap + 63) / 64 * 64);
@@ -1197,7 +1244,7 @@ size_t carve_flow(FlowWs &w, void *base, int B, int depth, int H) {
   w.dh1 = c.take<float>(Rf * H);
   w.dh2 = c.take<float>(Rf * H);
   const size_t hm = (size_t)(H > ZD ? H : ZD);
-  w.wT = c.take<float>(hm * hm);
+  w.wT = c.take<float>(NPART * hm * hm);
   const size_t ns = (size_t)(B + 63) / 64 + 1;
   w.pb.part_floats = ns * hm * hm;
   w.pb.part = c.take<float>(w.pb.part_floats);
@@ -1213,6 +1260,22 @@ int check_flow(const float *const *flow, int depth, int H, const void *ws, size_
   DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
   for (int k = 0; k < NPART * depth * 6; ++k) DFX_REQUIRE(flow[k], "%s: null flow parameter %d", what, k);
   return DFX_OK;
+}
+// Y_g = [relu](X_g W_g^T + b_g) (+ R_g) for the four parts in one launch: X / Y / R at uniform group strides, W_g / b_g separate
+// tensors (tables) or a contiguous array of transposed copies (W + g * w_gs)
+template <int EPI>
+int lin_g4(hipStream_t st, const float *X, int ldx, long long x_gs, const float *const *Wt, const float *const *bt, const float *Wc,
+           long long w_gs, float *Y, int ldy, long long y_gs, int M, int N_, int K, const float *R = nullptr, int ldr = 0, long long r_gs = 0) {
+  LinArgs a{};
+  a.X = X, a.ldx = ldx, a.x_gs = x_gs, a.Y = Y, a.ldy = ldy, a.y_gs = y_gs, a.M = M, a.N = N_, a.K = K;
+  a.R = R, a.ldr = ldr, a.r_gs = r_gs;
+  if (Wt) {
+    for (int g = 0; g < NPART; ++g) a.Wtab[g] = Wt[g], a.btab[g] = bt ? bt[g] : nullptr;
+  } else {
+    a.W = Wc, a.w_gs = w_gs;
+  }
+  dfx::lin::k_lin<EPI><<<dim3((N_ + 31) / 32, (M + 31) / 32, NPART), 64, 0, st>>>(a);
+  return dfx::check_launch("train: grouped linear");
 }
 int lin_relu(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N_, int K) {
   LinArgs a{};
@@ -1406,7 +1469,7 @@ int dfx_pointnet_v2_train_forward(const dfx_pointnet_v2_weights *wt, void *works
                      w.mean[l], w.rstd[l], w.y[l], l < 3))) return rc;
   }
   const float scale = wt->reweight_by_anchor ? (float)A : 1.0f;
-  k_pool_fwd<4><<<dim3(2, B), 256, 0, st>>>(w.y[3], attn, w.pooled, w.arg, N, 512, scale);
+  k_pool_fwd<4><<<dim3(512 / 64, B), 256, 0, st>>>(w.y[3], attn, w.pooled, w.arg, N, 512, scale);
   const int hc[3] = {512, 256, 128};
   for (int k = 0; k < 2; ++k) {
     const float *in = w.pooled;
@@ -1497,13 +1560,13 @@ int dfx_prior_loss_forward(const float *const *flow, int flow_depth, int flow_hi
   DFX_HIP_TRY(hipMemsetAsync(w.logdet, 0, sizeof(float) * Rf, st));
   for (int l = 0; l < flow_depth; ++l) {
     const int swap = (l % 2 == 0), xc = swap ? ZH : 0;
-    for (int i = 0; i < NPART; ++i) {
-      const float *const *p = flow + ((size_t)i * flow_depth + l) * 6;
-      const size_t r0 = (size_t)i * B;
-      if ((rc = lin_relu(st, w.xs[l] + r0 * ZD + xc, ZD, p[0], p[1], w.h1[l] + r0 * H, H, B, H, ZH))) return rc;
-      if ((rc = lin_relu(st, w.h1[l] + r0 * H, H, p[2], p[3], w.h2[l] + r0 * H, H, B, H, H))) return rc;
-      if ((rc = lin(st, w.h2[l] + r0 * H, H, p[4], p[5], w.st[l] + r0 * ZD, ZD, B, ZD, H))) return rc;
-    }
+    const float *wt[3][NPART], *bt[3][NPART];
+    for (int i = 0; i < NPART; ++i)
+      for (int k = 0; k < 3; ++k) wt[k][i] = flow[((size_t)i * flow_depth + l) * 6 + 2 * k], bt[k][i] = flow[((size_t)i * flow_depth + l) * 6 + 2 * k + 1];
+    // net_s_t of the four parts in one launch each (rows part-major: group stride = B rows)
+    if ((rc = lin_g4<dfx::lin::EPI_RELU>(st, w.xs[l] + xc, ZD, (long long)B * ZD, wt[0], bt[0], nullptr, 0, w.h1[l], H, (long long)B * H, B, H, ZH))) return rc;
+    if ((rc = lin_g4<dfx::lin::EPI_RELU>(st, w.h1[l], H, (long long)B * H, wt[1], bt[1], nullptr, 0, w.h2[l], H, (long long)B * H, B, H, H))) return rc;
+    if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, w.h2[l], H, (long long)B * H, wt[2], bt[2], nullptr, 0, w.st[l], ZD, (long long)B * ZD, B, ZD, H))) return rc;
     k_coupling_fwd<<<Rf, 128, 0, st>>>(w.xs[l], w.st[l], w.xs[l + 1], w.logdet, swap);
   }
   k_prior_terms<<<Rf, 256, 0, st>>>(w.xs[flow_depth], w.logdet, logvar, valid, prior_var, kl_weight, B, w.logp, w.ent, w.acoef);
@@ -1536,27 +1599,31 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
   for (int l = flow_depth - 1; l >= 0; --l) {
     const int swap = (l % 2 == 0), xc = swap ? ZH : 0;
     k_coupling_bwd<<<Rf, 128, 0, st>>>(dy, w.xs[l], w.st[l], w.dlogdet, w.dst, dx, swap);
-    for (int i = 0; i < NPART; ++i) {
-      const float *const *p = flow + ((size_t)i * flow_depth + l) * 6;
-      float *const *g = flow_grads + ((size_t)i * flow_depth + l) * 6;
-      const size_t r0 = (size_t)i * B;
-      const float *dst = w.dst + r0 * ZD;
-      float *dh2 = w.dh2 + r0 * H, *dh1 = w.dh1 + r0 * H;
-      // net_s_t.4: s_t = h2 W3^T + b3
-      if ((rc = wgrad(st, w.pb, dst, ZD, w.h2[l] + r0 * H, H, g[4], g[5], ZD, H, H, B))) return rc;
-      transpose(st, p[4], w.wT, ZD, H);
-      if ((rc = lin(st, dst, ZD, w.wT, nullptr, dh2, H, B, H, ZD))) return rc;
-      k_relu_mask<<<(int)(((long long)B * H + 255) / 256), 256, 0, st>>>(dh2, w.h2[l] + r0 * H, (long long)B * H);
-      // net_s_t.2
-      if ((rc = wgrad(st, w.pb, dh2, H, w.h1[l] + r0 * H, H, g[2], g[3], H, H, H, B))) return rc;
-      transpose(st, p[2], w.wT, H, H);
-      if ((rc = lin(st, dh2, H, w.wT, nullptr, dh1, H, B, H, H))) return rc;
-      k_relu_mask<<<(int)(((long long)B * H + 255) / 256), 256, 0, st>>>(dh1, w.h1[l] + r0 * H, (long long)B * H);
-      // net_s_t.0: input = the conditioning half of x
-      if ((rc = wgrad(st, w.pb, dh1, H, w.xs[l] + r0 * ZD + xc, ZD, g[0], g[1], H, ZH, ZH, B))) return rc;
-      transpose(st, p[0], w.wT, H, ZH);
-      if ((rc = lin(st, dh1, H, w.wT, nullptr, dx + r0 * ZD + xc, ZD, B, ZH, H, dx + r0 * ZD + xc, ZD))) return rc;
-    }
+    CPtr4 wp[3];
+    Ptr4 gw[3], gb[3];
+    for (int i = 0; i < NPART; ++i)
+      for (int k = 0; k < 3; ++k) {
+        wp[k].p[i] = flow[((size_t)i * flow_depth + l) * 6 + 2 * k];
+        gw[k].p[i] = flow_grads[((size_t)i * flow_depth + l) * 6 + 2 * k];
+        gb[k].p[i] = flow_grads[((size_t)i * flow_depth + l) * 6 + 2 * k + 1];
+      }
+    const long long gsZ = (long long)B * ZD, gsH = (long long)B * H;
+    const size_t hm = (size_t)(H > ZD ? H : ZD);
+    const long long wt_gs = (long long)(hm * hm);
+    // net_s_t.4: s_t = h2 W3^T + b3   (the four parts per launch)
+    k_wgrad_g4<<<dim3((H + 63) / 64, (ZD + 63) / 64, NPART), 64, 0, st>>>(w.dst, ZD, gsZ, w.h2[l], H, gsH, gw[2], gb[2], ZD, H, B);
+    k_transpose_g4<<<dim3((H + 31) / 32, (ZD + 31) / 32, NPART), 256, 0, st>>>(wp[2], w.wT, wt_gs, ZD, H);
+    if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, w.dst, ZD, gsZ, nullptr, nullptr, w.wT, wt_gs, w.dh2, H, gsH, B, H, ZD))) return rc;
+    k_relu_mask<<<(int)(((long long)Rf * H + 255) / 256), 256, 0, st>>>(w.dh2, w.h2[l], (long long)Rf * H);
+    // net_s_t.2
+    k_wgrad_g4<<<dim3((H + 63) / 64, (H + 63) / 64, NPART), 64, 0, st>>>(w.dh2, H, gsH, w.h1[l], H, gsH, gw[1], gb[1], H, H, B);
+    k_transpose_g4<<<dim3((H + 31) / 32, (H + 31) / 32, NPART), 256, 0, st>>>(wp[1], w.wT, wt_gs, H, H);
+    if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, w.dh2, H, gsH, nullptr, nullptr, w.wT, wt_gs, w.dh1, H, gsH, B, H, H))) return rc;
+    k_relu_mask<<<(int)(((long long)Rf * H + 255) / 256), 256, 0, st>>>(w.dh1, w.h1[l], (long long)Rf * H);
+    // net_s_t.0: input = the conditioning half of x; its gradient is added to the pass-through gradient already in dx
+    k_wgrad_g4<<<dim3((ZH + 63) / 64, (H + 63) / 64, NPART), 64, 0, st>>>(w.dh1, H, gsH, w.xs[l] + xc, ZD, gsZ, gw[0], gb[0], H, ZH, B);
+    k_transpose_g4<<<dim3((ZH + 31) / 32, (H + 31) / 32, NPART), 256, 0, st>>>(wp[0], w.wT, wt_gs, H, ZH);
+    if ((rc = lin_g4<dfx::lin::EPI_RESID>(st, w.dh1, H, gsH, nullptr, nullptr, w.wT, wt_gs, dx + xc, ZD, gsZ, B, ZH, H, dx + xc, ZD, gsZ))) return rc;
     float *t = dy;
     dy = dx, dx = t;
   }
