@@ -1,4 +1,6 @@
-// Training-mode evaluation of the cross-diffusion denoiser and its backward:
+// The stage-1 training step: the cross-diffusion denoiser in training mode and its backward (below),
+// PointNetV2 in train mode and the prior loss through the latent flows (further down), the loss gradient and the optimiser.
+// Denoiser:
 //   TransformerNet.forward / _forward_attn (attention.py:385-440, BasicTransformerBlock :296-306 with single_attn,
 //   CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94, timestep_embedding utils.py:7-24), optional dropout,
 // in exact fp32 or with bf16 matrix products (gemm_bf16.h) (v_mfma_f32_32x32x2_f32 through the shared row-batched linear kernels), every intermediate that the
