@@ -196,6 +196,31 @@ def test_dropout_factors_and_replayed_mask_parity():
         assert np.abs(r[k] - ref[k]).max() <= 5e-4 * np.abs(ref[k]).max() + 1e-8, k
 
 
+def test_smallest_shapes_and_no_validity_mask():
+    """B = 1, N = 32 (one attention block, one product slab) with valid = None (all parts present), no flags, both precisions'
+    code paths: against the oracle."""
+    from difffacto_amd import synth
+    from oracle import train
+    rng = np.random.Generator(np.random.PCG64(1))
+    B, N = 1, 32
+    W = synth.make_denoiser_weights(5)
+    pc, mean, logvar, _ = synth.make_latents(B, seed=3, all_valid=True)
+    seg = rng.integers(0, 4, size=(B, N)).astype(np.int32)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=np.array([999], np.int64), ctx_code=pc,
+             ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32), anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)),
+             variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)), valid=None, assignment=seg,
+             noise=rng.standard_normal((B, 3, N)).astype(np.float32), flags=None)
+    ref = train.loss_and_grads(**c)
+    for prec in ("f32", "bf16"):       # bf16 falls back to the fp32 kernels below 256 rows: same numbers
+        r = _run(c, False, precision=prec)
+        assert abs(r["loss"] - ref["loss"]) < 5e-6 * max(1.0, abs(ref["loss"]))
+        for k, gr in ref["grads"].items():
+            assert np.abs(r["grads"][k] - gr).max() <= 5e-4 * max(np.abs(gr).max(), 1e-30) + 1e-7, (prec, k)
+
+
 def test_adam_with_clipping_matches_torch():
     """Three steps of dfx Adam + clip_grad_norm_(max_norm) against torch.optim.Adam + torch.nn.utils.clip_grad_norm_ on
     the CPU (what Runner.train does, runner.py:312-316), on tensors of awkward sizes."""
