@@ -120,13 +120,15 @@ class PointNetV2(nn.Module):
             return m, v
         if self.training and x.is_cuda and B >= 2 and A == 4 and self.zdim % 4 == 0:
             # train() mode: batch-statistics BatchNorm forward (running statistics updated in place like nn.BatchNorm1d) and
-            # the backward on libdfx's training kernels (exact fp32; difffacto_amd/training.py)
+            # the backward on libdfx's training kernels (difffacto_amd/training.py).  Exact fp32 unless the caller sets
+            # `module.train_precision = "bf16"` (bf16 operands for the trunk's products: the max-pool's arg-max may flip under
+            # that noise, so results then differ from fp32 discontinuously)
             from . import training as _training
             sd_p, sd_b = dict(self.named_parameters()), dict(self.named_buffers())
             momentum = self.bn1.momentum if self.bn1.momentum is not None else 0.1
             m, v = _training.pointnet_v2_train_forward(sd_p, sd_b, x, attn_weight, num_anchors=A, zdim=self.zdim,
                                                        reweight_by_anchor=self.reweight_by_anchor, eps=self.bn1.eps, momentum=momentum,
-                                                       precision="f32")
+                                                       precision=getattr(self, "train_precision", "f32"))
             with torch.no_grad():
                 for mod in self.modules():
                     if isinstance(mod, nn.BatchNorm1d) and mod.num_batches_tracked is not None:

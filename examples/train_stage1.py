@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"], help="matrix products of the denoiser")
     ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--encoder-precision", default="f32", choices=["bf16", "f32"], help="matrix products of the PointNetV2 trunk")
     ap.add_argument("--lr", type=float, default=2e-3)
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -41,6 +42,7 @@ def main():
     diff = AnchoredDiffusion(net=net, num_timesteps=a.timesteps, beta_1=1e-4, beta_T=.02, k=1.0, res=False, mode='linear', use_beta=False,
                              rescale_timesteps=False, model_mean_type="epsilon", learn_variance=True, loss_type='mse', include_anchors=False,
                              precision=a.precision)
+    enc.encoder.train_precision = a.encoder_precision
     enc, diff = enc.cuda().train(), diff.cuda().train()
     opt = training.Adam(list(enc.parameters()) + list(diff.model.parameters()), lr=a.lr, max_norm=10.0)   # clip over everything
     rng = np.random.Generator(np.random.PCG64(0))
