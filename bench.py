@@ -75,10 +75,61 @@ def train_iteration(Wnp, B, N, iters=4):
             it()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / iters * 1e3
-        return {"what": "denoiser forward + backward + clip + Adam, bf16 matrix products, fp32 master weights (tools/bench_train.py)",
-                "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters}
+        out = {"what": "denoiser forward + backward + clip + Adam, bf16 matrix products, fp32 master weights (tools/bench_train.py)",
+               "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters}
+        del P, a, noise, opt
+        torch.cuda.empty_cache()
+        out["stage1"] = stage1_iteration(B, N, iters)
+        return out
     except Exception as e:   # secondary line: never fail the headline measurement
         return {"error": repr(e)[:200]}
+
+
+def stage1_iteration(B, N, iters=4):
+    """The whole stage-1 training iteration of configs/train_chair_stage1.py (PointNetV2 part encoder in train mode + prior loss
+    through the latent flows + denoiser + clip + Adam) through the drop-in modules (examples/train_stage1.py)."""
+    import numpy as np
+    import torch
+    from difffacto_amd import synth, training
+    from difffacto_amd.encoders import PartEncoderForTransformerDecoder
+    from difffacto_amd.modules import AnchoredDiffusion
+    enc = PartEncoderForTransformerDecoder(encoder=dict(type="PointNetV2", zdim=256, per_part_mlp=True), n_class=4, part_aligner=None,
+                                           include_z=False, include_part_code=True, include_params=True, use_gt_params=True, kl_weight=5e-4,
+                                           use_flow=True, latent_flow_depth=14, latent_flow_hidden_dim=256, gen=True, prior_var=1.0)
+    net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=0.0, context_dim=256 + 6,
+               n_class=4, class_cond=True, use_linear=True, cat_params_to_x=True, use_checkpoint=False, single_attn=True, cat_class_to_x=True)
+    diff = AnchoredDiffusion(net=net, num_timesteps=1000, beta_1=1e-4, beta_T=.02, k=1.0, res=False, mode='linear', use_beta=False,
+                             rescale_timesteps=False, model_mean_type="epsilon", learn_variance=True, loss_type='mse', include_anchors=False,
+                             precision="bf16")
+    enc, diff = enc.cuda().train(), diff.cuda().train()
+    opt = training.Adam(list(enc.parameters()) + list(diff.model.parameters()), lr=1e-4, max_norm=10.0)
+    rng = np.random.Generator(np.random.PCG64(0))
+    cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    _, shift, lv, valid = synth.make_latents(B, seed=0)
+    seg = synth.make_seg_mask(valid, N)
+    std = np.exp(0.5 * lv).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    pts = (np.take_along_axis(shift, idx, 2) + np.take_along_axis(std, idx, 2) * rng.standard_normal((B, 3, N))).astype(np.float32)
+    pcds = {"input": cu(pts.transpose(0, 2, 1)), "ref": cu(pts.transpose(0, 2, 1)), "present": cu(valid), "dp_present": cu(valid),
+            "ref_seg_mask": cu(seg.astype(np.int64)), "ref_attn_map": cu(np.eye(4, dtype=np.float32)[seg]), "part_shift": cu(shift),
+            "part_scale": cu(std), "noise": torch.zeros(B, 32).cuda()}
+
+    def it():
+        opt.zero_grad()
+        losses = training.stage1_losses(enc, diff, pcds)
+        sum(v.sum() for k, v in losses.items() if "loss" in k).backward()
+        opt.step()
+
+    for _ in range(2):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"what": "PointNetV2 (train mode, fp32) + prior loss through 4 x 14 coupling layers + denoiser (bf16 products) + clip + Adam",
+            "ms": ms, "shapes_per_s": B / ms * 1e3}
 
 
 def measured_traffic(T, B, N):
