@@ -1126,7 +1126,7 @@ struct PnWs {
   PartBufs pb;
 };
 constexpr int PN_C[5] = {8, 128, 128, 256, 512};   // trunk widths (input padded 3 -> 8)
-size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int zdim) {
+size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int /*zdim: the heads write straight into the caller's outputs*/) {
   Carver c{static_cast<char *>(base)};
   const size_t R = (size_t)B * N;
   w.X8 = c.take<float>(R * 8);
@@ -1278,12 +1278,6 @@ int lin_g4(hipStream_t st, const float *X, int ldx, long long x_gs, const float 
   }
   dfx::lin::k_lin<EPI><<<dim3((N_ + 31) / 32, (M + 31) / 32, NPART), 64, 0, st>>>(a);
   return dfx::check_launch("train: grouped linear");
-}
-int lin_relu(hipStream_t st, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N_, int K) {
-  LinArgs a{};
-  a.X = X, a.ldx = ldx, a.W = W, a.b = b, a.Y = Y, a.ldy = ldy, a.M = M, a.N = N_, a.K = K;
-  dfx::lin::k_lin<dfx::lin::EPI_RELU><<<dim3((N_ + 31) / 32, (M + 31) / 32, 1), 64, 0, st>>>(a);
-  return dfx::check_launch("train: linear + relu");
 }
 
 }  // namespace

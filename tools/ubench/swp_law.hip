@@ -25,7 +25,8 @@ template <int NV> struct VS;
 // polynomial variant (no transcendentals): clamp, square, 4 fma, fma, mul, mul = 10 packed ops per pair
 #define GP0 "v_pk_max_f16 %[t0], %[g0], %[g1]\n v_pk_min_f16 %[t0], %[t0], %[g1]\n v_pk_mul_f16 %[t1], %[t0], %[t0]\n v_pk_fma_f16 %[t2], %[t1], %[g1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n"
 #define GP1 "v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t1], %[g1]\n v_pk_fma_f16 %[t2], %[t2], %[t0], %[g1]\n v_pk_mul_f16 %[t3], %[g0], %[g1]\n v_pk_mul_f16 %[t3], %[t3], %[t2]\n"
-template <int NV, int NT, bool MFMA, bool LDS>
+// LDS: 0 = fragments stay in registers, 1 = one ds_read_b128 per MFMA (the kernel's in-place refill), 2 = one per two MFMAs
+template <int NV, int NT, bool MFMA, int LDS>
 __global__ void __launch_bounds__(512, 2) k(float *out, int iters, int rnd) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   for (int i = threadIdx.x; i < 32 * 1024 / 4; i += blockDim.x) {
@@ -39,6 +40,10 @@ __global__ void __launch_bounds__(512, 2) k(float *out, int iters, int rnd) {
   v16f a0 = {0}, a1 = a0, h0 = a0, h1 = a0;
   v4f f0 = {0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0, f5 = f0, f6 = f0, f7 = f0, b = f0;
   if (rnd) { b = reinterpret_cast<v4f *>(smem)[threadIdx.x & 63]; }
+  if (rnd && LDS != 1) {   // fragments that are not refilled every MFMA still hold random operands
+    const v4f *fs = reinterpret_cast<const v4f *>(smem) + lane;
+    f0 = fs[64], f1 = fs[128], f2 = fs[192], f3 = fs[256], f4 = fs[320], f5 = fs[384], f6 = fs[448], f7 = fs[512];
+  }
   unsigned g0 = rnd ? (0x3c003c00u ^ (threadIdx.x * 0x01230123u & 0x03ff03ffu)) : 0x3c003c00u, g1 = rnd ? (0x38003800u ^ (threadIdx.x * 0x04560457u & 0x03ff03ffu)) : 0x38003800u, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
 #define OPS : [a0] "+v"(a0), [a1] "+v"(a1), [h0] "+v"(h0), [h1] "+v"(h1), [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3), \
               [f4] "+v"(f4), [f5] "+v"(f5), [f6] "+v"(f6), [f7] "+v"(f7), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [t4] "+v"(t4), \
@@ -46,7 +51,7 @@ __global__ void __launch_bounds__(512, 2) k(float *out, int iters, int rnd) {
   for (int it = 0; it < iters; ++it) {
 #define GRP(acc, fr, off)                                                                                          \
     if (MFMA) asm volatile("s_waitcnt lgkmcnt(7)\n v_mfma_f32_32x32x16_bf16 %[" acc "], %[" fr "], %[b], %[" acc "]\n" OPS); \
-    if (LDS) asm volatile("ds_read_b128 %[" fr "], %[la] offset:" #off "\n" OPS);                                 \
+    if (LDS == 1 || (LDS == 2 && !(((off) >> 10) & 1))) asm volatile("ds_read_b128 %[" fr "], %[la] offset:" #off "\n" OPS);                                 \
     if (NV >= 1) asm volatile(PK0 OPS); if (NV >= 2) asm volatile(PK1 OPS); if (NV >= 3) asm volatile(PK2 OPS);      \
     if (NV >= 4) asm volatile(PK3 OPS); if (NV >= 5) asm volatile(PK0 OPS); if (NV >= 6) asm volatile(PK1 OPS);      \
     if (NV >= 7) asm volatile(PK2 OPS); if (NV >= 8) asm volatile(PK3 OPS);                                         \
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(512, 2) k(float *out, int iters, int rnd) {
 
 static double clk_ghz = 2.1;
 static int g_rnd = 0;
-template <int NV, int NT, bool MFMA = true, bool LDS = true>
+template <int NV, int NT, bool MFMA = true, int LDS = 1>
 void run(float *d) {
   const int iters = 4000;
   hipEvent_t a, b;
@@ -82,16 +87,16 @@ void run(float *d) {
 int main(int argc, char **argv) {
   float *d; (void)hipMalloc(&d, 64);
   if (argc > 1) {   // power check: the same streams on zero operands and on random operands
-    for (g_rnd = 0; g_rnd < 2; ++g_rnd) { run<0, 0>(d); run<4, 0>(d); run<0, 11>(d); run<0, 10>(d); run<0, 11, false, true>(d); }
+    for (g_rnd = 0; g_rnd < 2; ++g_rnd) { run<0, 0>(d); run<4, 0>(d); run<0, 11>(d); run<0, 10>(d); run<0, 11, false, 1>(d); run<0, 0, true, 0>(d); run<0, 0, true, 2>(d); run<4, 0, true, 0>(d); run<4, 0, true, 2>(d); }
     return 0;
   }
   run<0, 0>(d); run<2, 0>(d); run<3, 0>(d); run<4, 0>(d); run<5, 0>(d); run<6, 0>(d); run<8, 0>(d);
   run<0, 1>(d); run<0, 2>(d); run<3, 1>(d); run<4, 1>(d); run<3, 2>(d);
-  run<4, 0, false, true>(d); run<8, 0, false, true>(d); run<0, 2, false, true>(d); run<3, 1, false, false>(d);
-  run<4, 0, true, false>(d);
+  run<4, 0, false, 1>(d); run<8, 0, false, 1>(d); run<0, 2, false, 1>(d); run<3, 1, false, 0>(d);
+  run<4, 0, true, 0>(d);
   printf("exact GELU sequence (12 instr + 3 s_nop per pair, 4 transcendentals), one pair per 2 MFMAs, 24 MFMAs:\n");
-  run<0, 10>(d); run<0, 10, false, true>(d); run<0, 10, true, false>(d);
+  run<0, 10>(d); run<0, 10, false, 1>(d); run<0, 10, true, 0>(d);
   printf("polynomial GELU (10 packed ops per pair, no transcendentals):\n");
-  run<0, 11>(d); run<0, 11, false, true>(d);
+  run<0, 11>(d); run<0, 11, false, 1>(d);
   return 0;
 }
