@@ -1,4 +1,4 @@
-"""Random-shape sweep of the GPU parity tests: python tools/fuzz_parity.py [seconds] [seed].
+"""Random-shape sweep of the GPU parity tests: python tools/fuzz_parity.py [seconds] [seed] [family filter].
 
 Calls the parametrised oracle comparisons of tests/test_gpu_*.py (the same assertions, the same tolerances) with shapes
 drawn at random instead of the fixed lists, until the time budget is spent; prints one line per family with the number of
@@ -16,6 +16,7 @@ import numpy as np  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = sys.argv[3] if len(sys.argv) > 3 else ""      # substring of the family names to run
 rng = np.random.default_rng(seed)
 ri = lambda lo, hi: int(rng.integers(lo, hi + 1))
 rb = lambda: bool(rng.integers(0, 2))
@@ -23,6 +24,7 @@ rb = lambda: bool(rng.integers(0, 2))
 import test_gpu_denoiser as td  # noqa: E402
 import test_gpu_emd as te  # noqa: E402
 import test_gpu_encoder_train as tet  # noqa: E402
+import test_gpu_latents as tl  # noqa: E402
 import test_gpu_pointnet2 as tp  # noqa: E402
 import test_gpu_train as tt  # noqa: E402
 from difffacto_amd import synth  # noqa: E402
@@ -44,7 +46,58 @@ def gemm_case():
     return (1, 128 * ri(1, 8), 128 * ri(1, 4), ri(33, 9000), ri(0, 1), ri(0, 1))
 
 
+def chain_case(T, B, N, all_valid, interval, seed):
+    """DDPM chain in one launch, explicit noise, trajectory snapshots: tests/test_gpu_denoiser.py::test_chain_f32_vs_oracle_T100
+    at other sizes."""
+    import torch
+    from oracle import diffusion as odf
+    eng = td._engine(W, T, "f32")
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=seed, all_valid=all_valid)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    r = np.random.default_rng(seed)
+    xT = r.standard_normal((B, 3, N)).astype(np.float32)
+    zs = r.standard_normal((T, B, 3, N)).astype(np.float32)
+    anchors, variance = odf.gather_params(seg, mean, var)
+    dec = odf.decode(odf.Tables(T), W, anchors, [part_code, np.concatenate([mean, var], 1)], variance, seg, valid, xT, zs,
+                     ret_traj=True, ret_interval=interval)
+    ctx = eng.prepare_shapes(*map(torch.from_numpy, (part_code, mean, var, valid)))
+    pred, traj = eng.sample_chain(ctx, torch.from_numpy(seg), x_T_noise=torch.from_numpy(xT), step_noise=torch.from_numpy(zs),
+                                  ret_interval=interval)
+    assert np.abs(pred.cpu().numpy() - dec["pred"]).max() < td.TOL_F32_CHAIN
+    for k, t in enumerate(eng.snapshot_times(interval)):
+        assert np.abs(traj[k].cpu().numpy() - dec[t]).max() < td.TOL_F32_CHAIN, t
+
+
+LW = synth.make_latent_weights(seed=0)
+_sampler = []
+
+
+def latents_case(S, K, N, fixed, seed):
+    """flows in reverse + part aligner + sample_latents glue: tests/test_gpu_latents.py::test_sample_latents_vs_oracle_full_batch
+    at other sizes and fixed-part patterns."""
+    import torch
+    from difffacto_amd.latents import LatentSampler
+    from oracle import latents as ol
+    if not _sampler:
+        _sampler.append(LatentSampler(LW, noise_scale=100.0))
+    r = np.random.Generator(np.random.PCG64(seed))
+    w = r.standard_normal((S, 256, 4)).astype(np.float32)
+    an = r.standard_normal((S * K, 32)).astype(np.float32)
+    _, _, _, valid = synth.make_latents(S, seed=seed)
+    ref = ol.sample_latents(LW, w, an, valid, fixed, K, N, noise_scale=100.0)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    out = _sampler[0].sample_latents(cu(w), cu(an), cu(valid), fixed_id=fixed, K=K, npoints=N)
+    assert np.array_equal(out["seg_mask"].cpu().numpy(), ref["seg_mask"])
+    assert np.array_equal(out["valid_id"].cpu().numpy(), ref["valid_id"])
+    for k in ("part_code", "mean", "logvar", "mean_per_point", "logvar_per_point"):
+        tl._close(out[k], ref[k])
+
+
 FAMILIES = [
+    ("DDPM chain f32 vs oracle", lambda a: chain_case(*a), lambda: (ri(2, 40), ri(1, 4), 32 * ri(1, 12), rb(), ri(1, 12), ri(0, 10 ** 6))),
+    ("sample_latents vs oracle", lambda a: latents_case(*a),
+     lambda: (ri(1, 70), ri(1, 4), 4 * ri(8, 128), [ri(0, 1) for _ in range(4)], ri(0, 10 ** 6))),
     # name, callable, argument generator, rough cost weight
     ("denoiser eps f32 vs oracle", lambda a: unwrap(td.test_eps_f32_vs_oracle_seeded)(W, *a), lambda: (ri(1, 6), 32 * ri(1, 50), rb())),
     ("denoiser train fwd/bwd vs oracle", lambda a: tt.test_forward_backward_vs_oracle_full_gradients(*a),
@@ -66,6 +119,7 @@ FAMILIES = [
 for name in ("test_fps_matches_oracle", "test_ball_query_matches_oracle"):
     assert hasattr(tp, name), name
 
+FAMILIES = [f for f in FAMILIES if only in f[0]]
 t_end = time.time() + budget
 stats = {n: [0, []] for n, _, _ in [(f[0], 0, 0) for f in FAMILIES]}
 k = 0
