@@ -135,11 +135,29 @@ class DenoiserEngine:
         seg = seg.detach().to(device=device, dtype=torch.int32).contiguous()
         return seg
 
+    # The kernels take N % 32 == 0 (one wavefront = 32 points of one shape); the reference takes any N.  Points are
+    # independent in the denoiser and in the posterior update, so other sizes run padded to the next multiple of 32 --
+    # zeros for coordinates / noise, the shape's first label for seg -- and the padding is cut off again: exact.
+    @staticmethod
+    def _pad(N):
+        return (-int(N)) % 32
+
+    @staticmethod
+    def _pad_last(t, pad):
+        return None if t is None else torch.nn.functional.pad(t, (0, pad))
+
+    @staticmethod
+    def _pad_seg(seg, pad):
+        return torch.cat([seg, seg[:, :1].expand(-1, pad)], dim=1).contiguous()
+
     def eps(self, ctx, x, seg, t):
         """TransformerNet.forward: x (B,3,N), seg (B,N) -> eps (B,3,N)."""
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
         B, _, N = x.shape
+        pad = self._pad(N)
+        if pad:
+            return self.eps(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t)[..., :N].contiguous()
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_denoise_eps(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t),
@@ -154,6 +172,10 @@ class DenoiserEngine:
         if noise is not None:
             noise = noise.detach().to(device=self.device, dtype=torch.float32).contiguous()
             assert noise.shape == x.shape
+        pad = self._pad(N)
+        if pad:
+            r = self.p_sample(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, self._pad_last(noise, pad), seed, want_xstart)
+            return tuple(a[..., :N].contiguous() for a in r) if want_xstart else r[..., :N].contiguous()
         out = torch.empty_like(x)
         xs = torch.empty_like(x) if want_xstart else None
         with torch.cuda.device(self.device):
@@ -175,6 +197,11 @@ class DenoiserEngine:
             assert tuple(x_T_noise.shape) == (B, 3, N)
         if step_noise is not None:
             assert tuple(step_noise.shape) == (T, B, 3, N)
+        pad = self._pad(N)
+        if pad:
+            pred, traj = self.sample_chain(ctx, self._pad_seg(seg, pad), self._pad_last(x_T_noise, pad), self._pad_last(step_noise, pad),
+                                           seed, ret_interval)
+            return pred[:, :N].contiguous(), None if traj is None else traj[:, :, :N].contiguous()
         pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
         traj = None
         ri = 0
@@ -200,6 +227,9 @@ class DenoiserEngine:
         f = lambda a: a.detach().to(device=self.device, dtype=torch.float32).contiguous()
         x_start, noise, seg = f(x_start), f(noise), self._seg(seg, self.device)
         B, _, N = x_start.shape
+        pad = self._pad(N)
+        if pad:
+            return self.q_sample(ctx, self._pad_seg(seg, pad), self._pad_last(x_start, pad), t, self._pad_last(noise, pad))[..., :N].contiguous()
         out = torch.empty_like(x_start)
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_q_sample_f32(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), _ffi.ptr(self._tvec(t, B)), _ffi.ptr(x_start),
@@ -212,6 +242,9 @@ class DenoiserEngine:
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
         B, _, N = x.shape
+        pad = self._pad(N)
+        if pad:
+            return self.eps_t(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t)[..., :N].contiguous()
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_denoise_eps_t(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), _ffi.ptr(self._tvec(t, B)),
@@ -240,6 +273,10 @@ class DenoiserEngine:
         if noise is not None:
             noise = noise.detach().to(device=self.device, dtype=torch.float32).contiguous()
             assert noise.shape == x.shape
+        pad = self._pad(N)
+        if pad:
+            r = self.p_sample_ddim(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, eta, self._pad_last(noise, pad), seed, want_xstart)
+            return tuple(a[..., :N].contiguous() for a in r) if want_xstart else r[..., :N].contiguous()
         out = torch.empty_like(x)
         xs = torch.empty_like(x) if want_xstart else None
         with torch.cuda.device(self.device):
@@ -259,6 +296,11 @@ class DenoiserEngine:
         x_T_noise, step_noise = f(x_T_noise), f(step_noise)
         if step_noise is not None:
             assert tuple(step_noise.shape) == (len(steps), B, 3, N)
+        pad = self._pad(N)
+        if pad:
+            pred, traj = self.sample_chain_ddim(ctx, self._pad_seg(seg, pad), steps, eta, self._pad_last(x_T_noise, pad),
+                                                self._pad_last(step_noise, pad), seed, ret_interval)
+            return pred[:, :N].contiguous(), None if traj is None else traj[:, :, :N].contiguous()
         pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
         traj, ri = None, 0
         if ret_interval:

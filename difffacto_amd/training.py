@@ -149,6 +149,13 @@ def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, v
     depth = 0
     while f"transformer_blocks.{depth}.norm2.weight" in params:
         depth += 1
+    N = x.shape[-1]
+    pad = (-N) % 32
+    if pad:   # the kernels take N % 32 == 0: run padded (points are independent), cut the padding off; its gradient is zero
+        pf = torch.nn.functional.pad
+        assignment = torch.cat([assignment, assignment[:, :1].expand(-1, pad)], dim=1).contiguous()
+        return denoiser_train_forward(params, pf(x, (0, pad)), t, ctx_code, ctx_mv, pf(anchors, (0, 0, 0, pad)),
+                                      pf(variances, (0, 0, 0, pad), value=1.0), valid, assignment, precision, dropout)[..., :N]
     return DenoiserTrainFn.apply(depth, precision, dropout, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment,
                                  *[params[n] for n in param_names(depth)])
 

@@ -117,7 +117,7 @@ def test_pred_xstart_output(eng10, W):
     assert np.abs(xstart.cpu().numpy() - out["pred_xstart"]).max() < 5e-3   # x0-hat is amplified by sqrt(1/abar - 1)
 
 
-@pytest.mark.parametrize("B,N,all_valid", [(5, 256, False), (2, 2048, True), (1, 8192, False), (7, 32, False)])
+@pytest.mark.parametrize("B,N,all_valid", [(5, 256, False), (2, 2048, True), (1, 8192, False), (7, 32, False), (3, 100, False), (2, 8, True)])
 def test_eps_f32_vs_oracle_seeded(W, B, N, all_valid):
     eng = _engine(W, 100, "f32")
     part_code, mean, logvar, valid = synth.make_latents(B, seed=B * 1000 + N, all_valid=all_valid)
@@ -135,6 +135,40 @@ def test_eps_f32_vs_oracle_seeded(W, B, N, all_valid):
                                           anchors.transpose(0, 2, 1), variance.transpose(0, 2, 1), valid, seg)
         eps = eng.eps(ctx, torch.from_numpy(x), torch.from_numpy(seg), t).cpu().numpy()
         assert np.abs(eps - ref).max() < TOL_F32_EPS, (t, np.abs(eps - ref).max())
+
+
+def test_point_counts_that_are_not_multiples_of_32(W):
+    """The reference takes any N; the kernels take N % 32 == 0 and the host side pads (points are independent): one posterior
+    step with pred_xstart, the DDPM chain with snapshots and q_sample at N = 100 against the oracle."""
+    T, B, N = 12, 3, 100
+    eng = _engine(W, T, "f32")
+    part_code, mean, logvar, valid = synth.make_latents(B, seed=41)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    rng = np.random.default_rng(3)
+    xT = rng.standard_normal((B, 3, N)).astype(np.float32)
+    zs = rng.standard_normal((T, B, 3, N)).astype(np.float32)
+    anchors, variance = odf.gather_params(seg, mean, var)
+    cctx = [part_code, np.concatenate([mean, var], 1)]
+    tb = odf.Tables(T)
+    ctx = eng.prepare_shapes(*map(torch.from_numpy, (part_code, mean, var, valid)))
+    x = (np.sqrt(variance) * xT + anchors).astype(np.float32)
+    ref = odf.p_sample(tb, W, x, 7, anchors, cctx, variance, seg, valid, zs[0])
+    out, xs = eng.p_sample(ctx, torch.from_numpy(x), torch.from_numpy(seg), 7, noise=torch.from_numpy(zs[0]), want_xstart=True)
+    assert out.shape == (B, 3, N) and out.is_contiguous()
+    assert np.abs(out.cpu().numpy() - ref["sample"]).max() < TOL_F32_EPS * 10
+    assert np.abs(xs.cpu().numpy() - ref["pred_xstart"]).max() < TOL_F32_EPS * 10
+    dec = odf.decode(tb, W, anchors, cctx, variance, seg, valid, xT, zs, ret_traj=True, ret_interval=4)
+    pred, traj = eng.sample_chain(ctx, torch.from_numpy(seg), x_T_noise=torch.from_numpy(xT), step_noise=torch.from_numpy(zs), ret_interval=4)
+    assert pred.shape == (B, N, 3) and traj.shape[1:] == (B, N, 3)
+    assert np.abs(pred.cpu().numpy() - dec["pred"]).max() < TOL_F32_CHAIN
+    for k, t in enumerate(eng.snapshot_times(4)):
+        assert np.abs(traj[k].cpu().numpy() - dec[t]).max() < TOL_F32_CHAIN
+    tt = np.array([0, 5, 11])
+    q = eng.q_sample(ctx, torch.from_numpy(seg), torch.from_numpy(x), torch.from_numpy(tt), torch.from_numpy(zs[1]))
+    assert np.abs(q.cpu().numpy() - odf.q_sample(tb, x, tt, anchors, zs[1], variance)).max() < 1e-5
+    pred2, _ = eng.sample_chain(ctx, torch.from_numpy(seg), seed=5)          # in-kernel noise: shape and finiteness
+    assert pred2.shape == (B, N, 3) and bool(torch.isfinite(pred2).all())
 
 
 def test_chain_f32_vs_oracle_T100(W):
@@ -202,8 +236,13 @@ def test_philox_chain_deterministic_and_statistical(W):
 def test_argument_validation(eng10):
     g = np.load(os.path.join(GOLDEN, "denoiser_eps_B2_N128_mixed.npz"))
     ctx = _prep(eng10, g)
+    # the C entry points take N % 32 == 0 and say so; the engine pads other sizes (test_point_counts_that_are_not_multiples_of_32)
+    from difffacto_amd import _ffi
+    x48, s48, o48 = torch.zeros(2, 3, 48, device="cuda"), torch.zeros(2, 48, dtype=torch.int32, device="cuda"), torch.empty(2, 3, 48, device="cuda")
+    rc = _ffi.lib().dfx_denoise_eps(eng10._h, _ffi.ptr(ctx.buf), _ffi.ptr(x48), _ffi.ptr(s48), 0, _ffi.ptr(o48), 2, 48, _ffi.current_stream())
     with pytest.raises(RuntimeError, match="multiple of 32"):
-        eng10.eps(ctx, torch.zeros(2, 3, 48), torch.zeros(2, 48, dtype=torch.int32), 0)
+        _ffi.check(rc, "dfx_denoise_eps")
+    assert eng10.eps(ctx, x48, s48, 0).shape == (2, 3, 48)
     with pytest.raises(RuntimeError, match="outside"):
         eng10.eps(ctx, torch.from_numpy(g["x"]), torch.from_numpy(g["seg"]), 10)
     # empty batch is a no-op

@@ -48,10 +48,10 @@ def test_forward_backward_vs_reference_autograd_golden():
         assert err <= 5e-4 * np.abs(g[k]).max() + 1e-8, (k, err)
 
 
-@pytest.mark.parametrize("B,N,all_valid,with_flags", [(2, 96, True, False), (5, 32, False, True), (1, 2048, False, True)])
+@pytest.mark.parametrize("B,N,all_valid,with_flags", [(2, 96, True, False), (5, 32, False, True), (1, 2048, False, True), (3, 100, False, True)])
 def test_forward_backward_vs_oracle_full_gradients(B, N, all_valid, with_flags):
     """Every element of every gradient against oracle/train.py (pinned to the reference by the golden above) on seeded
-    inputs of other shapes: ragged part validity, no flags, N = 2048."""
+    inputs of other shapes: ragged part validity, no flags, N = 2048, N = 100 (not a multiple of 32: padded on the host side)."""
     from difffacto_amd import synth
     from oracle import train
     rng = np.random.Generator(np.random.PCG64(100 + B + N))
