@@ -888,6 +888,7 @@ struct PointState {
   float x[3], anc[3], var[3], L[3];
   int s, n, sg;
   unsigned long long gid;
+  bool live = true;   // false: a wavefront past the end of its shape's last (partial) 256-point tile recomputes that shape's last 32 points and stores nothing
 };
 
 __device__ __forceinline__ void point_init(const KParams &p, PointState &ps, int s, int n, unsigned long long gid,
@@ -916,7 +917,7 @@ __device__ __forceinline__ void point_init(const KParams &p, PointState &ps, int
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) ps.x[i] = ps.L[i] * z[i] + ps.anc[i];  // anchored_diffusion.py:563-564
-    if (p.traj && p.d.T % p.ret_interval == 0 && hf == 0) {
+    if (p.traj && p.d.T % p.ret_interval == 0 && hf == 0 && ps.live) {
       float *o = p.traj + ((size_t)s * p.N + n) * 3;  // snapshot 0 <-> t = T
       o[0] = ps.x[0]; o[1] = ps.x[1]; o[2] = ps.x[2];
     }
@@ -930,7 +931,7 @@ __device__ __forceinline__ void point_init(const KParams &p, PointState &ps, int
 // (anchored_diffusion.py:306-319,365-367,378-380,401-409,175-213,476-483; reference op order, no contraction)
 // plus the bookkeeping of AnchorDiffAE.decode (anchor_gen.py:160-167).  Returns true when the kernel is done.
 __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, const float (&eps)[3], int step, int t) {
-  const int hf = (threadIdx.x >> 5) & 1;
+  const int hf = ps.live ? (threadIdx.x >> 5) & 1 : 1;   // stores are done by half-wave 0 of live wavefronts
   const int s = ps.s, n = ps.n;
   if (p.mode == MODE_EPS) {
     if (hf == 0) {
@@ -1037,7 +1038,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// LDS-pipelined kernel (bf16, N % 256 == 0): one workgroup = 8 wavefronts = 256 points of ONE shape.
+// LDS-pipelined kernel (bf16): one workgroup = 8 wavefronts = 256 points of ONE shape (a partial last tile idles wavefronts).
 //
 // Weight streaming.  All weights stream L2 -> LDS through a 5-slot ring of 24 KiB records filled by LDS-DMA
 // (global_load_lds_dwordx4: 1 KiB per wavefront-instruction, 3 per wave per record), three records ahead of the
@@ -1491,7 +1492,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   int bid = blockIdx.x;
 #ifndef DFX_NO_XCD_REMAP
   {
-    const int wpg = p.N / (PIPE_NW * 32);          // workgroups per shape
+    const int wpg = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);   // workgroups per shape (the last one may be partial)
     const int per = 8 * wpg;                        // workgroups of 8 shapes = one remap period
     const int full = ((int)gridDim.x / per) * per;  // the tail (B % 8 shapes) keeps the natural order
     if (bid < full) {
@@ -1500,9 +1501,15 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
     }
   }
 #endif
-  const long long g0 = ((long long)bid * PIPE_NW + wave) * 32;
-  const int s = __builtin_amdgcn_readfirstlane((int)(((long long)bid * PIPE_NW * 32) / p.N));  // one shape per WG
-  const int n = (int)(g0 - (long long)s * p.N) + pj;
+  // one shape per workgroup; N % 32 == 0, so whole wavefronts fall off the end of a shape's last tile: those recompute the
+  // shape's last 32 points (same barriers, same DMA duties) and store nothing
+  const int wpg_ = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);
+  const int s = __builtin_amdgcn_readfirstlane(bid / wpg_);
+  int n0 = __builtin_amdgcn_readfirstlane((bid - s * wpg_) * (PIPE_NW * 32) + wave * 32);
+  const bool live = n0 < p.N;
+  if (!live) n0 = p.N - 32;
+  const long long g0 = (long long)s * p.N + n0;
+  const int n = n0 + pj;
   const int depth = p.d.depth;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
@@ -1538,6 +1545,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const int pt = wave * 32 + pj;   // point slot inside the workgroup (both half-waves hold the same point)
   {
     PointState ps0;
+    ps0.live = live;
     point_init(p, ps0, s, n, (unsigned long long)g0 + pj, vmask);
     pstate_store(ps_lds, pt, ps0, true);   // both half-waves hold the same point: identical values
   }
@@ -1627,7 +1635,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
                         BCONST_B2_OFF + hf * 64);
       if (b == 0) {
         PointState ps;
-        ps.s = s, ps.n = n, ps.gid = (unsigned long long)g0 + pj;
+        ps.s = s, ps.n = n, ps.gid = (unsigned long long)g0 + pj, ps.live = live;
         pstate_load(ps_lds, pt, ps, step > 0);
         if (step > 0) {
           float eps[3];
@@ -1790,7 +1798,10 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
-  const bool pipe = d->dev.prec == DFX_PREC_BF16 && p.N % 256 == 0 && !g_force_direct;
+  // the pipelined kernel works on 256-point tiles of one shape (a partial last tile idles whole wavefronts) and is ~3x
+  // faster per point than the direct kernel: take it unless the padding of a small shape eats that factor
+  const long long wpg = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);
+  const bool pipe = d->dev.prec == DFX_PREC_BF16 && wpg * PIPE_NW * 32 <= 3LL * p.N && !g_force_direct;
   if (pipe) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1801,7 +1812,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe) k_denoise_pipe<<<(int)(waves / PIPE_NW), PIPE_NW * 64, L_TOTAL, st>>>(p);
+  if (pipe) k_denoise_pipe<<<(int)(wpg * p.B), PIPE_NW * 64, L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");
