@@ -96,6 +96,8 @@ def latents_case(S, K, N, fixed, seed):
 
 FAMILIES = [
     ("DDPM chain f32 vs oracle", lambda a: chain_case(*a), lambda: (ri(2, 40), ri(1, 4), 32 * ri(1, 12), rb(), ri(1, 12), ri(0, 10 ** 6))),
+    ("bf16 pipelined partial tiles = full tiles", lambda a: td.test_pipelined_kernel_partial_tiles_are_bit_identical_to_full_tiles(W, *a),
+     lambda: (32 * ri(3, 16),)),
     ("sample_latents vs oracle", lambda a: latents_case(*a),
      lambda: (ri(1, 70), ri(1, 4), 4 * ri(8, 128), [ri(0, 1) for _ in range(4)], ri(0, 10 ** 6))),
     # name, callable, argument generator, rough cost weight
