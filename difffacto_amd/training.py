@@ -326,9 +326,15 @@ class PriorLossFn(torch.autograd.Function):
         dlv = torch.empty(B, 4, 256, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(dev):
             _ffi.check(_ffi.lib().dfx_prior_loss_backward(_ptr_array(ctx.ps), depth, hidden, ctx.ws_ptr, ctx.nbytes, ctx.vd.data_ptr(),
-                                                          float(prior_var), float(g), _ptr_array(views), None if dz is None else dz.data_ptr(),
+                                                          float(prior_var), 1.0, _ptr_array(views), None if dz is None else dz.data_ptr(),
                                                           None if dlv is None else dlv.data_ptr(), B, _ffi.current_stream()),
                        "dfx_prior_loss_backward")
+        # scale by the upstream scalar on the device (float(g) would drain the stream in the middle of the backward pass)
+        views[0]._base.mul_(g)
+        if dz is not None:
+            dz.mul_(g)
+        if dlv is not None:
+            dlv.mul_(g)
         ctx.ws = None
         out = _assign_or_return(ctx.leaves, views)
         ctx.leaves = None
@@ -377,10 +383,11 @@ class MaskedMSEFn(torch.autograd.Function):
         d = torch.empty_like(pred)
         with torch.cuda.device(pred.device):
             _ffi.check(_ffi.lib().dfx_masked_mse_backward_f32(target.data_ptr(), pred.data_ptr(),
-                                                              None if fl is None else fl.data_ptr(), ws2.data_ptr(), float(g),
+                                                              None if fl is None else fl.data_ptr(), ws2.data_ptr(), 1.0,
                                                               d.data_ptr(), B, N, _ffi.current_stream()),
                        "dfx_masked_mse_backward_f32")
-        return None, d, None
+        # the upstream scalar stays on the device: reading it (float(g)) would stall the host until the whole forward has run
+        return None, d.mul_(g), None
 
 
 def masked_mse(target, pred, flags=None):
