@@ -329,13 +329,21 @@ class PartEncoderForTransformerDecoder(nn.Module):
         else:
             kl = self.kl_weight
         params = {n: p for n, p in self.named_parameters() if n.startswith("flow.")}
+        # `prior_loss_stream` (set by training.stage1_losses for the duration of its call, else None): the whole branch,
+        # logging values included, runs on that stream and the caller waits for it before it reads the dict
+        side = getattr(self, "prior_loss_stream", None)
         loss, log_p, ent = _training.prior_loss(params, part_code, logvar, valid_id, depth=self.latent_flow_depth,
-                                                hidden=self.latent_flow_hidden_dim, prior_var=self.prior_var, kl_weight=kl)
+                                                hidden=self.latent_flow_hidden_dim, prior_var=self.prior_var, kl_weight=kl, stream=side)
         d = {"prior_loss": loss, "kl_weight": torch.ones(1, device=part_code.device) * kl}
-        with torch.no_grad():                                                             # logging values only
+        main = torch.cuda.current_stream(part_code.device)
+        with torch.no_grad(), torch.cuda.stream(side if side is not None else main):      # logging values only
             nv = valid_id.sum(0)
             mlp, ment = (log_p * valid_id).sum(0) / nv, (ent * valid_id).sum(0) / nv
             mmean, mlv = mean.mean(2).sum(0) / nv, logvar.mean(2).sum(0) / nv
+            if side is not None:
+                mean.record_stream(side)
+                for t in (mlp, ment, mmean, mlv):
+                    t.record_stream(main)
         for i in range(self.n_class):
             d[f"log_p_part_{i}"], d[f"entropy_{i}"] = mlp[i], ment[i]
             d[f"part_{i}_mean"], d[f"part_{i}_logvar"] = mmean[i], mlv[i]

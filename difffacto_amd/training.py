@@ -288,7 +288,8 @@ class PriorLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, part_code, logvar, valid, *params):
-        depth, hidden, prior_var, kl_weight = cfg
+        depth, hidden, prior_var, kl_weight = cfg[:4]
+        ctx.consumer = cfg[4] if len(cfg) > 4 else None     # see prior_loss(stream=...)
         if len(params) != 4 * depth * 6:
             raise ValueError(f"expected {4 * depth * 6} flow parameter tensors")
         ps = [_need(p.detach(), "flow parameter") for p in params]
@@ -318,7 +319,7 @@ class PriorLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _glp, _gent):
-        depth, hidden, prior_var, kl_weight = ctx.cfg
+        depth, hidden, prior_var, kl_weight = ctx.cfg[:4]
         B = ctx.B
         dev = ctx.vd.device
         views = _flat_slices([p.shape for p in ctx.ps], dev)
@@ -336,15 +337,52 @@ class PriorLossFn(torch.autograd.Function):
         if dlv is not None:
             dlv.mul_(g)
         ctx.ws = None
+        if ctx.consumer is not None:
+            # autograd runs this node on the stream of its forward (the side stream) and orders dz / dlv for their consumers
+            # itself; the parameter gradients are assigned by hand below, so the consuming stream is made to wait here
+            side = torch.cuda.current_stream()
+            if side != ctx.consumer:
+                ctx.consumer.wait_stream(side)
+                for t in (views[0]._base, dz, dlv):
+                    if t is not None:
+                        t.record_stream(ctx.consumer)
         out = _assign_or_return(ctx.leaves, views)
         ctx.leaves = None
         return (None, dz, dlv, None) + tuple(out)
 
 
-def prior_loss(flow_params, part_code, logvar, valid, depth=14, hidden=256, prior_var=1.0, kl_weight=5e-4):
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that is independent of the main stream's (the prior-loss branch of the
+    stage-1 step: ~170 few-row kernels that leave most of the chip idle, beside the denoiser's HBM-bound ones)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
+
+
+def prior_loss(flow_params, part_code, logvar, valid, depth=14, hidden=256, prior_var=1.0, kl_weight=5e-4, stream=None):
     """`flow_params`: dict with the encoder's state_dict names 'flow.{i}.chain.{l}.net_s_t.{0,2,4}.{weight,bias}'.
-    Returns (prior_loss, log_p_part (B,4), entropy (B,4))."""
-    return PriorLossFn.apply((depth, hidden, prior_var, kl_weight), part_code, logvar, valid, *[flow_params[n] for n in flow_param_names(depth)])
+    Returns (prior_loss, log_p_part (B,4), entropy (B,4)).
+    `stream`: run forward (and, through autograd, backward) on this stream instead of the current one.  The inputs are
+    taken as of now (the stream waits for the current one); the CALLER makes the current stream wait for `stream` before
+    it reads the outputs (`torch.cuda.current_stream().wait_stream(stream)`); the backward pass needs nothing from the
+    caller: gradients are handed back in stream order."""
+    names = flow_param_names(depth)
+    if stream is None or stream == torch.cuda.current_stream(part_code.device):
+        return PriorLossFn.apply((depth, hidden, prior_var, kl_weight), part_code, logvar, valid, *[flow_params[n] for n in names])
+    main = torch.cuda.current_stream(part_code.device)
+    stream.wait_stream(main)
+    with torch.cuda.stream(stream):
+        out = PriorLossFn.apply((depth, hidden, prior_var, kl_weight, main), part_code, logvar, valid, *[flow_params[n] for n in names])
+    for t in (part_code, logvar, valid):
+        t.record_stream(stream)
+    for t in out:
+        t.record_stream(main)
+    return out
 
 
 def dropout_factors(seed, site, p, n, device="cuda"):
@@ -533,17 +571,23 @@ def linear_lr(epoch, start_epoch, end_epoch, start_lr, end_lr):
     return start_lr * f
 
 
-def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None):
+def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None, overlap_prior=True):
     """The training forward of the reference's agent for stage 1 (AnchorDiffAE.forward, anchor_gen.py:970-1020): the encoder's
     training forward (part codes, prior loss, ground-truth anchors per point, ctx), one timestep per shape, and the denoiser's
     masked MSE.  `encoder` / `diffusion`: difffacto_amd.encoders.PartEncoderForTransformerDecoder / modules.AnchoredDiffusion in
     train() mode; `t`: (B,) timesteps (the reference draws them with its Uniform sampler, samplers/sampler.py:25-40); `noise`: the
-    diffusion noise (B,3,N) or None.  Returns the loss dict; sum the entries whose key contains 'loss' and call backward()."""
+    diffusion noise (B,3,N) or None.  Returns the loss dict; sum the entries whose key contains 'loss' and call backward().
+    overlap_prior: the prior loss (flows) runs on a second stream beside the denoiser, forward and backward; results are the same."""
     import numpy as np
     ref = pcds["ref"].to(device)
     seg = pcds["ref_seg_mask"].to(device).to(torch.int32)
     B = ref.shape[0]
-    ctx, mean_pp, logvar_pp, _flag_pp, losses, _ = encoder(pcds, device, epoch=epoch)
+    side = side_stream(ref.device) if overlap_prior else None
+    encoder.prior_loss_stream = side      # the prior-loss branch does not feed the denoiser: it runs beside it
+    try:
+        ctx, mean_pp, logvar_pp, _flag_pp, losses, _ = encoder(pcds, device, epoch=epoch)
+    finally:
+        encoder.prior_loss_stream = None
     variance_pp = torch.exp(logvar_pp)
     if t is None:
         t = torch.from_numpy(np.random.choice(diffusion.num_timesteps, size=(B,))).to(device)
@@ -554,6 +598,8 @@ def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diff
         flags = torch.gather(dp[:, None, :], 2, seg.long()[:, None, :])
     d = diffusion.training_losses(ref.transpose(1, 2).contiguous(), t, anchors=mean_pp, variance=variance_pp, ctx=ctx,
                                   anchor_assignment=seg, valid_id=dp, flags=flags, noise=noise)
+    if side is not None:
+        torch.cuda.current_stream(ref.device).wait_stream(side)      # from here on the encoder's loss entries may be read
     losses = dict(losses)
     losses["mse_loss"] = diffusion_loss_weight * d["mse_loss"]
     return losses

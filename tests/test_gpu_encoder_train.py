@@ -292,3 +292,68 @@ def test_stage1_training_step_against_composed_oracles():
         worst["denoiser"] = max(worst.get("denoiser", 0.0), rel(p.grad.cpu().numpy(), Wd[name].grad.numpy()))
     print("stage-1 step, worst relative L2 gradient error per group:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert worst["pn"] < 2e-3 and worst["flow"] < 2e-3 and worst["denoiser"] < 2e-3, worst
+
+
+def test_stage1_prior_branch_on_a_second_stream_is_bit_identical():
+    """stage1_losses(overlap_prior=True) runs the prior loss (flows) on a second stream beside the denoiser, forward and
+    backward.  Same kernels, same order within each branch: every loss entry and every parameter gradient must equal the
+    single-stream run bit for bit, repeatedly (a missing stream dependency would show up as a mismatch or a NaN), and an
+    optimiser step taken right after backward() must see the finished gradients."""
+    from difffacto_amd import synth, training
+    from difffacto_amd.encoders import PartEncoderForTransformerDecoder
+    from difffacto_amd.modules import AnchoredDiffusion
+    from test_modules_cpu import DIFF_CFG
+    B, N, T = 48, 1024, 100
+    rng = np.random.Generator(np.random.PCG64(5))
+    W_pn, W_lat, W_dn = synth.make_pointnet_v2_weights(0), synth.make_latent_weights(0), synth.make_denoiser_weights(0)
+    _, gt_shift, lvv, valid = synth.make_latents(B, seed=3)
+    seg = synth.make_seg_mask(valid, N)
+    ref = rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pcds = {"input": cu(ref), "ref": cu(ref), "present": cu(valid), "dp_present": cu(valid), "ref_seg_mask": cu(seg.astype(np.int64)),
+            "ref_attn_map": cu(np.eye(4, dtype=np.float32)[seg]), "part_shift": cu(gt_shift), "part_scale": cu(np.exp(0.5 * lvv).astype(np.float32)),
+            "noise": torch.zeros(B, 32).cuda()}
+    t, noise = cu(rng.integers(0, T, size=(B,)).astype(np.int64)), cu(rng.standard_normal((B, 3, N)).astype(np.float32))
+
+    def build():
+        enc = PartEncoderForTransformerDecoder(encoder=dict(type="PointNetV2", zdim=256, per_part_mlp=True), n_class=4, part_aligner=None,
+                                               include_z=False, include_part_code=True, include_params=True, use_gt_params=True,
+                                               kl_weight=5e-4, use_flow=True, gen=True, prior_var=1.0)
+        sd = enc.state_dict()
+        sd.update({"encoder." + k: torch.from_numpy(a.copy()) for k, a in W_pn.items()})
+        sd.update({k: torch.from_numpy(a.copy()) for k, a in W_lat.items() if k.startswith("flow.")})
+        enc.load_state_dict(sd)
+        diff = AnchoredDiffusion(num_timesteps=T, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)})
+        diff.model.load_state_dict({k: torch.from_numpy(v) for k, v in W_dn.items()})
+        return enc.cuda().train(), diff.cuda().train()
+
+    def step(overlap, iters):
+        enc, diff = build()
+        params = [p for p in list(enc.parameters()) + list(diff.parameters()) if p.requires_grad]
+        opt = training.Adam(params, lr=1e-3, max_norm=10.0)
+        outs = []
+        for _ in range(iters):
+            opt.zero_grad()
+            g = torch.Generator(device="cuda").manual_seed(11)
+            real = torch.randn
+            try:
+                torch.randn = lambda *a, **k: real(*a, generator=g, **{kk: v for kk, v in k.items() if kk != "generator"})
+                losses = training.stage1_losses(enc, diff, pcds, t=t, noise=noise, overlap_prior=overlap)
+            finally:
+                torch.randn = real
+            (losses["prior_loss"] + losses["fit_loss"].sum() + losses["mse_loss"]).backward()
+            grads = [None if p.grad is None else p.grad.clone() for p in params]
+            opt.step()                                      # reads the gradients on the main stream, no synchronize in between
+            outs.append((losses["prior_loss"].detach().clone(), losses["mse_loss"].detach().clone(), grads, [p.detach().clone() for p in params]))
+        torch.cuda.synchronize()
+        return outs
+
+    serial, over = step(False, 3), step(True, 3)
+    for (pa, ma, ga, wa), (pb, mb, gb, wb) in zip(serial, over):
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and bool(torch.isfinite(pb))
+        for x, y in zip(ga, gb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
+        for x, y in zip(wa, wb):
+            assert torch.equal(x, y)
