@@ -125,3 +125,19 @@ def test_encoder_mirror_matches_reference_state_dict():
     assert {k for k in mirror.state_dict() if not k.startswith("encoder.")} == {k for k in ref if not k.startswith("encoder.")}
     assert mirror.part_aligner.noise_scale == 100
     assert model.encoder.sample_latents.__name__ == "sample_latents"
+
+
+def test_point_padding_helpers_of_the_engine():
+    """Host logic behind 'any N like the reference': the kernels take N % 32 == 0, the engine pads with zeros / the shape's first
+    label and cuts the padding off (points are independent).  The helpers are plain tensor code: checked here without a GPU."""
+    import torch
+    from difffacto_amd.engine import DenoiserEngine as E
+    assert [E._pad(n) for n in (0, 1, 31, 32, 33, 100, 2048, 2080)] == [0, 31, 1, 0, 31, 28, 0, 0]
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
+    xp = E._pad_last(x, 3)
+    assert xp.shape == (2, 3, 8) and torch.equal(xp[..., :5], x) and float(xp[..., 5:].abs().sum()) == 0.0
+    assert E._pad_last(None, 3) is None
+    seg = torch.tensor([[2, 1, 0, 3, 3], [1, 1, 1, 0, 2]], dtype=torch.int32)
+    sp = E._pad_seg(seg, 3)
+    assert sp.shape == (2, 8) and sp.is_contiguous() and torch.equal(sp[:, :5], seg)
+    assert sp[0, 5:].tolist() == [2, 2, 2] and sp[1, 5:].tolist() == [1, 1, 1]      # a label that is present in that shape
