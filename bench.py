@@ -200,6 +200,82 @@ def cpu_baseline(W, N, budget_s=20.0):
             "ms_per_step_per_shape": s_per_step_shape * 1e3}
 
 
+def parity_block(Wnp, N, T=100, B=2):
+    """BASELINE.md §3 / SURVEY.md §8(d) 'quality parity', from the same run and outside the timed region: the bf16 HIP chain
+    (the headline kernel) and the exact-fp32 HIP chain against the PyTorch-CPU oracle (oracle/torch_cpu.py, pinned to the
+    reference goldens) on IDENTICAL explicit noise, B shapes x N points, T steps: max-abs point deviation, Chamfer-L2 and
+    auction EMD (the evaluation's setting 0.002 / 10000 on unit-box-normalised clouds; libdfx's own metric kernels)."""
+    from oracle import diffusion as odf
+    from oracle import torch_cpu as tc
+    from difffacto_amd.engine import DenoiserEngine
+    from difffacto_amd.metrics import EMD, chamfer_l2
+    try:
+        pc, mean, logvar, valid = synth.make_latents(B, seed=5)
+        var = np.exp(logvar).astype(np.float32)
+        seg = synth.make_seg_mask(valid, N)
+        anchors, variance = odf.gather_params(seg, mean, var)
+        g = torch.Generator().manual_seed(T)
+        xT = torch.randn(B, 3, N, generator=g)
+        zs = torch.randn(T, B, 3, N, generator=g)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        Wt = {k: tt(v) for k, v in Wnp.items()}
+        tb = odf.Tables(T)
+        ctx = [tt(pc), tt(np.concatenate([mean, var], 1))]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            x = torch.sqrt(tt(variance)) * xT + tt(anchors)
+            for i, t in enumerate(range(T - 1, -1, -1)):
+                x, _ = tc.p_sample(tb, Wt, x, t, tt(anchors), ctx, tt(variance), tt(seg), tt(valid), zs[i])
+        ref = x.transpose(1, 2).contiguous().cuda()
+        cpu_s = time.perf_counter() - t0
+        out = {"what": f"HIP chain vs PyTorch-CPU oracle on identical explicit noise: {B} shapes x {N} pts, T={T}; part sigma "
+                       f"~{float(np.sqrt(var).mean()):.3f}; EMD on unit-box-normalised clouds (eps 0.002, 10000 iterations)",
+               "oracle_cpu_s": cpu_s}
+
+        def emd_pair(x, y):
+            lo = torch.minimum(x.amin((1, 2), keepdim=True), y.amin((1, 2), keepdim=True))
+            hi = torch.maximum(x.amax((1, 2), keepdim=True), y.amax((1, 2), keepdim=True))
+            return EMD(0.002, 10000, True)(((x - lo) / (hi - lo)).contiguous(), ((y - lo) / (hi - lo)).contiguous())
+        for prec in ("bf16", "f32"):
+            eng = DenoiserEngine(Wt, T, precision=prec)
+            c = eng.prepare_shapes(tt(pc), tt(mean), tt(var), tt(valid))
+            pred, _ = eng.sample_chain(c, tt(seg), x_T_noise=xT, step_noise=zs)
+            eng.close()
+            out[prec] = {"max_abs": float((pred - ref).abs().max()), "mean_abs": float((pred - ref).abs().mean()),
+                         "chamfer_l2": float(chamfer_l2(pred, ref).mean()), "emd": float(emd_pair(pred, ref).mean())}
+        return out
+    except Exception as e:   # secondary block: never fail the headline measurement
+        return {"error": repr(e)[:200]}
+
+
+def t100_line(params, names, sampler, valid, B, N, precision, dev, launches=5):
+    """The shipped configs run num_timesteps=100 (configs/gen_chair.py:88): the same step at T=100, HIP-event time of the
+    chain launch, reported beside the T=1000 headline."""
+    from difffacto_amd.engine import DenoiserEngine
+    try:
+        T = 100
+        eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=precision, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99)
+        lat = sampler.sample_latents(torch.randn(B, 256, 4, device=dev, generator=gen), torch.randn(B, 32, device=dev, generator=gen),
+                                     valid, K=1, npoints=N)
+        ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
+        eng.sample_chain(ctx, lat["seg_mask"], seed=1)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in ev:
+            a.record()
+            eng.sample_chain(ctx, lat["seg_mask"], seed=2)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        eng.close()
+        ach = flops_per_step(N) * T * B / (ms * 1e-3) / 1e12
+        return {"num_timesteps": T, "kernel_ms": ms, "shapes_per_s": B / ms * 1e3, "achieved_tflops": ach,
+                "frac": ach / PEAK_TFLOPS[precision], "launches": launches}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +289,8 @@ def main():
     ap.add_argument("--no-train-line", action="store_true", help="skip the secondary training-iteration measurement")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing ablations (invalid results)")
     ap.add_argument("--force-direct", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (HIP vs PyTorch-CPU oracle, T=100, 2 shapes)")
+    ap.add_argument("--dump-clouds", default=None, help="rank 0 writes the last step's gathered clouds (shapes, N, 3) to this .npy")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -263,25 +341,31 @@ def main():
     sampler = LatentSampler({k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")},
                             noise_scale=100.0, device=dev)          # configs/gen_chair.py:14-31
 
-    # per-rank synthetic part-presence patterns, resident in HBM
-    valid = torch.from_numpy(synth.make_latents(B, seed=1000 + rank)[3]).to(dev)
+    # Synthetic part-presence patterns, resident in HBM.  The JOB is `world * B` shapes, block-partitioned over the ranks
+    # (rank r owns global shapes [r B, (r + 1) B), parallel.shard_range): every per-shape input — presence pattern, latent
+    # draws, the chain's Philox stream (keyed by the global point id through shape_offset) — is a function of the GLOBAL
+    # shape index only, so the generated clouds do not depend on the number of GPUs.
+    from difffacto_amd.parallel import shard_range
+    lo, hi = shard_range(B * world, rank, world)
+    assert hi - lo == B
+    valid = torch.from_numpy(synth.make_latents(B * world, seed=1000)[3][lo:hi].copy()).to(dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def one_step(i, timed):
-        w = torch.randn(B, 256, 4, device=dev, generator=gen)           # part_encoders.py:1054
-        an = torch.randn(B, 32, device=dev, generator=gen)              # :1065 (K = 1 noise per shape)
+        gen.manual_seed(1234 + i)                                        # the whole job's draws, then this rank's block
+        w = torch.randn(B * world, 256, 4, device=dev, generator=gen)[lo:hi]    # part_encoders.py:1054
+        an = torch.randn(B * world, 32, device=dev, generator=gen)[lo:hi]       # :1065 (K = 1 noise per shape)
         lat = sampler.sample_latents(w, an, valid, K=1, npoints=N)
         ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
         if timed:
             ev[i][0].record()
-        pred, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=(rank << 32) + i)
+        pred, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=7000 + i, shape_offset=lo)
         if timed:
             ev[i][1].record()
         if dist is not None:
-            pred = gather_clouds(pred, dst=0)
+            pred = gather_clouds(pred, dst=0, sizes=[B] * world)   # block partition: sizes known, no size exchange / host sync
         return pred
 
     for i in range(args.warmup):
@@ -308,6 +392,9 @@ def main():
 
     if rank == 0:
         assert out is not None and (args.debug_flags or torch.isfinite(out).all())
+        assert out.shape[0] == B * world, (out.shape, B, world)
+        if args.dump_clouds:
+            np.save(args.dump_clouds, out.cpu().numpy())
         total_shapes = B * world * args.steps
         value = total_shapes / dt
         F = flops_per_step(N) * T * B                      # algorithmic FLOPs per launch (one rank)
@@ -331,6 +418,10 @@ def main():
             # power -> profiles/r01_ubench_power.txt): the chip throttles its clock on real data, this is what it sustains
             res["roofline"]["sustained_mfma_tflops_random_operands"] = SUSTAINED_BF16_TFLOPS
             res["roofline"]["frac_of_sustained"] = achieved / SUSTAINED_BF16_TFLOPS
+        res["config"]["shapes_gathered"] = int(out.shape[0])
+        if world == 1 and not args.no_parity:
+            res["parity"] = parity_block(Wnp, N)
+            res["t100"] = t100_line(params, names, sampler, valid, B, N, args.precision, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(Wnp, N)
         if world == 1 and not args.no_train_line and args.precision == "bf16":

@@ -87,9 +87,9 @@ SIGNATURES = {
     "dfx_shape_ctx_bytes": (_SZ, [_P, _I]),
     "dfx_shape_ctx_prepare": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "dfx_denoise_eps": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
-    "dfx_p_sample": (_I, [_P, _P, _P, _P, _I, _P, _U64, _P, _P, _I, _I, _P]),
+    "dfx_p_sample": (_I, [_P, _P, _P, _P, _I, _P, _U64, _U64, _P, _P, _I, _I, _P]),
     "dfx_chain_num_snapshots": (_I, [_I, _I]),
-    "dfx_sample_chain": (_I, [_P, _P, _P, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
+    "dfx_sample_chain": (_I, [_P, _P, _P, _P, _P, _U64, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_latents_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(LatentWeights), _P]),
     "dfx_latents_destroy": (None, [_P]),
     "dfx_flow_reverse": (_I, [_P, _P, _P, _I, _P]),
@@ -124,8 +124,8 @@ SIGNATURES = {
     "dfx_masked_mse_backward_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "dfx_grad_sumsq_accumulate": (_I, [_P, ctypes.c_longlong, _P, _P, _P]),
     "dfx_adam_step_f32": (_I, [_P, _P, _P, _P, ctypes.c_longlong, _P, _F, _F, _F, _F, _F, _F, _I, _P]),
-    "dfx_p_sample_ddim": (_I, [_P, _P, _P, _P, _I, _F, _P, _U64, _P, _P, _I, _I, _P]),
-    "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _I, _P, _P, _I, _I, _P]),
+    "dfx_p_sample_ddim": (_I, [_P, _P, _P, _P, _I, _F, _P, _U64, _U64, _P, _P, _I, _I, _P]),
+    "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
     "dfx_debug_flags": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),

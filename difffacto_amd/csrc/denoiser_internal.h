@@ -75,24 +75,12 @@ struct BlockPack {
 };
 
 // bf16 path, feed-forward: the GELU runs in packed fp16 (two hidden values per VALU instruction: v_pk_*_f16 does not
-// contend with the matrix pipe, unlike v_pk_*_f32) and its output is the fp16 B operand of GEMM2
+// contend with the matrix pipe, unlike v_pk_*_f32) as a transcendental-free polynomial gelu(g) = g Phi(g),
+// Phi(g) ~ 1/2 + u R(u^2 - m) with u = g / 2 (denoiser_kernel.hip), and its output is the fp16 B operand of GEMM2
 // (v_mfma_f32_32x32x16_f16), so W2 is packed as fp16.  To keep a * g inside the fp16 range the `a` half of W1 / b1 is
-// pre-scaled by FF_A_SCALE (and the `g` half by FF_G_SCALE for the polynomial variant, which works on g/2) and W2 by
-// the inverse of their product (exact powers of two).
-//   -DDFX_GELU_F32   the all-bf16 variant (fp32 GELU arithmetic, bf16 hidden operand)
-//   -DDFX_GELU_POLY  packed fp16 with a transcendental-free polynomial Phi(g) instead of the exp/rcp sigmoid form
-//                    (same accuracy, same speed: the chain kernel is power-limited); g is then
-//                    pre-scaled by FF_G_SCALE = 1/2 as well
-#ifdef DFX_GELU_F32
-constexpr bool GELU_F16 = false, GELU_POLY = false;
-constexpr float FF_A_SCALE = 1.0f, FF_G_SCALE = 1.0f;
-#elif defined(DFX_GELU_POLY)
-constexpr bool GELU_F16 = true, GELU_POLY = true;
+// pre-scaled by FF_A_SCALE, the `g` half by FF_G_SCALE (the polynomial works on u = g / 2), and W2 by the inverse of
+// their product (exact powers of two).
 constexpr float FF_A_SCALE = 0.0625f, FF_G_SCALE = 0.5f;
-#else
-constexpr bool GELU_F16 = true, GELU_POLY = false;
-constexpr float FF_A_SCALE = 0.0625f, FF_G_SCALE = 1.0f;
-#endif
 
 struct DenoiserDev {
   int depth, T, prec;

@@ -30,11 +30,7 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 enum { MODE_EPS = 0, MODE_PSAMPLE = 1, MODE_CHAIN = 2 };
-#ifdef DFX_AB_NO_DDIM   // A/B build without the DDIM branch (tools/ab.sh)
-constexpr int DDIM_MAX_STEPS = 1;
-#else
 constexpr int DDIM_MAX_STEPS = 128;
-#endif
 
 struct KParams {
   DenoiserDev d;
@@ -49,6 +45,7 @@ struct KParams {
   float *traj;           // chain snapshots (n_keep,B,N,3) or null
   float *xstart;         // p_sample: optional pred_xstart (B,3,N)
   unsigned long long seed;
+  unsigned long long shape0;   // global index of this launch's shape 0 (Philox counters are keyed by the GLOBAL point id)
   int B, N, t0, nsteps, ret_interval, mode;
   // DDIM branch (anchored_diffusion.py:114-124, :368-377, :480-481): ddim_n > 0 = the executed timestep list
   // (descending, e.g. 'quad' [32,23,16,10,5,2,0,0]) and xt_dir_coeff[t] = sqrt(1 - acp[t] - eta^2 posterior_variance[t])
@@ -151,7 +148,6 @@ __device__ __forceinline__ void ln_stats_fast(const v16f (&h)[4], float &mean, f
 template <int PREC>
 __device__ __forceinline__ void ln_to_act(const v16f (&h)[4], Act<PREC> (&xn)[4]) {
   float mean, rstd;
-#if !defined(DFX_LN_TWO_PASS)
   if (PREC == DFX_PREC_BF16) {
     ln_stats_fast(h, mean, rstd);
     const float nmr = -mean * rstd;
@@ -164,7 +160,6 @@ __device__ __forceinline__ void ln_to_act(const v16f (&h)[4], Act<PREC> (&xn)[4]
     }
     return;
   }
-#endif
   ln_stats(h, mean, rstd);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -320,86 +315,18 @@ __device__ __forceinline__ float gelu_for(float x) {
 }
 
 // ---- packed-fp16 GELU (bf16 path; see denoiser_internal.h) ----------------------------------------------------------
-// B operand of GEMM2: 16 hidden values of this lane as fp16 (or bf16 with -DDFX_GELU_F32), same element order as Act.
+// B operand of GEMM2: 16 hidden values of this lane as fp16, same element order as Act.
 struct HidAct {
   uint4 f[2];
 };
 __device__ __forceinline__ h2 pk_f16(float lo, float hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
-// Eight packed pairs through the transcendental unit: the low halves first, then the high halves written into the upper
-// half of the same registers in place (SDWA, no repacking).  gfx950 needs wait states between a transcendental write and a
-// VALU read of that register (hipcc inserts them for its own code; inline asm has to): the eight instructions in between
-// cover the in-place update, one s_nop covers the first consumer after the block.
-#define DFX_TRANS8(op)                                                                                                    \
-  asm("v_" op "_f16_e32 %0, %8\n\tv_" op "_f16_e32 %1, %9\n\tv_" op "_f16_e32 %2, %10\n\tv_" op "_f16_e32 %3, %11\n\t"  \
-      "v_" op "_f16_e32 %4, %12\n\tv_" op "_f16_e32 %5, %13\n\tv_" op "_f16_e32 %6, %14\n\tv_" op "_f16_e32 %7, %15\n\t" \
-      "v_" op "_f16_sdwa %0, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
-      "v_" op "_f16_sdwa %1, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
-      "v_" op "_f16_sdwa %2, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
-      "v_" op "_f16_sdwa %3, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
-      "v_" op "_f16_sdwa %4, %12 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
-      "v_" op "_f16_sdwa %5, %13 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
-      "v_" op "_f16_sdwa %6, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                         \
-      "v_" op "_f16_sdwa %7, %15 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 1"                  \
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])            \
-      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]))
-__device__ __forceinline__ void exp2_h2x8(h2 (&y)[8]) {
-  h2 o[8];
-  DFX_TRANS8("exp");
-#pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = o[i];
-}
-__device__ __forceinline__ void rcp_h2x8(h2 (&y)[8]) {
-  h2 o[8];
-  DFX_TRANS8("rcp");
-#pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = o[i];
-}
-#undef DFX_TRANS8
-// hid = a' * g * sigmoid(g (c1 + c3 g^2)) for 16 (a', g) pairs, a' = a * FF_A_SCALE: 4 packed VALU + 2 conversions per
-// PAIR of values + one exp and one rcp per value (the fp32 version: 6 VALU + exp + rcp per value).  fp16 overflow is
-// benign: |g| > 255 makes g^2 = inf, the argument -+inf and the sigmoid exactly 1 / 0.
-// Polynomial form (-DDFX_GELU_POLY): gelu(g) = g Phi(g),  Phi(g) ~ 1/2 + u R(u^2 - m),  u = clamp(g / 2, -+1.8), R of degree 5
-// (minimax fit of g Phi(g) on [-6, 6]: 3.9e-4 in exact arithmetic; evaluated in fp16 with the centred argument
-// z = u^2 - m the error of a * gelu(g) is the same as that of the exp/rcp sigmoid form: rms 8.5e-4 for a, g ~ N(0, 1.5),
-// tools/fit_gelu_poly.py).  Eleven packed instructions per PAIR of values and no transcendental: a dependent chain of
-// plain v_pk_* operations hides completely behind the MFMAs of the same wavefront (tools/ubench/swp_law.hip), the
-// exp/rcp chain (12 instructions, 4 of them quarter-rate with wait states) does not.  g arrives as g/2 (FF_G_SCALE).
-struct GeluPoly {
-  h2 u, r, z;
-};
+// gelu(g) = g Phi(g),  Phi(g) ~ 1/2 + u R(z),  u = g / 2,  z = min(u^2 - m, L^2 - m),  R of degree 5 (minimax fit of g Phi(g) on
+// [-6, 6]: 3.9e-4 in exact arithmetic; evaluated in fp16 with the centred argument z the error of a * gelu(g) is rms 8.5e-4 for
+// a, g ~ N(0, 1.5), tools/fit_gelu_poly.py).  Ten packed instructions per PAIR of values and no transcendental (an exp / rcp
+// pair is quarter rate and not packed: the sigmoid form cost 6 packed + 4 transcendental instructions per pair = 2.2x the
+// VALU cycles).  g arrives as g / 2 (FF_G_SCALE), a as a / 16 (FF_A_SCALE); fp16 overflow is benign: z saturates at the
+// min, the clamp modifier saturates Phi to [0, 1].
 __device__ __forceinline__ h2 h2c(float v) { return h2{(_Float16)v, (_Float16)v}; }
-__device__ __forceinline__ void gelu_poly_half0(GeluPoly &t, h2 gp) {
-  t.u = __builtin_elementwise_min(__builtin_elementwise_max(gp, h2c(-1.8f)), h2c(1.8f));
-  t.z = __builtin_elementwise_fma(t.u, t.u, h2c(-1.62f));
-  h2 r = __builtin_elementwise_fma(t.z, h2c(-0.0011402554f), h2c(0.0057853916f));
-  r = __builtin_elementwise_fma(r, t.z, h2c(-0.0158536041f));
-  t.r = __builtin_elementwise_fma(r, t.z, h2c(0.0409006897f));
-}
-// the same chain in four quarters: two pairs run side by side behind four MFMAs of the software-pipelined stage, so
-// that consecutive instructions are independent (a dependent packed op costs a wait state on gfx950)
-template <int Q>
-__device__ __forceinline__ void gelu_poly_quarter(GeluPoly &t, h2 ap, h2 gp, h2 &out) {
-  if (Q == 0) {
-    t.u = __builtin_elementwise_min(__builtin_elementwise_max(gp, h2c(-1.8f)), h2c(1.8f));
-    t.z = __builtin_elementwise_fma(t.u, t.u, h2c(-1.62f));
-  } else if (Q == 1) {
-    h2 r = __builtin_elementwise_fma(t.z, h2c(-0.0011402554f), h2c(0.0057853916f));
-    r = __builtin_elementwise_fma(r, t.z, h2c(-0.0158536041f));
-    t.r = __builtin_elementwise_fma(r, t.z, h2c(0.0409006897f));
-  } else if (Q == 2) {
-    h2 r = __builtin_elementwise_fma(t.r, t.z, h2c(-0.1098130657f));
-    r = __builtin_elementwise_fma(r, t.z, h2c(0.3885767652f));
-    t.r = __builtin_elementwise_fma(t.u, r, h2c(0.5f));   // Phi
-  } else {
-    out = (ap * gp) * t.r;
-  }
-}
-__device__ __forceinline__ h2 gelu_poly_half1(const GeluPoly &t, h2 ap, h2 gp) {
-  h2 r = __builtin_elementwise_fma(t.r, t.z, h2c(-0.1098130657f));
-  r = __builtin_elementwise_fma(r, t.z, h2c(0.3885767652f));
-  const h2 phi = __builtin_elementwise_fma(t.u, r, h2c(0.5f));
-  return (ap * gp) * phi;
-}
 // (a, g) -> packed fp16 first: after these sixteen conversions the accumulators are dead and their next initialisers
 // (b1 of the next chunk) can be fetched from LDS underneath the GELU arithmetic instead of after it.
 __device__ __forceinline__ void gelu16_f16_cvt(const v16f &a, const v16f &g, h2 (&aa)[8], h2 (&gg)[8]) {
@@ -409,33 +336,25 @@ __device__ __forceinline__ void gelu16_f16_cvt(const v16f &a, const v16f &g, h2 
   for (int i = 0; i < 8; ++i) aa[i] = pk_f16(a[2 * i], a[2 * i + 1]);
 }
 __device__ __forceinline__ void gelu16_f16_math(const h2 (&aa)[8], const h2 (&gg)[8], HidAct &hid) {
-  h2 y[8];
-  if (GELU_POLY) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      GeluPoly t;
-      gelu_poly_half0(t, gg[i]);
-      y[i] = gelu_poly_half1(t, aa[i], gg[i]);
-    }
-  } else {
-    const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
-    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-    h2 ag[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = gg[i] * gg[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = __builtin_elementwise_fma(y[i], c3, c1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = gg[i] * y[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ag[i] = aa[i] * gg[i];
-    exp2_h2x8(y);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = one + y[i];
-    rcp_h2x8(y);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = ag[i] * y[i];
-  }
+  // Stage by stage over the eight packed pairs: eight independent instructions between any two dependent ones (a
+  // dependent v_pk_* costs a wait state on gfx950; written pair by pair hipcc serialises the whole chain through three
+  // registers: 88 dependent instructions + 53 s_nop, 1176 cycles per slot against 984 like this).
+  h2 y[8], z[8], r[8];
+#define DFX_STAGE(expr)                                   \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) { expr; } \
+  __builtin_amdgcn_sched_barrier(0)
+  __builtin_amdgcn_sched_barrier(0);
+  DFX_STAGE(z[i] = __builtin_elementwise_fma(gg[i], gg[i], h2c(-1.62f)));
+  DFX_STAGE(y[i] = aa[i] * gg[i]);
+  DFX_STAGE(z[i] = __builtin_elementwise_min(z[i], h2c(1.62f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(z[i], h2c(-0.0011402554f), h2c(0.0057853916f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(-0.0158536041f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(0.0409006897f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(-0.1098130657f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(0.3885767652f)));
+  DFX_STAGE(asm("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(z[i]) : "v"(gg[i]), "v"(r[i])));   // Phi
+  DFX_STAGE(y[i] = y[i] * z[i]);
+#undef DFX_STAGE
   hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
                         __builtin_bit_cast(unsigned, y[3]));
   hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
@@ -443,8 +362,7 @@ __device__ __forceinline__ void gelu16_f16_math(const h2 (&aa)[8], const h2 (&gg
 }
 // h_tile += W2 fragment (A, from LDS / L2) x hid fragment (B)
 __device__ __forceinline__ v16f mma_hid(const uint4 &w, const uint4 &hid, v16f acc) {
-  if (GELU_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, hid), acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, hid), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, hid), acc, 0, 0, 0);
 }
 
 // One hidden chunk (32 units) of the GEGLU feed-forward (attention.py:50-57,77-94):
@@ -464,12 +382,12 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
   v16f hid;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if (PREC == DFX_PREC_BF16 && FF_G_SCALE != 1.0f)   // g arrives pre-scaled, hid carries the same factor (denoiser_internal.h)
+    if (PREC == DFX_PREC_BF16)   // g arrives pre-scaled, hid carries the same factor (denoiser_internal.h)
       hid[r] = a[r] * gelu_for<PREC>(g[r] * (1.0f / FF_G_SCALE)) * FF_G_SCALE;
     else
       hid[r] = a[r] * gelu_for<PREC>(g[r]);
   }
-  if (PREC == DFX_PREC_BF16 && GELU_F16) {   // `a` arrives pre-scaled, W2 is fp16 (denoiser_internal.h)
+  if (PREC == DFX_PREC_BF16) {   // `a` arrives pre-scaled, W2 is fp16 (denoiser_internal.h)
     HidAct hf16;
     h2 y[8];
 #pragma unroll
@@ -504,12 +422,7 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
 //   * LDS delivers ~240 B/clk/CU with eight wavefronts reading; one wavefront sustains ~32 B/clk (latency bound).
 __device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
 
-#ifndef DFX_MFMA_PRIO
-#define DFX_MFMA_PRIO 0
-#endif
-#ifndef DFX_VALU_PRIO
-#define DFX_VALU_PRIO 3
-#endif
+constexpr int MFMA_PRIO = 0, VALU_PRIO = 3;   // s_setprio inside M / V slots
 
 // M slot of FF record j: h += W2[:, chunk j-1] hid (S3: 8 MFMAs) then a,g = b1[j] + W1[chunk j] xn (S1: 16 MFMAs).
 // The 24 A-fragment units are fetched in batches of eight ds_read_b128 running one batch ahead of the MFMAs.
@@ -543,208 +456,79 @@ __device__ __forceinline__ constexpr int ms_frag(int i) { return (4 + (i >> 1)) 
 // and the wave has nothing else to issue — so the burst starts without the LDS round trip (~300 cycles per slot) and the
 // VALU-bound V slot in between carries no extra LDS instructions.  Needs the next record complete in LDS one management
 // barrier earlier: the ring runs three records ahead in five slots.
-#ifdef DFX_NO_TAIL_PREFETCH   // A/B build (tools/ab.sh): 4-slot ring, every M slot fetches all of its operands itself (-4 %)
-constexpr bool TAILP = false;
-#else
-constexpr bool TAILP = true;
-#endif
-enum { NEXT_W2 = 0, NEXT_AS = 1, NEXT_MS = 2, NEXT_W1 = 3 };
-template <int KIND>
-__device__ __forceinline__ void tail_prefetch(uint4 (&P)[8], const uint4 *ck) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) P[i] = ck[KIND == NEXT_W2 ? w2_frag(i) : KIND == NEXT_AS ? as_frag(i) : KIND == NEXT_MS ? ms_frag(i) : w1_frag(i, 0)];
-}
-
-// `issue` = hook for the A/B variant that issues the ring's DMA from inside the M slot, behind the first MFMA batch,
-// instead of right after the management barrier (-DDFX_ISSUE_IN_M; measured 1 % slower, so the default hook is empty).
-// Interleaved M slots (default; -DDFX_M_BATCHED restores the batch-of-eight form): every MFMA is followed by ONE LDS read
-// that refills the fragment register it has just consumed with the fragment needed eight MFMAs later (in place: the
-// MFMA reads its A operand at issue), so the wavefront's read instructions issue while the matrix pipe works instead of
-// in bursts during which it drains.  The last eight refills are the tail prefetch for the next M slot.
-#ifdef DFX_M_BATCHED
-constexpr bool M_INTERLEAVED = false;
-#else
-constexpr bool M_INTERLEAVED = TAILP;
-#endif
+// Interleaved M slots: every MFMA is followed by ONE LDS read that refills the fragment register it has just consumed with
+// the fragment needed eight MFMAs later (in place: the MFMA reads its A operand at issue), so the wavefront's read
+// instructions issue while the matrix pipe works instead of in bursts during which it drains.  The last eight refills are
+// the tail prefetch for the next M slot.  `issue.at(i, n)` issues the wave's ring-DMA pieces between the MFMAs.
 
 template <bool S3, bool S1, class Issue>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
                                      const HidAct &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
                                      Issue &issue) {
   uint4 A1[8];
-  if (M_INTERLEAVED) {
-    __builtin_amdgcn_sched_barrier(0);
-    tr.stamp(4);
-    if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(DFX_MFMA_PRIO);
-    auto gemm1 = [&](int i, int half, const uint4 &w) {
-      v16f &acc = (i & 1) ? g : a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
-    };
-    if (S3 && S1) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {   // GEMM2 of the previous chunk on the prefetched W2 fragments; fetch W1 (first half)
-        h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
-        issue.at(i, 24);
-        A1[i] = ck[w1_frag(i, 0)];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {   // GEMM1 first half; refill in place with the second half
-        gemm1(i, 0, A1[i]);
-        issue.at(8 + i, 24);
-        A1[i] = ck[w1_frag(i, 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {   // GEMM1 second half; tail prefetch of the next record's W2 fragments
-        gemm1(i, 1, A1[i]);
-        issue.at(16 + i, 24);
-        P[i] = ck_next[w2_frag(i)];
-      }
-    } else if (S1) {                  // first FF record of a block: P holds W1 (first half)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        gemm1(i, 0, P[i]);
-        issue.at(i, 16);
-        A1[i] = ck[w1_frag(i, 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        gemm1(i, 1, A1[i]);
-        issue.at(8 + i, 16);
-        P[i] = ck_next[w2_frag(i)];
-      }
-    } else {                          // last FF record of a block: GEMM2 only; tail prefetch = A_s of the next block
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
-        issue.at(i, 8);
-        P[i] = ck_next[as_frag(i)];
-      }
-    }
-    // keep the program order MFMA, read, MFMA, read, ...
-#pragma unroll
-    for (int i = 0; i < (S3 && S1 ? 24 : S1 ? 16 : 8); ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    issue();
-    if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
-    return;
-  }
-  if (!TAILP) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) P[i] = ck[S3 ? w2_frag(i) : w1_frag(i, 0)];
-  }
-  if (S1) {
-    // a, g already hold b1 of this chunk: loaded at the end of the preceding V slot (ff_v / V2), where the LDS
-    // reads cost nothing on the M slot's operand-fetch critical path (+1 %)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) A1[i] = ck[w1_frag(i, S3 ? 0 : 1)];
-  }
   __builtin_amdgcn_sched_barrier(0);
   tr.stamp(4);
-  if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(DFX_MFMA_PRIO);
-  if (S3) {
+  if (MFMA_PRIO) __builtin_amdgcn_s_setprio(MFMA_PRIO);
+  auto gemm1 = [&](int i, int half, const uint4 &w) {
+    v16f &acc = (i & 1) ? g : a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
+  };
+  if (S3 && S1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {   // GEMM2 of the previous chunk on the prefetched W2 fragments; fetch W1 (first half)
       h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
-  } else {
+      issue.at(i, 24);
+      A1[i] = ck[w1_frag(i, 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // GEMM1 first half; refill in place with the second half
+      gemm1(i, 0, A1[i]);
+      issue.at(8 + i, 24);
+      A1[i] = ck[w1_frag(i, 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // GEMM1 second half; tail prefetch of the next record's W2 fragments
+      gemm1(i, 1, A1[i]);
+      issue.at(16 + i, 24);
+      P[i] = ck_next[w2_frag(i)];
+    }
+  } else if (S1) {                  // first FF record of a block: P holds W1 (first half)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      v16f &acc = (i & 1) ? g : a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
+      gemm1(i, 0, P[i]);
+      issue.at(i, 16);
+      A1[i] = ck[w1_frag(i, 1)];
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      gemm1(i, 1, A1[i]);
+      issue.at(8 + i, 16);
+      P[i] = ck_next[w2_frag(i)];
+    }
+  } else {                          // last FF record of a block: GEMM2 only; tail prefetch = A_s of the next block
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+      issue.at(i, 8);
+      P[i] = ck_next[as_frag(i)];
+    }
+  }
+  // keep the program order MFMA, read, MFMA, read, ...
+#pragma unroll
+  for (int i = 0; i < (S3 && S1 ? 24 : S1 ? 16 : 8); ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  issue();
-  if (S1) {
-    __builtin_amdgcn_sched_barrier(0);
-    tr.stamp(5);
-    if (S3) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) P[i] = ck[w1_frag(i, 1)];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v16f &acc = (i & 1) ? g : a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[i >> 2].f[(i >> 1) & 1], acc, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      tr.stamp(6);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v16f &acc = (i & 1) ? g : a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v16f &acc = (i & 1) ? g : a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A1[i]), xn[2 + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
-      }
-    }
-  }
-  if (TAILP) {   // the next M slot of this wave: FF record -> its W2 batch; last FF record of the block -> A_s of the next block
-    __builtin_amdgcn_sched_barrier(0);
-    if (S1) tail_prefetch<NEXT_W2>(P, ck_next);
-    else tail_prefetch<NEXT_AS>(P, ck_next);
-  }
-  if (DFX_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+  if (MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
-// V slot of the feed-forward: hid = a * gelu(g) as the B operand of GEMM2 (fp16 pairs, or bf16 with -DDFX_GELU_F32).
-// Written stage by stage over 8 elements at a time so that eight independent dependency chains are in flight (hipcc
-// otherwise interleaves only two and every instruction waits for its predecessor's result).
+// V slot of the feed-forward: hid = a * gelu(g) as the fp16 B operand of GEMM2.
 __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float *b1_next, Tracer &tr) {
-  if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(DFX_VALU_PRIO);
-  bool b1_loaded = false;
-  if (GELU_F16) {
-    h2 aa[8], gg[8];
-    gelu16_f16_cvt(a, g, aa, gg);
-#ifdef DFX_B1_EARLY   // A/B variant (1.4 % slower: the eight reads delay the slot's first VALU results)
-    if (b1_next) {
-      // the address goes through an asm statement that consumes the sixteen packed values: the reads cannot be placed
-      // above the conversions (where they would need 32 more VGPRs), and the sched_barrier keeps them above the math
-      typedef __attribute__((address_space(3))) const float lds_cf;
-      unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1_next;
-      asm volatile("" : "+v"(addr) : "v"(gg[0]), "v"(gg[1]), "v"(gg[2]), "v"(gg[3]), "v"(gg[4]), "v"(gg[5]), "v"(gg[6]), "v"(gg[7]),
-                   "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]));
-      const float *src = (const float *)(lds_cf *)(uintptr_t)addr;
-      load16(a, src);
-      load16(g, src + 32);
-      __builtin_amdgcn_sched_barrier(0);
-      b1_loaded = true;
-    }
-#endif
-#ifdef DFX_ABL_NO_GELU   // timing ablation only (wrong results): no GELU arithmetic
-    hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, aa[0]), __builtin_bit_cast(unsigned, aa[1]), __builtin_bit_cast(unsigned, gg[2]), __builtin_bit_cast(unsigned, gg[3]));
-    hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, aa[4]), __builtin_bit_cast(unsigned, aa[5]), __builtin_bit_cast(unsigned, gg[6]), __builtin_bit_cast(unsigned, gg[7]));
-#else
-    gelu16_f16_math(aa, gg, hid);
-#endif
-  } else {
-    v16f t;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float u[8], ag[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = gelu_sigmoid_arg(g[half * 8 + i]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ag[i] = a[half * 8 + i] * g[half * 8 + i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = 1.0f + u[i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_rcpf(u[i]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t[half * 8 + i] = ag[i] * u[i];
-    }
-    Act<DFX_PREC_BF16> hb;
-    hb.set(t);
-    hid.f[0] = __builtin_bit_cast(uint4, hb.f[0]);
-    hid.f[1] = __builtin_bit_cast(uint4, hb.f[1]);
-  }
+  if (VALU_PRIO) __builtin_amdgcn_s_setprio(VALU_PRIO);
+  h2 aa[8], gg[8];
+  gelu16_f16_cvt(a, g, aa, gg);
+  gelu16_f16_math(aa, gg, hid);
   // Pin the result here: without a use in this slot LLVM sinks the whole GELU past the record barrier into the
   // consumer's M slot, and the two groups' VALU bursts collide instead of running in anti-phase.
 #pragma unroll
@@ -755,78 +539,51 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float 
     hid.f[q] = __builtin_bit_cast(uint4, w);
   }
   tr.stamp(8);
-  if (b1_next && !b1_loaded) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
+  if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
     load16(a, b1_next);
     load16(g, b1_next + 32);
   }
-  if (DFX_VALU_PRIO) __builtin_amdgcn_s_setprio(0);
+  if (VALU_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // attention M slots: sim = sbias + A_s xn (8 MFMAs);  h += M_s P (8 MFMAs)
 template <class Issue>
 __device__ __forceinline__ void attn_m0(v16f &sim, const Act<DFX_PREC_BF16> (&xn)[4], const uint4 *rec, const float *sbias,
                                         uint4 (&P)[8], bool have_p, Issue &issue) {
-  if (!TAILP || !have_p) {
+  if (!have_p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) P[i] = rec[as_frag(i)];
   }
   load16(sim, sbias);
   __builtin_amdgcn_sched_barrier(0);
-  if (M_INTERLEAVED) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
-      issue.at(i, 8);
-      P[i] = rec[ms_frag(i)];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    issue();
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 8; ++i) {
     sim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[i >> 1].f[i & 1], sim, 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  issue();
-  if (TAILP) {
-    __builtin_amdgcn_sched_barrier(0);
-    tail_prefetch<NEXT_MS>(P, rec);
+    issue.at(i, 8);
+    P[i] = rec[ms_frag(i)];
   }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &pa, const uint4 *rec, uint4 (&P)[8],
                                         const uint4 *ck_next) {
-  if (!TAILP) {
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) P[i] = rec[ms_frag(i)];
+  for (int i = 0; i < 8; ++i) {
+    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+    P[i] = ck_next[w1_frag(i, 0)];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (M_INTERLEAVED) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
-      P[i] = ck_next[w1_frag(i, 0)];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
-  if (TAILP) {
-    __builtin_amdgcn_sched_barrier(0);
-    tail_prefetch<NEXT_W1>(P, ck_next);
-  }
 }
 
 // attention V slot: masked softmax over the 4 keys of each head (registers 4g..4g+3 = keys of head 2g+hf)
@@ -877,9 +634,7 @@ __device__ __forceinline__ void post_eps(const v16f (&h)[4], const float4 *wout,
 // Timestep of the step-th executed step (wave-uniform): T-1, T-2, ... for DDPM, the list for DDIM.
 __device__ __forceinline__ int step_t(const KParams &p, int step, int s) {
   if (p.t_shape) return __builtin_amdgcn_readfirstlane(p.t_shape[s]);   // wave-uniform (one shape per wave)
-#ifndef DFX_AB_NO_DDIM
   if (p.ddim_n > 0) return p.ddim_t[step < p.ddim_n ? step : p.ddim_n - 1];
-#endif
   return p.t0 - step;
 }
 
@@ -952,11 +707,7 @@ __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, 
     const float *tb = p.d.tab + (size_t)t * 8;
     const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
     const float nz = t != 0 ? 1.0f : 0.0f;
-#ifdef DFX_AB_NO_DDIM
-    const bool ddim = false;
-#else
     const bool ddim = p.ddim_n > 0;
-#endif
     const float sap = sqrtf(tb[6]);   // torch.sqrt of the fp32 alphas_cumprod_prev[t] (:481)
     const float xdc = ddim ? p.ddim_xdc[step < p.ddim_n ? step : p.ddim_n - 1] : 0.f;
 #pragma unroll
@@ -1010,7 +761,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
   const int depth = p.d.depth;
   PointState ps;
   unsigned vmask;
-  point_init(p, ps, s, n, (unsigned long long)g0 + pj, vmask);
+  point_init(p, ps, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
   const float *cpart = p.cpart + ((size_t)s * NCLS + ps.sg) * INNER + hf * 64;
   const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
 
@@ -1065,182 +816,11 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 //        management barrier of r) finished at least one barrier earlier.
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
-constexpr int NSLOT = TAILP ? 5 : 4;   // records in flight ahead of the compute: NSLOT - 2
-// ---- software-pipelined feed-forward (-DDFX_SWP) ----------------------------------------------------------------
-// No M/V slots and no anti-phase groups: every wavefront runs, for FF record j,
-//     stage A   GEMM1 of chunk j (16 MFMAs)      beside   GELU of chunk j-1 (VALU / transcendental, packed fp16)
-//     stage B   GEMM2 of chunk j-1 (8 MFMAs)     beside   (a, g) of chunk j -> packed fp16, b1 of chunk j+1 -> (a, g)
-// in ONE instruction stream: GEMM1(j) does not depend on GELU(j-1), so the wavefront's own VALU work fills the issue
-// cycles between its MFMAs (measured rule: next to MFMAs a VALU instruction costs ~3 cycles, a transcendental ~10), and
-// the serial chain of a record shrinks from M + V to about max(M, V).  The transcendentals are compiler-generated
-// here (three instructions per pair instead of two) so that the scheduler can spread them between the MFMAs.
-#ifdef DFX_SWP
-constexpr bool SWP = true;
-#else
-constexpr bool SWP = false;
-#endif
-__device__ __forceinline__ void gelu16_f16_math_c(const h2 (&aa)[8], const h2 (&gg)[8], HidAct &hid) {
-  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
-  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  h2 y[8], ag[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    y[i] = gg[i] * gg[i];
-    y[i] = __builtin_elementwise_fma(y[i], c3, c1);
-    y[i] = gg[i] * y[i];
-    ag[i] = aa[i] * gg[i];
-    y[i] = __builtin_elementwise_exp2(y[i]);
-    y[i] = one + y[i];
-    h2 r;
-    r[0] = __builtin_amdgcn_rcph(y[i][0]);
-    r[1] = __builtin_amdgcn_rcph(y[i][1]);
-    y[i] = ag[i] * r;
-  }
-  hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
-                        __builtin_bit_cast(unsigned, y[3]));
-  hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]),
-                        __builtin_bit_cast(unsigned, y[7]));
-}
-template <int KIND>
-__device__ __forceinline__ constexpr int next_frag(int i) {
-  return KIND == NEXT_W2 ? w2_frag(i) : KIND == NEXT_AS ? as_frag(i) : KIND == NEXT_MS ? ms_frag(i) : w1_frag(i, 0);
-}
-#ifndef DFX_SWP_VALU_PER_MFMA
-#define DFX_SWP_VALU_PER_MFMA 5
-#endif
-#ifndef DFX_SWP_TRANS_PER_MFMA
-#define DFX_SWP_TRANS_PER_MFMA 2
-#endif
-// FIRST: record F0 (no chunk before it); LAST: record F16 (no chunk after it); NEXT: what the first eight MFMAs of the
-// wave's next record need (tail prefetch): W1 of the next chunk, W2 if the next record is the last, A_s after the last.
-// GELU of one packed pair, in two halves (so that one half fits behind each MFMA of stage A)
-struct GeluPair {
-  h2 y, ag;
-};
-__device__ __forceinline__ void gelu_half0(GeluPair &t, h2 aa, h2 gg) {
-  const h2 c1 = {(_Float16)-2.30876530f, (_Float16)-2.30876530f}, c3 = {(_Float16)-0.100125614f, (_Float16)-0.100125614f};
-  h2 y = gg * gg;
-  y = __builtin_elementwise_fma(y, c3, c1);
-  y = gg * y;
-  t.ag = aa * gg;
-  t.y = __builtin_elementwise_exp2(y);
-}
-__device__ __forceinline__ h2 gelu_half1(const GeluPair &t) {
-  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-  const h2 y = one + t.y;
-  h2 r;
-  r[0] = __builtin_amdgcn_rcph(y[0]);
-  r[1] = __builtin_amdgcn_rcph(y[1]);
-  return t.ag * r;
-}
-// FIRST: record F0 (no chunk before it); LAST: record F16 (no chunk after it); NEXT: what the first eight MFMAs of the
-// wave's next record need (tail prefetch): W1 of the next chunk, W2 if the next record is the last, A_s after the last.
-// The interleaving is written out in source order and pinned with a sched_barrier after every MFMA group (LLVM's
-// sched_group_barrier pipelines would not spread the VALU work between the MFMAs here).
-template <bool FIRST, bool LAST, int NEXT, class Issue>
-__device__ __forceinline__ void ff_swp(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g, h2 (&aa)[8],
-                                       h2 (&gg)[8], const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next,
-                                       const float *b1_next, Issue &issue) {
-  constexpr int NM = (LAST ? 0 : 16) + (FIRST ? 0 : 8);
-  h2 hv[8];
-  GeluPair t;
-  GeluPoly tp, tq;
-  __builtin_amdgcn_sched_barrier(0);
-  if (!LAST) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = i & 7, half = i >> 3;
-      v16f &acc = (k & 1) ? g : a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[k]), xn[2 * half + (k >> 2)].f[(k >> 1) & 1], acc, 0, 0, 0);
-      issue.at(i, NM);
-#ifndef DFX_ABL_NO_LDSREAD
-      P[k] = half == 0 ? ck[w1_frag(k, 1)] : FIRST ? ck_next[next_frag<NEXT>(k)] : ck[w2_frag(k)];
-#endif
-#ifndef DFX_ABL_NO_GELU
-      if (!FIRST) {
-        if (GELU_POLY) {
-          const int e0 = 2 * (i >> 2), e1 = e0 + 1;
-          switch (i & 3) {
-            case 0: gelu_poly_quarter<0>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<0>(tq, aa[e1], gg[e1], hv[e1]); break;
-            case 1: gelu_poly_quarter<1>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<1>(tq, aa[e1], gg[e1], hv[e1]); break;
-            case 2: gelu_poly_quarter<2>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<2>(tq, aa[e1], gg[e1], hv[e1]); break;
-            default: gelu_poly_quarter<3>(tp, aa[e0], gg[e0], hv[e0]); gelu_poly_quarter<3>(tq, aa[e1], gg[e1], hv[e1]); break;
-          }
-        } else {
-          if ((i & 1) == 0) gelu_half0(t, aa[i >> 1], gg[i >> 1]);
-          else hv[i >> 1] = gelu_half1(t);
-        }
-      }
-#else
-      if (!FIRST) hv[i >> 1] = aa[i >> 1];
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (GELU_POLY) {
-        gelu_poly_half0(tp, gg[e]);
-        hv[e] = gelu_poly_half1(tp, aa[e], gg[e]);
-      } else {
-        gelu_half0(t, aa[e], gg[e]);
-        hv[e] = gelu_half1(t);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!FIRST) {
-    HidAct hid;
-    hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, hv[0]), __builtin_bit_cast(unsigned, hv[1]),
-                          __builtin_bit_cast(unsigned, hv[2]), __builtin_bit_cast(unsigned, hv[3]));
-    hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, hv[4]), __builtin_bit_cast(unsigned, hv[5]),
-                          __builtin_bit_cast(unsigned, hv[6]), __builtin_bit_cast(unsigned, hv[7]));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
-      issue.at((LAST ? 0 : 16) + i, NM);
-#ifndef DFX_ABL_NO_LDSREAD
-      P[i] = ck_next[next_frag<NEXT>(i)];
-#endif
-      if (!LAST) {
-        // (a, g) of this chunk: `a` got its last MFMA 3+ MFMAs ago at i = 2, `g` 5+ at i = 4: the results are there.
-        // Their next initialisers (b1 of the next chunk) are fetched behind the last two MFMAs, a barrier and the
-        // start of the next record away from their first use.
-        if (i == 2 || i == 3) {
-#pragma unroll
-          for (int e = 4 * (i - 2); e < 4 * (i - 2) + 4; ++e) aa[e] = pk_f16(a[2 * e], a[2 * e + 1]);
-        }
-        if (i == 4 || i == 5) {
-#pragma unroll
-          for (int e = 4 * (i - 4); e < 4 * (i - 4) + 4; ++e) gg[e] = pk_f16(g[2 * e], g[2 * e + 1]);
-        }
-#ifndef DFX_ABL_NO_B1
-        if (i == 6 && b1_next) load16(a, b1_next);
-        if (i == 7 && b1_next) load16(g, b1_next + 32);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    gelu16_f16_cvt(a, g, aa, gg);
-    __builtin_amdgcn_sched_barrier(0);
-    if (b1_next) {
-      load16(a, b1_next);
-      load16(g, b1_next + 32);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
+constexpr int NSLOT = 5;   // records in flight ahead of the compute: NSLOT - 2
 
-// Ring DMA: 24 pieces of 1 KiB per record, CALLS_A per wave of group A (waves 0-3) and CALLS_B per wave of group B
-// (4 CALLS_A + 4 CALLS_B = 24).  Group B's V slot is on the critical path of a record, so it may carry fewer pieces
-// (-DDFX_DMA_SPLIT=AB, e.g. 42 or 60).
-#ifndef DFX_DMA_SPLIT
-#define DFX_DMA_SPLIT 33
-#endif
-constexpr int CALLS_A = DFX_DMA_SPLIT / 10, CALLS_B = DFX_DMA_SPLIT % 10;
+// Ring DMA: 24 pieces of 1 KiB per record, three per wavefront.
+constexpr int CALLS_A = 3, CALLS_B = 3, CALLS_MAX = 3;
 static_assert(4 * CALLS_A + 4 * CALLS_B == SLOT_BYTES / 1024, "24 pieces per record");
-constexpr int CALLS_MAX = CALLS_A > CALLS_B ? CALLS_A : CALLS_B;
 constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
@@ -1334,7 +914,7 @@ __device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int
 }
 
 // The same bookkeeping, but only the (wave-uniform) source / destination of this wave's pieces: the loads themselves are
-// issued one at a time from inside the wave's next M slot (DFX_ISSUE_SPREAD).
+// issued one at a time from inside the wave's next M slot (Issuer).
 struct Pieces {
   const char *src[CALLS_MAX];
   unsigned dst[CALLS_MAX];
@@ -1390,63 +970,27 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
   advance_record(p, st);
 }
 
-// Where the DMA of the record three ahead is issued:
-//   DFX_ISSUE_AT_BARRIER     all of a wave's pieces right after the record's management barrier.  The eight waves'
-//                            24 KiB hit the texture-address path (64 B/clk) at once: every wave sits ~400 cycles in
-//                            the issue stall, on the critical path of the record period (slot trace, tools/run_trace.sh)
-//   default (spread)         one piece at a time from inside the wave's own M slot, between MFMAs (the two groups' M
-//                            slots are in anti-phase, so at most four waves issue at a time, one KiB per ~250 cycles)
-//   DFX_ISSUE_IN_M[_GROUP_B] earlier A/B variants: all pieces behind the first MFMA batch of the M slot
-#if defined(DFX_ISSUE_IN_M) || defined(DFX_ISSUE_IN_M_GROUP_B) || defined(DFX_ISSUE_AT_BARRIER)
-constexpr bool ISSUE_SPREAD = false;
-#else
-constexpr bool ISSUE_SPREAD = M_INTERLEAVED;
-#endif
+// The DMA of the record three ahead is issued one piece at a time from inside the wave's own M slot, between MFMAs (the two
+// groups' M slots are in anti-phase, so at most four waves issue at a time, one KiB per ~250 cycles).  Issued all at once
+// behind the record's management barrier, the eight waves' 24 KiB hit the texture-address path (64 B/clk) together and
+// every wave sits ~400 cycles in the issue stall on the critical path of the record (slot trace, tools/run_trace.sh).
 struct Issuer {
   const KParams &p;
   DmaState &st;
   int wave;
   unsigned voff, lds0;
   int s;
-  bool grpA;
   Pieces pc;
-  __device__ __forceinline__ void whole() { issue_record(p, st, wave, voff, lds0, s); }
-  // right after the management barrier
-  __device__ __forceinline__ void at_barrier() {
-#if defined(DFX_ISSUE_IN_M)
-#elif defined(DFX_ISSUE_IN_M_GROUP_B)
-    if (grpA) whole();
-#else
-    if (!ISSUE_SPREAD) whole();
-#endif
-  }
-  // start of an M slot that consumes a record
+  // (scalar) source / destination bookkeeping of the pieces of the next M slot; runs in the V slot before it
   __device__ __forceinline__ void m_begin() {
-    if (ISSUE_SPREAD) {
-      static_assert(!ISSUE_SPREAD || CALLS_A == CALLS_B, "spread issue: same piece count in both groups");
-      prepare_pieces<CALLS_A>(p, st, wave * CALLS_A, lds0, s, pc);
-      advance_record(p, st);
-    }
-  }
-  // behind the first MFMA batch of the M slot (A/B variants)
-  __device__ __forceinline__ void operator()() {
-#if defined(DFX_ISSUE_IN_M)
-    whole();
-#elif defined(DFX_ISSUE_IN_M_GROUP_B)
-    if (!grpA) whole();
-#endif
+    prepare_pieces<CALLS_A>(p, st, wave * CALLS_A, lds0, s, pc);
+    advance_record(p, st);
   }
   // after MFMA i of the n of an M slot
   __device__ __forceinline__ void at(int i, int n) {
-    if (ISSUE_SPREAD) {
 #pragma unroll
-      for (int k = 0; k < CALLS_A; ++k)
-#ifndef DFX_ABL_NO_DMA   // timing ablation only (wrong results): the ring is never refilled
-        if (i == (k * n) / CALLS_A) dma1k(pc.src[k], voff, pc.dst[k]);
-#else
-        ;
-#endif
-    }
+    for (int k = 0; k < CALLS_A; ++k)
+      if (i == (k * n) / CALLS_A) dma1k(pc.src[k], voff, pc.dst[k]);
   }
 };
 
@@ -1489,10 +1033,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   // L2.  All workgroups stream the same block weights (2 MiB per step), but the attention records are per shape
   // (85 KiB each): with the natural order the wpg workgroups of one shape land on wpg different XCDs and every L2 sees
   // every shape.  Remap so that consecutive workgroups of ONE XCD walk through the workgroups of one shape.
+  const int wpg = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);   // workgroups per shape (the last one may be partial)
   int bid = blockIdx.x;
-#ifndef DFX_NO_XCD_REMAP
   {
-    const int wpg = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);   // workgroups per shape (the last one may be partial)
     const int per = 8 * wpg;                        // workgroups of 8 shapes = one remap period
     const int full = ((int)gridDim.x / per) * per;  // the tail (B % 8 shapes) keeps the natural order
     if (bid < full) {
@@ -1500,31 +1043,25 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       bid = (bid / per) * per + x * wpg + q;        // shape (period*8 + x), workgroup q of it
     }
   }
-#endif
   // one shape per workgroup; N % 32 == 0, so whole wavefronts fall off the end of a shape's last tile: those recompute the
   // shape's last 32 points (same barriers, same DMA duties) and store nothing
-  const int wpg_ = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);
-  const int s = __builtin_amdgcn_readfirstlane(bid / wpg_);
-  int n0 = __builtin_amdgcn_readfirstlane((bid - s * wpg_) * (PIPE_NW * 32) + wave * 32);
+  const int s = __builtin_amdgcn_readfirstlane(bid / wpg);
+  int n0 = __builtin_amdgcn_readfirstlane((bid - s * wpg) * (PIPE_NW * 32) + wave * 32);
   const bool live = n0 < p.N;
   if (!live) n0 = p.N - 32;
-  const long long g0 = (long long)s * p.N + n0;
   const int n = n0 + pj;
+  const unsigned long long gid = ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n;   // Philox key: GLOBAL point id
   const int depth = p.d.depth;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
   const unsigned voff = lane * 16;
-#if defined(DFX_SYMMETRIC) || defined(DFX_SWP)   // A/B variant: no anti-phase groups, every wave takes the record barrier at the start of its M slot
-  const bool grpA = true;
-#else
   const bool grpA = wave < PIPE_NW / 2;
-#endif
 
-  // ---- prologue DMA: records 0 and 1 in flight while the per-point state is set up ----
+  // ---- prologue DMA: records 0, 1, 2 in flight while the per-point state is set up ----
   DmaState dma{0, 0, 0, 0, 0, nullptr};
   issue_record(p, dma, wave, voff, lds0, s);
   issue_record(p, dma, wave, voff, lds0, s);
-  if (TAILP) issue_record(p, dma, wave, voff, lds0, s);
+  issue_record(p, dma, wave, voff, lds0, s);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
   {
@@ -1546,7 +1083,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   {
     PointState ps0;
     ps0.live = live;
-    point_init(p, ps0, s, n, (unsigned long long)g0 + pj, vmask);
+    point_init(p, ps0, s, n, gid, vmask);
     pstate_store(ps_lds, pt, ps0, true);   // both half-waves hold the same point: identical values
   }
   __syncthreads();
@@ -1555,53 +1092,29 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-  // DMA of the record three ahead: right after the management barrier (default), or from inside the M slot that
-  // follows it, behind the first MFMA batch (-DDFX_ISSUE_IN_M, the A/B variant: 1 % slower)
-  Issuer issue_in_m{p, dma, wave, voff, lds0, s, grpA, {}};
-#define DFX_ISSUE_HERE() issue_in_m.at_barrier()
-  // the (scalar) bookkeeping of the pieces a wave issues in an M slot runs in the V slot before it, beside the VALU work
-#ifdef DFX_PREP_IN_M
-#define DFX_M_BEGIN_EARLY() ((void)0)
-#define DFX_M_BEGIN_LATE() issue_in_m.m_begin()
-#else
-#define DFX_M_BEGIN_EARLY() issue_in_m.m_begin()
-#define DFX_M_BEGIN_LATE() ((void)0)
-#endif
+  Issuer issue_in_m{p, dma, wave, voff, lds0, s, {}};
   // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
-#define DFX_STAMP(tag) tr.stamp(tag)
-#ifdef DFX_LOCKSTEP  // A/B variant: a barrier at every slot boundary
-#define DFX_LOCKSTEP_BARRIER() __builtin_amdgcn_s_barrier()
-#else
-#define DFX_LOCKSTEP_BARRIER() ((void)0)
-#endif
-#ifdef DFX_ABL_NO_BARRIER   // timing ablation only (racy)
-#define DFX_ABL_BARRIER() ((void)0)
-#else
-#define DFX_ABL_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
-#define DFX_SLOT(mgmt)                                  \
-  do {                                                  \
-    __builtin_amdgcn_sched_barrier(0);                  \
-    if (mgmt) {                                         \
-      DFX_STAMP(1);                                     \
-      if (grpA) wait_vmcnt<CALLS_A>();                  \
-      else wait_vmcnt<CALLS_B>();                       \
-      DFX_ABL_BARRIER();                                \
-      DFX_STAMP(2);                                     \
-      DFX_ISSUE_HERE();                                 \
-      DFX_STAMP(7);                                     \
-    } else {                                            \
-      DFX_STAMP(3);                                     \
-      DFX_LOCKSTEP_BARRIER();                           \
-    }                                                   \
-    __builtin_amdgcn_sched_barrier(0);                  \
+#define DFX_SLOT(mgmt)                   \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    if (mgmt) {                          \
+      tr.stamp(1);                       \
+      wait_vmcnt<CALLS_A>();             \
+      __builtin_amdgcn_s_barrier();      \
+      tr.stamp(2);                       \
+    } else {                             \
+      tr.stamp(3);                       \
+    }                                    \
+    __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
   // pointer to this lane's view of the record in ring slot `cur`, then advance
-#define DFX_NEXT_RECORD()                                                             \
-  do {                                                                                \
+#define DFX_NEXT_RECORD()                                                               \
+  do {                                                                                  \
     ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane; \
-    cur = cur + 1 == NSLOT ? 0 : cur + 1;                                             \
+    cur = cur + 1 == NSLOT ? 0 : cur + 1;                                               \
   } while (0)
+  // the record that the next DFX_NEXT_RECORD() will hand out (complete in LDS since the previous management barrier)
+#define DFX_PEEK_RECORD() (reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane)
 
 #ifdef DFX_TRACE
   Tracer tr{(p.trace != nullptr && bid == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr,
@@ -1609,13 +1122,7 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 #else
   Tracer tr;
 #endif
-#ifdef DFX_LOCKSTEP
-  if (!grpA) __builtin_amdgcn_s_barrier();  // lock-step variant: B runs one barrier behind A
-#endif
 
-  // the record that the next DFX_NEXT_RECORD() will hand out (with DFX_TAIL_PREFETCH: complete in LDS since the previous
-  // management barrier)
-#define DFX_PEEK_RECORD() (reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane)
   uint4 P[8];   // first MFMA batch of the next M slot (tail prefetch)
   int cur = 0;  // ring slot of the next record to be consumed
   int seq = 0;  // running block number (parity selects the block-constant buffer)
@@ -1629,13 +1136,13 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       Act<PREC> xn[4];
       // ---- V0: finish the previous block / step, start this one ----
       DFX_SLOT(!grpA && step < p.nsteps);
-      DFX_M_BEGIN_EARLY();
+      issue_in_m.m_begin();
       if (seq > 0)  // b2 of the previous block (other block-constant buffer)
         add_cvec(h, reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) +
                         BCONST_B2_OFF + hf * 64);
       if (b == 0) {
         PointState ps;
-        ps.s = s, ps.n = n, ps.gid = (unsigned long long)g0 + pj, ps.live = live;
+        ps.s = s, ps.n = n, ps.gid = gid, ps.live = live;
         pstate_load(ps_lds, pt, ps, step > 0);
         if (step > 0) {
           float eps[3];
@@ -1654,7 +1161,6 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       // ---- M0: sim = sbias + A_s xn ----
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      DFX_M_BEGIN_LATE();
       const uint4 *rec = ck;
       v16f sim;
       attn_m0(sim, xn, rec, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16, P, seq > 0, issue_in_m);
@@ -1667,36 +1173,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       attn_m1(h, pa, rec, P, DFX_PEEK_RECORD());
       // ---- V2: + c_t, LN3 ----
       DFX_SLOT(!grpA);
-      DFX_M_BEGIN_EARLY();
+      issue_in_m.m_begin();
       add_cvec(h, reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
       ln_to_act<PREC>(h, xn);
-#ifdef DFX_SWP
-      // ---- feed-forward, software-pipelined: records F0 .. F16 ----
-      {
-        v16f a, g;
-        h2 aa[8], gg[8];
-        load16(a, b1);  // accumulator initialisers of chunk 0 (block constants: resident since the attention record)
-        load16(g, b1 + 32);
-        DFX_SLOT(true);   // (the pieces of this record's M stage were prepared in V2)
-        DFX_NEXT_RECORD();
-        ff_swp<true, false, NEXT_W1>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), b1 + 64, issue_in_m);
-#pragma unroll 1
-        for (int j = 1; j < FF_CHUNKS - 1; ++j) {
-          issue_in_m.m_begin();
-          DFX_SLOT(true);
-          DFX_NEXT_RECORD();
-          ff_swp<false, false, NEXT_W1>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), b1 + (j + 1) * 64, issue_in_m);
-        }
-        issue_in_m.m_begin();
-        DFX_SLOT(true);
-        DFX_NEXT_RECORD();
-        ff_swp<false, false, NEXT_W2>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), nullptr, issue_in_m);
-        issue_in_m.m_begin();
-        DFX_SLOT(true);
-        DFX_NEXT_RECORD();
-        ff_swp<false, true, NEXT_AS>(h, xn, a, g, aa, gg, ck, P, DFX_PEEK_RECORD(), nullptr, issue_in_m);
-      }
-#else
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
       v16f a, g;
       HidAct hid;
@@ -1704,38 +1183,27 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      DFX_M_BEGIN_LATE();
       ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_SLOT(!grpA);
-        DFX_M_BEGIN_EARLY();
+        issue_in_m.m_begin();
         ff_v(a, g, hid, b1 + j * 64, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
-        DFX_M_BEGIN_LATE();
         ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);
-      DFX_M_BEGIN_EARLY();
+      issue_in_m.m_begin();
       ff_v(a, g, hid, nullptr, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      DFX_M_BEGIN_LATE();
       ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
-#endif
     }
   }
-#ifdef DFX_LOCKSTEP
-  if (grpA) __builtin_amdgcn_s_barrier();  // lock-step variant: A's extra barrier
-#endif
 #undef DFX_SLOT
-#undef DFX_STAMP
 #undef DFX_NEXT_RECORD
 #undef DFX_PEEK_RECORD
-#undef DFX_ISSUE_HERE
-#undef DFX_M_BEGIN_EARLY
-#undef DFX_M_BEGIN_LATE
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
@@ -1846,14 +1314,14 @@ int dfx_denoise_eps(const dfx_denoiser *d, const void *shape_ctx, const float *x
 }
 
 int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t,
-                 const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                 const float *noise, uint64_t seed, uint64_t shape_offset, float *x_prev, float *pred_xstart, int B, int N,
                  dfx_stream_t stream) {
   const int rc = check_common(d, shape_ctx, seg, B, N, "p_sample");
   if (rc) return rc < 0 ? rc : DFX_OK;
   DFX_REQUIRE(x && x_prev, "p_sample: null pointer");
   DFX_REQUIRE(t >= 0 && t < d->dev.T, "p_sample: t=%d outside [0,%d)", t, d->dev.T);
   KParams p{};
-  p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed;
+  p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed; p.shape0 = shape_offset;
   p.B = B; p.N = N; p.t0 = t; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_PSAMPLE;
   return launch(d, shape_ctx, p, as_stream(stream));
 }
@@ -1875,7 +1343,7 @@ static int fill_ddim(const dfx_denoiser *d, KParams &p, const int32_t *steps, in
 }
 
 int dfx_p_sample_ddim(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t, float eta,
-                      const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                      const float *noise, uint64_t seed, uint64_t shape_offset, float *x_prev, float *pred_xstart, int B, int N,
                       dfx_stream_t stream) {
   const int rc = check_common(d, shape_ctx, seg, B, N, "p_sample_ddim");
   if (rc) return rc < 0 ? rc : DFX_OK;
@@ -1883,14 +1351,14 @@ int dfx_p_sample_ddim(const dfx_denoiser *d, const void *shape_ctx, const float 
   KParams p{};
   const int32_t one[1] = {t};
   if (int e = fill_ddim(d, p, one, 1, eta, "p_sample_ddim")) return e;
-  p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed;
+  p.x_in = x; p.seg = seg; p.noise = noise; p.out = x_prev; p.xstart = pred_xstart; p.seed = seed; p.shape0 = shape_offset;
   p.B = B; p.N = N; p.t0 = t; p.nsteps = 1; p.ret_interval = 1; p.mode = MODE_PSAMPLE;
   return launch(d, shape_ctx, p, as_stream(stream));
 }
 
 int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *steps,
                           int n_steps, float eta, const float *x_T_noise, const float *step_noise, uint64_t seed,
-                          int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream) {
+                          uint64_t shape_offset, int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream) {
   const int rc = check_common(d, shape_ctx, seg, B, N, "sample_chain_ddim");
   if (rc) return rc < 0 ? rc : DFX_OK;
   DFX_REQUIRE(pred, "sample_chain_ddim: null pred");
@@ -1898,7 +1366,7 @@ int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const in
   KParams p{};
   if (int e = fill_ddim(d, p, steps, n_steps, eta, "sample_chain_ddim")) return e;
   DFX_REQUIRE(steps[0] == 0, "sample_chain_ddim: the step list must start at 0 (decode keeps the t == 0 sample as 'pred')");
-  p.seg = seg; p.noise = step_noise; p.xT_noise = x_T_noise; p.out = pred; p.traj = traj; p.seed = seed;
+  p.seg = seg; p.noise = step_noise; p.xT_noise = x_T_noise; p.out = pred; p.traj = traj; p.seed = seed; p.shape0 = shape_offset;
   p.B = B; p.N = N; p.t0 = p.ddim_t[0]; p.nsteps = n_steps; p.ret_interval = ret_interval >= 1 ? ret_interval : 1;
   p.mode = MODE_CHAIN;
   return launch(d, shape_ctx, p, as_stream(stream));
@@ -1953,14 +1421,14 @@ int dfx_chain_num_snapshots(int num_timesteps, int ret_interval) {
 }
 
 int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const float *x_T_noise,
-                     const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
-                     int N, dfx_stream_t stream) {
+                     const float *step_noise, uint64_t seed, uint64_t shape_offset, int ret_interval, float *traj, float *pred,
+                     int B, int N, dfx_stream_t stream) {
   const int rc = check_common(d, shape_ctx, seg, B, N, "sample_chain");
   if (rc) return rc < 0 ? rc : DFX_OK;
   DFX_REQUIRE(pred, "sample_chain: null pred");
   DFX_REQUIRE(!traj || ret_interval >= 1, "sample_chain: ret_interval must be >= 1 when traj is given");
   KParams p{};
-  p.seg = seg; p.noise = step_noise; p.xT_noise = x_T_noise; p.out = pred; p.traj = traj; p.seed = seed;
+  p.seg = seg; p.noise = step_noise; p.xT_noise = x_T_noise; p.out = pred; p.traj = traj; p.seed = seed; p.shape0 = shape_offset;
   p.B = B; p.N = N; p.t0 = d->dev.T - 1; p.nsteps = d->dev.T; p.ret_interval = ret_interval >= 1 ? ret_interval : 1;
   p.mode = MODE_CHAIN;
   return launch(d, shape_ctx, p, as_stream(stream));

@@ -116,7 +116,7 @@ __global__ void k_pack_w2(const float *__restrict__ W2, void *__restrict__ dst) 
   const int ct = tile & 3, u = tile >> 2;
   const long long di = ((long long)((u + FF_SKEW) * CHUNK_TILES + 8 + ct) << 10) + (gi & 1023);
   const float w = W2[(size_t)(32 * ct + i) * FF_HID + 32 * u + kk];
-  if (PREC == DFX_PREC_BF16 && GELU_F16) reinterpret_cast<_Float16 *>(dst)[di] = (_Float16)(w * (1.0f / (FF_A_SCALE * FF_G_SCALE)));
+  if (PREC == DFX_PREC_BF16) reinterpret_cast<_Float16 *>(dst)[di] = (_Float16)(w * (1.0f / (FF_A_SCALE * FF_G_SCALE)));
   else tile_store<PREC>(dst, di, w);
 }
 

@@ -32,6 +32,13 @@ def _unsupported(what):
     raise NotImplementedError(f"libdfx implements the shipped gen_* encoder configuration only: {what}")
 
 
+
+def _training_generation():
+    """training.Adam updates parameters through raw pointers (no torch version bump): packed-weight caches key on its counter."""
+    from . import training
+    return training.param_generation()
+
+
 class PointNetV2(nn.Module):
     """``ENCODERS['PointNetV2']`` (python/difffacto/models/encoders/pointnet.py:124-213): per-point MLP, attention-weighted
     max-pool per part, per-part heads -> (m, v) of shape (B, num_anchors, zdim).  Same constructor arguments and parameter
@@ -61,7 +68,7 @@ class PointNetV2(nn.Module):
     # ---- libdfx handle, rebuilt when a parameter / buffer changes ----
     def _handle(self):
         ts = [t for t in list(self.parameters()) + list(self.buffers()) if t.dtype == torch.float32]
-        ver = tuple((t._version, t.data_ptr()) for t in ts)
+        ver = (_training_generation(),) + tuple((t._version, t.data_ptr()) for t in ts)
         if self.__dict__.get("_h") is None or self.__dict__.get("_ver") != ver:
             self._close()
             keep = []
@@ -226,7 +233,7 @@ class _StandaloneAligner:
 
     def sampler(self):
         al = self._al()
-        ver = tuple(p._version for p in al.parameters())
+        ver = (_training_generation(),) + tuple(p._version for p in al.parameters())
         if self._s is None or ver != self._ver:
             sd = {"part_aligner." + k: v for k, v in al.state_dict().items()}
             self._s = LatentSampler(sd, n_class=al.n_class, zdim=al.zdim, n_heads=al.n_heads, d_head=al.d_head,
@@ -284,7 +291,7 @@ class PartEncoderForTransformerDecoder(nn.Module):
     def sampler(self):
         """The libdfx handle for the current parameters (rebuilt when a parameter was modified in place or reloaded)."""
         own = [p for n, p in self.named_parameters() if not n.startswith("encoder.")]
-        ver = tuple(p._version for p in own) + (own[0].device,)
+        ver = (_training_generation(),) + tuple(p._version for p in own) + (own[0].device,)
         if self._sampler is None or ver != self._ver:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.")}
             al = self.part_aligner

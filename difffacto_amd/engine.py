@@ -165,7 +165,7 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_denoise_eps")
         return out
 
-    def p_sample(self, ctx, x, seg, t, noise=None, seed=0, want_xstart=False):
+    def p_sample(self, ctx, x, seg, t, noise=None, seed=0, want_xstart=False, shape_offset=0):
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
         B, _, N = x.shape
@@ -174,20 +174,22 @@ class DenoiserEngine:
             assert noise.shape == x.shape
         pad = self._pad(N)
         if pad:
-            r = self.p_sample(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, self._pad_last(noise, pad), seed, want_xstart)
+            r = self.p_sample(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, self._pad_last(noise, pad), seed, want_xstart, shape_offset)
             return tuple(a[..., :N].contiguous() for a in r) if want_xstart else r[..., :N].contiguous()
         out = torch.empty_like(x)
         xs = torch.empty_like(x) if want_xstart else None
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_p_sample(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t),
-                                        _ffi.ptr(noise), int(seed), _ffi.ptr(out), _ffi.ptr(xs), B, N,
+                                        _ffi.ptr(noise), int(seed), int(shape_offset), _ffi.ptr(out), _ffi.ptr(xs), B, N,
                                         _ffi.current_stream())
         _ffi.check(rc, "dfx_p_sample")
         return (out, xs) if want_xstart else out
 
-    def sample_chain(self, ctx, seg, x_T_noise=None, step_noise=None, seed=0, ret_interval=None):
+    def sample_chain(self, ctx, seg, x_T_noise=None, step_noise=None, seed=0, ret_interval=None, shape_offset=0):
         """Whole reverse chain in one launch.  Returns (pred (B,N,3), traj or None) where traj is
-        (n_keep,B,N,3) with snapshot k <-> t = (T // ret_interval - k) * ret_interval."""
+        (n_keep,B,N,3) with snapshot k <-> t = (T // ret_interval - k) * ret_interval.  `shape_offset` = global index of
+        shape 0 of this call: the in-kernel Philox noise is keyed by the global point id, so a batch split over calls / ranks
+        gives the clouds of the unsplit call."""
         seg = self._seg(seg, self.device)
         B, N = seg.shape
         T = self.num_timesteps
@@ -200,7 +202,7 @@ class DenoiserEngine:
         pad = self._pad(N)
         if pad:
             pred, traj = self.sample_chain(ctx, self._pad_seg(seg, pad), self._pad_last(x_T_noise, pad), self._pad_last(step_noise, pad),
-                                           seed, ret_interval)
+                                           seed, ret_interval, shape_offset)
             return pred[:, :N].contiguous(), None if traj is None else traj[:, :, :N].contiguous()
         pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
         traj = None
@@ -211,7 +213,7 @@ class DenoiserEngine:
             traj = torch.empty(nk, B, N, 3, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_sample_chain(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), _ffi.ptr(x_T_noise),
-                                            _ffi.ptr(step_noise), int(seed), ri, _ffi.ptr(traj), _ffi.ptr(pred), B, N,
+                                            _ffi.ptr(step_noise), int(seed), int(shape_offset), ri, _ffi.ptr(traj), _ffi.ptr(pred), B, N,
                                             _ffi.current_stream())
         _ffi.check(rc, "dfx_sample_chain")
         return pred, traj
@@ -265,7 +267,7 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_masked_mse_f32")
         return loss[0]
 
-    def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=0, want_xstart=False):
+    def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=0, want_xstart=False, shape_offset=0):
         """One DDIM update (anchored_diffusion.py:368-377, :480-481)."""
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
@@ -275,18 +277,18 @@ class DenoiserEngine:
             assert noise.shape == x.shape
         pad = self._pad(N)
         if pad:
-            r = self.p_sample_ddim(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, eta, self._pad_last(noise, pad), seed, want_xstart)
+            r = self.p_sample_ddim(ctx, self._pad_last(x, pad), self._pad_seg(seg, pad), t, eta, self._pad_last(noise, pad), seed, want_xstart, shape_offset)
             return tuple(a[..., :N].contiguous() for a in r) if want_xstart else r[..., :N].contiguous()
         out = torch.empty_like(x)
         xs = torch.empty_like(x) if want_xstart else None
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_p_sample_ddim(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(x), _ffi.ptr(seg), int(t), float(eta),
-                                             _ffi.ptr(noise), int(seed), _ffi.ptr(out), _ffi.ptr(xs), B, N,
+                                             _ffi.ptr(noise), int(seed), int(shape_offset), _ffi.ptr(out), _ffi.ptr(xs), B, N,
                                              _ffi.current_stream())
         _ffi.check(rc, "dfx_p_sample_ddim")
         return (out, xs) if want_xstart else out
 
-    def sample_chain_ddim(self, ctx, seg, steps, eta, x_T_noise=None, step_noise=None, seed=0, ret_interval=None):
+    def sample_chain_ddim(self, ctx, seg, steps, eta, x_T_noise=None, step_noise=None, seed=0, ret_interval=None, shape_offset=0):
         """DDIM chain in one launch over the ascending step list ``steps`` (executed in reverse).  Returns
         (pred, traj or None); traj slots follow ``snapshot_times``; only timesteps in ``steps`` are written."""
         seg = self._seg(seg, self.device)
@@ -299,7 +301,7 @@ class DenoiserEngine:
         pad = self._pad(N)
         if pad:
             pred, traj = self.sample_chain_ddim(ctx, self._pad_seg(seg, pad), steps, eta, self._pad_last(x_T_noise, pad),
-                                                self._pad_last(step_noise, pad), seed, ret_interval)
+                                                self._pad_last(step_noise, pad), seed, ret_interval, shape_offset)
             return pred[:, :N].contiguous(), None if traj is None else traj[:, :, :N].contiguous()
         pred = torch.empty(B, N, 3, dtype=torch.float32, device=self.device)
         traj, ri = None, 0
@@ -310,7 +312,7 @@ class DenoiserEngine:
         arr = (ctypes.c_int32 * len(steps))(*steps)
         with torch.cuda.device(self.device):
             rc = _ffi.lib().dfx_sample_chain_ddim(self._h, _ffi.ptr(ctx.buf), _ffi.ptr(seg), arr, len(steps), float(eta),
-                                                 _ffi.ptr(x_T_noise), _ffi.ptr(step_noise), int(seed), ri, _ffi.ptr(traj),
+                                                 _ffi.ptr(x_T_noise), _ffi.ptr(step_noise), int(seed), int(shape_offset), ri, _ffi.ptr(traj),
                                                  _ffi.ptr(pred), B, N, _ffi.current_stream())
         _ffi.check(rc, "dfx_sample_chain_ddim")
         return pred, traj

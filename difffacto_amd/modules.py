@@ -109,7 +109,8 @@ class TransformerNet(nn.Module):
 
     def engine(self):
         params = dict(self.named_parameters())
-        key = (self._dfx_T, self._dfx_betas, self._dfx_precision,
+        # training.Adam updates parameters through raw pointers (no version bump): its generation counter is part of the key
+        key = (self._dfx_T, self._dfx_betas, self._dfx_precision, _training.param_generation(),
                tuple((p.data_ptr(), p._version) for p in params.values()))
         if self._engine is None or key != self._engine_key:
             dev = next(self.parameters()).device
@@ -196,7 +197,7 @@ class AnchoredDiffusion(nn.Module):
         super().__init__()
         if (mode != 'linear' or res or use_beta or rescale_timesteps or model_mean_type != 'epsilon'
                 or model_var_type != 'fixed_small' or clip_xstart or include_anchors or include_cov
-                or not learn_anchor or not learn_variance or guidance):
+                or not learn_anchor or not learn_variance or guidance or scale_loss or loss_type != 'mse'):
             _unsupported("AnchoredDiffusion options other than those of configs/gen_*.py")
         if isinstance(net, nn.Module):
             self.model = net
@@ -275,20 +276,22 @@ class AnchoredDiffusion(nn.Module):
             return pred.transpose(1, 2).contiguous()
         final = None
         for _, sample in self.p_sample_loop_progressive(shape, anchors, ctx=ctx, variance=variance, noise=noise,
-                                                        anchor_assignment=anchor_assignment, valid_id=valid_id):
+                                                        anchor_assignment=anchor_assignment, valid_id=valid_id, seed=seed):
             final = sample
         return final["sample"]
 
     @torch.no_grad()
     def sample_chain(self, ctx, anchor_assignment, valid_id=None, x_T_noise=None, step_noise=None, seed=0,
-                     ret_interval=None):
-        """Whole reverse chain in ONE persistent launch: (pred (B,N,3), traj (n_keep,B,N,3) | None)."""
+                     ret_interval=None, shape_offset=0):
+        """Whole reverse chain in ONE persistent launch: (pred (B,N,3), traj (n_keep,B,N,3) | None).  `shape_offset`: global
+        index of shape 0 (a rank of a sharded run passes its first shape's index: same clouds for any GPU count)."""
         if self.ddim_sampling:
             return self.model.engine().sample_chain_ddim(self._sc(ctx, valid_id), anchor_assignment, self.steps, self.ddim_eta,
                                                          x_T_noise=x_T_noise, step_noise=step_noise, seed=seed,
-                                                         ret_interval=ret_interval)
+                                                         ret_interval=ret_interval, shape_offset=shape_offset)
         return self.model.engine().sample_chain(self._sc(ctx, valid_id), anchor_assignment, x_T_noise=x_T_noise,
-                                                step_noise=step_noise, seed=seed, ret_interval=ret_interval)
+                                                step_noise=step_noise, seed=seed, ret_interval=ret_interval,
+                                                shape_offset=shape_offset)
 
     def training_losses(self, x_start, t, anchors=None, variance=None, ctx=None, reduce=True, anchor_assignment=None,
                         valid_id=None, flags=None, noise=None):
@@ -328,10 +331,10 @@ class AnchoredDiffusion(nn.Module):
 
 @torch.no_grad()
 def decode(diffusion, ctx, anchor_assignments, valid_id=None, ret_traj=False, ret_interval=20, seed=0,
-           x_T_noise=None, step_noise=None):
+           x_T_noise=None, step_noise=None, shape_offset=0):
     """``AnchorDiffAE.decode`` (anchor_gen.py:145-169): {'pred': (B,N,3), t: (B,N,3) for t % ret_interval == 0}."""
     pred, traj = diffusion.sample_chain(ctx, anchor_assignments, valid_id, x_T_noise=x_T_noise, step_noise=step_noise,
-                                        seed=seed, ret_interval=ret_interval if ret_traj else None)
+                                        seed=seed, ret_interval=ret_interval if ret_traj else None, shape_offset=shape_offset)
     final = {"pred": pred}
     if ret_traj:
         visited = set(diffusion.steps) | {diffusion.num_timesteps}   # the prior sample t = T is always yielded (:565)

@@ -24,9 +24,11 @@ def _needs_cpu_staging(t):
     return dist.get_backend() == "gloo" and t.is_cuda
 
 
+@torch.no_grad()
 def broadcast_params(params, src=0):
     """One collective for the whole frozen parameter set: pack -> broadcast -> unpack in place.
-    `params` is an ordered dict name -> tensor, same shapes on every rank."""
+    `params` is an ordered dict name -> tensor, same shapes on every rank (plain tensors or leaf nn.Parameters: the
+    in-place unpack runs under no_grad)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return params
     names = list(params)
@@ -45,18 +47,23 @@ def broadcast_params(params, src=0):
     return params
 
 
-def gather_clouds(pred, dst=0):
+def gather_clouds(pred, dst=0, sizes=None):
     """Gather per-rank generated clouds (B_r, N, 3) to `dst`; returns the concatenation on dst
-    (rank order) and None elsewhere.  Ragged B_r is allowed (sizes exchanged first)."""
+    (rank order) and None elsewhere.  Ragged B_r is allowed: `sizes` = the per-rank shape counts when the caller knows them
+    (a block partition does: shard_range) — otherwise they are exchanged first with one small all_gather and a host sync."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return pred
     world, rank = dist.get_world_size(), dist.get_rank()
     out_device = pred.device
     if _needs_cpu_staging(pred):
         pred = pred.cpu()
-    sizes = [torch.zeros(1, dtype=torch.int64, device=pred.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([pred.shape[0]], dtype=torch.int64, device=pred.device))
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=pred.device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([pred.shape[0]], dtype=torch.int64, device=pred.device))
+        sizes = [int(s.item()) for s in sizes]
+    else:
+        sizes = [int(x) for x in sizes]
+        assert len(sizes) == world and sizes[rank] == pred.shape[0], (sizes, rank, tuple(pred.shape))
     bmax = max(sizes)
     pad = pred
     if pred.shape[0] < bmax:

@@ -42,6 +42,12 @@ def _need(t, name):
     return t
 
 
+def _check_first_backward(ctx, who):
+    if ctx.ws_ptr is None:
+        raise RuntimeError(f"{who}.backward ran twice on one forward (retain_graph / two losses sharing the forward): the saved-"
+                           "activation workspace is released by the first backward; run the forward again")
+
+
 class DenoiserTrainFn(torch.autograd.Function):
     """eps = TransformerNet(x, t, [ctx_code, ctx_mv], anchors, variances, valid_id, anchor_assignment), differentiable in
     the parameters and in the two context tensors (x_t, anchors and variances are data: anchored_diffusion.py detaches
@@ -103,6 +109,7 @@ class DenoiserTrainFn(torch.autograd.Function):
         names = param_names(depth)
         d_eps = _need(d_eps.contiguous(), "d_eps")
         dev = d_eps.device
+        _check_first_backward(ctx, "DenoiserTrainFn")
         # one flat buffer, handed out as views in parameter order: clip + Adam can then run as ONE launch each over the
         # whole parameter set (training.Adam), and a data-parallel all-reduce needs no packing copy
         # (every slice starts on a 256-byte boundary: the product kernels want 16-byte aligned weights once the optimiser
@@ -124,6 +131,7 @@ class DenoiserTrainFn(torch.autograd.Function):
                                                               ctx.prec, ctx.drop[0], ctx.drop[1], _ffi.current_stream()),
                        "dfx_denoiser_train_backward")
         ctx.ws = None
+        ctx.ws_ptr = None   # the workspace goes back to the allocator: a second backward must not reuse its address
         # Leaf parameters get their slice of the flat buffer assigned to .grad directly (accumulating if one is already
         # there): returned through autograd, AccumulateGrad would clone every tensor out of the flat buffer, because the
         # Python wrappers of the returned views still hold references when it runs.
@@ -246,6 +254,7 @@ class PointNetV2TrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dm, dv):
+        _check_first_backward(ctx, "PointNetV2TrainFn")
         num_anchors, zdim, reweight, eps, momentum, precision = ctx.cfg
         B, N = ctx.shape
         dm = _need(dm.contiguous(), "dm")
@@ -258,6 +267,7 @@ class PointNetV2TrainFn(torch.autograd.Function):
                                                                  dm.data_ptr(), dv.data_ptr(), ctypes.byref(gw), B, N, ctx.prec,
                                                                  _ffi.current_stream()), "dfx_pointnet_v2_train_backward")
         ctx.ws = None
+        ctx.ws_ptr = None   # the workspace goes back to the allocator: a second backward must not reuse its address
         out = _assign_or_return(ctx.leaves, views)
         ctx.leaves = None
         return (None, None, None, None) + tuple(out)
@@ -319,6 +329,7 @@ class PriorLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _glp, _gent):
+        _check_first_backward(ctx, "PriorLossFn")
         depth, hidden, prior_var, kl_weight = ctx.cfg[:4]
         B = ctx.B
         dev = ctx.vd.device
@@ -337,6 +348,7 @@ class PriorLossFn(torch.autograd.Function):
         if dlv is not None:
             dlv.mul_(g)
         ctx.ws = None
+        ctx.ws_ptr = None   # the workspace goes back to the allocator: a second backward must not reuse its address
         if ctx.consumer is not None:
             # autograd runs this node on the stream of its forward (the side stream) and orders dz / dlv for their consumers
             # itself; the parameter gradients are assigned by hand below, so the consuming stream is made to wait here
@@ -430,6 +442,15 @@ class MaskedMSEFn(torch.autograd.Function):
 
 def masked_mse(target, pred, flags=None):
     return MaskedMSEFn.apply(target, pred, flags)
+
+
+_PARAM_GENERATION = [0]
+
+
+def param_generation():
+    """Counter bumped by every `Adam.step`: the kernels update parameters through raw pointers, which torch's in-place
+    version counters do not see; caches of packed weights (modules.TransformerNet.engine, encoders.PointNetV2) key on it."""
+    return _PARAM_GENERATION[0]
 
 
 class Adam:
@@ -544,6 +565,7 @@ class Adam:
         lib = _ffi.lib()
         norm = self.grad_norm() if self.max_norm and self.max_norm > 0 else None
         self.step_count += 1
+        _PARAM_GENERATION[0] += 1
         work = self._flat_work()
         if work is None:
             self.last_step_was_flat = False

@@ -160,10 +160,12 @@ int dfx_denoise_eps(const dfx_denoiser *d, const void *shape_ctx, const float *x
 
 /* One p_sample (anchored_diffusion.py:450-484): x_prev = mean + 1[t!=0] sqrt(var) z.
  * noise (B,3,N) = the z of :476, or NULL -> in-kernel Philox4x32-10 normals keyed by
- * (seed, global point id, t).  x_prev may alias x.  pred_xstart (B,3,N) is optional (NULL to skip):
+ * (seed, global point id, t), global point id = (shape_offset + b) * N + n: `shape_offset` is the global index of this
+ * call's shape 0, so a batch that is split over several calls or GPUs draws exactly the normals of
+ * the unsplit call, whatever the split.  x_prev may alias x.  pred_xstart (B,3,N) is optional (NULL to skip):
  * the x_0 prediction p_sample returns next to the sample (:484). */
 int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t,
-                 const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                 const float *noise, uint64_t seed, uint64_t shape_offset, float *x_prev, float *pred_xstart, int B, int N,
                  dfx_stream_t stream);
 
 /* The whole reverse chain in ONE persistent launch (p_sample_loop_progressive :528-588 driven by
@@ -171,13 +173,15 @@ int dfx_p_sample(const dfx_denoiser *d, const void *shape_ctx, const float *x, c
  * for all T steps.
  *   x_T_noise  (B,3,N) the randn of :564, or NULL -> Philox
  *   step_noise (T,B,3,N), step_noise[i] = z of the i-th executed step (t = T-1-i), or NULL -> Philox
+ *   seed, shape_offset  Philox key and global index of shape 0 (see dfx_p_sample): rank r of a sharded run passes the
+ *              index of its first shape, and the clouds do not depend on the number of GPUs
  *   pred       (B,N,3)  final cloud, already transposed like decode's 'pred'
  *   traj       NULL, or (n_keep,B,N,3) snapshots for t = T, then every t>0 with t % ret_interval == 0 in
  *              descending order (decode's ret_traj entries); n_keep = dfx_chain_num_snapshots(T, ret_interval). */
 int dfx_chain_num_snapshots(int num_timesteps, int ret_interval);
 int dfx_sample_chain(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const float *x_T_noise,
-                     const float *step_noise, uint64_t seed, int ret_interval, float *traj, float *pred, int B,
-                     int N, dfx_stream_t stream);
+                     const float *step_noise, uint64_t seed, uint64_t shape_offset, int ret_interval, float *traj, float *pred,
+                     int B, int N, dfx_stream_t stream);
 
 /* Training-style forward evaluation (forward only; anchored_diffusion.py:760-853 in eval mode):
  *   dfx_q_sample_f32    x_t = sqrt_acp[t_b] (x0 - a) + a + sqrt(1 - acp[t_b]) L noise   (:148-173), t (B,) int32 on the device
@@ -200,11 +204,11 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
  * traj slot k still means t = (T / ret_interval - k) * ret_interval; slots of timesteps that are not visited are
  * left untouched. */
 int dfx_p_sample_ddim(const dfx_denoiser *d, const void *shape_ctx, const float *x, const int32_t *seg, int t, float eta,
-                      const float *noise, uint64_t seed, float *x_prev, float *pred_xstart, int B, int N,
+                      const float *noise, uint64_t seed, uint64_t shape_offset, float *x_prev, float *pred_xstart, int B, int N,
                       dfx_stream_t stream);
 int dfx_sample_chain_ddim(const dfx_denoiser *d, const void *shape_ctx, const int32_t *seg, const int32_t *steps,
                           int n_steps, float eta, const float *x_T_noise, const float *step_noise, uint64_t seed,
-                          int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream);
+                          uint64_t shape_offset, int ret_interval, float *traj, float *pred, int B, int N, dfx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Chamfer-L2 — replaces the `chamfer` extension

@@ -1,0 +1,158 @@
+"""GPU parity gates on the HEADLINE configuration (BASELINE.json configs[1]: gen_chair, 2048 points x 4 parts, T = 1000 DDPM
+steps, bf16 `k_denoise_pipe`) and on the multi-GPU contract of SURVEY.md §8(e) (results independent of the GPU count;
+`bench.py --gpus 2` executed as two ranks on the one GPU of the box).
+
+Weight set: with random-init weights eps_theta is an arbitrary O(1) function of x and the T = 1000 chain is chaotic (clouds blow
+up to +-20): parity numbers on it say little.  `contractive_weights` scales `proj_out` by 0.05, so eps_theta ~ 0 and
+the reverse chain is the linear map (x - a) -> (x - a) / sqrt(alpha_t) per step (anchored_diffusion.py:175-193 with eps = 0):
+deviations grow by at most 1 / sqrt(alphas_cumprod[T-1]) = 157 like the cloud itself, so errors RELATIVE to the cloud extent are
+meaningful.  Every kernel path (all GEMMs, LayerNorms, softmax, GELU, posterior) runs exactly as in the headline bench."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from difffacto_amd import synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# measured on MI355X (profiles/r02_parity_headline.txt), gates at <= 3x the measured value
+HEADLINE_BF16_VS_F32_REL = 3e-3     # max-abs / cloud extent, bf16 pipe vs exact-fp32 chain, T = 1000
+HEADLINE_F32_VS_ORACLE_REL = 3e-5   # exact-fp32 HIP chain vs numpy oracle on a 256-point subset, T = 1000
+HEADLINE_CD_REL = 1e-5              # Chamfer-L2(bf16, fp32) / extent^2
+HEADLINE_EMD = 3e-4                 # auction EMD(bf16, fp32) on the unit-box-normalised clouds
+
+
+def contractive_weights():
+    W = synth.make_denoiser_weights(seed=0)
+    W["proj_out.weight"] = (W["proj_out.weight"] * 0.05).astype(np.float32)
+    W["proj_out.bias"] = (W["proj_out.bias"] * 0.05).astype(np.float32)
+    return W
+
+
+def _engine(W, T, prec):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from difffacto_amd.engine import DenoiserEngine
+    return DenoiserEngine({k: torch.from_numpy(v) for k, v in W.items()}, num_timesteps=T, precision=prec)
+
+
+def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle():
+    from difffacto_amd.metrics import EMD, chamfer_l2
+    from oracle import diffusion as odf
+    from oracle import torch_cpu as tc
+    T, B, N = 1000, 8, 2048
+    W = contractive_weights()
+    pc, mean, logvar, valid = synth.make_latents(B, seed=5)
+    var = np.exp(logvar).astype(np.float32)
+    seg = synth.make_seg_mask(valid, N)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xT = torch.randn(B, 3, N, device="cuda", generator=g)
+    zs = torch.randn(T, B, 3, N, device="cuda", generator=g)
+    args = tuple(map(torch.from_numpy, (pc, mean, var, valid)))
+    out = {}
+    for prec in ("f32", "bf16"):
+        eng = _engine(W, T, prec)
+        out[prec], _ = eng.sample_chain(eng.prepare_shapes(*args), torch.from_numpy(seg), x_T_noise=xT, step_noise=zs)
+        eng.close()
+    assert torch.isfinite(out["bf16"]).all() and torch.isfinite(out["f32"]).all()
+    extent = float((out["f32"].amax((1, 2)) - out["f32"].amin((1, 2))).mean())
+    rel = float((out["bf16"] - out["f32"]).abs().max()) / extent
+    cd = float(chamfer_l2(out["bf16"], out["f32"]).mean()) / extent ** 2
+    lo = torch.minimum(out["bf16"].amin((1, 2), keepdim=True), out["f32"].amin((1, 2), keepdim=True))
+    hi = torch.maximum(out["bf16"].amax((1, 2), keepdim=True), out["f32"].amax((1, 2), keepdim=True))
+    emd = float(EMD(0.002, 10000, True)(((out["bf16"] - lo) / (hi - lo)).contiguous(), ((out["f32"] - lo) / (hi - lo)).contiguous()).mean())
+
+    # the oracle on a subset: points are independent given the shape's 4 part tokens, so 256 points of shape 0 with their
+    # own noise columns reproduce those points of the full run (PyTorch-CPU restatement, pinned to the reference goldens)
+    sub = np.arange(0, N, N // 256)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    anchors, variance = odf.gather_params(seg[:1, sub], mean[:1], var[:1])
+    ctx = [tt(pc[:1]), tt(np.concatenate([mean[:1], var[:1]], 1))]
+    Wt = {k: tt(v) for k, v in W.items()}
+    tb = odf.Tables(T)
+    xTs, zss = xT[:1, :, sub].cpu(), zs[:, :1][:, :, :, sub].cpu()
+    with torch.no_grad():
+        x = torch.sqrt(tt(variance)) * xTs + tt(anchors)
+        for i, t in enumerate(range(T - 1, -1, -1)):
+            x, _ = tc.p_sample(tb, Wt, x, t, tt(anchors), ctx, tt(variance), tt(seg[:1, sub]), tt(valid[:1]), zss[i])
+    ref = x.transpose(1, 2)[0]
+    rel_or = float((out["f32"][0, sub].cpu() - ref).abs().max()) / extent
+    rel_or_bf16 = float((out["bf16"][0, sub].cpu() - ref).abs().max()) / extent
+    print(f"headline T={T} B={B} N={N}: extent {extent:.2f}; bf16 vs f32 max-abs/extent {rel:.3e}, Chamfer-L2/extent^2 {cd:.3e}, "
+          f"EMD(unit box) {emd:.3e}; f32 vs oracle (256 pts) {rel_or:.3e}; bf16 vs oracle {rel_or_bf16:.3e}")
+    assert rel < HEADLINE_BF16_VS_F32_REL
+    assert rel_or < HEADLINE_F32_VS_ORACLE_REL
+    assert rel_or_bf16 < HEADLINE_BF16_VS_F32_REL
+    assert cd < HEADLINE_CD_REL
+    assert emd < HEADLINE_EMD
+
+
+@pytest.mark.parametrize("prec,N", [("bf16", 2048), ("f32", 256)])
+def test_philox_noise_is_keyed_by_the_global_shape_id(prec, N):
+    """one call over 6 shapes == two calls over 4 + 2 shapes with shape_offset, bit for bit (in-kernel
+    Philox, both the persistent pipelined kernel and the direct one)."""
+    T, B = 5, 6
+    W = synth.make_denoiser_weights(seed=0)
+    eng = _engine(W, T, prec)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=3)
+    var = np.exp(logvar).astype(np.float32)
+    seg = torch.from_numpy(synth.make_seg_mask(valid, N))
+    t = lambda a, lo, hi: torch.from_numpy(np.ascontiguousarray(a[lo:hi]))
+    full, _ = eng.sample_chain(eng.prepare_shapes(*(t(a, 0, B) for a in (pc, mean, var, valid))), seg, seed=11)
+    parts = []
+    for lo, hi in ((0, 4), (4, 6)):
+        c = eng.prepare_shapes(*(t(a, lo, hi) for a in (pc, mean, var, valid)))
+        parts.append(eng.sample_chain(c, seg[lo:hi], seed=11, shape_offset=lo)[0])
+    assert torch.equal(full, torch.cat(parts))
+    wrong = eng.sample_chain(eng.prepare_shapes(*(t(a, 4, 6) for a in (pc, mean, var, valid))), seg[4:6], seed=11)[0]
+    assert not torch.equal(full[4:], wrong)   # without the offset the second block would repeat the first block's stream
+
+
+def _run_bench(nproc, extra, env_extra, dump):
+    env = dict(os.environ, **env_extra)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    base = ["--steps", "1", "--warmup", "0", "--timesteps", "20", "--no-cpu-baseline", "--no-train-line", "--no-parity",
+            "--dump-clouds", dump] + extra
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + base
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_and_gpu_count_independence(tmp_path):
+    """the N > 1 path of bench.py (process-group init, weight broadcast, sharded chain with shape_offset,
+    gather of the clouds, max-over-ranks timing) executed on hardware as two ranks sharing the box's GPU (gloo backend, device
+    tensors staged through the host), and the same job (8 shapes) on one rank: identical clouds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    two = _run_bench(2, ["--batch", "4"], {"DFX_BENCH_BACKEND": "gloo"}, str(tmp_path / "two.npy"))
+    assert two["n_gpus"] == 2 and two["config"]["shapes_gathered"] == 8 and np.isfinite(two["value"]) and two["value"] > 0
+    assert two["config"]["weights_bcast_ms"] > 0 and two["scaling"] == "weak"
+    one = _run_bench(1, ["--batch", "8"], {}, str(tmp_path / "one.npy"))
+    assert one["n_gpus"] == 1 and one["config"]["shapes_gathered"] == 8
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert a.shape == b.shape == (8, 2048, 3)
+    assert np.array_equal(a, b)
+
+
+def test_bench_two_ranks_rccl():
+    """The same through RCCL ("nccl"), one rank per GPU: only on boxes with >= 2 GPUs (the driver's scaling node)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        two = _run_bench(2, ["--batch", "4"], {}, os.path.join(d, "two.npy"))
+        one = _run_bench(1, ["--batch", "8"], {}, os.path.join(d, "one.npy"))
+        assert two["n_gpus"] == 2 and np.array_equal(np.load(os.path.join(d, "one.npy")), np.load(os.path.join(d, "two.npy")))

@@ -317,3 +317,45 @@ def test_module_api_training_losses_backward_like_the_reference():
     torch.manual_seed(7)
     l1b = float(d2.training_losses(cu(g["x_start"]), cu(g["t"]), **args)["mse_loss"].detach())
     assert l1 == l1b and l1 != l2 and abs(l1 - float(g["loss"])) > 1e-4 and np.isfinite([l1, l2]).all()
+
+
+def test_inference_engine_follows_the_weights_across_adam_steps():
+    """training.Adam writes parameters through raw pointers (no torch version bump); the packed-weight cache of
+    TransformerNet.engine() must still notice.  train -> validate -> train -> validate: every engine().eps after a step equals
+    a freshly built engine on the current weights and differs from the previous one.  A second backward through one forward
+    (released workspace) raises instead of reading freed memory."""
+    from difffacto_amd import training
+    from difffacto_amd.engine import DenoiserEngine
+    from difffacto_amd.modules import AnchoredDiffusion
+    from test_modules_cpu import DIFF_CFG
+    g, c = load_case("B3_N64_T10")
+    d = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)})
+    d.model.load_state_dict({k: torch.from_numpy(v) for k, v in c["W"].items()})
+    d = d.cuda().train()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ctx = [cu(c["ctx_code"]), cu(c["ctx_mv"])]
+    anchors, variance = cu(c["anchors_pt"].transpose(0, 2, 1)), cu(c["variances_pt"].transpose(0, 2, 1))
+    seg, valid, x = cu(c["assignment"]), cu(c["valid"]), cu(g["x_start"])
+    opt = training.Adam(list(d.model.parameters()), lr=5e-2, max_norm=10.0)
+
+    def validate():
+        with torch.no_grad():
+            return d.model.engine().eps(d.model.shape_context(ctx, valid), x, seg, 3).clone()
+
+    prev = validate()
+    for it in range(3):
+        opt.zero_grad()
+        loss = d.training_losses(x, cu(g["t"]), anchors=anchors, variance=variance, ctx=ctx, anchor_assignment=seg, valid_id=valid,
+                                 flags=cu(c["flags"]), noise=cu(c["noise"]))["mse_loss"]
+        loss.backward()
+        if it == 0:
+            with pytest.raises(RuntimeError, match="ran twice"):
+                loss.backward()
+        opt.step()
+        cur = validate()
+        fresh = DenoiserEngine({k: v.detach() for k, v in d.model.named_parameters()}, 10, precision="f32")
+        ref = fresh.eps(fresh.prepare_shapes(ctx[0], ctx[1][:, :3], ctx[1][:, 3:], valid), x, seg, 3)
+        fresh.close()
+        assert torch.equal(cur, ref), it
+        assert (cur - prev).abs().max().item() > 1e-4, it
+        prev = cur

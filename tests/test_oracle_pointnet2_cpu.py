@@ -169,3 +169,46 @@ def test_oracle_emd_auction_properties():
         assert np.allclose(d[i], ((a[i] - b[i][asg[i]]) ** 2).sum(1), atol=1e-6)
     d1, as1 = opn.emd_forward(a, b, 0.002, 1)   # one iteration = the forced last assignment: everybody gets its best target
     assert (as1 >= 0).all() and np.array_equal(as1[0], cdist(a[0], b[0]).argmin(1))
+
+
+# ---- reference pins added in round 2 (tests/golden/make_golden_pins.py: outputs of the reference's own pure-torch helpers) ----
+FPS_PINS = ["fps_ref_N512_M128.npz", "fps_ref_N2048_M512.npz", "fps_ref_N8192_M2048.npz"]
+BALLQ_PINS = ["pn2_torch_ballquery_nohit.npz", "pn2_torch_ballquery_overflow.npz", "pn2_torch_ballquery_pad.npz"]
+CHAMFER_PINS = ["chamfer_ref_B3_N256.npz", "chamfer_ref_B2_N2048.npz"]
+# distChamfer (evaluation_utils.py:93-103) uses |a|^2 + |b|^2 - 2 a.b in fp32: for unit-box coordinates its rounding error is a
+# few ulp of |a|^2 + |b|^2 <= 6, i.e. ~2e-6 absolute, while chamfer.cu's direct differences are exact to 1 ulp of the result
+CHAMFER_ATOL = 4e-6
+
+
+@pytest.mark.parametrize("name", FPS_PINS)
+def test_fps_oracle_matches_reference_torch_fps(name):
+    """oracle/pointnet2.c FPS == the reference's pure-torch farthest_point_sample started at index 0 (tie-free, origin-free clouds)."""
+    g = np.load(os.path.join(GOLDEN, name))
+    idx = opn.furthest_point_sampling(g["xyz"], int(g["npoint"]))
+    assert np.array_equal(idx, g["idx"])
+
+
+def check_ballquery_pin(idx, g):
+    ref = g["idx"]
+    nohit = (ref < 0).all(-1)
+    assert np.array_equal(idx[~nohit].astype(np.int64), ref[~nohit])
+    assert (idx[nohit] == 0).all()      # SRC/ball_query.cpp:19-21: torch::zeros output, rows without a hit stay 0
+    assert not (ref[~nohit] < 0).any()
+
+
+@pytest.mark.parametrize("name", BALLQ_PINS)
+def test_ball_query_oracle_matches_reference_torch_helper_more_cases(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    check_ballquery_pin(opn.ball_query(float(g["radius"]), int(g["nsample"]), g["xyz"], g["new_xyz"]), g)
+
+
+@pytest.mark.parametrize("name", CHAMFER_PINS)
+def test_chamfer_oracle_matches_reference_distChamfer(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    d1, d2, i1, i2 = opn.chamfer_forward(g["a"], g["b"])
+    np.testing.assert_allclose(d1, g["dist_a"], rtol=0, atol=CHAMFER_ATOL)
+    np.testing.assert_allclose(d2, g["dist_b"], rtol=0, atol=CHAMFER_ATOL)
+    # the arg-min the kernel reports really attains the reference's minimum
+    a, b = g["a"].astype(np.float64), g["b"].astype(np.float64)
+    pick = ((a - np.take_along_axis(b, i1[..., None].astype(np.int64), 1)) ** 2).sum(-1)
+    np.testing.assert_allclose(pick, g["dist_a"], rtol=0, atol=CHAMFER_ATOL)

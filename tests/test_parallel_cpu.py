@@ -36,11 +36,20 @@ def _worker(rank, world, port, q):
         lo, hi = parallel.shard_range(total, rank, world)
         mine = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 5, 3).contiguous()
         got = parallel.gather_clouds(mine, dst=0)
+        # the same with the per-rank counts handed in (what bench.py does: block partition, no size exchange)
+        got2 = parallel.gather_clouds(mine, dst=0, sizes=[b - a for a, b in (parallel.shard_range(total, r, world) for r in range(world))])
         if rank == 0:
             exp = torch.arange(total, dtype=torch.float32).view(-1, 1, 1).expand(-1, 5, 3)
-            ok_g = got is not None and torch.equal(got, exp)
+            ok_g = got is not None and torch.equal(got, exp) and torch.equal(got2, exp)
         else:
-            ok_g = got is None
+            ok_g = got is None and got2 is None
+        # leaf nn.Parameters (requires_grad) are unpacked in place under no_grad (examples/train_denoiser.py's call)
+        lin = torch.nn.Linear(4, 3)
+        with torch.no_grad():
+            for p in lin.parameters():
+                p.fill_(float(rank + 1))
+        parallel.broadcast_params(dict(lin.named_parameters()), src=0)
+        ok_b = ok_b and all(bool((p == 1.0).all()) and p.requires_grad for p in lin.parameters())
         q.put((rank, ok_b, ok_g))
     finally:
         dist.destroy_process_group()
