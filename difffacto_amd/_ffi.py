@@ -144,6 +144,9 @@ def lib():
             raise DfxLibraryError(
                 f"{LIB_PATH} not found: build it with `python -m difffacto_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        # torch ships its own HIP runtime (same SONAME as /opt/rocm's libamdhip64, which libdfx is linked against): load torch's
+        # first so that the process holds ONE runtime — in the other order torch ends up on the system copy and finds no device
+        import torch  # noqa: F401
         try:
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover

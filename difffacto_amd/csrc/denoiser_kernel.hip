@@ -540,8 +540,14 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float 
   }
   tr.stamp(8);
   if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
-    load16(a, b1_next);
-    load16(g, b1_next + 32);
+    // one opaque base register: the eight reads then use immediate offsets (hipcc otherwise rebuilds every address from
+    // the workgroup's LDS base with its own v_add: eight VALU instructions per slot)
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1_next;
+    asm volatile("" : "+v"(addr));
+    const float *src = (const float *)(lds_cf *)(uintptr_t)addr;
+    load16(a, src);
+    load16(g, src + 32);
   }
   if (VALU_PRIO) __builtin_amdgcn_s_setprio(0);
 }

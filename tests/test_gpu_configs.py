@@ -39,18 +39,27 @@ def test_config_sweep(name):
     R = S * K
     xT = torch.from_numpy(rng.standard_normal((R, 3, N)).astype(np.float32))
     sn = torch.from_numpy(rng.standard_normal((T, R, 3, N)).astype(np.float32))
-    # tame the random-init aligner's spread so that the T-step chain stays O(1): use its means, fixed small variances
-    var = torch.full_like(lat["params"][:, 3:], 0.05)
-    out = {}
-    for prec in ("f32", "bf16"):
-        eng = DenoiserEngine(W, num_timesteps=T, precision=prec)
-        ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], var, lat["valid_id"])
-        out[prec], _ = eng.sample_chain(ctx, lat["seg_mask"], x_T_noise=xT, step_noise=sn)
-        if prec == "bf16":
-            a, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=5)
-            b, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=5)
-            c, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=6)
-            assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
-    assert tuple(out["bf16"].shape) == (R, N, 3)
-    err = (out["bf16"] - out["f32"]).abs().max().item()
-    assert err < 3e-2, err
+    # two passes: (i) the latents exactly as the config's sampler produced them (random-init aligner: variances e^logvar span
+    # orders of magnitude, so the cloud is wide and errors are judged relative to its extent), (ii) the same means with fixed
+    # small variances so that the T-step chain stays O(1) and the deviation can be judged in absolute terms
+    for tag, var, rel_tol, abs_tol in (("config latents", lat["params"][:, 3:].contiguous(), 6e-4, None)   # measured 1.7e-4 .. 2.1e-4 of the extent,
+                                       ("var=0.05", torch.full_like(lat["params"][:, 3:], 0.05), None, 1.6e-3)   # measured 3.2e-4 .. 5.4e-4):
+        out = {}
+        for prec in ("f32", "bf16"):
+            eng = DenoiserEngine(W, num_timesteps=T, precision=prec)
+            ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], var, lat["valid_id"])
+            out[prec], _ = eng.sample_chain(ctx, lat["seg_mask"], x_T_noise=xT, step_noise=sn)
+            if prec == "bf16":
+                a, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=5)
+                b, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=5)
+                c, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=6)
+                assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+            eng.close()
+        assert tuple(out["bf16"].shape) == (R, N, 3) and torch.isfinite(out["f32"]).all()
+        err = (out["bf16"] - out["f32"]).abs().max().item()
+        extent = float((out["f32"].amax((1, 2)) - out["f32"].amin((1, 2))).mean())
+        print(f"{name} [{tag}] T={T} N={N}: bf16 vs f32 max-abs {err:.3e}, cloud extent {extent:.3e}, relative {err / extent:.3e}")
+        if abs_tol is not None:
+            assert err < abs_tol, err
+        else:
+            assert err < rel_tol * extent, (err, extent)

@@ -18,8 +18,13 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 # BASELINE.md config 1 gate for the HIP fp32 path is 1e-3; measured error is ~1e-5.
 TOL_F32_EPS = 1e-4
 TOL_F32_CHAIN = 1e-3
-# bf16 operands / fp32 accumulate: |eps| ~ 1, measured max-abs ~2e-2 for one evaluation
-TOL_BF16_EPS = 6e-2
+# bf16 operands / fp32 accumulate, packed-fp16 polynomial GELU: |eps| <= 1.9, measured max-abs 2.3e-3 for one evaluation
+# (N = 2048 golden; rms 6.6e-4) -> gate at <= 3x measured
+TOL_BF16_EPS = 6e-3
+# T = 100 chain, bf16 vs exact fp32 on identical noise: measured max-abs 1.17e-3 (part sigma 0.22) -> gate at 3x
+TOL_BF16_CHAIN_T100 = 3.5e-3
+# the pipelined and the direct bf16 kernels share the bf16 operands and differ in the GELU / LayerNorm formulation
+TOL_PIPE_VS_DIRECT = 4e-3   # measured 1.3e-3 (one evaluation), 9e-5 (T = 3 chain)
 
 
 @pytest.fixture(scope="module")
@@ -235,7 +240,7 @@ def test_chain_bf16_vs_f32_reported(W):
     d = (pf - pb).abs()
     scale = float(np.sqrt(var).mean())
     print(f"bf16 vs f32 chain T=100: max-abs {d.max().item():.3e}, mean-abs {d.mean().item():.3e}, part sigma ~{scale:.3f}")
-    assert d.max().item() < 0.25 * scale + 1e-2
+    assert d.max().item() < TOL_BF16_CHAIN_T100
 
 
 def test_philox_chain_deterministic_and_statistical(W):
@@ -363,7 +368,8 @@ def test_training_losses_forward_vs_reference_golden(W, prec, tol):
     b = e.eps_t(cx, x, sg, tt)
     _ffi.lib().dfx_debug_force_direct(0)
     one = torch.stack([e.eps(cx, x, sg, int(t))[i] for i, t in enumerate(tt)])
-    assert (a - b).abs().max().item() < 2e-2 and (a - one).abs().max().item() == 0.0   # `one` also takes the pipelined kernel
+    print(f"pipelined vs direct bf16 kernel, one evaluation: max-abs {(a - b).abs().max().item():.3e}")
+    assert (a - b).abs().max().item() < TOL_PIPE_VS_DIRECT and (a - one).abs().max().item() == 0.0   # `one` also takes the pipelined kernel
 
 
 def test_pipelined_kernel_any_batch_size_matches_direct(W):
@@ -384,4 +390,5 @@ def test_pipelined_kernel_any_batch_size_matches_direct(W):
         b, _ = e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn)
         _ffi.lib().dfx_debug_force_direct(0)
         per_shape = (a - b).abs().amax(dim=(1, 2))
-        assert per_shape.max().item() < 2e-2, per_shape   # same bf16 operands, different (fast) GELU / LayerNorm formulation
+        print(f"pipelined vs direct bf16 chain T={T} B={B}: max-abs per shape {per_shape.max().item():.3e}")
+        assert per_shape.max().item() < TOL_PIPE_VS_DIRECT, per_shape   # same bf16 operands, different (fast) GELU / LayerNorm formulation

@@ -22,11 +22,15 @@ from difffacto_amd import synth  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# measured on MI355X (profiles/r02_parity_headline.txt), gates at <= 3x the measured value
-HEADLINE_BF16_VS_F32_REL = 3e-3     # max-abs / cloud extent, bf16 pipe vs exact-fp32 chain, T = 1000
-HEADLINE_F32_VS_ORACLE_REL = 3e-5   # exact-fp32 HIP chain vs numpy oracle on a 256-point subset, T = 1000
-HEADLINE_CD_REL = 1e-5              # Chamfer-L2(bf16, fp32) / extent^2
-HEADLINE_EMD = 3e-4                 # auction EMD(bf16, fp32) on the unit-box-normalised clouds
+# measured on MI355X (profiles/r02_parity_headline.txt); every gate is <= 3x the measured value:
+#   bf16_f32   max-abs / cloud extent, bf16 pipelined kernel vs exact-fp32 chain            (measured 1.2e-5 | see below)
+#   f32_oracle exact-fp32 HIP chain vs the PyTorch-CPU oracle on a 256-point subset / extent (measured 4.8e-7)
+#   cd         Chamfer-L2(bf16, fp32) / extent^2                                             (measured 6.0e-11)
+#   emd        auction EMD(bf16, fp32) on the unit-box-normalised clouds                     (measured 5.0e-6)
+GATES = {"contractive": dict(bf16_f32=3.6e-5, f32_oracle=1.5e-6, cd=1.8e-10, emd=1.5e-5),
+         # the random-init set is chaotic over 1000 steps (no oracle leg: fp32 rounding differences between two fp32
+         # implementations grow the same way); it is kept as the worst case for the bf16 deviation
+         "random-init": dict(bf16_f32=9e-4, f32_oracle=None, cd=6.5e-8, emd=2.8e-4)}   # measured 3.1e-4, 2.2e-8, 9.3e-5
 
 
 def contractive_weights():
@@ -43,12 +47,14 @@ def _engine(W, T, prec):
     return DenoiserEngine({k: torch.from_numpy(v) for k, v in W.items()}, num_timesteps=T, precision=prec)
 
 
-def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle():
+@pytest.mark.parametrize("wset", ["contractive", "random-init"])
+def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle(wset):
     from difffacto_amd.metrics import EMD, chamfer_l2
     from oracle import diffusion as odf
     from oracle import torch_cpu as tc
     T, B, N = 1000, 8, 2048
-    W = contractive_weights()
+    W = contractive_weights() if wset == "contractive" else synth.make_denoiser_weights(seed=0)
+    gate = GATES[wset]
     pc, mean, logvar, valid = synth.make_latents(B, seed=5)
     var = np.exp(logvar).astype(np.float32)
     seg = synth.make_seg_mask(valid, N)
@@ -69,6 +75,11 @@ def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle():
     hi = torch.maximum(out["bf16"].amax((1, 2), keepdim=True), out["f32"].amax((1, 2), keepdim=True))
     emd = float(EMD(0.002, 10000, True)(((out["bf16"] - lo) / (hi - lo)).contiguous(), ((out["f32"] - lo) / (hi - lo)).contiguous()).mean())
 
+    print(f"headline[{wset}] T={T} B={B} N={N}: extent {extent:.2f}; bf16 vs f32 max-abs/extent {rel:.3e}, Chamfer-L2/extent^2 {cd:.3e}, "
+          f"EMD(unit box) {emd:.3e}")
+    assert rel < gate["bf16_f32"] and cd < gate["cd"] and emd < gate["emd"]
+    if gate["f32_oracle"] is None:
+        return
     # the oracle on a subset: points are independent given the shape's 4 part tokens, so 256 points of shape 0 with their
     # own noise columns reproduce those points of the full run (PyTorch-CPU restatement, pinned to the reference goldens)
     sub = np.arange(0, N, N // 256)
@@ -85,13 +96,9 @@ def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle():
     ref = x.transpose(1, 2)[0]
     rel_or = float((out["f32"][0, sub].cpu() - ref).abs().max()) / extent
     rel_or_bf16 = float((out["bf16"][0, sub].cpu() - ref).abs().max()) / extent
-    print(f"headline T={T} B={B} N={N}: extent {extent:.2f}; bf16 vs f32 max-abs/extent {rel:.3e}, Chamfer-L2/extent^2 {cd:.3e}, "
-          f"EMD(unit box) {emd:.3e}; f32 vs oracle (256 pts) {rel_or:.3e}; bf16 vs oracle {rel_or_bf16:.3e}")
-    assert rel < HEADLINE_BF16_VS_F32_REL
-    assert rel_or < HEADLINE_F32_VS_ORACLE_REL
-    assert rel_or_bf16 < HEADLINE_BF16_VS_F32_REL
-    assert cd < HEADLINE_CD_REL
-    assert emd < HEADLINE_EMD
+    print(f"headline[{wset}]: f32 vs oracle (256 pts) / extent {rel_or:.3e}; bf16 vs oracle {rel_or_bf16:.3e}")
+    assert rel_or < gate["f32_oracle"]
+    assert rel_or_bf16 < gate["bf16_f32"]
 
 
 @pytest.mark.parametrize("prec,N", [("bf16", 2048), ("f32", 256)])

@@ -2,14 +2,16 @@
 # Collect rocprofv3 PMC counters for the chain kernel (separate passes; --pmc never combined with tracing).
 # usage: tools/prof_pmc.sh <outdir> [bench args...]
 set -u
-OUT=$1; shift
+REPO=$PWD
+OUT=$(realpath -m $1); shift
 mkdir -p $OUT
+cd /tmp   # rocprofv3 wants a writable cwd / TMPDIR
 export TMPDIR=/tmp
 run() { # name, counters
   local name=$1; shift
-  rocprofv3 --pmc "$@" -d $OUT/$name --output-format csv -- python bench.py --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" -d $OUT/$name --output-format csv -- python $REPO/bench.py --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python tools/pmc_summary.py "$f" k_denoise > $OUT/$name.summary.txt 2>&1
+  [ -n "$f" ] && python $REPO/tools/pmc_summary.py "$f" k_denoise > $OUT/$name.summary.txt 2>&1
   cat $OUT/$name.summary.txt
 }
 BENCH_ARGS="$*"
