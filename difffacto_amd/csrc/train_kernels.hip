@@ -16,6 +16,7 @@
 //                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
 #include "dfx_common.h"
 #include "gemm_bf16.h"
+#include "train_ff_fused.h"
 #include "mfma_linear.h"
 
 namespace {
@@ -923,6 +924,9 @@ struct TrainWs {
   float *dh, *dh2, *dwide, *dhid, *dq, *datt, *dk, *dv, *dctx, *dte_out, *dte_hid, *dte_ag, *wT, *wpad, *part, *bpart, *apart;
   float *valid;
   size_t part_floats, bpart_floats;
+  // fused feed-forward (train_ff_fused.h): the block's W1 / W2 as bf16 MFMA fragments, re-packed by every forward
+  uint4 *ff_frags[DFX_MAX_DEPTH];
+  float *ff_b1p[DFX_MAX_DEPTH], *ff_b2p[DFX_MAX_DEPTH];
 };
 
 constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab (64 for the few-row products over the context tokens / the batch)
@@ -990,8 +994,18 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.bpart_floats = (ns_max > 2048 ? ns_max : 2048) * (size_t)(2 * TEH);   // room for 2048 slabs of the widest bias
   w.bpart = c.take<float>(w.bpart_floats);
   w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
+  for (int i = 0; i < depth; ++i) {
+    w.ff_frags[i] = c.take<uint4>(dfx::ffused::pack_bytes_frags() / sizeof(uint4));
+    w.ff_b1p[i] = c.take<float>(dfx::ffused::B1P_FLOATS);
+    w.ff_b2p[i] = c.take<float>(dfx::ffused::B2P_FLOATS);
+  }
   return c.off;
 }
+
+// Fused feed-forward kernels (train_ff_fused.h) for bf16 products without dropout; dfx_debug_train_fused(0) restores the
+// layer-by-layer path (A/B timing, and the reference for the fused path's own test).
+bool g_ff_fused = true;
+inline bool ff_fused(bool bf, float dropout_p, long long R) { return g_ff_fused && bf && dropout_p == 0.f && R % 32 == 0; }
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
 thread_local int g_prec = DFX_PREC_F32;
@@ -1338,6 +1352,14 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     } else if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
     if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
     else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
+    if (ff_fused(bf, dropout_p, R)) {   // [a | g] and hid stay in registers: h_out = h1 + W2 (a gelu(g)) + b2
+      dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
+      dfx::ffused::FfArgs fa{};
+      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i];
+      fa.xn3 = reinterpret_cast<const __bf16 *>(a.xn3), fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
+      if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
+      continue;
+    }
     if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf, bf && AG_BF16))) return rc;
     const Drop dff{dropout_p, dropout_seed, (unsigned)(2 * i + 1)};
     if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH, dff);
@@ -1377,6 +1399,17 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
     BlockAct &a = w.blk[i];
     // feed-forward: h2 = h1 + W2 hid + b2, hid = a gelu(g), [a | g] = W1 xn3 + b1
+    if (ff_fused(bf, dropout_p, R)) {
+      // one pass over the points: [a | g] recomputed from xn3, d hid = W2^T dh, GEGLU backward, dxn3 = W1^T d[a | g]; hid and
+      // d[a | g] leave the kernel once, as bf16, for the two weight-gradient products
+      dfx::ffused::FfArgs fa{};
+      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i];
+      fa.xn3 = reinterpret_cast<const __bf16 *>(a.xn3), fa.dh = w.dh, fa.hid = reinterpret_cast<__bf16 *>(a.hid);
+      fa.dag = reinterpret_cast<__bf16 *>(w.dwide), fa.dxn = w.dh2, fa.R = R;
+      if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
+      if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, true))) return rc;
+      if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, true, true))) return rc;
+    } else {
     if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
     if ((rc = lin(st, w.dh, C, w.wT, nullptr, w.dhid, FH, R, FH, C))) return rc;
@@ -1386,6 +1419,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, bf, bf))) return rc;
     transpose(st, bw.ff0_w, w.wT, 2 * FH, C);                                // (128, 1024)
     if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH, nullptr, 0, bf))) return rc;
+    }
     if ((rc = ln_bwd(st, w, w.dh2, a.h1, a.st3, bw.norm3_w, w.dh, w.dh, mut(gw.norm3_w), mut(gw.norm3_b), R))) return rc;
     // attention: h1 = hin + Wo att + bo
     const float *dho = w.dh;   // gradient at the output of to_out: dh behind the dropout
@@ -1630,6 +1664,8 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
+void dfx_debug_train_fused(int on) { g_ff_fused = on != 0; }
+
 int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream) {
   DFX_REQUIRE(out && n >= 4 && n % 4 == 0 && p > 0.f && p < 1.f, "debug_dropout_factors: bad argument");
   k_dropout_factors<<<(int)((n / 4 + 255) / 256), 256, 0, dfx::as_stream(stream)>>>(out, n, Drop{p, seed, (unsigned)site});

@@ -154,6 +154,46 @@ def test_bf16_matrix_products_within_stated_tolerance():
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
 
 
+@pytest.mark.parametrize("B,N", [(2, 1024), (3, 160), (1, 4096)])
+def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
+    """train_ff_fused.h (one kernel per direction for the GEGLU feed-forward: [a | g] and hid stay in registers, recomputed in
+    the backward) against the layer-by-layer bf16 kernels it replaces: same bf16 operands; differences = fp32 summation order,
+    the fast sigmoid-form GELU (2.7e-4) instead of erf, and [a | g] no longer rounded to bf16 between forward and backward.
+    Both must sit inside the stated bf16 tolerance against the fp32 oracle; here they are compared with each other.
+    N = 160: a workgroup's trailing wavefronts fall off the end of the rows (ragged last tile)."""
+    from difffacto_amd import _ffi, synth
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + N))
+    W = synth.make_denoiser_weights(5)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=11, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    fused = _run(c, True, precision="bf16")
+    _ffi.lib().dfx_debug_train_fused(0)
+    try:
+        layer = _run(c, True, precision="bf16")
+    finally:
+        _ffi.lib().dfx_debug_train_fused(1)
+    assert any(not np.array_equal(fused["grads"][k], layer["grads"][k]) for k in layer["grads"]), "fused path not taken"
+    e_eps = np.abs(fused["eps"] - layer["eps"]).max()
+    worst_max = worst_l2 = 0.0
+    for k, gr in layer["grads"].items():
+        scale = max(np.abs(gr).max(), 1e-30)
+        e_max = np.abs(fused["grads"][k] - gr).max() / scale
+        e_l2 = np.linalg.norm((fused["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
+        worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
+        assert e_max < 2e-2 and e_l2 < 1e-2, (k, e_max, e_l2)
+    print(f"fused vs layer-by-layer FF (B={B}, N={N}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
+          f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
+    assert abs(fused["loss"] - layer["loss"]) < 1e-3 * abs(layer["loss"]) and e_eps < 5e-3
+
+
 def test_dropout_factors_and_replayed_mask_parity():
     """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
     seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the

@@ -54,3 +54,15 @@ peak = 157.3 if PREC == "f32" else 2500.0
 print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
       f"{flops / ms / 1e9:.1f} TFLOP/s of the {peak} TFLOP/s {PREC} matrix peak ({flops / ms / 1e9 / peak * 100:.1f} %), loss {float(loss.detach()):.4f}, "
       f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak, optimiser in {'one launch' if opt.last_step_was_flat else 'one launch per tensor'}")
+if PREC == "bf16" and "--ab" in sys.argv:   # the same loop through the layer-by-layer feed-forward kernels
+    from difffacto_amd import _ffi
+    _ffi.lib().dfx_debug_train_fused(0)
+    for _ in range(2):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = it()
+    torch.cuda.synchronize()
+    print(f"layer-by-layer feed-forward (dfx_debug_train_fused(0)): {(time.perf_counter() - t0) / K * 1e3:.1f} ms, loss {float(loss.detach()):.4f}")
+    _ffi.lib().dfx_debug_train_fused(1)
