@@ -128,6 +128,7 @@ SIGNATURES = {
     "dfx_p_sample_ddim": (_I, [_P, _P, _P, _P, _I, _F, _P, _U64, _U64, _P, _P, _I, _I, _P]),
     "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
+    "dfx_debug_pipe_waves": (None, [_I]),
     "dfx_debug_flags": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),
     "dfx_set_event_timing": (None, [_I]),

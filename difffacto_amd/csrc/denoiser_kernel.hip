@@ -443,13 +443,14 @@ struct Tracer {
 #endif
 };
 
-// Fragment indices (uint4 units relative to this lane's record pointer).  FF record: W2 tile ct = i/2, unit q = i&1;
+// Fragment indices (uint4 units relative to this lane's record pointer).  FF record: W2 tile ct = i&3, unit q = i>>2 (a tile's
+// two MFMAs are four MFMAs apart: a dependent accumulate right behind its predecessor waits for it when the wave is alone on its SIMD);
 // W1 unit order (c, q, part) -> tile part*4 + c, unit q (half 0: c = 0,1; half 1: c = 2,3).  Attention record: A_s tiles
 // 0..3, M_s tiles 4..7.
-__device__ __forceinline__ constexpr int w2_frag(int i) { return (8 + (i >> 1)) * 128 + (i & 1) * 64; }
+__device__ __forceinline__ constexpr int w2_frag(int i) { return (8 + (i & 3)) * 128 + (i >> 2) * 64; }   // tile i & 3, unit i >> 2: four accumulators in rotation
 __device__ __forceinline__ constexpr int w1_frag(int i, int half) { return ((i & 1) * 4 + 2 * half + (i >> 2)) * 128 + ((i >> 1) & 1) * 64; }
 __device__ __forceinline__ constexpr int as_frag(int i) { return (i >> 1) * 128 + (i & 1) * 64; }
-__device__ __forceinline__ constexpr int ms_frag(int i) { return (4 + (i >> 1)) * 128 + (i & 1) * 64; }
+__device__ __forceinline__ constexpr int ms_frag(int i) { return (4 + (i & 3)) * 128 + (i >> 2) * 64; }
 
 // Tail prefetch: every M slot finds the A fragments of its first eight MFMAs in registers (P): they are read at the
 // TAIL of the previous M slot of the same wavefront — after its last MFMA has been issued, while the matrix pipe drains
@@ -476,7 +477,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
   if (S3 && S1) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {   // GEMM2 of the previous chunk on the prefetched W2 fragments; fetch W1 (first half)
-      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+      h[i & 3] = mma_hid(P[i], hid.f[i >> 2], h[i & 3]);
       issue.at(i, 24);
       A1[i] = ck[w1_frag(i, 0)];
     }
@@ -508,7 +509,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
   } else {                          // last FF record of a block: GEMM2 only; tail prefetch = A_s of the next block
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      h[i >> 1] = mma_hid(P[i], hid.f[i & 1], h[i >> 1]);
+      h[i & 3] = mma_hid(P[i], hid.f[i >> 2], h[i & 3]);
       issue.at(i, 8);
       P[i] = ck_next[as_frag(i)];
     }
@@ -581,7 +582,7 @@ __device__ __forceinline__ void attn_m1(v16f (&h)[4], const Act<DFX_PREC_BF16> &
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    h[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i & 1], h[i >> 1], 0, 0, 0);
+    h[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa.f[i >> 2], h[i & 3], 0, 0, 0);
     P[i] = ck_next[w1_frag(i, 0)];
   }
 #pragma unroll
@@ -820,13 +821,14 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
 //   RAW: the issuing waves' vmcnt + the barrier precede every read of r and every tail-prefetch read of r+1.
 //   WAR: slot (r+3)%5 held record r-2, whose last reader (B; for an attention record B's V2, which ends before the
 //        management barrier of r) finished at least one barrier earlier.
+// Wavefronts per workgroup: 8 (256 points) when that fills the chip; 4 or 2 for small batches, so that a single shape still
+// spreads over 16 / 32 CUs (same per-wave instruction stream, bit-identical results; the ring then takes 6 / 12 pieces per wave).
 constexpr int PIPE_NW = 8;
 constexpr int SLOT_BYTES = 24 * 1024;
 constexpr int NSLOT = 5;   // records in flight ahead of the compute: NSLOT - 2
 
-// Ring DMA: 24 pieces of 1 KiB per record, three per wavefront.
-constexpr int CALLS_A = 3, CALLS_B = 3, CALLS_MAX = 3;
-static_assert(4 * CALLS_A + 4 * CALLS_B == SLOT_BYTES / 1024, "24 pieces per record");
+// Ring DMA: 24 pieces of 1 KiB per record, 24 / NW per wavefront.
+constexpr int RING_PIECES = SLOT_BYTES / 1024;
 constexpr int RECORDS_PER_BLOCK = 1 + FF_STAGES;
 // LDS map (bytes)
 constexpr int L_RING = 0;
@@ -835,11 +837,17 @@ constexpr int L_WINX = L_BCONST + 2 * BCONST_BYTES;    // float4[128]
 constexpr int L_PREGB = L_WINX + 2048;                 // float2[128]
 constexpr int L_WOUT = L_PREGB + 1024;                 // float4[128]
 constexpr int L_CPART = L_WOUT + 2048;                 // float[4][128]
-constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs
-constexpr int L_PSTATE = L_DUMMY + CALLS_MAX * 1024;               // per-point chain state parked between steps: float[13][256]
+constexpr int L_DUMMY = L_CPART + 2048;                // sink for padding DMAs (one wave's pieces)
 constexpr int PSTATE_FIELDS = 13;                      // x[3] anc[3] var[3] L[3] seg
-constexpr int L_TOTAL = L_PSTATE + PSTATE_FIELDS * 256 * 4;
-static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+template <int NW>
+struct PipeCfg {
+  static_assert(NW == 8 || NW == 4 || NW == 2, "wavefronts per workgroup");
+  static constexpr int CALLS = RING_PIECES / NW;                       // ring pieces per wave and record
+  static constexpr int PTS = NW * 32;                                  // points per workgroup
+  static constexpr int L_PSTATE = L_DUMMY + CALLS * 1024;              // per-point chain state parked between steps: float[13][PTS]
+  static constexpr int L_TOTAL = L_PSTATE + PSTATE_FIELDS * PTS * 4;
+  static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+};
 static_assert(asms_bytes(DFX_PREC_BF16) + 1024 <= SLOT_BYTES && chunk_bytes(DFX_PREC_BF16) == SLOT_BYTES, "slot layout");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char pipe_smem[];
@@ -849,6 +857,16 @@ __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr)
                : "memory");  // m0 is reserved: hipcc re-materialises it before each of its own uses
 }
+__device__ __forceinline__ const char *pin_ptr(const char *q) {   // wave-uniform pointer -> scalar registers
+  const unsigned long long g = (unsigned long long)(uintptr_t)q;
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(g >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)g);
+  return (const char *)(uintptr_t)(((unsigned long long)hi << 32) | lo);   // (the builtin returns int: no sign extension of `lo`)
+}
+// the same with the (wave-uniform by construction) operands pinned to scalar registers: behind a chain of uniform selects hipcc
+// may hold them in VGPRs, which the "s" constraints reject
+__device__ __forceinline__ void dma1k_pinned(const void *gbase, unsigned voff, unsigned lds_addr) {
+  dma1k(pin_ptr(reinterpret_cast<const char *>(gbase)), voff, (unsigned)__builtin_amdgcn_readfirstlane(lds_addr));
+}
 
 // N consecutive 1 KiB pieces: the instruction's immediate offset applies to BOTH the global and the LDS address
 // (checked on gfx950: tools/ubench/dma_offset.hip), so one M0 / one SGPR base serve all of them
@@ -856,14 +874,17 @@ __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned
 #define DFX_DMA_MORE(off) "\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #off
 #define DFX_DMA_ASM(str) asm volatile(str ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory")
 template <int N>
-__device__ __forceinline__ void dma_nk(const void *gbase, unsigned voff, unsigned lds_addr) {   // ONE asm block: M0 stays ours
-  static_assert(N >= 0 && N <= 6, "pieces per wave");
-  if (N == 1) DFX_DMA_ASM(DFX_DMA_HEAD);
-  if (N == 2) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024));
-  if (N == 3) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048));
-  if (N == 4) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072));
-  if (N == 5) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072) DFX_DMA_MORE(4096));
-  if (N == 6) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072) DFX_DMA_MORE(4096) DFX_DMA_MORE(5120));
+__device__ __forceinline__ void dma_nk(const void *gbase, unsigned voff, unsigned lds_addr) {   // ONE asm block per four pieces: M0 stays ours
+  static_assert(N >= 0 && N <= 12, "pieces per wave");
+  if constexpr (N > 4) {   // the immediate offset has 12 bits
+    dma_nk<4>(gbase, voff, lds_addr);
+    dma_nk<N - 4>(reinterpret_cast<const char *>(gbase) + 4096, voff, lds_addr + 4096);
+  } else {
+    if (N == 1) DFX_DMA_ASM(DFX_DMA_HEAD);
+    if (N == 2) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024));
+    if (N == 3) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048));
+    if (N == 4) DFX_DMA_ASM(DFX_DMA_HEAD DFX_DMA_MORE(1024) DFX_DMA_MORE(2048) DFX_DMA_MORE(3072));
+  }
 }
 
 template <int N>
@@ -913,7 +934,7 @@ __device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int
         src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step, s) * CT_ROW);
         dst = ring + 17 * 1024;
       }
-      dma1k(src, voff, dst);
+      dma1k_pinned(src, voff, dst);
     }
     st.ff_src = reinterpret_cast<const char *>(bp.chunks) + q0 * 1024;
   }
@@ -921,12 +942,13 @@ __device__ __forceinline__ void issue_pieces(const KParams &p, DmaState &st, int
 
 // The same bookkeeping, but only the (wave-uniform) source / destination of this wave's pieces: the loads themselves are
 // issued one at a time from inside the wave's next M slot (Issuer).
+template <int NC>
 struct Pieces {
-  const char *src[CALLS_MAX];
-  unsigned dst[CALLS_MAX];
+  const char *src[NC];
+  unsigned dst[NC];
 };
 template <int NC>
-__device__ __forceinline__ void prepare_pieces(const KParams &p, DmaState &st, int q0, unsigned lds0, int s, Pieces &pc) {
+__device__ __forceinline__ void prepare_pieces(const KParams &p, DmaState &st, int q0, unsigned lds0, int s, Pieces<NC> &pc) {
   const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
   if (st.step >= p.nsteps) {
 #pragma unroll
@@ -952,7 +974,8 @@ __device__ __forceinline__ void prepare_pieces(const KParams &p, DmaState &st, i
         src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step, s) * CT_ROW);
         dst = ring + 17 * 1024;
       }
-      pc.src[j] = src, pc.dst[j] = dst;
+      // (the 64-bit address arithmetic above may run on the VALU: back to scalar registers for the "s" operands of the DMA)
+      pc.src[j] = pin_ptr(src), pc.dst[j] = (unsigned)__builtin_amdgcn_readfirstlane(dst);
     }
     st.ff_src = reinterpret_cast<const char *>(bp.chunks) + q0 * 1024;
   }
@@ -970,9 +993,9 @@ __device__ __forceinline__ void advance_record(const KParams &p, DmaState &st) {
   }
 }
 
+template <int NW>
 __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int wave, unsigned voff, unsigned lds0, int s) {
-  if (wave < PIPE_NW / 2) issue_pieces<CALLS_A>(p, st, wave * CALLS_A, voff, lds0, s);
-  else issue_pieces<CALLS_B>(p, st, 4 * CALLS_A + (wave - PIPE_NW / 2) * CALLS_B, voff, lds0, s);
+  issue_pieces<PipeCfg<NW>::CALLS>(p, st, wave * PipeCfg<NW>::CALLS, voff, lds0, s);
   advance_record(p, st);
 }
 
@@ -980,58 +1003,74 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
 // groups' M slots are in anti-phase, so at most four waves issue at a time, one KiB per ~250 cycles).  Issued all at once
 // behind the record's management barrier, the eight waves' 24 KiB hit the texture-address path (64 B/clk) together and
 // every wave sits ~400 cycles in the issue stall on the critical path of the record (slot trace, tools/run_trace.sh).
+template <int NW>
 struct Issuer {
+  static constexpr int CALLS = PipeCfg<NW>::CALLS;
+  // 8-wave workgroups fill the chip: their pieces are spread over the M slot (comment above).  The 4- and 2-wave workgroups of
+  // small batches (<= 32 workgroups in flight, no contention on the texture-address path) issue theirs at once behind the
+  // record's management barrier: 6 / 12 (source, destination) pairs would not fit the scalar registers of the M slot.
+  static constexpr bool SPREAD = NW == 8;
   const KParams &p;
   DmaState &st;
   int wave;
   unsigned voff, lds0;
   int s;
-  Pieces pc;
+  Pieces<SPREAD ? CALLS : 1> pc;
   // (scalar) source / destination bookkeeping of the pieces of the next M slot; runs in the V slot before it
   __device__ __forceinline__ void m_begin() {
-    prepare_pieces<CALLS_A>(p, st, wave * CALLS_A, lds0, s, pc);
-    advance_record(p, st);
+    if constexpr (SPREAD) {
+      prepare_pieces<CALLS>(p, st, wave * CALLS, lds0, s, pc);
+      advance_record(p, st);
+    }
+  }
+  // right behind a record's management barrier
+  __device__ __forceinline__ void after_barrier() {
+    if constexpr (!SPREAD) issue_record<NW>(p, st, wave, voff, lds0, s);
   }
   // after MFMA i of the n of an M slot
   __device__ __forceinline__ void at(int i, int n) {
+    if constexpr (SPREAD) {
 #pragma unroll
-    for (int k = 0; k < CALLS_A; ++k)
-      if (i == (k * n) / CALLS_A) dma1k(pc.src[k], voff, pc.dst[k]);
+      for (int k = 0; k < CALLS; ++k)
+        if (i == (k * n) / CALLS) dma1k(pc.src[k], voff, pc.dst[k]);
+    }
   }
 };
 
 // The per-point state (x_t, anchor, variance, sqrt(variance), part id) is touched once per diffusion step; parked in LDS
 // in between (13 KiB per workgroup) it costs no VGPRs during the 90 record slots of a step — hipcc would otherwise keep
 // it in scratch memory (80 B per lane: ~8 MB of write-back traffic per step and launch).
-__device__ __forceinline__ void pstate_store(float *ps_lds, int pt, const PointState &ps, bool all) {
+__device__ __forceinline__ void pstate_store(float *ps_lds, int pt, int PTS, const PointState &ps, bool all) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) ps_lds[i * 256 + pt] = ps.x[i];
+  for (int i = 0; i < 3; ++i) ps_lds[i * PTS + pt] = ps.x[i];
   if (all) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      ps_lds[(3 + i) * 256 + pt] = ps.anc[i];
-      ps_lds[(6 + i) * 256 + pt] = ps.var[i];
-      ps_lds[(9 + i) * 256 + pt] = ps.L[i];
+      ps_lds[(3 + i) * PTS + pt] = ps.anc[i];
+      ps_lds[(6 + i) * PTS + pt] = ps.var[i];
+      ps_lds[(9 + i) * PTS + pt] = ps.L[i];
     }
-    ps_lds[12 * 256 + pt] = __int_as_float(ps.sg);
+    ps_lds[12 * PTS + pt] = __int_as_float(ps.sg);
   }
 }
-__device__ __forceinline__ void pstate_load(const float *ps_lds, int pt, PointState &ps, bool all) {
+__device__ __forceinline__ void pstate_load(const float *ps_lds, int pt, int PTS, PointState &ps, bool all) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) ps.x[i] = ps_lds[i * 256 + pt];
+  for (int i = 0; i < 3; ++i) ps.x[i] = ps_lds[i * PTS + pt];
   if (all) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      ps.anc[i] = ps_lds[(3 + i) * 256 + pt];
-      ps.var[i] = ps_lds[(6 + i) * 256 + pt];
-      ps.L[i] = ps_lds[(9 + i) * 256 + pt];
+      ps.anc[i] = ps_lds[(3 + i) * PTS + pt];
+      ps.var[i] = ps_lds[(6 + i) * PTS + pt];
+      ps.L[i] = ps_lds[(9 + i) * PTS + pt];
     }
   }
-  ps.sg = __float_as_int(ps_lds[12 * 256 + pt]);
+  ps.sg = __float_as_int(ps_lds[12 * PTS + pt]);
 }
 
-__global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams p) {
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
   constexpr int PREC = DFX_PREC_BF16;
+  constexpr int PIPE_NW = NW, PTS = PipeCfg<NW>::PTS;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
@@ -1065,9 +1104,9 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
 
   // ---- prologue DMA: records 0, 1, 2 in flight while the per-point state is set up ----
   DmaState dma{0, 0, 0, 0, 0, nullptr};
-  issue_record(p, dma, wave, voff, lds0, s);
-  issue_record(p, dma, wave, voff, lds0, s);
-  issue_record(p, dma, wave, voff, lds0, s);
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
 
   // ---- chain-invariant small operands -> LDS (plain loads; not part of the ring) ----
   {
@@ -1081,16 +1120,16 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       pregb[tid] = p.d.pre_gb[tid];
       wout[tid] = p.d.wout[tid];
     }
-    cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+    for (int i = tid; i < NCLS * INNER; i += NW * 64) cp[i] = p.cpart[(size_t)s * NCLS * INNER + i];
   }
   unsigned vmask;
-  float *ps_lds = reinterpret_cast<float *>(pipe_smem + L_PSTATE);
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + PipeCfg<NW>::L_PSTATE);
   const int pt = wave * 32 + pj;   // point slot inside the workgroup (both half-waves hold the same point)
   {
     PointState ps0;
     ps0.live = live;
     point_init(p, ps0, s, n, gid, vmask);
-    pstate_store(ps_lds, pt, ps0, true);   // both half-waves hold the same point: identical values
+    pstate_store(ps_lds, pt, PTS, ps0, true);   // both half-waves hold the same point: identical values
   }
   __syncthreads();
 
@@ -1098,16 +1137,17 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-  Issuer issue_in_m{p, dma, wave, voff, lds0, s, {}};
+  Issuer<NW> issue_in_m{p, dma, wave, voff, lds0, s, {}};
   // slot boundary; `mgmt` = this barrier is a record's management barrier for this wave's group
 #define DFX_SLOT(mgmt)                   \
   do {                                   \
     __builtin_amdgcn_sched_barrier(0);   \
     if (mgmt) {                          \
       tr.stamp(1);                       \
-      wait_vmcnt<CALLS_A>();             \
+      wait_vmcnt<PipeCfg<NW>::CALLS>();  \
       __builtin_amdgcn_s_barrier();      \
       tr.stamp(2);                       \
+      issue_in_m.after_barrier();        \
     } else {                             \
       tr.stamp(3);                       \
     }                                    \
@@ -1149,12 +1189,12 @@ __global__ void __launch_bounds__(PIPE_NW * 64, 2) k_denoise_pipe(const KParams 
       if (b == 0) {
         PointState ps;
         ps.s = s, ps.n = n, ps.gid = gid, ps.live = live;
-        pstate_load(ps_lds, pt, ps, step > 0);
+        pstate_load(ps_lds, pt, PTS, ps, step > 0);
         if (step > 0) {
           float eps[3];
           post_eps<true>(h, wout, p.d.bout, eps);
           done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1, s));
-          if (!done) pstate_store(ps_lds, pt, ps, false);   // both half-waves hold the same point and write the same x
+          if (!done) pstate_store(ps_lds, pt, PTS, ps, false);   // both half-waves hold the same point and write the same x
         }
         if (step == p.nsteps) done = true;
         if (!done) {
@@ -1254,6 +1294,8 @@ __global__ void k_mse_finish(const double *acc, float *loss, int has_flags, doub
 }
 
 bool g_force_direct = false;
+int g_force_nw = 0;       // debug: wavefronts per workgroup of the pipelined kernel (0 = by batch size)
+int g_num_cus = 256;
 int g_debug = 0;
 unsigned long long *g_trace = nullptr;
 int g_trace_cap = 0;
@@ -1272,21 +1314,30 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
-  // the pipelined kernel works on 256-point tiles of one shape (a partial last tile idles whole wavefronts) and is ~3x
-  // faster per point than the direct kernel: take it unless the padding of a small shape eats that factor
-  const long long wpg = (p.N + PIPE_NW * 32 - 1) / (PIPE_NW * 32);
-  const bool pipe = d->dev.prec == DFX_PREC_BF16 && wpg * PIPE_NW * 32 <= 3LL * p.N && !g_force_direct;
+  // the pipelined kernel works on tiles of NW x 32 points of one shape (a partial last tile idles whole wavefronts) and is ~3x
+  // faster per point than the direct kernel: take it unless the padding of a small shape eats that factor.  NW = 8 when that
+  // gives every CU a workgroup; small batches take 4 or 2 wavefronts per workgroup to spread over more CUs (a single 2048-point
+  // shape: 8 -> 32 workgroups; the per-wave instruction stream and the results are the same)
+  auto tiles = [&](int nw) { return (long long)((p.N + nw * 32 - 1) / (nw * 32)); };
+  int nw = PIPE_NW;
+  while (nw > 2 && tiles(nw) * p.B < g_num_cus) nw >>= 1;
+  if (g_force_nw) nw = g_force_nw;
+  const long long wpg = tiles(nw);
+  const bool pipe = d->dev.prec == DFX_PREC_BF16 && wpg * nw * 32 <= 3LL * p.N && !g_force_direct;
   if (pipe) {
     static bool attr_set = false;
     if (!attr_set) {
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<8>::L_TOTAL));
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<4>::L_TOTAL));
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<2>::L_TOTAL));
       attr_set = true;
     }
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe) k_denoise_pipe<<<(int)(wpg * p.B), PIPE_NW * 64, L_TOTAL, st>>>(p);
+  if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
+  else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
+  else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");
@@ -1415,6 +1466,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
+void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2) ? nw : 0; }
 void dfx_debug_flags(int flags) { g_debug = flags; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);

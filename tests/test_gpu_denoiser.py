@@ -392,3 +392,30 @@ def test_pipelined_kernel_any_batch_size_matches_direct(W):
         per_shape = (a - b).abs().amax(dim=(1, 2))
         print(f"pipelined vs direct bf16 chain T={T} B={B}: max-abs per shape {per_shape.max().item():.3e}")
         assert per_shape.max().item() < TOL_PIPE_VS_DIRECT, per_shape   # same bf16 operands, different (fast) GELU / LayerNorm formulation
+
+
+@pytest.mark.parametrize("N", [2048, 2080, 512])
+def test_small_batch_workgroup_sizes_are_bit_identical(W, N):
+    """The pipelined kernel runs 8, 4 or 2 wavefronts per workgroup (small batches take the smaller ones so that a single
+    shape spreads over 16 / 32 CUs instead of 8): same per-wave instruction stream, so the clouds must agree bit for bit,
+    with explicit noise and with the in-kernel Philox stream, full and ragged last tiles."""
+    from difffacto_amd import _ffi
+    T, B = 4, 3
+    e = _engine(W, T, "bf16")
+    pc, mean, logvar, va = synth.make_latents(B, seed=N)
+    cx = e.prepare_shapes(*map(torch.from_numpy, (pc, mean, np.exp(logvar).astype(np.float32), va)))
+    sg = torch.from_numpy(synth.make_seg_mask(va, N))
+    g = torch.Generator().manual_seed(N)
+    xT, sn = torch.randn(B, 3, N, generator=g), torch.randn(T, B, 3, N, generator=g)
+    out = {}
+    try:
+        for nw in (8, 4, 2):
+            _ffi.lib().dfx_debug_pipe_waves(nw)
+            out[nw] = (e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn, ret_interval=2), e.sample_chain(cx, sg, seed=9)[0])
+    finally:
+        _ffi.lib().dfx_debug_pipe_waves(0)
+    auto = e.sample_chain(cx, sg, seed=9)[0]     # B = 3 is a small batch: the automatic choice is one of the three
+    for nw in (4, 2):
+        assert torch.equal(out[nw][0][0], out[8][0][0]) and torch.equal(out[nw][0][1], out[8][0][1]), nw
+        assert torch.equal(out[nw][1], out[8][1]), nw
+    assert torch.equal(auto, out[8][1]) and torch.isfinite(auto).all()
