@@ -462,56 +462,60 @@ __device__ __forceinline__ constexpr int ms_frag(int i) { return (4 + (i & 3)) *
 // instructions issue while the matrix pipe works instead of in bursts during which it drains.  The last eight refills are
 // the tail prefetch for the next M slot.  `issue.at(i, n)` issues the wave's ring-DMA pieces between the MFMAs.
 
-template <bool S3, bool S1, class Issue>
+// MFMA order of a full FF record (GEMM2 of chunk j-1 and GEMM1 of chunk j are independent): eight groups of
+//     GEMM2 MFMA k (accumulator h[k & 3])  |  GEMM1 MFMA 2k (a)  |  GEMM1 MFMA 2k+1 (g)
+// so that an accumulator is touched every third MFMA at the earliest (the r01 order — 8 x GEMM2, then 16 x GEMM1 with its two
+// accumulators alternating — made every GEMM1 MFMA depend on the one two before it).  Measured: no difference (B = 1: 87.7 vs
+// 87.0 ms per chain, B = 128: within box noise) — a lone wavefront's M slot takes 41 cycles per MFMA in either order (slot trace:
+// 984 cycles), so the accumulate latency is not what stretches it; the order stays because it costs nothing and one ring loop
+// is simpler than three.
+// m-th MFMA of the record -> its A fragment (uint4 index relative to the lane's record pointer)
+__device__ __forceinline__ constexpr int ff_frag(int m) {
+  const int k = m / 3, r = m % 3;
+  if (r == 0) return w2_frag(k);
+  const int e = 2 * k + r - 1;             // GEMM1 MFMA 0..15: half e >> 3, index e & 7 within the half
+  return w1_frag(e & 7, e >> 3);
+}
+// what the next M slot of this wavefront starts with (tail prefetch): a full record (mixed order), the block's last record
+// (GEMM2 only) or the next block's attention record (A_s)
+enum { NEXT_FULL = 0, NEXT_LAST = 1, NEXT_AS = 2 };
+template <int NEXT>
+__device__ __forceinline__ constexpr int next_frag(int i) { return NEXT == NEXT_FULL ? ff_frag(i) : NEXT == NEXT_LAST ? w2_frag(i) : as_frag(i); }
+
+template <bool S3, bool S1, int NEXT, class Issue>
 __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn)[4], v16f &a, v16f &g,
                                      const HidAct &hid, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next, Tracer &tr,
                                      Issue &issue) {
-  uint4 A1[8];
   __builtin_amdgcn_sched_barrier(0);
   tr.stamp(4);
   if (MFMA_PRIO) __builtin_amdgcn_s_setprio(MFMA_PRIO);
-  auto gemm1 = [&](int i, int half, const uint4 &w) {
+  auto gemm1 = [&](int e, const uint4 &w) {   // GEMM1 MFMA e = 0..15
+    const int i = e & 7, half = e >> 3;
     v16f &acc = (i & 1) ? g : a;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
   };
   if (S3 && S1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {   // GEMM2 of the previous chunk on the prefetched W2 fragments; fetch W1 (first half)
-      h[i & 3] = mma_hid(P[i], hid.f[i >> 2], h[i & 3]);
-      issue.at(i, 24);
-      A1[i] = ck[w1_frag(i, 0)];
+    for (int m = 0; m < 24; ++m) {   // P is a ring of eight fragment registers: MFMA m takes P[m & 7], refilled in place with fragment m + 8
+      const int k = m / 3, r = m % 3;
+      if (r == 0) h[k & 3] = mma_hid(P[m & 7], hid.f[k >> 2], h[k & 3]);
+      else gemm1(2 * k + r - 1, P[m & 7]);
+      issue.at(m, 24);
+      P[m & 7] = m + 8 < 24 ? ck[ff_frag(m + 8)] : ck_next[next_frag<NEXT>(m + 8 - 24)];
     }
+  } else if (S1) {                  // first FF record of a block: GEMM1 only; P holds its first eight fragments
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {   // GEMM1 first half; refill in place with the second half
-      gemm1(i, 0, A1[i]);
-      issue.at(8 + i, 24);
-      A1[i] = ck[w1_frag(i, 1)];
+    for (int m = 0; m < 16; ++m) {
+      gemm1(m, P[m & 7]);
+      issue.at(m, 16);
+      P[m & 7] = m + 8 < 16 ? ck[w1_frag((m + 8) & 7, (m + 8) >> 3)] : ck_next[next_frag<NEXT>(m + 8 - 16)];
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {   // GEMM1 second half; tail prefetch of the next record's W2 fragments
-      gemm1(i, 1, A1[i]);
-      issue.at(16 + i, 24);
-      P[i] = ck_next[w2_frag(i)];
-    }
-  } else if (S1) {                  // first FF record of a block: P holds W1 (first half)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      gemm1(i, 0, P[i]);
-      issue.at(i, 16);
-      A1[i] = ck[w1_frag(i, 1)];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      gemm1(i, 1, A1[i]);
-      issue.at(8 + i, 16);
-      P[i] = ck_next[w2_frag(i)];
-    }
-  } else {                          // last FF record of a block: GEMM2 only; tail prefetch = A_s of the next block
+  } else {                          // last FF record of a block: GEMM2 only
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       h[i & 3] = mma_hid(P[i], hid.f[i >> 2], h[i & 3]);
       issue.at(i, 8);
-      P[i] = ck_next[as_frag(i)];
+      P[i] = ck_next[next_frag<NEXT>(i)];
     }
   }
   // keep the program order MFMA, read, MFMA, read, ...
@@ -1229,22 +1233,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
       load16(g, b1 + 32);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<false, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
+      ff_m<false, true, NEXT_FULL>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
 #pragma unroll 1
-      for (int j = 1; j < FF_CHUNKS; ++j) {
+      for (int j = 1; j < FF_CHUNKS - 1; ++j) {
         DFX_SLOT(!grpA);
         issue_in_m.m_begin();
         ff_v(a, g, hid, b1 + j * 64, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
-        ff_m<true, true>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
+        ff_m<true, true, NEXT_FULL>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
+      DFX_SLOT(!grpA);   // record F15: the next one is the block's last (GEMM2 only): its tail prefetch differs
+      issue_in_m.m_begin();
+      ff_v(a, g, hid, b1 + (FF_CHUNKS - 1) * 64, tr);
+      DFX_SLOT(grpA);
+      DFX_NEXT_RECORD();
+      ff_m<true, true, NEXT_LAST>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       DFX_SLOT(!grpA);
       issue_in_m.m_begin();
       ff_v(a, g, hid, nullptr, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
-      ff_m<true, false>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
+      ff_m<true, false, NEXT_AS>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
     }
   }
 #undef DFX_SLOT

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes
 from difffacto_amd import synth, _ffi
 from difffacto_amd.engine import DenoiserEngine
-T, B, N, CAP = 4, 128, 2048, 2048
+import os
+T, B, N, CAP = 4, int(os.environ.get("DFX_TRACE_B", "128")), 2048, 2048
 FLAGS = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 W = synth.make_denoiser_weights(0)
 eng = DenoiserEngine({k: torch.from_numpy(v) for k, v in W.items()}, num_timesteps=T, precision="bf16")
