@@ -1263,6 +1263,131 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
+// ----------------------------------------------------------------------------------------------
+// Latency kernel for very small batches (a single 2048-point shape = 64 tiles of 32 points): ONE 32-point tile per workgroup,
+// eight wavefronts co-operating on it.  The pipelined kernel gives such a batch 8 .. 32 workgroups and every wavefront walks
+// the whole network alone (87 us per step whatever the workgroup size: M and V slots of one wave are serial).  Here
+//   wave 0 (owner)     holds h for the whole chain: proj_in, LayerNorms, attention, the step epilogue and ALL GEMM2
+//                      accumulations, chunk after chunk in the pipelined kernel's order
+//   waves 1..7         the chunk-independent part: [a | g] = b1 + W1 xn3 and the packed-fp16 GELU for chunks r * 7 + wave - 1,
+//                      r = 0, 1, 2, handed to the owner through LDS (2 KiB per chunk)
+// with two workgroup barriers per block (xn3 ready, hid ready).  Every floating-point operation is the pipelined kernel's (same
+// device functions, same MFMA order per accumulator), so the results are bit-identical to it; operands come straight from L2
+// (fragments prefetched one round / four chunks ahead in registers), no ring.
+constexpr int COOP_NW = 8, COOP_HELPERS = COOP_NW - 1, COOP_ROUNDS = (FF_CHUNKS + COOP_HELPERS - 1) / COOP_HELPERS;
+__global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams p) {
+  constexpr int PREC = DFX_PREC_BF16;
+  constexpr int TSTRIDE = tile_units(PREC) * 64, AREC = asms_bytes(PREC) / 16;
+  __shared__ uint4 s_xn[8][64];                 // LN3 output as the B operand of GEMM1 (tile c, unit q)
+  __shared__ uint4 s_hid[FF_CHUNKS][2][64];     // GELU output of every chunk (fp16 B operand of GEMM2)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const long long g0 = (long long)blockIdx.x * 32;
+  const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));
+  const int n = (int)(g0 - (long long)s * p.N) + pj;
+  const int depth = p.d.depth;
+  const bool owner = wave == 0;
+  PointState ps;
+  unsigned vmask = 0;
+  if (owner) point_init(p, ps, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
+  const float *cpart = p.cpart + ((size_t)s * NCLS + (owner ? ps.sg : 0)) * INNER + hf * 64;
+  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
+
+  // One register file for both roles (the compiler cannot overlay two arrays that are live across the same barriers):
+  //   R[32]   helpers: GEMM1 fragments of this round (R[0..15] / R[16..31] alternating) and of the next one, in the accumulation
+  //           order a(c,0) a(c,1) g(c,0) g(c,1), c = 0..3;   owner: W2 fragments of four chunks, R[8 (u & 3) + i]
+  //   h[4]    owner: the residual stream;                     helpers: h[0], h[1] carry the bits of xn3 (8 x uint4)
+  uint4 R[32];
+  auto load_w1 = [&](int base, const uint4 *chunks, int u) {
+    const uint4 *ck = chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      R[base + 4 * c + 0] = ck[(0 + c) * TSTRIDE], R[base + 4 * c + 1] = ck[(0 + c) * TSTRIDE + 64];
+      R[base + 4 * c + 2] = ck[(4 + c) * TSTRIDE], R[base + 4 * c + 3] = ck[(4 + c) * TSTRIDE + 64];
+    }
+  };
+  auto load_w2 = [&](int base, const uint4 *chunks, int u) {   // W2 of chunk u sits in FF record u + FF_SKEW, tiles 8..11
+    const uint4 *ck = chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) R[base + i] = ck[w2_frag(i)];
+  };
+
+  v16f h[4];
+  auto xn_frag = [&](int k) -> v8bf {   // helpers: k-th uint4 of xn3 (tile k >> 1, unit k & 1) out of h[0] / h[1]
+    const v16f &src = h[k >> 2];
+    const int o = 4 * (k & 3);
+    return __builtin_bit_cast(v8bf, v4f{src[o], src[o + 1], src[o + 2], src[o + 3]});
+  };
+  for (int step = 0; step < p.nsteps; ++step) {
+    const int t = step_t(p, step, s);
+    if (owner) proj_in_prenorm<true>(h, ps.x, cpart, p.d.win_x + hf * 64, p.d.pre_gb + hf * 64);
+    for (int b = 0; b < depth; ++b) {
+      const BlockPack bp = block_pack(p, b);
+      if (!owner) {
+        load_w1(0, bp.chunks, wave - 1);   // round 0: in flight while the owner runs the attention
+      } else {
+        const uint4 *rec = asms_s + (size_t)b * AREC;
+        attention<PREC>(h, rec, reinterpret_cast<const float *>(rec - lane + 8 * TSTRIDE) + hf * 16, bp.ct + (size_t)t * CT_ROW + hf * 64, vmask);
+        Act<PREC> xo[4];
+        ln_to_act<PREC>(h, xo);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_xn[2 * c][lane] = __builtin_bit_cast(uint4, xo[c].f[0]), s_xn[2 * c + 1][lane] = __builtin_bit_cast(uint4, xo[c].f[1]);
+      }
+      __syncthreads();   // xn3 of this block is in LDS
+      if (!owner) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const v4f x = __builtin_bit_cast(v4f, s_xn[k][lane]);
+          h[k >> 2][4 * (k & 3) + 0] = x[0], h[k >> 2][4 * (k & 3) + 1] = x[1], h[k >> 2][4 * (k & 3) + 2] = x[2], h[k >> 2][4 * (k & 3) + 3] = x[3];
+        }
+#pragma unroll
+        for (int r = 0; r < COOP_ROUNDS; ++r) {
+          const int u = r * COOP_HELPERS + wave - 1;
+          if (u >= FF_CHUNKS) break;   // wave-uniform
+          const int cur = (r & 1) * 16, nxt = 16 - cur;
+          const int un = u + COOP_HELPERS;
+          if (r + 1 < COOP_ROUNDS && un < FF_CHUNKS) load_w1(nxt, bp.chunks, un);
+          v16f a, g;
+          load16(a, bp.bconst + u * 64 + hf * 16);
+          load16(g, bp.bconst + u * 64 + hf * 16 + 32);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), xn_frag(2 * c), a, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 2]), xn_frag(2 * c), g, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 1]), xn_frag(2 * c + 1), a, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 3]), xn_frag(2 * c + 1), g, 0, 0, 0);
+          }
+          h2 aa[8], gg[8];
+          HidAct hid;
+          gelu16_f16_cvt(a, g, aa, gg);
+          gelu16_f16_math(aa, gg, hid);
+          s_hid[u][0][lane] = hid.f[0], s_hid[u][1][lane] = hid.f[1];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_w2(8 * u, bp.chunks, u);   // in flight while the helpers work
+      }
+      __syncthreads();   // hid of all chunks is in LDS
+      if (owner) {
+#pragma unroll
+        for (int u = 0; u < FF_CHUNKS; ++u) {   // GEMM2 in chunk order: the accumulation order of the pipelined kernel
+          const uint4 h0 = s_hid[u][0][lane], h1 = s_hid[u][1][lane];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i & 3] = mma_hid(R[8 * (u & 3) + i], (i >> 2) ? h1 : h0, h[i & 3]);
+          if (u + 4 < FF_CHUNKS) load_w2(8 * (u & 3), bp.chunks, u + 4);
+        }
+        add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
+      }
+    }
+    if (owner) {
+      float eps[3];
+      post_eps<true>(h, p.d.wout + hf * 64, p.d.bout, eps);
+      if (step_epilogue(p, ps, eps, step, t)) break;   // (the helpers leave through the loop bound: nsteps = 1 in these modes)
+    }
+  }
+}
+
 // q_sample (anchored_diffusion.py:148-173): x_t = sqrt_acp[t] (x0 - a) + a + sqrt_1m_acp[t] L noise, per-shape t,
 // anchors / variances of the point's part from the shape context (learn_anchor, learn_variance)
 __global__ void k_q_sample(const float *__restrict__ part, const float *__restrict__ qtab, const int32_t *__restrict__ seg,
@@ -1331,9 +1456,12 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   auto tiles = [&](int nw) { return (long long)((p.N + nw * 32 - 1) / (nw * 32)); };
   int nw = PIPE_NW;
   while (nw > 2 && tiles(nw) * p.B < g_num_cus) nw >>= 1;
-  if (g_force_nw) nw = g_force_nw;
+  if (g_force_nw > 1) nw = g_force_nw;
   const long long wpg = tiles(nw);
   const bool pipe = d->dev.prec == DFX_PREC_BF16 && wpg * nw * 32 <= 3LL * p.N && !g_force_direct;
+  // very small batches: one 32-point tile per workgroup, eight wavefronts co-operating on it (k_denoise_coop), while that still
+  // gives every workgroup a CU of its own (a second round would double the latency again)
+  const bool coop = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && (g_force_nw == 1 || (g_force_nw == 0 && waves <= g_num_cus));
   if (pipe) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1345,7 +1473,8 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
+  if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, 0, st>>>(p);
+  else if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
   else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
@@ -1476,7 +1605,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2) ? nw : 0; }
+void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1) ? nw : 0; }
 void dfx_debug_flags(int flags) { g_debug = flags; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);

@@ -438,8 +438,8 @@ int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *
                         dfx_stream_t stream);
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
-/* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2; 0 = chosen from the batch size so that small
- * batches spread over more CUs).  The variants are bit-identical. */
+/* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
+ * 32-point tile per workgroup, eight wavefronts on it); 0 = chosen from the batch size.  All variants are bit-identical. */
 void dfx_debug_pipe_waves(int nw);
 /* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */
 void dfx_debug_flags(int flags);

@@ -397,8 +397,10 @@ def test_pipelined_kernel_any_batch_size_matches_direct(W):
 @pytest.mark.parametrize("N", [2048, 2080, 512])
 def test_small_batch_workgroup_sizes_are_bit_identical(W, N):
     """The pipelined kernel runs 8, 4 or 2 wavefronts per workgroup (small batches take the smaller ones so that a single
-    shape spreads over 16 / 32 CUs instead of 8): same per-wave instruction stream, so the clouds must agree bit for bit,
-    with explicit noise and with the in-kernel Philox stream, full and ragged last tiles."""
+    shape spreads over 16 / 32 CUs instead of 8), and the smallest batches take the co-operative latency kernel (`1`: one
+    32-point tile per workgroup, eight wavefronts on it): same floating-point operations in the same order per accumulator, so
+    the clouds must agree bit for bit, with explicit noise and with the in-kernel Philox stream, full and ragged last tiles,
+    and so must single evaluations / single steps."""
     from difffacto_amd import _ffi
     T, B = 4, 3
     e = _engine(W, T, "bf16")
@@ -409,13 +411,16 @@ def test_small_batch_workgroup_sizes_are_bit_identical(W, N):
     xT, sn = torch.randn(B, 3, N, generator=g), torch.randn(T, B, 3, N, generator=g)
     out = {}
     try:
-        for nw in (8, 4, 2):
+        for nw in (8, 4, 2, 1):
             _ffi.lib().dfx_debug_pipe_waves(nw)
-            out[nw] = (e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn, ret_interval=2), e.sample_chain(cx, sg, seed=9)[0])
+            out[nw] = (e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn, ret_interval=2), e.sample_chain(cx, sg, seed=9)[0],
+                       e.eps(cx, xT, sg, 2), e.p_sample(cx, xT, sg, 1, noise=sn[0], want_xstart=True))
     finally:
         _ffi.lib().dfx_debug_pipe_waves(0)
     auto = e.sample_chain(cx, sg, seed=9)[0]     # B = 3 is a small batch: the automatic choice is one of the three
-    for nw in (4, 2):
+    for nw in (4, 2, 1):
         assert torch.equal(out[nw][0][0], out[8][0][0]) and torch.equal(out[nw][0][1], out[8][0][1]), nw
         assert torch.equal(out[nw][1], out[8][1]), nw
+        assert torch.equal(out[nw][2], out[8][2]), nw
+        assert torch.equal(out[nw][3][0], out[8][3][0]) and torch.equal(out[nw][3][1], out[8][3][1]), nw
     assert torch.equal(auto, out[8][1]) and torch.isfinite(auto).all()
