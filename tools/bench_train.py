@@ -30,6 +30,9 @@ args = [x_t, t, cu(pc), cu(np.concatenate([mean, var], 1).astype(np.float32)), c
         cu(valid), cu(seg.astype(np.int32))]
 noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
 opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
+if "--layerwise" in sys.argv:   # the layer-by-layer feed-forward kernels (A/B against the fused ones)
+    from difffacto_amd import _ffi
+    _ffi.lib().dfx_debug_train_fused(0)
 
 
 def it():
