@@ -169,20 +169,21 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ dy, co
 }
 
 // out[c] = sum over nparts of part[p][c]  (second pass of every column reduction).  Block = 32 columns x 8 part groups;
-// group q adds parts q, q+8, ... in order, the eight group sums are added in order: a fixed summation tree.
-__global__ __launch_bounds__(256) void k_sum_parts(const float *__restrict__ part, float *__restrict__ out, int nparts, int cols,
-                                                    int ld_part) {
-  __shared__ float red[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+// group q of G = blockDim.x / 32 adds parts q, q+G, ... in order, the G group sums are added in order: a fixed summation tree.
+// (G = 32: the LayerNorm / bias column sums have 4 .. 32 blocks of 512 partial rows each — with 8 groups a launch was 16 us of
+// serial adds, 35 launches per iteration.)
+__global__ __launch_bounds__(1024) void k_sum_parts(const float *__restrict__ part, float *__restrict__ out, int nparts, int cols,
+                                                     int ld_part) {
+  __shared__ float red[32][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5, G = blockDim.x >> 5;
   float a = 0.f;
   if (c < cols)
-    for (int p = q; p < nparts; p += 8) a += part[(size_t)p * ld_part + c];
+    for (int p = q; p < nparts; p += G) a += part[(size_t)p * ld_part + c];
   red[q][threadIdx.x & 31] = a;
   __syncthreads();
   if (q == 0 && c < cols) {
     float t = red[0][threadIdx.x];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    for (int k = 1; k < G; ++k) t += red[k][threadIdx.x];
     out[c] = t;
   }
 }
@@ -1096,6 +1097,9 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
   if (!done) {
     int slab = pick_slab(R, (long long)((O + 63) / 64) * ((I + 63) / 64), 2048, w.part_floats, (size_t)O * I);
     if (R <= 512) slab = (int)((R + 63) / 64 * 64);   // a handful of rows: one slab, the tile is written straight into dW / db
+    // ... unless the output has too few tiles to occupy the chip and goes through the finish kernel anyway (to_k / to_v over the
+    // B x 4 context tokens: 18 workgroups walking 512 rows each took 71 us, ten times per iteration): slabs of 64 rows
+    if (R <= 512 && R > 64 && I_valid != I && (long long)((O + 63) / 64) * ((I + 63) / 64) < 64) slab = 64;
     ns = (int)((R + slab - 1) / slab);
     if ((size_t)ns > bcap) {
       slab = (int)(((R + (long long)bcap - 1) / (long long)bcap + 63) / 64 * 64);
@@ -1107,9 +1111,9 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
     }
     k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
   }
-  if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
+  if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 1024, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
   else k_wgrad_finish<<<(O * I_valid + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
-  if (db) k_sum_parts<<<(O + 31) / 32, 256, 0, st>>>(w.bpart, db, ns, O, O);
+  if (db) k_sum_parts<<<(O + 31) / 32, 1024, 0, st>>>(w.bpart, db, ns, O, O);
   return dfx::check_launch("train: wgrad");
 }
 
@@ -1122,8 +1126,8 @@ int ln_bwd(hipStream_t st, TrainWs &w, const float *dy, const float *x, const fl
            float *out, float *dg, float *db, long long R) {
   const int nb = (int)((R + LNB_ROWS - 1) / LNB_ROWS);
   k_ln_bwd<<<nb, 256, 0, st>>>(dy, x, stats, g, resid, out, w.part, R);
-  k_sum_parts<<<C / 32, 256, 0, st>>>(w.part, dg, nb, C, 2 * C);
-  k_sum_parts<<<C / 32, 256, 0, st>>>(w.part + C, db, nb, C, 2 * C);
+  k_sum_parts<<<C / 32, 1024, 0, st>>>(w.part, dg, nb, C, 2 * C);
+  k_sum_parts<<<C / 32, 1024, 0, st>>>(w.part + C, db, nb, C, 2 * C);
   return dfx::check_launch("train: ln_bwd");
 }
 
@@ -1197,10 +1201,10 @@ int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, c
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
   k_col_stats<0><<<grid, 256, 0, st>>>(z, nullptr, w.pb.part, R, Cc);
-  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
   k_bn_mean<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, 1.0f / (float)R, Cc);
   k_col_stats<1><<<grid, 256, 0, st>>>(z, mean, w.pb.part, R, Cc);
-  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
   k_bn_rstd<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, rstd, run_mean, run_var, 1.0f / (float)R,
                                               R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
   const long long total = R * Cc;
@@ -1215,8 +1219,8 @@ int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *y, const
   const dim3 grid((Cc + 63) / 64, ns);
   if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
   else k_bn_bwd_part<false><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
-  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
-  k_sum_parts<<<(Cc + 31) / 32, 256, 0, st>>>(w.pb.part + Cc, dgamma, ns, Cc, 2 * Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
+  k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part + Cc, dgamma, ns, Cc, 2 * Cc);
   const long long total = R * Cc;
   if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
   else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
@@ -1402,8 +1406,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   {
     const int nb = (int)((R + EPSB_ROWS - 1) / EPSB_ROWS);
     k_eps_bwd<<<nb, 128, 0, st>>>(d_eps, w.hn, wt->proj_out_w, w.dh2, w.part, N, R);
-    k_sum_parts<<<3 * C / 32, 256, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
-    k_sum_parts<<<1, 256, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
+    k_sum_parts<<<3 * C / 32, 1024, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
+    k_sum_parts<<<1, 1024, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
   }
   if ((rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
   DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));
@@ -1708,7 +1712,7 @@ int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *
   DFX_REQUIRE(dfx::gemm::tn_ok(g), "debug_gemm_bf16: shape not supported by the TN kernel");
   dfx::gemm::launch_tn(st, g, ns);
   k_wgrad_finish<<<(M * N + 31) / 32, 256, 0, st>>>(workspace, Cout, ns, M, N, N);
-  if (db) k_sum_parts<<<(M + 31) / 32, 256, 0, st>>>(g.bpart, db, ns, M, M);
+  if (db) k_sum_parts<<<(M + 31) / 32, 1024, 0, st>>>(g.bpart, db, ns, M, M);
   return dfx::check_launch("debug_gemm_bf16 tn");
 }
 
