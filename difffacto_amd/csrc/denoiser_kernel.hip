@@ -1270,16 +1270,35 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
 //   wave 0 (owner)     holds h for the whole chain: proj_in, LayerNorms, attention, the step epilogue and ALL GEMM2
 //                      accumulations, chunk after chunk in the pipelined kernel's order
 //   waves 1..7         the chunk-independent part: [a | g] = b1 + W1 xn3 and the packed-fp16 GELU for chunks r * 7 + wave - 1,
-//                      r = 0, 1, 2, handed to the owner through LDS (2 KiB per chunk)
-// with two workgroup barriers per block (xn3 ready, hid ready).  Every floating-point operation is the pipelined kernel's (same
-// device functions, same MFMA order per accumulator), so the results are bit-identical to it; operands come straight from L2
-// (fragments prefetched one round / four chunks ahead in registers), no ring.
+//                      r = 0, 1, 2, handed to the owner through LDS (2 KiB per chunk) — and, while the owner works, the staging
+//                      of everything the owner is about to read (attention record, c_t row, block constants, W2) L2 -> LDS,
+//                      so that the one wavefront on the critical path never waits out an L2 round trip
+// with three workgroup barriers per block.  Every floating-point operation is the pipelined kernel's (same device functions,
+// same MFMA order per accumulator), so the results are bit-identical to it.
+//   barrier 0   attention record + c_t + block constants of block b are in LDS (copied during the owner's GEMM2 of block b-1)
+//   barrier 1   xn3 of block b is in LDS, h parked (owner: attention + LayerNorm3; helpers meanwhile: W2 chunks 8..15 -> LDS, W1 round 0 -> registers)
+//   barrier 2   hid of all chunks is in LDS (helpers: three rounds; owner meanwhile: W2 chunks 0..3 -> registers)
+//   then        owner: 16 x GEMM2 (fragments four chunks ahead: chunks 0..7 from L2, 8..15 from LDS; hid one chunk ahead), + b2
 constexpr int COOP_NW = 8, COOP_HELPERS = COOP_NW - 1, COOP_ROUNDS = (FF_CHUNKS + COOP_HELPERS - 1) / COOP_HELPERS;
+constexpr int COOP_W2_FIRST = 8;                                  // first W2 chunk staged in LDS (the LDS budget holds eight)
+constexpr int CL_XN = 0;                                          // 8 x 64 uint4: LN3 output as the B operand of GEMM1
+constexpr int CL_HID = CL_XN + 8 * 1024;                          // [16][2][64] uint4: GELU output of every chunk
+constexpr int CL_BC = CL_HID + FF_CHUNKS * 2048;                  // 2 x block constants (b1', b2), by block parity
+constexpr int CL_AT = CL_BC + 2 * BCONST_BYTES;                   // attention record (17 KiB) + c_t row (1 KiB)
+constexpr int CL_HS = CL_AT + asms_bytes(DFX_PREC_BF16) + 1024;   // the owner's residual stream h, parked while the helpers work (16 KiB)
+constexpr int CL_CONST = CL_HS + 16 * 1024;                       // chain-invariant operands: W_in x-columns (2 KiB) | pre_norm (1 KiB) | W_out (2 KiB) | cpart (2 KiB)
+constexpr int CL_W2 = CL_CONST + 7 * 1024;                        // W2 tiles of chunks 8..15 (8 KiB each)
+constexpr int CL_TOTAL = CL_W2 + (FF_CHUNKS - COOP_W2_FIRST) * 8192;
+static_assert(CL_TOTAL <= 160 * 1024, "LDS budget of the co-operative kernel");
+
 __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams p) {
   constexpr int PREC = DFX_PREC_BF16;
   constexpr int TSTRIDE = tile_units(PREC) * 64, AREC = asms_bytes(PREC) / 16;
-  __shared__ uint4 s_xn[8][64];                 // LN3 output as the B operand of GEMM1 (tile c, unit q)
-  __shared__ uint4 s_hid[FF_CHUNKS][2][64];     // GELU output of every chunk (fp16 B operand of GEMM2)
+  uint4 (*s_xn)[64] = reinterpret_cast<uint4 (*)[64]>(pipe_smem + CL_XN);
+  uint4 (*s_hid)[2][64] = reinterpret_cast<uint4 (*)[2][64]>(pipe_smem + CL_HID);
+  uint4 *s_at = reinterpret_cast<uint4 *>(pipe_smem + CL_AT);
+  uint4 *s_w2 = reinterpret_cast<uint4 *>(pipe_smem + CL_W2);
+  float *s_hs = reinterpret_cast<float *>(pipe_smem + CL_HS);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
@@ -1291,8 +1310,21 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   PointState ps;
   unsigned vmask = 0;
   if (owner) point_init(p, ps, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
-  const float *cpart = p.cpart + ((size_t)s * NCLS + (owner ? ps.sg : 0)) * INNER + hf * 64;
-  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC + lane;
+  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC;
+  {   // chain-invariant small operands -> LDS (the owner reads them at every step boundary)
+    float4 *c_winx = reinterpret_cast<float4 *>(pipe_smem + CL_CONST);
+    float2 *c_pregb = reinterpret_cast<float2 *>(pipe_smem + CL_CONST + 2048);
+    float4 *c_wout = reinterpret_cast<float4 *>(pipe_smem + CL_CONST + 3072);
+    float *c_cp = reinterpret_cast<float *>(pipe_smem + CL_CONST + 5120);
+    const int tid = threadIdx.x;
+    if (tid < 128) c_winx[tid] = p.d.win_x[tid], c_pregb[tid] = p.d.pre_gb[tid], c_wout[tid] = p.d.wout[tid];
+    c_cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+    __syncthreads();
+  }
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + CL_CONST) + hf * 64;
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + CL_CONST + 2048) + hf * 64;
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + CL_CONST + 3072) + hf * 64;
+  const float *cpart = reinterpret_cast<const float *>(pipe_smem + CL_CONST + 5120) + (owner ? ps.sg : 0) * INNER + hf * 64;
 
   // One register file for both roles (the compiler cannot overlay two arrays that are live across the same barriers):
   //   R[32]   helpers: GEMM1 fragments of this round (R[0..15] / R[16..31] alternating) and of the next one, in the accumulation
@@ -1300,47 +1332,98 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   //   h[4]    owner: the residual stream;                     helpers: h[0], h[1] carry the bits of xn3 (8 x uint4)
   uint4 R[32];
   auto load_w1 = [&](int base, const uint4 *chunks, int u) {
-    const uint4 *ck = chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane;
+    // (scalar base + lane offset: with the base pinned to SGPRs the sixteen loads share one address VGPR; left to itself hipcc
+    // keeps 64-bit per-lane addresses, spills them, and every scratch reload — a vector-memory operation like the prefetches
+    // in flight — drains the whole prefetch with s_waitcnt vmcnt(0))
+    const uint4 *ck = reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)u * CHUNK_TILES * TSTRIDE))) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       R[base + 4 * c + 0] = ck[(0 + c) * TSTRIDE], R[base + 4 * c + 1] = ck[(0 + c) * TSTRIDE + 64];
       R[base + 4 * c + 2] = ck[(4 + c) * TSTRIDE], R[base + 4 * c + 3] = ck[(4 + c) * TSTRIDE + 64];
     }
   };
-  auto load_w2 = [&](int base, const uint4 *chunks, int u) {   // W2 of chunk u sits in FF record u + FF_SKEW, tiles 8..11
-    const uint4 *ck = chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + lane;
+  // W2 of chunk u sits in FF record u + FF_SKEW, tiles 8..11 (8 KiB contiguous): from L2, or from its LDS copy
+  auto load_w2 = [&](int base, const uint4 *chunks, int u) {
+    const uint4 *ck = u < COOP_W2_FIRST
+                          ? reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + 8 * TSTRIDE))) + lane
+                          : s_w2 + (size_t)(u - COOP_W2_FIRST) * 4 * TSTRIDE + lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) R[base + i] = ck[w2_frag(i)];
+    for (int i = 0; i < 8; ++i) R[base + i] = ck[w2_frag(i) - 8 * TSTRIDE];
   };
+  // helpers: L2 -> LDS staging with LDS-DMA (1 KiB per wave instruction, no registers, asynchronous): piece k of a list goes
+  // to helper wave k % 7
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
 
+#ifdef DFX_TRACE   // phase stamps of the owner (row 0 of the trace buffer) and of helper wave 1 (row 1) of workgroup 0
+  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && wave < 2) ? p.trace + (size_t)wave * p.trace_cap : nullptr, p.trace_cap, 0};
+#else
+  Tracer tr;
+#endif
   v16f h[4];
-  auto xn_frag = [&](int k) -> v8bf {   // helpers: k-th uint4 of xn3 (tile k >> 1, unit k & 1) out of h[0] / h[1]
-    const v16f &src = h[k >> 2];
-    const int o = 4 * (k & 3);
-    return __builtin_bit_cast(v8bf, v4f{src[o], src[o + 1], src[o + 2], src[o + 3]});
+  auto xn_frag = [&](int k) -> v8bf { return __builtin_bit_cast(v8bf, s_xn[k][lane]); };   // helpers: k-th uint4 of xn3 (tile k >> 1, unit k & 1)
+  // the owner parks h in LDS while the helpers work: its 64 registers are then free for the helpers' fragment double buffer
+  // (one kernel = one register allocation for both roles)
+  auto h_park = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v4f *>(s_hs + ((c * 4 + q) * 64 + lane) * 4) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
   };
+  auto h_unpark = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f x = *reinterpret_cast<const v4f *>(s_hs + ((c * 4 + q) * 64 + lane) * 4);
+        h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
+      }
+  };
+  int seq = 0;
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = step_t(p, step, s);
-    if (owner) proj_in_prenorm<true>(h, ps.x, cpart, p.d.win_x + hf * 64, p.d.pre_gb + hf * 64);
-    for (int b = 0; b < depth; ++b) {
+    if (owner) proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
+    for (int b = 0; b < depth; ++b, ++seq) {
       const BlockPack bp = block_pack(p, b);
+      float *s_bc = reinterpret_cast<float *>(pipe_smem + CL_BC + (seq & 1) * BCONST_BYTES);
       if (!owner) {
-        load_w1(0, bp.chunks, wave - 1);   // round 0: in flight while the owner runs the attention
+        constexpr int NA = asms_bytes(PREC) / 1024, NB = BCONST_BYTES / 1024;   // 17 + 1 + 5 pieces
+#pragma unroll
+        for (int i = 0; i < (NA + 1 + NB + COOP_HELPERS - 1) / COOP_HELPERS; ++i) {
+          const int k = i * COOP_HELPERS + wave - 1;
+          if (k < NA) dma1k_pinned(reinterpret_cast<const char *>(asms_s + (size_t)b * AREC) + k * 1024, voff, lds0 + CL_AT + k * 1024);
+          else if (k == NA) dma1k_pinned(reinterpret_cast<const char *>(bp.ct + (size_t)t * CT_ROW), voff, lds0 + CL_AT + NA * 1024);
+          else if (k < NA + 1 + NB) dma1k_pinned(reinterpret_cast<const char *>(bp.bconst) + (k - NA - 1) * 1024, voff, lds0 + CL_BC + (seq & 1) * BCONST_BYTES + (k - NA - 1) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_w1(0, bp.chunks, wave - 1);   // round 0: in flight until the helpers' turn
+      }
+      tr.stamp(10);
+      __syncthreads();   // 0: attention record, c_t, block constants of this block are in LDS
+      tr.stamp(11);
+      if (!owner) {
+        constexpr int NP = (FF_CHUNKS - COOP_W2_FIRST) * 8;   // 64 pieces: W2 tiles of chunks 8..15
+#pragma unroll
+        for (int i = 0; i < (NP + COOP_HELPERS - 1) / COOP_HELPERS; ++i) {
+          const int k = i * COOP_HELPERS + wave - 1;
+          if (k < NP)
+            dma1k_pinned(reinterpret_cast<const char *>(bp.chunks + (size_t)(COOP_W2_FIRST + (k >> 3) + FF_SKEW) * CHUNK_TILES * TSTRIDE + 8 * TSTRIDE) + (k & 7) * 1024,
+                         voff, lds0 + CL_W2 + k * 1024);
+        }
       } else {
-        const uint4 *rec = asms_s + (size_t)b * AREC;
-        attention<PREC>(h, rec, reinterpret_cast<const float *>(rec - lane + 8 * TSTRIDE) + hf * 16, bp.ct + (size_t)t * CT_ROW + hf * 64, vmask);
+        const uint4 *rec = s_at + lane;
+        attention<PREC>(h, rec, reinterpret_cast<const float *>(s_at + 8 * TSTRIDE) + hf * 16, reinterpret_cast<const float *>(s_at + AREC) + hf * 64, vmask);
         Act<PREC> xo[4];
         ln_to_act<PREC>(h, xo);
 #pragma unroll
         for (int c = 0; c < 4; ++c) s_xn[2 * c][lane] = __builtin_bit_cast(uint4, xo[c].f[0]), s_xn[2 * c + 1][lane] = __builtin_bit_cast(uint4, xo[c].f[1]);
+        h_park();
       }
-      __syncthreads();   // xn3 of this block is in LDS
+      tr.stamp(12);
+      __syncthreads();   // 1: xn3 of this block is in LDS
+      tr.stamp(13);
       if (!owner) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const v4f x = __builtin_bit_cast(v4f, s_xn[k][lane]);
-          h[k >> 2][4 * (k & 3) + 0] = x[0], h[k >> 2][4 * (k & 3) + 1] = x[1], h[k >> 2][4 * (k & 3) + 2] = x[2], h[k >> 2][4 * (k & 3) + 3] = x[3];
-        }
 #pragma unroll
         for (int r = 0; r < COOP_ROUNDS; ++r) {
           const int u = r * COOP_HELPERS + wave - 1;
@@ -1349,8 +1432,8 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
           const int un = u + COOP_HELPERS;
           if (r + 1 < COOP_ROUNDS && un < FF_CHUNKS) load_w1(nxt, bp.chunks, un);
           v16f a, g;
-          load16(a, bp.bconst + u * 64 + hf * 16);
-          load16(g, bp.bconst + u * 64 + hf * 16 + 32);
+          load16(a, s_bc + u * 64 + hf * 16);
+          load16(g, s_bc + u * 64 + hf * 16 + 32);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), xn_frag(2 * c), a, 0, 0, 0);
@@ -1364,25 +1447,31 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
           gelu16_f16_math(aa, gg, hid);
           s_hid[u][0][lane] = hid.f[0], s_hid[u][1][lane] = hid.f[1];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W2 pieces have landed (long ago: loads complete in order)
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load_w2(8 * u, bp.chunks, u);   // in flight while the helpers work
+        for (int u = 0; u < 4; ++u) load_w2(8 * u, bp.chunks, u);   // from L2, in flight while the helpers work
       }
-      __syncthreads();   // hid of all chunks is in LDS
+      tr.stamp(14);
+      __syncthreads();   // 2: hid of all chunks and the W2 copies are in LDS
+      tr.stamp(15);
       if (owner) {
+        h_unpark();
+        uint4 hq[2][2];   // hid of this chunk / the next one (LDS reads one chunk ahead)
+        hq[0][0] = s_hid[0][0][lane], hq[0][1] = s_hid[0][1][lane];
 #pragma unroll
         for (int u = 0; u < FF_CHUNKS; ++u) {   // GEMM2 in chunk order: the accumulation order of the pipelined kernel
-          const uint4 h0 = s_hid[u][0][lane], h1 = s_hid[u][1][lane];
+          if (u + 1 < FF_CHUNKS) hq[(u + 1) & 1][0] = s_hid[u + 1][0][lane], hq[(u + 1) & 1][1] = s_hid[u + 1][1][lane];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) h[i & 3] = mma_hid(R[8 * (u & 3) + i], (i >> 2) ? h1 : h0, h[i & 3]);
+          for (int i = 0; i < 8; ++i) h[i & 3] = mma_hid(R[8 * (u & 3) + i], hq[u & 1][i >> 2], h[i & 3]);
           if (u + 4 < FF_CHUNKS) load_w2(8 * (u & 3), bp.chunks, u + 4);
         }
-        add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
+        add_cvec(h, s_bc + BCONST_B2_OFF + hf * 64);
       }
     }
     if (owner) {
       float eps[3];
-      post_eps<true>(h, p.d.wout + hf * 64, p.d.bout, eps);
+      post_eps<true>(h, wout, p.d.bout, eps);
       if (step_epilogue(p, ps, eps, step, t)) break;   // (the helpers leave through the loop bound: nsteps = 1 in these modes)
     }
   }
@@ -1462,18 +1551,19 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   // very small batches: one 32-point tile per workgroup, eight wavefronts co-operating on it (k_denoise_coop), while that still
   // gives every workgroup a CU of its own (a second round would double the latency again)
   const bool coop = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && (g_force_nw == 1 || (g_force_nw == 0 && waves <= g_num_cus));
-  if (pipe) {
+  if (pipe || coop) {
     static bool attr_set = false;
     if (!attr_set) {
       DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<8>::L_TOTAL));
       DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<4>::L_TOTAL));
       DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<2>::L_TOTAL));
+      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_coop), hipFuncAttributeMaxDynamicSharedMemorySize, CL_TOTAL));
       attr_set = true;
     }
   }
   EventTimer tm;
   tm.begin(st);
-  if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, 0, st>>>(p);
+  if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
   else if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
   else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);

@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
-DFX_TRACE_B=1 bash tools/run_trace.sh > gpurun_out/r2/exp13.log 2>&1
+python - <<PY
+from difffacto_amd import build
+build.build(force=True, verbose=False, extra_flags=["-DDFX_TRACE"])
+PY
+python tools/trace_coop.py 2>&1 | grep -v "amdgpu.ids\|warning" > gpurun_out/r2/exp13.log
