@@ -13,6 +13,8 @@ Imports the reference's own pure-torch helpers (never shipped to the GPU box) an
                        (<= 2 ulp = 1.2e-7 relative), and the fp32 reference is checked to reproduce the float64 selection.
   chamfer_ref_*.npz    `distChamfer` (python/difffacto/datasets/evaluation_utils.py:93-103): expanded-form squared
                        distances, so it pins chamfer.cu's direct-difference form only to a tolerance (stated in the test).
+  three_nn_ref_*.npz   3-NN indices / squared distances and the inverse-distance interpolation through the reference's pure-torch
+                       feature-propagation path (pointnet2_utils.py:289-299, index_points :41-57).
   pn2_torch_ballquery_*.npz  three more `query_ball_point` cases (pointnet2_utils.py:84-104): centres with no point in
                        range, nsample overflow (more hits than nsample), nsample > hits (padding), N not a multiple of 64.
                        The helper excludes d2 > r^2, the kernel includes d2 < r^2: identical unless d2 == r^2 exactly,
@@ -115,7 +117,36 @@ def gen_ballquery():
         print("wrote pn2_torch_ballquery_" + tag, "centres without a hit:", int(nohit.sum()), "of", nohit.size)
 
 
+def gen_three_nn():
+    """3-NN + inverse-distance interpolation through the reference's own pure-torch feature-propagation code path
+    (models/encoders/pointnet2_utils.py:289-299: square_distance -> sort -> first three; index_points + weighted sum).  Pins the
+    three_nn kernel's neighbour choice and order (interpolate_gpu.cu:13-59: ascending distance) and three_interpolate's
+    weighted gather (:72-101) on clouds whose four nearest distances are separated by > 1e-4 relative (no ties to break)."""
+    ref_import.import_reference()
+    from difffacto.models.encoders.pointnet2_utils import index_points, square_distance
+    for tag, B, n, m, c, seed in (("n300_m64_c5", 2, 300, 64, 5, 401), ("n64_m700_c3", 1, 64, 700, 3, 402)):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        for attempt in range(100):
+            unknown = rng.uniform(-1, 1, size=(B, n, 3)).astype(F32)
+            known = rng.uniform(-1, 1, size=(B, m, 3)).astype(F32)
+            d64 = np.sort(((unknown[:, :, None].astype(np.float64) - known[:, None].astype(np.float64)) ** 2).sum(-1), axis=-1)[:, :, :4]
+            if ((d64[:, :, 1:] - d64[:, :, :-1]) / d64[:, :, 1:]).min() > 1e-4:
+                break
+        else:
+            raise RuntimeError("no tie-free case found")
+        d, idx = square_distance(torch.from_numpy(unknown), torch.from_numpy(known)).sort(dim=-1)
+        d, idx = d[:, :, :3], idx[:, :, :3]
+        feats = rng.standard_normal((B, c, m)).astype(F32)
+        recip = 1.0 / (torch.sqrt(d.clamp_min(0)) + 1e-8)          # PointnetFPModule's weights (pointnet2_modules.py:196-199)
+        weight = (recip / recip.sum(2, keepdim=True)).numpy().astype(F32)
+        interp = torch.sum(index_points(torch.from_numpy(feats).permute(0, 2, 1), idx) * torch.from_numpy(weight)[..., None], dim=2)
+        np.savez_compressed(os.path.join(HERE, f"three_nn_ref_{tag}.npz"), unknown=unknown, known=known, idx=idx.numpy().astype(np.int32),
+                            dist2=d.numpy().astype(F32), feats=feats, weight=weight, interp=interp.permute(0, 2, 1).numpy().astype(F32))
+        print("wrote three_nn_ref_" + tag)
+
+
 if __name__ == "__main__":
+    gen_three_nn()
     gen_fps()
     gen_chamfer()
     gen_ballquery()

@@ -212,3 +212,24 @@ def test_chamfer_oracle_matches_reference_distChamfer(name):
     a, b = g["a"].astype(np.float64), g["b"].astype(np.float64)
     pick = ((a - np.take_along_axis(b, i1[..., None].astype(np.int64), 1)) ** 2).sum(-1)
     np.testing.assert_allclose(pick, g["dist_a"], rtol=0, atol=CHAMFER_ATOL)
+
+
+THREE_NN_PINS = ["three_nn_ref_n300_m64_c5.npz", "three_nn_ref_n64_m700_c3.npz"]
+# square_distance (pointnet2_utils.py:19-38) is the expanded form |a|^2 + |b|^2 - 2 a.b in fp32: absolute error a few ulp of 6 on
+# unit-box clouds; interpolate_gpu.cu computes direct differences
+THREE_NN_ATOL = 4e-6
+
+
+def check_three_nn_pin(d2, idx, interp, g):
+    assert np.array_equal(idx, g["idx"])                                  # neighbour choice and ascending order
+    np.testing.assert_allclose(d2, g["dist2"], rtol=0, atol=THREE_NN_ATOL)
+    np.testing.assert_allclose(interp, g["interp"], rtol=1e-5, atol=1e-6)  # weighted gather, fp32 sum of three products
+
+
+@pytest.mark.parametrize("name", THREE_NN_PINS)
+def test_three_nn_and_interpolate_oracle_match_the_reference_torch_path(name):
+    """oracle/pointnet2.c three_nn / three_interpolate == the reference's pure-torch feature-propagation path
+    (square_distance -> sort -> first three; index_points + weighted sum) on tie-free clouds."""
+    g = np.load(os.path.join(GOLDEN, name))
+    d2, idx = opn.three_nn_dist2(g["unknown"], g["known"])
+    check_three_nn_pin(d2, idx, opn.three_interpolate(g["feats"], g["idx"], g["weight"]), g)
