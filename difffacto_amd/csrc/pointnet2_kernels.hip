@@ -141,14 +141,19 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
   for (int i = 0; i < PPT; ++i) {
     const int k = tid + i * NT;
     px[i] = py[i] = pz[i] = 0.f;
-    tmp[i] = 1e10f;  // sampling.cpp:74-76
+    // skipped / absent points: running distance 0 and key 0 — min(d, 0) = 0 keeps both, and their packed value (0 << 32) | 0 is
+    // "no candidate" by itself: no select in the loop (the reference never reads a skipped point's temp entry)
+    tmp[i] = 0.f;
     nkey[i] = 0u;
     if (k < N) {
       px[i] = ds[k * 3 + 0];
       py[i] = ds[k * 3 + 1];
       pz[i] = ds[k * 3 + 2];
       const float mag = sq3(px[i], py[i], pz[i]);
-      if (!(mag <= __uint_as_float(FPS_SKIP_THRESH_BITS))) nkey[i] = (unsigned)(fps_pack(0.f, k, log2bs) & 0xffffffffull);
+      if (!(mag <= __uint_as_float(FPS_SKIP_THRESH_BITS))) {
+        nkey[i] = (unsigned)(fps_pack(0.f, k, log2bs) & 0xffffffffull);
+        tmp[i] = 1e10f;  // sampling.cpp:74-76
+      }
       if (COORDS_LDS) {
         sx[k] = px[i];
         sy[k] = py[i];
@@ -177,9 +182,8 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
     for (int i = 0; i < PPT; ++i) {
       const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
       const float d2 = fminf(d, tmp[i]);
-      // skipped points keep nkey == 0 and their packed value is forced to 0 ("no candidate")
-      tmp[i] = nkey[i] ? d2 : tmp[i];
-      const unsigned long long v = nkey[i] ? (((unsigned long long)__float_as_uint(d2) << 32) | nkey[i]) : 0ull;
+      tmp[i] = d2;
+      const unsigned long long v = ((unsigned long long)__float_as_uint(d2) << 32) | nkey[i];
       best = v > best ? v : best;
     }
     best = wave_max_u64(best);
