@@ -163,3 +163,26 @@ def test_bench_two_ranks_rccl():
         two = _run_bench(2, ["--batch", "4"], {}, os.path.join(d, "two.npy"))
         one = _run_bench(1, ["--batch", "8"], {}, os.path.join(d, "one.npy"))
         assert two["n_gpus"] == 2 and np.array_equal(np.load(os.path.join(d, "one.npy")), np.load(os.path.join(d, "two.npy")))
+
+
+def test_bench_line_contract_single_gpu(tmp_path):
+    """The N = 1 JSON line of bench.py (driver contract + the tier's `roofline` / `cpu_baseline` objects + round 2's `parity` and
+    `t100` blocks) on a reduced run: every key present, numbers finite, the workload named."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--timesteps", "20", "--batch", "32",
+                        "--no-train-line"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity", "t100"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "shapes/s" and d["dtype"] == "bf16" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert "error" not in d["parity"] and d["parity"]["bf16"]["max_abs"] < 3e-3 and d["parity"]["f32"]["max_abs"] < 1e-4   # measured 9.2e-4 / 2.4e-6
+    assert "error" not in d["t100"] and d["t100"]["shapes_per_s"] > 0
