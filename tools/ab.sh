@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B timing of two builds of libdfx on the same box: tools/ab.sh "<extra flags A>" "<extra flags B>" [bench args]
 A="$1"; B="$2"; shift 2
-ARGS=${*:---timesteps 50 --steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${*:---timesteps 50 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-train-line}
 for v in A B A B; do
   if [ $v = A ]; then F="$A"; else F="$B"; fi
   python - <<PY
