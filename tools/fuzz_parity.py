@@ -116,6 +116,12 @@ FAMILIES = [
     ("three_nn / interpolate", lambda a: tp.test_three_nn_interpolate_match_oracle(pu, *a), lambda: (ri(1, 3), ri(1, 2500), ri(3, 3000), ri(1, 20))),
     ("chamfer", lambda a: tp.test_chamfer_matches_oracle(pu, *a), lambda: (ri(1, 3), ri(1, 2500), ri(1, 2500))),
     ("EMD auction", lambda a: te.test_emd_forward_bit_exact_vs_oracle(*a), lambda: (ri(1, 3), ri(8, 1200), ri(1, 80))),
+    # round 2: the bf16 chain kernels' workgroup-size variants and the co-operative latency kernel against each other (bit for bit),
+    # and the fused training feed-forward against the layer-by-layer kernels
+    ("bf16 kernels 8/4/2-wave + co-operative: bit-identical", lambda a: td.test_small_batch_workgroup_sizes_are_bit_identical(W, *a),
+     lambda: (32 * ri(3, 100),)),
+    ("fused vs layer-by-layer training FF", lambda a: tt.test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(*a),
+     lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 3), n))(32 * ri(1, 40))),
 ]
 
 for name in ("test_fps_matches_oracle", "test_ball_query_matches_oracle"):
