@@ -100,7 +100,12 @@ def allreduce_gradients(params, average=True, bucket=None):
         else:
             bucket[off:off + k].copy_(p.grad.reshape(-1))
         off += k
-    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    if _needs_cpu_staging(bucket):   # gloo moves host memory (test configurations; RCCL takes the device bucket as it is)
+        host = bucket.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        bucket.copy_(host)
+    else:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
     if average:
         bucket.div_(dist.get_world_size())
     off = 0

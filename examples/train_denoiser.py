@@ -37,10 +37,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")   # RCCL on ROCm
+        # "nccl" = RCCL on ROCm, one rank per GPU; DFX_BENCH_BACKEND=gloo runs several ranks on one GPU (plumbing test: the flat
+        # gradient bucket is then staged through the host)
+        dist.init_process_group(os.environ.get("DFX_BENCH_BACKEND", "nccl"))
     net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=a.dropout, context_dim=256 + 6,
                n_class=4, class_cond=True, use_linear=True, cat_params_to_x=True, use_checkpoint=False, single_attn=True,
                cat_class_to_x=True)

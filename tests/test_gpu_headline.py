@@ -186,3 +186,19 @@ def test_bench_line_contract_single_gpu(tmp_path):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["parity"] and d["parity"]["bf16"]["max_abs"] < 3e-3 and d["parity"]["f32"]["max_abs"] < 1e-4   # measured 9.2e-4 / 2.4e-6
     assert "error" not in d["t100"] and d["t100"]["shapes_per_s"] > 0
+
+
+def test_data_parallel_training_example_two_ranks_on_one_gpu():
+    """the documented multi-GPU training launch (examples/train_denoiser.py under torch.distributed.run) executed as two
+    ranks sharing the box's GPU (gloo): parameter broadcast of leaf nn.Parameters, one flat gradient all-reduce per iteration,
+    clip + Adam on identical gradients; rank 0 reports every iteration."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, DFX_BENCH_BACKEND="gloo")
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "examples", "train_denoiser.py"), "--iters", "3", "--batch", "4", "--npoints", "256", "--timesteps", "100"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("iter ")]
+    assert len(lines) >= 3 and all("mse_loss" in l and "grad norm" in l for l in lines), r.stdout[-1500:]
