@@ -696,7 +696,8 @@ __device__ __forceinline__ void point_init(const KParams &p, PointState &ps, int
 // What happens to eps after the network: store it (MODE_EPS), or the anchored posterior update
 // (anchored_diffusion.py:306-319,365-367,378-380,401-409,175-213,476-483; reference op order, no contraction)
 // plus the bookkeeping of AnchorDiffAE.decode (anchor_gen.py:160-167).  Returns true when the kernel is done.
-__device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, const float (&eps)[3], int step, int t) {
+__device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, const float (&eps)[3], int step, int t,
+                                              const float *z_ready = nullptr, const float *tab_row = nullptr) {
   const int hf = ps.live ? (threadIdx.x >> 5) & 1 : 1;   // stores are done by half-wave 0 of live wavefronts
   const int s = ps.s, n = ps.n;
   if (p.mode == MODE_EPS) {
@@ -707,7 +708,10 @@ __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, 
     return true;
   }
   float z[3];
-  if (p.noise) {
+  if (z_ready) {   // (co-operative kernel: an idle wavefront has drawn the noise and fetched the table row already)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) z[i] = z_ready[i];
+  } else if (p.noise) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
   } else {
@@ -715,7 +719,7 @@ __device__ __forceinline__ bool step_epilogue(const KParams &p, PointState &ps, 
   }
   {
 #pragma clang fp contract(off)
-    const float *tb = p.d.tab + (size_t)t * 8;
+    const float *tb = tab_row ? tab_row : p.d.tab + (size_t)t * 8;
     const float sra = tb[0], srm1 = tb[1], c1 = tb[2], c2 = tb[3], c3 = tb[4], pv = tb[5];
     const float nz = t != 0 ? 1.0f : 0.0f;
     const bool ddim = p.ddim_n > 0;
@@ -1263,32 +1267,102 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
-// ----------------------------------------------------------------------------------------------
-// Latency kernel for very small batches (a single 2048-point shape = 64 tiles of 32 points): ONE 32-point tile per workgroup,
-// eight wavefronts co-operating on it.  The pipelined kernel gives such a batch 8 .. 32 workgroups and every wavefront walks
-// the whole network alone (87 us per step whatever the workgroup size: M and V slots of one wave are serial).  Here
-//   wave 0 (owner)     holds h for the whole chain: proj_in, LayerNorms, attention, the step epilogue and ALL GEMM2
-//                      accumulations, chunk after chunk in the pipelined kernel's order
-//   waves 1..7         the chunk-independent part: [a | g] = b1 + W1 xn3 and the packed-fp16 GELU for chunks r * 7 + wave - 1,
-//                      r = 0, 1, 2, handed to the owner through LDS (2 KiB per chunk) — and, while the owner works, the staging
-//                      of everything the owner is about to read (attention record, c_t row, block constants, W2) L2 -> LDS,
-//                      so that the one wavefront on the critical path never waits out an L2 round trip
-// with three workgroup barriers per block.  Every floating-point operation is the pipelined kernel's (same device functions,
-// same MFMA order per accumulator), so the results are bit-identical to it.
-//   barrier 0   attention record + c_t + block constants of block b are in LDS (copied during the owner's GEMM2 of block b-1)
-//   barrier 1   xn3 of block b is in LDS, h parked (owner: attention + LayerNorm3; helpers meanwhile: W2 chunks 8..15 -> LDS, W1 round 0 -> registers)
-//   barrier 2   hid of all chunks is in LDS (helpers: three rounds; owner meanwhile: W2 chunks 0..3 -> registers)
-//   then        owner: 16 x GEMM2 (fragments four chunks ahead: chunks 0..7 from L2, 8..15 from LDS; hid one chunk ahead), + b2
-constexpr int COOP_NW = 8, COOP_HELPERS = COOP_NW - 1, COOP_ROUNDS = (FF_CHUNKS + COOP_HELPERS - 1) / COOP_HELPERS;
+// The step boundary runs on one wavefront with nobody to hide its LDS latency behind: the same arithmetic as post_eps /
+// proj_in_prenorm (operation for operation — the results are bit-identical), with the operand reads of a whole 16-channel tile
+// issued ahead of the tile before's arithmetic (hipcc, short of registers over the whole kernel, otherwise reads one operand at a time).
+// (fences: an empty asm that consumes the batch's results and clobbers memory — reads cannot cross it, the arithmetic is tied to it by its
+// data; a sched_barrier alone orders only what instruction selection has already laid out, and that is every read first.)
+#define DFX_TIE8(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7]) :: "memory")
+__device__ __forceinline__ void post_eps_tiles(const v16f (&h)[4], const float4 *wout, const float (&bout)[4], float (&eps)[3]) {
+  float mean, rstd;
+  ln_stats_fast(h, mean, rstd);
+  const float nmr = -mean * rstd;
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  float4 w[2][8];   // half a tile per batch
+#pragma unroll
+  for (int r = 0; r < 8; ++r) w[0][r] = wout[r];
+  asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2) :: "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < 7) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) w[(k + 1) & 1][r] = wout[(k + 1) * 8 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float v = fmaf(h[k >> 1][(k & 1) * 8 + r], rstd, nmr);
+      e0 = fmaf(w[k & 1][r].x, v, e0);
+      e1 = fmaf(w[k & 1][r].y, v, e1);
+      e2 = fmaf(w[k & 1][r].z, v, e2);
+    }
+    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2) :: "memory");
+  }
+  eps[0] = e0 + xhalf(e0) + bout[0];
+  eps[1] = e1 + xhalf(e1) + bout[1];
+  eps[2] = e2 + xhalf(e2) + bout[2];
+}
+
+__device__ __forceinline__ void proj_in_prenorm_tiles(v16f (&h)[4], const float (&x)[3], const float *cpart, const float4 *winx, const float2 *pregb) {
+  float4 w[2][8], cp[2][2];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int r4 = 0; r4 < 2; ++r4) cp[k & 1][r4] = *reinterpret_cast<const float4 *>(cpart + k * 8 + r4 * 4);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[k & 1][r] = winx[k * 8 + r];
+  };
+  fetch(0);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < 7) fetch(k + 1);
+    float o[8];
+#pragma unroll
+    for (int r4 = 0; r4 < 2; ++r4) {
+      const float cpv[4] = {cp[k & 1][r4].x, cp[k & 1][r4].y, cp[k & 1][r4].z, cp[k & 1][r4].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 ww = w[k & 1][r4 * 4 + e];
+        o[r4 * 4 + e] = fmaf(ww.z, x[2], fmaf(ww.y, x[1], fmaf(ww.x, x[0], cpv[e])));
+      }
+    }
+    DFX_TIE8(o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[k >> 1][(k & 1) * 8 + e] = o[e];
+  }
+  float2 gb[2][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) gb[0][r] = pregb[r];
+  float mean, rstd;
+  ln_stats_fast(h, mean, rstd);
+  asm volatile("" : "+v"(mean), "+v"(rstd) :: "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < 7) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) gb[(k + 1) & 1][r] = pregb[(k + 1) * 8 + r];
+    }
+    float o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = fmaf((h[k >> 1][(k & 1) * 8 + r] - mean) * rstd, gb[k & 1][r].x, gb[k & 1][r].y);
+    DFX_TIE8(o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[k >> 1][(k & 1) * 8 + e] = o[e];
+  }
+}
+
+constexpr int COOP_NW = 8, COOP_TILES = 4;
+static_assert(FF_CHUNKS == 2 * COOP_NW, "two rounds of one chunk per wavefront");
 constexpr int COOP_W2_FIRST = 8;                                  // first W2 chunk staged in LDS (the LDS budget holds eight)
 constexpr int CL_XN = 0;                                          // 8 x 64 uint4: LN3 output as the B operand of GEMM1
 constexpr int CL_HID = CL_XN + 8 * 1024;                          // [16][2][64] uint4: GELU output of every chunk
 constexpr int CL_BC = CL_HID + FF_CHUNKS * 2048;                  // 2 x block constants (b1', b2), by block parity
 constexpr int CL_AT = CL_BC + 2 * BCONST_BYTES;                   // attention record (17 KiB) + c_t row (1 KiB)
-constexpr int CL_HS = CL_AT + asms_bytes(DFX_PREC_BF16) + 1024;   // the owner's residual stream h, parked while the helpers work (16 KiB)
+constexpr int CL_HS = CL_AT + asms_bytes(DFX_PREC_BF16) + 1024;   // home of the residual stream h: 4 tiles x 4 KiB, [tile][q][lane] float4
 constexpr int CL_CONST = CL_HS + 16 * 1024;                       // chain-invariant operands: W_in x-columns (2 KiB) | pre_norm (1 KiB) | W_out (2 KiB) | cpart (2 KiB)
 constexpr int CL_W2 = CL_CONST + 7 * 1024;                        // W2 tiles of chunks 8..15 (8 KiB each)
-constexpr int CL_TOTAL = CL_W2 + (FF_CHUNKS - COOP_W2_FIRST) * 8192;
+constexpr int CL_Z = CL_W2 + (FF_CHUNKS - COOP_W2_FIRST) * 8192;   // this step's noise z[3][32] (384 B) | posterior table row (32 B at +512)
+constexpr int CL_PS = CL_Z + 1024;                                 // per-point chain state (x, anchor, variance, L, part id: 13 x 32 floats), home between step boundaries
+constexpr int CL_TOTAL = CL_PS + 2048;
 static_assert(CL_TOTAL <= 160 * 1024, "LDS budget of the co-operative kernel");
 
 __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams p) {
@@ -1306,12 +1380,16 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));
   const int n = (int)(g0 - (long long)s * p.N) + pj;
   const int depth = p.d.depth;
-  const bool owner = wave == 0;
-  PointState ps;
+  const bool w0 = wave == 0, tile_owner = wave < COOP_TILES;
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + CL_PS);
   unsigned vmask = 0;
-  if (owner) point_init(p, ps, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
+  if (w0) {   // (the state would otherwise sit in scratch memory for the whole chain: a global-memory round trip per field at every step boundary)
+    PointState ps0;
+    point_init(p, ps0, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
+    pstate_store(ps_lds, pj, 32, ps0, true);
+  }
   const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC;
-  {   // chain-invariant small operands -> LDS (the owner reads them at every step boundary)
+  {   // chain-invariant small operands -> LDS (wave 0 reads them at every step boundary)
     float4 *c_winx = reinterpret_cast<float4 *>(pipe_smem + CL_CONST);
     float2 *c_pregb = reinterpret_cast<float2 *>(pipe_smem + CL_CONST + 2048);
     float4 *c_wout = reinterpret_cast<float4 *>(pipe_smem + CL_CONST + 3072);
@@ -1324,17 +1402,18 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + CL_CONST) + hf * 64;
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + CL_CONST + 2048) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + CL_CONST + 3072) + hf * 64;
-  const float *cpart = reinterpret_cast<const float *>(pipe_smem + CL_CONST + 5120) + (owner ? ps.sg : 0) * INNER + hf * 64;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
 
-  // One register file for both roles (the compiler cannot overlay two arrays that are live across the same barriers):
-  //   R[32]   helpers: GEMM1 fragments of this round (R[0..15] / R[16..31] alternating) and of the next one, in the accumulation
-  //           order a(c,0) a(c,1) g(c,0) g(c,1), c = 0..3;   owner: W2 fragments of four chunks, R[8 (u & 3) + i]
-  //   h[4]    owner: the residual stream;                     helpers: h[0], h[1] carry the bits of xn3 (8 x uint4)
+  // One register file for every role (one kernel = one register allocation):
+  //   R[32]   phase H: GEMM1 fragments of round 0 (R[0..15]) / round 1 (R[16..31]), in the accumulation order a(c,0) a(c,1) g(c,0)
+  //           g(c,1), c = 0..3;   phase G (tile owners): W2 fragments of chunks 0..7 of the own tile, R[2 u + q]
+  //   h[4]    wave 0, phase A only;   ht   tile owners, phase G only — in between h lives in LDS
   uint4 R[32];
+  // (scalar base + lane offset: with the base pinned to SGPRs the sixteen loads share one address VGPR; left to itself hipcc keeps
+  // 64-bit per-lane addresses, spills them, and every scratch reload — a vector-memory operation like the prefetches in flight —
+  // drains the whole prefetch with s_waitcnt vmcnt(0))
   auto load_w1 = [&](int base, const uint4 *chunks, int u) {
-    // (scalar base + lane offset: with the base pinned to SGPRs the sixteen loads share one address VGPR; left to itself hipcc
-    // keeps 64-bit per-lane addresses, spills them, and every scratch reload — a vector-memory operation like the prefetches
-    // in flight — drains the whole prefetch with s_waitcnt vmcnt(0))
     const uint4 *ck = reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)u * CHUNK_TILES * TSTRIDE))) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1342,137 +1421,191 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
       R[base + 4 * c + 2] = ck[(4 + c) * TSTRIDE], R[base + 4 * c + 3] = ck[(4 + c) * TSTRIDE + 64];
     }
   };
-  // W2 of chunk u sits in FF record u + FF_SKEW, tiles 8..11 (8 KiB contiguous): from L2, or from its LDS copy
-  auto load_w2 = [&](int base, const uint4 *chunks, int u) {
-    const uint4 *ck = u < COOP_W2_FIRST
-                          ? reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + 8 * TSTRIDE))) + lane
-                          : s_w2 + (size_t)(u - COOP_W2_FIRST) * 4 * TSTRIDE + lane;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) R[base + i] = ck[w2_frag(i) - 8 * TSTRIDE];
-  };
-  // helpers: L2 -> LDS staging with LDS-DMA (1 KiB per wave instruction, no registers, asynchronous): piece k of a list goes
-  // to helper wave k % 7
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
-  const unsigned voff = lane * 16;
+  auto xn_frag = [&](int k) -> v8bf { return __builtin_bit_cast(v8bf, s_xn[k][lane]); };   // k-th uint4 of xn3 (tile k >> 1, unit k & 1)
+  // h's LDS home: tile c, quad q of lane l at float4 index (4 c + q) * 64 + l
+  auto hs_ptr = [&](int c, int q) -> v4f * { return reinterpret_cast<v4f *>(s_hs + ((c * 4 + q) * 64 + lane) * 4); };
 
-#ifdef DFX_TRACE   // phase stamps of the owner (row 0 of the trace buffer) and of helper wave 1 (row 1) of workgroup 0
-  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && wave < 2) ? p.trace + (size_t)wave * p.trace_cap : nullptr, p.trace_cap, 0};
+#ifdef DFX_TRACE   // phase stamps of wave 0 (row 0 of the trace buffer) and of wave 5 (row 1) of workgroup 0
+  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 5)) ? p.trace + (size_t)(wave ? 1 : 0) * p.trace_cap : nullptr, p.trace_cap, 0};
 #else
   Tracer tr;
 #endif
-  v16f h[4];
-  auto xn_frag = [&](int k) -> v8bf { return __builtin_bit_cast(v8bf, s_xn[k][lane]); };   // helpers: k-th uint4 of xn3 (tile k >> 1, unit k & 1)
-  // the owner parks h in LDS while the helpers work: its 64 registers are then free for the helpers' fragment double buffer
-  // (one kernel = one register allocation for both roles)
-  auto h_park = [&]() {
+  // proj_in + pre_norm of the chain state -> h's LDS home (wave 0: before the first step and at every step boundary)
+  auto enter_step = [&](const PointState &ps) {
+    v16f h[4];
+    proj_in_prenorm_tiles(h, ps.x, reinterpret_cast<const float *>(pipe_smem + CL_CONST + 5120) + ps.sg * INNER + hf * 64, winx, pregb);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v4f *>(s_hs + ((c * 4 + q) * 64 + lane) * 4) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
+      for (int q = 0; q < 4; ++q) *hs_ptr(c, q) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
   };
-  auto h_unpark = [&]() {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4f x = *reinterpret_cast<const v4f *>(s_hs + ((c * 4 + q) * 64 + lane) * 4);
-        h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
-      }
-  };
+  if (w0) {
+    PointState ps;
+    pstate_load(ps_lds, pj, 32, ps, false);
+    enter_step(ps);
+  }
   int seq = 0;
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = step_t(p, step, s);
-    if (owner) proj_in_prenorm<true>(h, ps.x, cpart, winx, pregb);
     for (int b = 0; b < depth; ++b, ++seq) {
       const BlockPack bp = block_pack(p, b);
       float *s_bc = reinterpret_cast<float *>(pipe_smem + CL_BC + (seq & 1) * BCONST_BYTES);
-      if (!owner) {
-        constexpr int NA = asms_bytes(PREC) / 1024, NB = BCONST_BYTES / 1024;   // 17 + 1 + 5 pieces
+      // ---- top of the block: operands of phase A -> LDS (waves 4..7, which left phase G's barrier first), round-0 fragments requested
+      if (!tile_owner) {
+        constexpr int NA = asms_bytes(PREC) / 1024, NB = BCONST_BYTES / 1024, NH = COOP_NW - COOP_TILES;   // 17 + 1 + 5 pieces over 4 waves
 #pragma unroll
-        for (int i = 0; i < (NA + 1 + NB + COOP_HELPERS - 1) / COOP_HELPERS; ++i) {
-          const int k = i * COOP_HELPERS + wave - 1;
+        for (int i = 0; i < (NA + 1 + NB + NH - 1) / NH; ++i) {
+          const int k = i * NH + wave - COOP_TILES;
           if (k < NA) dma1k_pinned(reinterpret_cast<const char *>(asms_s + (size_t)b * AREC) + k * 1024, voff, lds0 + CL_AT + k * 1024);
           else if (k == NA) dma1k_pinned(reinterpret_cast<const char *>(bp.ct + (size_t)t * CT_ROW), voff, lds0 + CL_AT + NA * 1024);
           else if (k < NA + 1 + NB) dma1k_pinned(reinterpret_cast<const char *>(bp.bconst) + (k - NA - 1) * 1024, voff, lds0 + CL_BC + (seq & 1) * BCONST_BYTES + (k - NA - 1) * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        load_w1(0, bp.chunks, wave - 1);   // round 0: in flight until the helpers' turn
       }
+      load_w1(0, bp.chunks, wave);   // round 0: in flight through phase A
       tr.stamp(10);
-      __syncthreads();   // 0: attention record, c_t, block constants of this block are in LDS
+      __syncthreads();   // 0: attention record, c_t, block constants of this block are in LDS; h's home holds the previous block's result
       tr.stamp(11);
-      if (!owner) {
-        constexpr int NP = (FF_CHUNKS - COOP_W2_FIRST) * 8;   // 64 pieces: W2 tiles of chunks 8..15
+      if (!w0) {         // ---- phase A for the idle waves: W2 tiles of chunks 8..15 -> LDS
+        constexpr int NP = (FF_CHUNKS - COOP_W2_FIRST) * 8, NH = COOP_NW - 1;   // 64 pieces over 7 waves
 #pragma unroll
-        for (int i = 0; i < (NP + COOP_HELPERS - 1) / COOP_HELPERS; ++i) {
-          const int k = i * COOP_HELPERS + wave - 1;
+        for (int i = 0; i < (NP + NH - 1) / NH; ++i) {
+          const int k = i * NH + wave - 1;
           if (k < NP)
             dma1k_pinned(reinterpret_cast<const char *>(bp.chunks + (size_t)(COOP_W2_FIRST + (k >> 3) + FF_SKEW) * CHUNK_TILES * TSTRIDE + 8 * TSTRIDE) + (k & 7) * 1024,
                          voff, lds0 + CL_W2 + k * 1024);
         }
-      } else {
+        if (wave == COOP_NW - 1 && b == depth - 1 && p.mode != MODE_EPS) {   // the step's noise and posterior coefficients, ready for wave 0's epilogue
+          float z[3];
+          if (p.noise) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
+          } else {
+            philox_normal3(p.seed, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, (unsigned)t, 0u, z);
+          }
+          float *s_z = reinterpret_cast<float *>(pipe_smem + CL_Z);
+          if (hf == 0) s_z[pj] = z[0], s_z[32 + pj] = z[1], s_z[64 + pj] = z[2];
+          if (lane < 8) s_z[128 + lane] = p.d.tab[(size_t)t * 8 + lane];
+        }
+      } else {           // ---- phase A: wave 0
+        v16f h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f x = *hs_ptr(c, q);
+            h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
+          }
         const uint4 *rec = s_at + lane;
         attention<PREC>(h, rec, reinterpret_cast<const float *>(s_at + 8 * TSTRIDE) + hf * 16, reinterpret_cast<const float *>(s_at + AREC) + hf * 64, vmask);
         Act<PREC> xo[4];
         ln_to_act<PREC>(h, xo);
 #pragma unroll
         for (int c = 0; c < 4; ++c) s_xn[2 * c][lane] = __builtin_bit_cast(uint4, xo[c].f[0]), s_xn[2 * c + 1][lane] = __builtin_bit_cast(uint4, xo[c].f[1]);
-        h_park();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *hs_ptr(c, q) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
       }
       tr.stamp(12);
-      __syncthreads();   // 1: xn3 of this block is in LDS
+      __syncthreads();   // 1: xn3 of this block and h are in LDS
       tr.stamp(13);
-      if (!owner) {
+      // ---- phase H: every wave, chunks `wave` and `wave + 8`
 #pragma unroll
-        for (int r = 0; r < COOP_ROUNDS; ++r) {
-          const int u = r * COOP_HELPERS + wave - 1;
-          if (u >= FF_CHUNKS) break;   // wave-uniform
-          const int cur = (r & 1) * 16, nxt = 16 - cur;
-          const int un = u + COOP_HELPERS;
-          if (r + 1 < COOP_ROUNDS && un < FF_CHUNKS) load_w1(nxt, bp.chunks, un);
-          v16f a, g;
-          load16(a, s_bc + u * 64 + hf * 16);
-          load16(g, s_bc + u * 64 + hf * 16 + 32);
+      for (int r = 0; r < 2; ++r) {
+        const int u = r * COOP_NW + wave, cur = r * 16;
+        if (r == 0) load_w1(16, bp.chunks, u + COOP_NW);
+        else if (tile_owner) {   // round 0's registers are free: the own tile's W2 fragments of chunks 0..7 (W2 of chunk c sits in FF record c + FF_SKEW, tiles 8..11)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), xn_frag(2 * c), a, 0, 0, 0);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 2]), xn_frag(2 * c), g, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 1]), xn_frag(2 * c + 1), a, 0, 0, 0);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 3]), xn_frag(2 * c + 1), g, 0, 0, 0);
+          for (int c = 0; c < COOP_W2_FIRST; ++c) {
+            const uint4 *ck = reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(bp.chunks + (size_t)(c + FF_SKEW) * CHUNK_TILES * TSTRIDE + (8 + wave) * TSTRIDE))) + lane;
+            R[2 * c] = ck[0], R[2 * c + 1] = ck[64];
           }
-          h2 aa[8], gg[8];
-          HidAct hid;
-          gelu16_f16_cvt(a, g, aa, gg);
-          gelu16_f16_math(aa, gg, hid);
-          s_hid[u][0][lane] = hid.f[0], s_hid[u][1][lane] = hid.f[1];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W2 pieces have landed (long ago: loads complete in order)
-      } else {
+        v16f a, g;
+        load16(a, s_bc + u * 64 + hf * 16);
+        load16(g, s_bc + u * 64 + hf * 16 + 32);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load_w2(8 * u, bp.chunks, u);   // from L2, in flight while the helpers work
+        for (int c = 0; c < 4; ++c) {
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), xn_frag(2 * c), a, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 2]), xn_frag(2 * c), g, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 1]), xn_frag(2 * c + 1), a, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 3]), xn_frag(2 * c + 1), g, 0, 0, 0);
+        }
+        h2 aa[8], gg[8];
+        HidAct hid;
+        gelu16_f16_cvt(a, g, aa, gg);
+        gelu16_f16_math(aa, gg, hid);
+        s_hid[u][0][lane] = hid.f[0], s_hid[u][1][lane] = hid.f[1];
       }
+      if (!w0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W2 pieces have landed (long ago: loads complete in order)
       tr.stamp(14);
       __syncthreads();   // 2: hid of all chunks and the W2 copies are in LDS
       tr.stamp(15);
-      if (owner) {
-        h_unpark();
-        uint4 hq[2][2];   // hid of this chunk / the next one (LDS reads one chunk ahead)
-        hq[0][0] = s_hid[0][0][lane], hq[0][1] = s_hid[0][1][lane];
+      // ---- phase G: wave t accumulates tile t of h, chunk after chunk (the accumulation order of the pipelined kernel), + b2
+      if (tile_owner) {
+        v16f ht;
 #pragma unroll
-        for (int u = 0; u < FF_CHUNKS; ++u) {   // GEMM2 in chunk order: the accumulation order of the pipelined kernel
-          if (u + 1 < FF_CHUNKS) hq[(u + 1) & 1][0] = s_hid[u + 1][0][lane], hq[(u + 1) & 1][1] = s_hid[u + 1][1][lane];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) h[i & 3] = mma_hid(R[8 * (u & 3) + i], hq[u & 1][i >> 2], h[i & 3]);
-          if (u + 4 < FF_CHUNKS) load_w2(8 * (u & 3), bp.chunks, u + 4);
+        for (int q = 0; q < 4; ++q) {
+          const v4f x = *hs_ptr(wave, q);
+          ht[4 * q] = x[0], ht[4 * q + 1] = x[1], ht[4 * q + 2] = x[2], ht[4 * q + 3] = x[3];
         }
-        add_cvec(h, s_bc + BCONST_B2_OFF + hf * 64);
+        // hid / LDS-resident W2 fragments: a ring three chunks deep (one chunk = two dependent MFMAs = less than one LDS round trip),
+        // fenced per chunk — left alone hipcc sinks every read next to its MFMA and the chain runs at LDS latency
+        uint4 hq[4][2], wq[4][2];
+        unsigned hoff = CL_HID + lane * 16, woff = CL_W2 + (wave * TSTRIDE + lane) * 16;
+        asm volatile("" : "+v"(hoff), "+v"(woff));   // one base register each, chunk offsets as immediates
+        const uint4 *hidb = reinterpret_cast<const uint4 *>(pipe_smem + hoff), *w2b = reinterpret_cast<const uint4 *>(pipe_smem + woff);
+        auto fetch = [&](int u) {
+          hq[u & 3][0] = hidb[u * 128], hq[u & 3][1] = hidb[u * 128 + 64];
+          if (u >= COOP_W2_FIRST) wq[u & 3][0] = w2b[(u - COOP_W2_FIRST) * 4 * TSTRIDE], wq[u & 3][1] = w2b[(u - COOP_W2_FIRST) * 4 * TSTRIDE + 64];
+        };
+        fetch(0), fetch(1), fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < FF_CHUNKS; ++u) {
+          if (u + 3 < FF_CHUNKS) fetch(u + 3);
+          const uint4 f0 = u < COOP_W2_FIRST ? R[2 * u] : wq[u & 3][0], f1 = u < COOP_W2_FIRST ? R[2 * u + 1] : wq[u & 3][1];
+          ht = mma_hid(f0, hq[u & 3][0], ht);
+          ht = mma_hid(f1, hq[u & 3][1], ht);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const float *b2 = s_bc + BCONST_B2_OFF + hf * 64 + wave * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f bb = *reinterpret_cast<const v4f *>(b2 + 4 * q);
+            *hs_ptr(wave, q) = v4f{ht[4 * q] + bb[0], ht[4 * q + 1] + bb[1], ht[4 * q + 2] + bb[2], ht[4 * q + 3] + bb[3]};
+          }
+        }
       }
     }
-    if (owner) {
+    tr.stamp(16);
+    __syncthreads();   // the last block's tiles are in h's home
+    tr.stamp(17);
+    if (w0) {
+      v16f h[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f x = *hs_ptr(c, q);
+          h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
+        }
       float eps[3];
-      post_eps<true>(h, wout, p.d.bout, eps);
-      if (step_epilogue(p, ps, eps, step, t)) break;   // (the helpers leave through the loop bound: nsteps = 1 in these modes)
+      post_eps_tiles(h, wout, p.d.bout, eps);
+      tr.stamp(18);
+      PointState ps;
+      ps.s = s, ps.n = n, ps.gid = 0;   // (gid: the noise was drawn by wave 7)
+      pstate_load(ps_lds, pj, 32, ps, true);
+      const float *s_z = reinterpret_cast<const float *>(pipe_smem + CL_Z);
+      const float zr[3] = {s_z[pj], s_z[32 + pj], s_z[64 + pj]};
+      const bool zok = p.mode != MODE_EPS;
+      if (step_epilogue(p, ps, eps, step, t, zok ? zr : nullptr, zok ? s_z + 128 : nullptr)) break;   // (the other waves leave through the loop bound: nsteps = 1 in these modes)
+      tr.stamp(19);
+      pstate_store(ps_lds, pj, 32, ps, false);
+      if (step + 1 < p.nsteps) enter_step(ps);
+      tr.stamp(20);
     }
   }
 }
@@ -1538,19 +1671,31 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
-  // the pipelined kernel works on tiles of NW x 32 points of one shape (a partial last tile idles whole wavefronts) and is ~3x
-  // faster per point than the direct kernel: take it unless the padding of a small shape eats that factor.  NW = 8 when that
-  // gives every CU a workgroup; small batches take 4 or 2 wavefronts per workgroup to spread over more CUs (a single 2048-point
-  // shape: 8 -> 32 workgroups; the per-wave instruction stream and the results are the same)
+  // Which kernel: the pipelined one works on tiles of nw x 32 points of one shape (a partial last tile idles whole wavefronts) with
+  // nw = 8, 4 or 2 wavefronts per workgroup — the per-wave instruction stream and the results are the same, fewer wavefronts spread a
+  // small batch over more CUs; the co-operative one (k_denoise_coop) puts eight wavefronts on ONE 32-point tile.  One workgroup per CU
+  // either way, so a launch runs in rounds of g_num_cus workgroups, and the cheapest estimate wins.  Per-round costs as measured at
+  // N = 2048, T = 1000 (profiles/r02_small_batch_sweep.txt; only their ratios matter): co-operative 32.7 ms, pipelined 86.5 / 88.5 /
+  // 93.5 ms for nw = 2 / 4 / 8, times 1 + 0.36 L^4 for a round that fills the fraction L of the chip's wavefront slots (the power cap).
   auto tiles = [&](int nw) { return (long long)((p.N + nw * 32 - 1) / (nw * 32)); };
+  auto rounds_cost = [&](long long wgs, double base, double fill_per_wg) {
+    const long long full = wgs / g_num_cus, rest = wgs % g_num_cus;
+    auto f = [](double L) { return 1.0 + 0.36 * L * L * L * L; };
+    return base * (full * f(g_num_cus * fill_per_wg) + (rest ? f(rest * fill_per_wg) : 0.0));
+  };
+  const bool bf16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct;
   int nw = PIPE_NW;
-  while (nw > 2 && tiles(nw) * p.B < g_num_cus) nw >>= 1;
+  double best = 1e300;
+  for (int c = 8; c >= 2; c >>= 1) {
+    if (tiles(c) * c * 32 > 3LL * p.N && c > 2) continue;   // padding of a small shape
+    const double cost = rounds_cost(tiles(c) * p.B, c == 8 ? 93.5 : c == 4 ? 88.5 : 86.5, c / (8.0 * g_num_cus));
+    if (cost < best) best = cost, nw = c;
+  }
   if (g_force_nw > 1) nw = g_force_nw;
   const long long wpg = tiles(nw);
-  const bool pipe = d->dev.prec == DFX_PREC_BF16 && wpg * nw * 32 <= 3LL * p.N && !g_force_direct;
-  // very small batches: one 32-point tile per workgroup, eight wavefronts co-operating on it (k_denoise_coop), while that still
-  // gives every workgroup a CU of its own (a second round would double the latency again)
-  const bool coop = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && (g_force_nw == 1 || (g_force_nw == 0 && waves <= g_num_cus));
+  // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
+  const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
+  const bool coop = bf16 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
   if (pipe || coop) {
     static bool attr_set = false;
     if (!attr_set) {
