@@ -7,7 +7,10 @@
 // 1024-wide [a | g] and the 512-wide hidden activation live in accumulator registers one 32-unit chunk at a time and never
 // touch HBM in the forward.  The layer-by-layer path wrote [a | g] (2 KB / point), hid (1 KB), d hid (2 KB) and d[a | g]
 // (2 KB) per block and read each of them back once or twice: ~22 KB per point and block; this path moves 1.3 KB (forward)
-// + 4.3 KB (backward: hid and d[a | g] are still written once, as bf16, for the weight-gradient products) = 4x less.
+// + 1.5 KB (backward: dh1 and, for the weight-gradient kernel, the tile's xn3 / dh as bf16 MFMA fragments in both orientations).
+// The weight gradients come from a second, weight-stationary kernel (k_ff_wgrad below) that recomputes hid and d[a | g] from
+// those fragments instead of reading them back: a sum over the points needs the points on the K axis of the MFMA, i.e. along
+// the registers, and here they are on the lanes.
 //
 // Weights: per optimiser step the block's W1 / W2 are re-packed (k_ff_pack) as bf16 MFMA A-fragments, 24 tiles of 32 x 32 per
 // hidden chunk (48 KiB): W1a, W1g (K = channels, natural order: the B operand comes from memory), W2 (K = hidden units in the
@@ -90,15 +93,18 @@ __global__ void k_ff_pack(PackArgs a) {
 struct FfArgs {
   const uint4 *frags;
   const float *b1p, *b2p;
-  const __bf16 *xn3;     // (R, 128) bf16
-  const float *h1;       // forward: (R, 128) residual input
+  const float *g3, *b3;  // LayerNorm3 affine: xn3 = LN3(h1) is computed here, forward and backward
+  const float *h1;       // (R, 128) input of the sub-block (behind the attention)
   float *h2;             // forward: (R, 128) output (may alias h1)
   const float *dh;       // backward: (R, 128) gradient at the block output
-  __bf16 *hid;           // backward: (R, 512) bf16
-  __bf16 *dag;           // backward: (R, 1024) bf16, [da | dg]
-  float *dxn;            // backward: (R, 128) fp32
+  uint4 *pk;             // backward: [R / 32][4][4][2][64] the tile's xn3 / dh as MFMA fragments and their transposes, for k_ff_wgrad
+  float *dh1;            // backward: (R, 128) gradient at h1 = dh + LN3'(W1^T d[a | g])
+  float *cpart;          // backward: [workgroups][3][128] column sums for d gamma3, d beta3, d b2
   long long R;           // multiple of 32
 };
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+constexpr float LN_EPS = 1e-5f;
 
 __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
@@ -119,6 +125,56 @@ __device__ __forceinline__ void load16(v16f &v, const float *src) {
     v[4 * q + 0] = t[0], v[4 * q + 1] = t[1], v[4 * q + 2] = t[2], v[4 * q + 3] = t[3];
   }
 }
+// This lane's row of h in the B-operand layout (8 consecutive channels 32 c + 16 u + 8 hf .. per (c, u)), LayerNorm statistics
+// (two passes like torch) and the normalised, affine row as bf16 fragments.  gb = LDS table [gamma(128) | beta(128)].
+__device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
+  v8f x[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float *p = hrow + 32 * c + k_nat(u, hf, 0);
+      const v4f lo = *reinterpret_cast<const v4f *>(p), hi = *reinterpret_cast<const v4f *>(p + 4);
+      x[c][u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[c][u][e];
+  s += xhalf(s);
+  mu = s * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = x[c][u][e] - mu;
+        q = fmaf(d, d, q);
+      }
+  q += xhalf(q);
+  rstd = 1.0f / sqrtf(q * (1.0f / C) + LN_EPS);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ch = 32 * c + k_nat(u, hf, 0);
+      const v4f g0 = *reinterpret_cast<const v4f *>(gb + ch), g1 = *reinterpret_cast<const v4f *>(gb + ch + 4);
+      const v4f b0 = *reinterpret_cast<const v4f *>(gb + C + ch), b1 = *reinterpret_cast<const v4f *>(gb + C + ch + 4);
+      v8f y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = fmaf((x[c][u][e] - mu) * rstd, g0[e], b0[e]);
+        y[4 + e] = fmaf((x[c][u][4 + e] - mu) * rstd, g1[e], b1[e]);
+      }
+      xn[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
+    }
+}
+
 // x * sigmoid(k(x)), k(x) = x (c1 + c3 x^2); returns gelu and d gelu / dx
 __device__ __forceinline__ void gelu_fd(float x, float &f, float &d) {
   const float x2 = x * x;
@@ -133,7 +189,9 @@ __device__ __forceinline__ float gelu_f(float x) {
 }
 
 constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
-constexpr int TILE_ROW = 80, TILE_BYTES = 32 * TILE_ROW;   // per-wave transposition tile of the backward's stores
+// per 32-point tile, for k_ff_wgrad: four sets of fragments [4 c][2 u][64 lanes] (8 KiB each)
+enum { PK_XN = 0, PK_DH = 1, PK_XNT = 2, PK_DHT = 3 };
+constexpr int PK_TILE_U4 = 4 * 8 * 64;   // 32 KiB
 constexpr int NW = 8;     // wavefronts per workgroup (256 points, one workgroup per CU)
 constexpr int NBUF = 3;   // LDS chunk buffers: the stream runs two chunks ahead of the compute
 // (measured, B = 128 x 2048, backward / forward per block: 8 waves x 3 buffers 441 / 161 us; 4 waves x 2 buffers, two workgroups
@@ -173,12 +231,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
   stage_chunk<BWD>(a.frags, 0, lds0, wave, voff);
   if (NBUF > 2) stage_chunk<BWD>(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
 
-  // B operand of the products over the channels: xn3 (bf16, natural K order) and, backward, dh rounded to bf16
+  // b1 of all chunks and LayerNorm3's affine -> LDS: inside the loop every operand must come from LDS — vector-memory loads
+  // complete in order, so a global load issued behind a chunk's LDS-DMA pieces could only be consumed after those pieces had
+  // landed as well, and the stream would never run ahead
+  float *b1s = reinterpret_cast<float *>(ff_smem + NBUF * BUF_BYTES);
+  float *gbs = b1s + B1P_FLOATS;
+  for (int i = threadIdx.x; i < B1P_FLOATS; i += NW * 64) b1s[i] = a.b1p[i];
+  for (int i = threadIdx.x; i < 2 * C; i += NW * 64) gbs[i] = i < C ? a.g3[i] : a.b3[i - C];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first NBUF - 1 chunks have landed (one-off)
+  __syncthreads();
+  // B operand of the products over the channels: xn3 = LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   uint4 xn[4][2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) xn[c][u] = *reinterpret_cast<const uint4 *>(a.xn3 + row * C + 32 * c + k_nat(u, hf, 0));
+  float mu, rstd;
+  ln_rows(a.h1 + row * C, hf, gbs, xn, mu, rstd);
   uint4 dhb[4][2];
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
   if (BWD) {
@@ -195,6 +260,31 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    // the tile for k_ff_wgrad: xn3 and dh as they are (B-operand fragments, points on the lanes) and turned around (channels on the
+    // lanes, points along the registers) by the matrix unit itself — a product with a 0/1 selection matrix, exact
+    if (live) {
+      uint4 sel[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        __bf16 o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(pj == 16 * u + 8 * hf + e ? 1.0f : 0.0f);
+        sel[u] = *reinterpret_cast<const uint4 *>(o);
+      }
+      uint4 *pk = a.pk + (size_t)((row - pj) / 32) * PK_TILE_U4 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
+        pk[(PK_DH * 8 + c * 2 + 0) * 64] = dhb[c][0], pk[(PK_DH * 8 + c * 2 + 1) * 64] = dhb[c][1];
+        v16f z, t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        t = mfma(xn[c][1], sel[1], mfma(xn[c][0], sel[0], z));
+        pk[(PK_XNT * 8 + c * 2 + 0) * 64] = pack8(t, 0), pk[(PK_XNT * 8 + c * 2 + 1) * 64] = pack8(t, 1);
+        t = mfma(dhb[c][1], sel[1], mfma(dhb[c][0], sel[0], z));
+        pk[(PK_DHT * 8 + c * 2 + 0) * 64] = pack8(t, 0), pk[(PK_DHT * 8 + c * 2 + 1) * 64] = pack8(t, 1);
+      }
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -208,36 +298,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
       }
     }
   }
-  // b1 of all chunks -> LDS: inside the loop every operand must come from LDS — vector-memory loads complete in order, so a
-  // global load issued behind a chunk's LDS-DMA pieces could only be consumed after those pieces had landed as well, and the
-  // stream would never run ahead
-  // b1 of all chunks -> LDS: inside the loop every operand must come from LDS — vector-memory loads complete in order, so a
-  // global load issued behind a chunk's LDS-DMA pieces could only be consumed after those pieces had landed as well, and the
-  // stream would never run ahead
-  float *b1s = reinterpret_cast<float *>(ff_smem + NBUF * BUF_BYTES);
-  for (int i = threadIdx.x; i < B1P_FLOATS; i += NW * 64) b1s[i] = a.b1p[i];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first NBUF - 1 chunks have landed (one-off)
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's loads and stores are done: the loop counts only LDS-DMA pieces (+ the backward's tile stores)
 
-  // backward: hid / d[a | g] leave through a per-wave LDS tile (32 points x 32 units bf16, rows padded to 80 B) that turns the
-  // accumulator layout (a lane holds four scattered 8-byte pieces of its point's row) into row-major 16-byte pieces: four
-  // consecutive lanes then write one point's 64 contiguous bytes and a store instruction covers 16 whole row segments.  Written
-  // straight from the accumulator layout — twelve 8-byte stores per chunk, 16 contiguous bytes per point and instruction — these
-  // stores were HALF of the kernel's time (timing ablation without them: 434 -> 225 us per block).
-  unsigned char *tile = ff_smem + NBUF * BUF_BYTES + B1P_FLOATS * 4 + wave * TILE_BYTES;
-  auto store_tile = [&](const v16f &x, __bf16 *dst, int ld, int col0) {   // dst[(row) * ld + col0 + unit]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4f t = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-      *reinterpret_cast<v4bf *>(tile + pj * TILE_ROW + (8 * q + 4 * hf) * 2) = __builtin_convertvector(t, v4bf);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int r = (lane >> 2) + 16 * k, sg = lane & 3;
-      const uint4 v = *reinterpret_cast<const uint4 *>(tile + r * TILE_ROW + sg * 16);
-      if (live) *reinterpret_cast<uint4 *>(dst + (row - pj + r) * ld + col0 + sg * 8) = v;
-    }
-  };
 #pragma unroll 1
   for (int j = 0; j < NCHUNK; ++j) {
     if (j + NBUF - 1 < NCHUNK) stage_chunk<BWD>(a.frags, j + NBUF - 1, lds0 + ((j + NBUF - 1) % NBUF) * BUF_BYTES, wave, voff);   // slot of chunk j - 1: every wave is past it
@@ -273,19 +335,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) dhid = mfma(frag(T_W2T + c, u), dhb[c][u], dhid);
-      // ---- GEGLU backward on the registers; hid and d[a | g] go out as bf16 for the weight-gradient products ----
-      v16f hv, da, dg;
+      // ---- GEGLU backward on the registers ----
+      v16f da, dg;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float f, d;
         gelu_fd(gv[r], f, d);
-        hv[r] = av[r] * f;
         da[r] = dhid[r] * f;
         dg[r] = dhid[r] * av[r] * d;
       }
-      store_tile(hv, a.hid, FH, 32 * j);
-      store_tile(da, a.dag, 2 * FH, 32 * j);
-      store_tile(dg, a.dag, 2 * FH, FH + 32 * j);
       // ---- dxn3 += W1a^T da + W1g^T dg ----
       const uint4 a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
 #pragma unroll
@@ -302,13 +360,227 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!live) return;
-  float *out = (BWD ? a.dxn : a.h2) + row * C;
+  if (!BWD) {
+    if (!live) return;
+    float *out = a.h2 + row * C;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v4f *>(out + 32 * c + 8 * q + 4 * hf) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+    return;
+  }
+  // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
+  // - xhat mean(dy g xhat)), and the column sums of dy xhat / dy over the workgroup's points for d gamma3 / d beta3 ----
+  // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
+  // [channel][point] from the accumulator layout, read back 16 points of one channel per lane.
+  v16f xh[4];
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<v4f *>(out + 32 * c + 8 * q + 4 * hf) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * c + 8 * q + 4 * hf;
+      const v4f x = *reinterpret_cast<const v4f *>(a.h1 + row * C + ch), g = *reinterpret_cast<const v4f *>(gbs + ch);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        xh[c][4 * q + m] = (x[m] - mu) * rstd;
+        const float dg = acc[c][4 * q + m] * g[m];
+        s1 += dg;
+        s2 = fmaf(dg, xh[c][4 * q + m], s2);
+      }
+    }
+  s1 += xhalf(s1), s2 += xhalf(s2);
+  s1 *= (1.0f / C), s2 *= (1.0f / C);
+  constexpr int TROW = 36;   // floats per tile row: 16-byte aligned rows, conflict-free column reads
+  float *tt = reinterpret_cast<float *>(ff_smem) + wave * 32 * TROW;
+  float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][3][128]
+  const float keep = live ? 1.f : 0.f;
+  auto colsum = [&](const v16f &v, int which, int c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tt[rho(r, hf) * TROW + pj] = v[r];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const v4f x = *reinterpret_cast<const v4f *>(tt + pj * TROW + 16 * hf + 4 * k);
+      t += (x[0] + x[1]) + (x[2] + x[3]);
+    }
+    t += xhalf(t);
+    if (hf == 0) cred[(wave * 3 + which) * C + 32 * c + pj] = t * keep;
+  };
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    v16f dv, gx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * c + 8 * q + 4 * hf;
+      const v4f d = *reinterpret_cast<const v4f *>(a.dh + row * C + ch), g = *reinterpret_cast<const v4f *>(gbs + ch);
+      v4f o;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int r = 4 * q + m;
+        dv[r] = d[m];
+        gx[r] = acc[c][r] * xh[c][r];
+        o[m] = d[m] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
+      }
+      if (live) *reinterpret_cast<v4f *>(a.dh1 + row * C + ch) = o;
+    }
+    colsum(gx, 0, c);
+    colsum(acc[c], 1, c);
+    colsum(dv, 2, c);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += cred[(w * 3 + threadIdx.x / C) * C + threadIdx.x % C];
+    a.cpart[(size_t)blockIdx.x * 3 * C + threadIdx.x] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradients of the feed-forward, weight-stationary:  dW1 = d[a | g]^T xn3 (1024 x 128),  dW2 = dh^T hid (128 x 512),
+// d b1 = column sums of d[a | g].  One wavefront owns ONE 32-unit chunk of the hidden layer for a slab of rows: its W1a / W1g /
+// W2 fragments (96 registers) and its twelve 32 x 32 gradient tiles (192 accumulator registers) stay in registers while the
+// slab's 32-point tiles stream by (32 KiB each, written by k_ff<true>, L2 -> LDS with LDS-DMA, shared by the workgroup's four
+// wavefronts = four chunks).  Per tile and wavefront, everything with the chunk's units on the lanes and the 32 points along
+// the registers (the transposed orientation: activations as the A operand, weights as B):
+//     a^T, g^T = xn3 W1^T + b1 (16 MFMAs)   d hid^T = dh W2 (8)   GEGLU forward / backward on the registers
+//     dW2^T chunk += hid^T dh (8)   dW1a += da^T xn3 (8)   dW1g += dg^T xn3 (8)            K = the 32 points
+// 1 wavefront per SIMD with up to 512 registers (the accumulators sit in the AGPR half).  Partials per (slab, chunk) are summed by
+// k_ff_wgrad_finish in slab order.
+struct FwArgs {
+  const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
+  const float *b1;       // (1024)
+  const uint4 *pk;       // [R / 32][4][4][2][64]
+  float *part;           // [nslab][NCHUNK][12][16][64] fp32 gradient tiles in accumulator layout
+  float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
+  long long ntiles;      // R / 32
+  int nslab;
+};
+constexpr int WG_NW = 4;
+__global__ __launch_bounds__(WG_NW * 64, 1) void k_ff_wgrad(FwArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 2 x 32 KiB
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pj = lane & 31;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)fw_smem);
+  const unsigned voff = lane * 16;
+  const int cg = blockIdx.x % (NCHUNK / WG_NW), slab = blockIdx.x / (NCHUNK / WG_NW), j = cg * WG_NW + wave;
+  const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
+  // this chunk's weights as B operands
+  uint4 w1a[4][2], w1g[4][2], w2t[4][2];
+  {
+    const uint4 *fr = a.frags + (size_t)j * CHUNK_U4 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        w1a[c][u] = fr[((T_W1A + c) * 2 + u) * 64];
+        w1g[c][u] = fr[((T_W1G + c) * 2 + u) * 64];
+        w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
+      }
+  }
+  const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
+  v16f dW2[4], dWa[4], dWg[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW2[c][r] = 0.f, dWa[c][r] = 0.f, dWg[c][r] = 0.f;
+  float sa = 0.f, sg = 0.f;
+  auto stage = [&](long long t, int buf) {   // 32 KiB tile -> LDS, eight 1 KiB pieces per wavefront
+    const char *src = reinterpret_cast<const char *>(a.pk + (size_t)t * PK_TILE_U4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dma1k(src + (wave * 8 + k) * 1024, voff, lds0 + buf * 32768 + (wave * 8 + k) * 1024);
+  };
+  if (t0 < t1) stage(t0, 0);
+  for (long long t = t0; t < t1; ++t) {
+    const int buf = (int)((t - t0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile t has landed; every wavefront is done with tile t - 1 (the other buffer)
+    if (t + 1 < t1) stage(t + 1, buf ^ 1);
+    const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + buf * 32768) + lane;
+    auto frag = [&](int kind, int c, int u) -> uint4 { return tl[(kind * 8 + c * 2 + u) * 64]; };
+    v16f av, gv, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 x = frag(PK_XN, c, u);
+        av = mfma(x, w1a[c][u], av);
+        gv = mfma(x, w1g[c][u], gv);
+        dv = mfma(frag(PK_DH, c, u), w2t[c][u], dv);
+      }
+    v16f hv, da, dg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float f, d;
+      gelu_fd(gv[r], f, d);
+      hv[r] = av[r] * f;
+      da[r] = dv[r] * f;
+      dg[r] = dv[r] * av[r] * d;
+      sa += da[r], sg += dg[r];
+    }
+    const uint4 h0 = pack8(hv, 0), h1 = pack8(hv, 1), a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint4 x0 = frag(PK_XNT, c, 0), x1 = frag(PK_XNT, c, 1), d0 = frag(PK_DHT, c, 0), d1 = frag(PK_DHT, c, 1);
+      dW2[c] = mfma(h1, d1, mfma(h0, d0, dW2[c]));
+      dWa[c] = mfma(a1, x1, mfma(a0, x0, dWa[c]));
+      dWg[c] = mfma(g1, x1, mfma(g0, x0, dWg[c]));
+    }
+  }
+  float *out = a.part + ((size_t)slab * NCHUNK + j) * 12 * 1024 + lane;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      out[((0 + c) * 16 + r) * 64] = dW2[c][r];
+      out[((4 + c) * 16 + r) * 64] = dWa[c][r];
+      out[((8 + c) * 16 + r) * 64] = dWg[c][r];
+    }
+  sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
+  if (lane < 32) {
+    float *bo = a.bpart + ((size_t)slab * NCHUNK + j) * 64;
+    bo[pj] = sa, bo[32 + pj] = sg;
+  }
+}
+// sums the slabs in order and scatters the tiles: gradient tile (which, c) of chunk j, register r, lane (i, hf) = unit rho(r, hf) of the
+// chunk, channel 32 c + i
+struct FwFinishArgs {
+  const float *part, *bpart;
+  float *dw1, *db1, *dw2;   // (1024, 128), (1024), (128, 512)
+  int nslab;
+};
+__global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // over NCHUNK * 12 * 1024 tile elements, then NCHUNK * 64 bias sums
+  constexpr int NT = NCHUNK * 12 * 1024;
+  if (idx < NT) {
+    float t = 0.f;
+    for (int s = 0; s < a.nslab; ++s) t += a.part[(size_t)s * NT + idx];
+    const int lane = idx & 63, r = (idx >> 6) & 15, tile = (idx >> 10) % 12, j = idx / (12 * 1024);
+    const int unit = 32 * j + rho(r, lane >> 5), ch = 32 * (tile & 3) + (lane & 31);
+    if (tile < 4) a.dw2[(size_t)ch * FH + unit] = t;
+    else a.dw1[(size_t)((tile < 8 ? 0 : FH) + unit) * C + ch] = t;
+  } else if (idx < NT + NCHUNK * 64) {
+    const int k = idx - NT, j = k >> 6, p = (k >> 5) & 1, i = k & 31;
+    float t = 0.f;
+    for (int s = 0; s < a.nslab; ++s) t += a.bpart[(size_t)s * NCHUNK * 64 + k];
+    a.db1[p * FH + 32 * j + i] = t;
+  }
+}
+inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
+inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &f) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return -1;
+    attr_set = true;
+  }
+  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_NW), WG_NW * 64, 65536, st>>>(a);
+  const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
+  k_ff_wgrad_finish<<<(total + 255) / 256, 256, 0, st>>>(f);
+  return 0;
 }
 
 inline size_t pack_bytes_frags() { return (size_t)NCHUNK * CHUNK_U4 * sizeof(uint4); }
@@ -319,7 +591,7 @@ inline void launch_pack(hipStream_t st, const PackArgs &a) {
 }
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) {
-  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + B1P_FLOATS * 4 + (BWD ? NW * TILE_BYTES : 0);
+  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

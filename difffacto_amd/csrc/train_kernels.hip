@@ -16,7 +16,7 @@
 //                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
 #include "dfx_common.h"
 #include "gemm_bf16.h"
-#include "train_ff_fused.h"
+#include "train_attn_fused.h"
 #include "mfma_linear.h"
 
 namespace {
@@ -185,6 +185,31 @@ __global__ __launch_bounds__(1024) void k_sum_parts(const float *__restrict__ pa
     float t = red[0][threadIdx.x];
     for (int k = 1; k < G; ++k) t += red[k][threadIdx.x];
     out[c] = t;
+  }
+}
+
+// The same for up to four outputs of `cols` columns each that sit side by side in the partial rows (part[p][which * cols + c]):
+// one launch for e.g. (d gamma, d beta, d bias); four independent partial sums per thread keep the loads in flight.
+struct SumOuts {
+  float *o[4];
+};
+__global__ __launch_bounds__(1024) void k_sum_parts_multi(const float *__restrict__ part, SumOuts outs, int nparts, int cols, int ld_part) {
+  __shared__ float red[32][32];
+  const int per = cols / 32, which = blockIdx.x / per, c = (blockIdx.x % per) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  const float *src = part + which * cols + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = q;
+  for (; p + 96 < nparts; p += 128) {
+    a0 += src[(size_t)p * ld_part], a1 += src[(size_t)(p + 32) * ld_part];
+    a2 += src[(size_t)(p + 64) * ld_part], a3 += src[(size_t)(p + 96) * ld_part];
+  }
+  for (; p < nparts; p += 32) a0 += src[(size_t)p * ld_part];
+  red[q][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0) {
+    float t = red[0][threadIdx.x];
+    for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
+    outs.o[which][c] = t;
   }
 }
 
@@ -940,6 +965,13 @@ struct TrainWs {
   // fused feed-forward (train_ff_fused.h): the block's W1 / W2 as bf16 MFMA fragments, re-packed by every forward
   uint4 *ff_frags[DFX_MAX_DEPTH];
   float *ff_b1p[DFX_MAX_DEPTH], *ff_b2p[DFX_MAX_DEPTH];
+  // fused attention (train_attn_fused.h): per shape the folded (A_s, M_s) fragments of each block; gradient partials
+  uint4 *at_frags[DFX_MAX_DEPTH];
+  float *at_part, *at_sum, *cpart;
+  int at_split;
+  // weight-stationary feed-forward gradients (k_ff_wgrad): per-slab partial tiles
+  float *ffw_part, *ffw_bpart;
+  int ffw_slabs;
 };
 
 constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab (64 for the few-row products over the context tokens / the batch)
@@ -1012,13 +1044,24 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
     w.ff_b1p[i] = c.take<float>(dfx::ffused::B1P_FLOATS);
     w.ff_b2p[i] = c.take<float>(dfx::ffused::B2P_FLOATS);
   }
+  for (int i = 0; i < depth; ++i) w.at_frags[i] = c.take<uint4>((size_t)B * dfx::afused::SHAPE_U4);
+  w.at_split = dfx::afused::param_split(B, N);
+  w.at_part = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
+  w.at_sum = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
+  {
+    const size_t groups = (R / 32 + dfx::ffused::NW - 1) / dfx::ffused::NW, a = groups * 3 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
+    w.cpart = c.take<float>(a > b ? a : b);
+  }
+  w.ffw_slabs = dfx::ffused::wgrad_slabs((long long)(R / 32));
+  w.ffw_part = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
+  w.ffw_bpart = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
   return c.off;
 }
 
 // Fused feed-forward kernels (train_ff_fused.h) for bf16 products without dropout; dfx_debug_train_fused(0) restores the
 // layer-by-layer path (A/B timing, and the reference for the fused path's own test).
 bool g_ff_fused = true;
-inline bool ff_fused(bool bf, float dropout_p, long long R) { return g_ff_fused && bf && dropout_p == 0.f && R % 32 == 0; }
+inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return g_ff_fused && bf && dropout_p == 0.f && R % 32 == 0 && N % 32 == 0; }
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
 thread_local int g_prec = DFX_PREC_F32;
@@ -1353,13 +1396,31 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     const dfx_block_weights &bw = wt->blk[i];
     BlockAct &a = w.blk[i];
     float *hout = i + 1 < wt->depth ? w.blk[i + 1].hin : w.hfin;
-    if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
-    else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
-    if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C, nullptr, 0, bf))) return rc;
+    const bool fused = ff_fused(bf, dropout_p, R, N);
+    if (!fused) {
+      if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+      else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+      if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C, nullptr, 0, bf))) return rc;
+    }
     k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_k, w.wpad, C, CTX, CTXP);
     if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.k, C, BJ, C, CTXP))) return rc;
     k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_v, w.wpad, C, CTX, CTXP);
     if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
+    if (fused) {
+      // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
+      // q, P, att, xn2, xn3, [a | g], hid never exist in memory
+      dfx::afused::k_attn_fold<<<B, 256, 0, st>>>(a.k, a.v, bw.to_q, bw.to_out_w, w.at_frags[i]);
+      dfx::afused::AttnArgs aa{};
+      aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
+      aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
+      dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
+      dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
+      dfx::ffused::FfArgs fa{};
+      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
+      fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
+      if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
+      continue;
+    }
     if (bf) k_attn_fwd<true><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
     else k_attn_fwd<false><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
     if (dropout_p > 0.f) {   // h1 = dropout(att Wo^T + bo) + hin   (attention.py:177: to_out = Sequential(Linear, Dropout))
@@ -1368,14 +1429,6 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     } else if ((rc = lin(st, a.att, C, bw.to_out_w, bw.to_out_b, a.h1, C, R, C, C, a.hin, C, bf))) return rc;
     if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
     else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.h1, bw.norm3_w, bw.norm3_b, a.xn3, a.st3, R);
-    if (ff_fused(bf, dropout_p, R)) {   // [a | g] and hid stay in registers: h_out = h1 + W2 (a gelu(g)) + b2
-      dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
-      dfx::ffused::FfArgs fa{};
-      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i];
-      fa.xn3 = reinterpret_cast<const __bf16 *>(a.xn3), fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
-      if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
-      continue;
-    }
     if ((rc = lin(st, a.xn3, C, bw.ff0_w, bw.ff0_b, a.ag, 2 * FH, R, 2 * FH, C, nullptr, 0, bf, bf && AG_BF16))) return rc;
     const Drop dff{dropout_p, dropout_seed, (unsigned)(2 * i + 1)};
     if (bf) k_geglu_fwd<true><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH, dff);
@@ -1415,16 +1468,40 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
     BlockAct &a = w.blk[i];
     // feed-forward: h2 = h1 + W2 hid + b2, hid = a gelu(g), [a | g] = W1 xn3 + b1
-    if (ff_fused(bf, dropout_p, R)) {
-      // one pass over the points: [a | g] recomputed from xn3, d hid = W2^T dh, GEGLU backward, dxn3 = W1^T d[a | g]; hid and
-      // d[a | g] leave the kernel once, as bf16, for the two weight-gradient products
+    const bool fused = ff_fused(bf, dropout_p, R, N);
+    if (fused) {
+      // one pass over the points: xn3 = LN3(h1) and [a | g] recomputed, d hid = W2^T dh, GEGLU backward, dxn3 = W1^T d[a | g], LayerNorm3
+      // backward -> dh1; hid, d[a | g] and xn3 leave the kernel once, as bf16, for the two weight-gradient products
       dfx::ffused::FfArgs fa{};
-      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i];
-      fa.xn3 = reinterpret_cast<const __bf16 *>(a.xn3), fa.dh = w.dh, fa.hid = reinterpret_cast<__bf16 *>(a.hid);
-      fa.dag = reinterpret_cast<__bf16 *>(w.dwide), fa.dxn = w.dh2, fa.R = R;
+      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
+      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R;
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
-      if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, true))) return rc;
-      if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, true, true))) return rc;
+      const int groups = (int)((R / 32 + dfx::ffused::NW - 1) / dfx::ffused::NW);
+      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
+      // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide
+      {
+        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part, w.ffw_bpart, R / 32, w.ffw_slabs};
+        dfx::ffused::FwFinishArgs wf{w.ffw_part, w.ffw_bpart, mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs};
+        if (dfx::ffused::launch_ff_wgrad(st, wa, wf)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
+      }
+      // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
+      dfx::afused::AttnArgs aa{};
+      aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
+      aa.h = a.hin, aa.dh1 = w.dh2, aa.dh = w.dh, aa.part = w.at_part, aa.cpart = w.cpart, aa.N = N, aa.split = w.at_split, aa.R = R;
+      dfx::afused::k_attn_bwd_param<<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
+      const int np = dfx::afused::dx_groups(R);
+      dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
+      dfx::afused::UnfoldArgs ua{w.at_part, a.k, a.v, bw.to_q, bw.to_out_w, w.dk, w.dv, mut(gw.to_q), mut(gw.to_out_w), w.at_sum, B, w.at_split};
+      {
+        static bool attr_set = false;
+        if (!attr_set) {
+          DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dfx::afused::k_attn_unfold_kv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C * (C + 1) * sizeof(float))));
+          attr_set = true;
+        }
+      }
+      dfx::afused::k_attn_unfold_kv<<<B, 512, C * (C + 1) * sizeof(float), st>>>(ua);
+      dfx::afused::k_attn_unfold_w<<<C, 1024, 0, st>>>(ua);
+      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
     } else {
     if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
@@ -1435,7 +1512,6 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = wgrad(st, w, w.dwide, 2 * FH, a.xn3, C, mut(gw.ff0_w), mut(gw.ff0_b), 2 * FH, C, C, R, bf, bf))) return rc;
     transpose(st, bw.ff0_w, w.wT, 2 * FH, C);                                // (128, 1024)
     if ((rc = lin(st, w.dwide, 2 * FH, w.wT, nullptr, w.dh2, C, R, C, 2 * FH, nullptr, 0, bf))) return rc;
-    }
     if ((rc = ln_bwd(st, w, w.dh2, a.h1, a.st3, bw.norm3_w, w.dh, w.dh, mut(gw.norm3_w), mut(gw.norm3_b), R))) return rc;
     // attention: h1 = hin + Wo att + bo
     const float *dho = w.dh;   // gradient at the output of to_out: dh behind the dropout
@@ -1454,6 +1530,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     transpose(st, bw.to_q, w.wT, C, C);
     if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C, nullptr, 0, bf))) return rc;
     if ((rc = ln_bwd(st, w, w.dh2, a.hin, a.st2, bw.norm2_w, w.dh, w.dh, mut(gw.norm2_w), mut(gw.norm2_b), R))) return rc;
+    }
     // keys / values of the 4 context tokens
     if ((rc = wgrad(st, w, w.dk, C, w.ctx, CTXP, mut(gw.to_k), nullptr, C, CTXP, CTX, BJ))) return rc;
     if ((rc = wgrad(st, w, w.dv, C, w.ctx, CTXP, mut(gw.to_v), nullptr, C, CTXP, CTX, BJ))) return rc;
