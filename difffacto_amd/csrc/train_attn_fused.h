@@ -55,14 +55,14 @@ enum { F_AS = 0, F_MS = 1, F_MST = 2, F_AST = 3, NSETS = 4 };
 constexpr int SET_U4 = 4 * 2 * 64, SHAPE_U4 = NSETS * SET_U4;   // 8 KiB per set, 32 KiB per shape
 
 // ---- fold: (k, v, Wq, Wo) -> fragments of A_s, M_s and their transposes; one workgroup per shape ----
-__global__ __launch_bounds__(256) void k_attn_fold(const float *__restrict__ k, const float *__restrict__ v,
+__global__ __launch_bounds__(256) void k_attn_fold(const float *__restrict__ k, const float *__restrict__ v, int ldkv,
                                                     const float *__restrict__ wq, const float *__restrict__ wo,
                                                     uint4 *__restrict__ frags) {
   __shared__ float As[HJ][C + 1], Ms[C][HJ + 1];
   const int s = blockIdx.x, t = threadIdx.x;
   for (int idx = t; idx < HJ * C; idx += 256) {
     const int m = idx / C, c = idx % C, hd = m >> 2, j = m & 3;
-    const float *kk = k + ((size_t)s * J + j) * C + hd * HD;
+    const float *kk = k + ((size_t)s * J + j) * ldkv + hd * HD;
     float a = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) a += kk[d] * wq[(size_t)(hd * HD + d) * C + c];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float *__restrict__ k, 
   }
   for (int idx = t; idx < HJ * C; idx += 256) {
     const int c = idx / HJ, m = idx % HJ, hd = m >> 2, j = m & 3;
-    const float *vv = v + ((size_t)s * J + j) * C + hd * HD;
+    const float *vv = v + ((size_t)s * J + j) * ldkv + hd * HD;
     float a = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) a += wo[(size_t)c * C + hd * HD + d] * vv[d];
@@ -426,34 +426,46 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
 // grid (B + 128): blocks < B do one shape's keys / values, the others one row d of the weights; 512 threads
 struct UnfoldArgs {
   const float *part;        // [B * split][2][32][128]
-  const float *k, *v;       // (B J, 128)
+  const float *k, *v;       // (B J, 128), row stride ldkv (the keys / values of all blocks sit side by side)
   const float *wq, *wo;     // (128, 128)
-  float *dk, *dv;           // (B J, 128)
+  float *dk, *dv;           // (B J, 128), row stride ldkv
   float *dwq, *dwo;         // (128, 128)
   float *sum;               // scratch [B][2][32][128]: partials of a shape summed (written by the shape blocks of launch 1)
-  int B, split;
+  int B, split, ldkv;
 };
-__global__ __launch_bounds__(512) void k_attn_unfold_kv(UnfoldArgs a) {
-  __shared__ float dA[HJ][C + 1], dM[HJ][C + 1];
-  extern __shared__ float wq_s[];   // Wq, rows padded to 129: a thread walks its own row (strided across the lanes in memory)
-  const int s = blockIdx.x, t = threadIdx.x;
-  for (int idx = t; idx < C * C; idx += 512) wq_s[(idx >> 7) * (C + 1) + (idx & 127)] = a.wq[idx];
-  for (int idx = t; idx < 2 * HJ * C; idx += 512) {
+// grid (J, B): one block per key / value token of a shape; 256 threads = 128 channels d x 2 halves of the sum over c
+__global__ __launch_bounds__(256) void k_attn_unfold_kv(UnfoldArgs a) {
+  __shared__ float dA[HEADS][C], dM[HEADS][C];   // rows (h, j) of this token: summed over the partials
+  __shared__ float half_k[C], half_v[C];
+  const int j = blockIdx.x, s = blockIdx.y, t = threadIdx.x;
+  for (int idx = t; idx < 2 * HEADS * C; idx += 256) {
+    const int which = idx >= HEADS * C, hd = (idx >> 7) & (HEADS - 1), c = idx & 127;
+    const size_t o = (size_t)which * HJ * C + (size_t)(hd * J + j) * C + c;
     float x = 0.f;
-    for (int q = 0; q < a.split; ++q) x += a.part[((size_t)s * a.split + q) * 2 * HJ * C + idx];
-    a.sum[(size_t)s * 2 * HJ * C + idx] = x;
-    if (idx < HJ * C) dA[idx / C][idx % C] = x;
-    else dM[(idx - HJ * C) / C][idx % C] = x;
+    for (int q = 0; q < a.split; ++q) x += a.part[((size_t)s * a.split + q) * 2 * HJ * C + o];
+    a.sum[(size_t)s * 2 * HJ * C + o] = x;
+    (which ? dM : dA)[hd][c] = x;
   }
   __syncthreads();
-  const int j = t >> 7, d = t & 127, m = (d >> 4) * J + j;   // 512 = J x 128
+  const int d = t & 127, hlf = t >> 7, hd = d >> 4, c0 = 64 * hlf;
+  const float *wq = a.wq + (size_t)d * C + c0;   // this thread's own row: 16-byte loads
   float ak = 0.f, av = 0.f;
-  for (int c = 0; c < C; ++c) {
-    ak = fmaf(dA[m][c], wq_s[d * (C + 1) + c], ak);
-    av = fmaf(dM[m][c], a.wo[(size_t)c * C + d], av);
+#pragma unroll 4
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const v4f w = *reinterpret_cast<const v4f *>(wq + 4 * c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + 4 * c4 + e;
+      ak = fmaf(dA[hd][c], w[e], ak);
+      av = fmaf(dM[hd][c], a.wo[(size_t)c * C + d], av);
+    }
   }
-  a.dk[((size_t)s * J + j) * C + d] = 0.25f * ak;
-  a.dv[((size_t)s * J + j) * C + d] = av;
+  if (hlf) half_k[d] = ak, half_v[d] = av;
+  __syncthreads();
+  if (!hlf) {
+    a.dk[((size_t)s * J + j) * a.ldkv + d] = 0.25f * (ak + half_k[d]);
+    a.dv[((size_t)s * J + j) * a.ldkv + d] = av + half_v[d];
+  }
 }
 // one block per weight row d (of Wq) / column d (of Wo); 128 channels c x 8 groups of shapes (summed in group order)
 __global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldArgs a) {
@@ -464,8 +476,8 @@ __global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldArgs a) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const float *sm = a.sum + (size_t)s * 2 * HJ * C + (size_t)(hd * J + j) * C + c;
-      aq = fmaf(a.k[((size_t)s * J + j) * C + d], sm[0], aq);
-      ao = fmaf(a.v[((size_t)s * J + j) * C + d], sm[HJ * C], ao);
+      aq = fmaf(a.k[((size_t)s * J + j) * a.ldkv + d], sm[0], aq);
+      ao = fmaf(a.v[((size_t)s * J + j) * a.ldkv + d], sm[HJ * C], ao);
     }
   rq[grp][c] = aq, ro[grp][c] = ao;
   __syncthreads();
@@ -484,7 +496,7 @@ inline int dx_groups(long long R) {   // workgroups of k_attn_bwd_dx = rows of i
 }
 inline int param_split(int B, int N) {   // workgroups per shape in the parameter kernel: ~4 workgroups per CU, at least two tiles per wavefront
   int split = 1;
-  while (B * split < 1024 && (N / 32) / (split * 2) >= 2 * NW) split *= 2;
+  while (B * split < 512 && (N / 32) / (split * 2) >= 2 * NW) split *= 2;
   return split;
 }
 

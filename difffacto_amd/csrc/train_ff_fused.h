@@ -192,7 +192,12 @@ constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
 // per 32-point tile, for k_ff_wgrad: four sets of fragments [4 c][2 u][64 lanes] (8 KiB each)
 enum { PK_XN = 0, PK_DH = 1, PK_XNT = 2, PK_DHT = 3 };
 constexpr int PK_TILE_U4 = 4 * 8 * 64;   // 32 KiB
-constexpr int NW = 8;     // wavefronts per workgroup (256 points, one workgroup per CU)
+constexpr int NW_BWD = 8;   // wavefronts per workgroup, backward (256 points, one workgroup per CU: three 40 KiB chunk buffers)
+#ifndef DFX_FF_NW_FWD
+#define DFX_FF_NW_FWD 4
+#endif
+constexpr int NW_FWD = DFX_FF_NW_FWD;   // forward: 128 points and 77 KiB of LDS, TWO workgroups per CU — one's row loads / stores run under the other's chunk loop
+template <bool BWD> constexpr int nw_of() { return BWD ? NW_BWD : NW_FWD; }
 constexpr int NBUF = 3;   // LDS chunk buffers: the stream runs two chunks ahead of the compute
 // (measured, B = 128 x 2048, backward / forward per block: 8 waves x 3 buffers 441 / 161 us; 4 waves x 2 buffers, two workgroups
 // per CU, 513 / 161 us; 8 x 2: 662 / 182 us)
@@ -202,6 +207,7 @@ template <bool BWD>
 __device__ __forceinline__ void stage_chunk(const uint4 *frags, int j, unsigned lds_buf, int wave, unsigned voff) {
   const char *src = reinterpret_cast<const char *>(frags + (size_t)j * CHUNK_U4);
   constexpr int NK = (BWD ? BWD_TILES : FWD_TILES) * 2;   // KiB to copy
+  constexpr int NW = nw_of<BWD>();
 #pragma unroll
   for (int k = 0; k < NK / NW; ++k) {
     const int piece = k * NW + wave;                                     // destination KiB
@@ -215,7 +221,8 @@ template <bool BWD>
 __device__ __forceinline__ constexpr int lt(int t) { return BWD && t >= 12 ? t - 4 : t; }
 
 template <bool BWD>
-__global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
+__global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
+  constexpr int NW = nw_of<BWD>();
   constexpr int BUF_BYTES = (BWD ? BWD_TILES : FWD_TILES) * 2048;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ff_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -447,8 +454,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_ff(FfArgs a) {
 // the registers (the transposed orientation: activations as the A operand, weights as B):
 //     a^T, g^T = xn3 W1^T + b1 (16 MFMAs)   d hid^T = dh W2 (8)   GEGLU forward / backward on the registers
 //     dW2^T chunk += hid^T dh (8)   dW1a += da^T xn3 (8)   dW1g += dg^T xn3 (8)            K = the 32 points
-// 1 wavefront per SIMD with up to 512 registers (the accumulators sit in the AGPR half).  Partials per (slab, chunk) are summed by
-// k_ff_wgrad_finish in slab order.
+// Partials per (slab, chunk) are summed by k_ff_wgrad_finish in slab order.
 struct FwArgs {
   const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
   const float *b1;       // (1024)
@@ -458,74 +464,121 @@ struct FwArgs {
   long long ntiles;      // R / 32
   int nslab;
 };
-constexpr int WG_NW = 4;
-__global__ __launch_bounds__(WG_NW * 64, 1) void k_ff_wgrad(FwArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 2 x 32 KiB
+constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chunk, on the same SIMD
+// LDS: the tile halves travel in separate rings of three 16 KiB slots, two tiles ahead of their reader (L2 latency under load is
+// longer than one tile's arithmetic): [xn3 | dh] of tile k for the producers, [xn3^T | dh^T] of tile k - 1 for the consumers
+constexpr int WG_RING_A = 0, WG_RING_B = 3 * 16384, WG_RING = 6 * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
+__global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 3 tiles x 32 KiB | 2 x 4 chunks x 6 KiB of hid / da / dg fragments
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pj = lane & 31;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)fw_smem);
   const unsigned voff = lane * 16;
-  const int cg = blockIdx.x % (NCHUNK / WG_NW), slab = blockIdx.x / (NCHUNK / WG_NW), j = cg * WG_NW + wave;
+#ifdef DFX_WG_PAIR_ADJACENT
+  const int cl = wave >> 1;
+  const bool consumer = wave & 1;
+#else
+  const int cl = wave & (WG_CHUNKS - 1);
+  const bool consumer = wave >= WG_CHUNKS;
+#endif
+  const int cg = blockIdx.x % (NCHUNK / WG_CHUNKS), slab = blockIdx.x / (NCHUNK / WG_CHUNKS), j = cg * WG_CHUNKS + cl;
   const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
-  // this chunk's weights as B operands
-  uint4 w1a[4][2], w1g[4][2], w2t[4][2];
-  {
-    const uint4 *fr = a.frags + (size_t)j * CHUNK_U4 + lane;
+  const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
+  // iteration k requests [xn3 | dh] of tile k + 2 and [xn3^T | dh^T] of tile k + 1: two + two 1 KiB pieces per wavefront
+  auto stage = [&](int k) {
+    if (k + 2 < nt) {
+      const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
+    }
+    if (k + 1 < nt && k + 1 >= 0) {
+      const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 1) * PK_TILE_U4) + 16384;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        w1a[c][u] = fr[((T_W1A + c) * 2 + u) * 64];
-        w1g[c][u] = fr[((T_W1G + c) * 2 + u) * 64];
-        w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
+      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_B + ((k + 1) % 3) * 16384 + (wave * 2 + q) * 1024);
+    }
+  };
+  // top of iteration k: everything requested before iteration k - 1 has landed (loads complete in order; the last iterations request
+  // less or nothing: drain)
+  auto arrive = [&](int k) {
+    if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  uint4 *packs = reinterpret_cast<uint4 *>(fw_smem + WG_RING);
+  // The two wavefronts of a chunk work one tile apart (one barrier per tile): the producer turns tile k into the chunk's hid / da / dg
+  // fragments (24 MFMAs + the GEGLU arithmetic, weights in registers), the consumer multiplies tile k - 1's fragments with the
+  // transposed tile (24 MFMAs into its 192 accumulator registers) — so the matrix pipe of the SIMD works through the producer's VALU
+  // stretch, and neither role needs more than 256 registers.
+  stage(-2), stage(-1);   // tiles 0, 1 for the producers, tile 0 for the consumers
+  if (!consumer) {
+    uint4 w1a[4][2], w1g[4][2], w2t[4][2];
+    {
+      const uint4 *fr = a.frags + (size_t)j * CHUNK_U4 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          w1a[c][u] = fr[((T_W1A + c) * 2 + u) * 64];
+          w1g[c][u] = fr[((T_W1G + c) * 2 + u) * 64];
+          w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
+        }
+    }
+    const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
+    float sa = 0.f, sg = 0.f;
+    for (int k = 0; k <= nt; ++k) {
+      arrive(k);   // tile k has landed; everybody is done with tile k - 1's producer half and tile k - 2's consumer half and fragments
+      stage(k);
+      if (k == nt) break;
+      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
+      v16f av, gv, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 x = tl[(PK_XN * 8 + c * 2 + u) * 64];
+          av = mfma(x, w1a[c][u], av);
+          gv = mfma(x, w1g[c][u], gv);
+          dv = mfma(tl[(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
+        }
+      v16f hv, da, dg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float f, d;
+        gelu_fd(gv[r], f, d);
+        hv[r] = av[r] * f;
+        da[r] = dv[r] * f;
+        dg[r] = dv[r] * av[r] * d;
+        sa += da[r], sg += dg[r];
       }
+      uint4 *po = packs + ((k & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
+      po[0 * 64] = pack8(hv, 0), po[1 * 64] = pack8(hv, 1), po[2 * 64] = pack8(da, 0), po[3 * 64] = pack8(da, 1);
+      po[4 * 64] = pack8(dg, 0), po[5 * 64] = pack8(dg, 1);
+    }
+    sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
+    if (lane < 32) {
+      float *bo = a.bpart + ((size_t)slab * NCHUNK + j) * 64;
+      bo[pj] = sa, bo[32 + pj] = sg;
+    }
+    return;
   }
-  const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
   v16f dW2[4], dWa[4], dWg[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dW2[c][r] = 0.f, dWa[c][r] = 0.f, dWg[c][r] = 0.f;
-  float sa = 0.f, sg = 0.f;
-  auto stage = [&](long long t, int buf) {   // 32 KiB tile -> LDS, eight 1 KiB pieces per wavefront
-    const char *src = reinterpret_cast<const char *>(a.pk + (size_t)t * PK_TILE_U4);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dma1k(src + (wave * 8 + k) * 1024, voff, lds0 + buf * 32768 + (wave * 8 + k) * 1024);
-  };
-  if (t0 < t1) stage(t0, 0);
-  for (long long t = t0; t < t1; ++t) {
-    const int buf = (int)((t - t0) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile t has landed; every wavefront is done with tile t - 1 (the other buffer)
-    if (t + 1 < t1) stage(t + 1, buf ^ 1);
-    const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + buf * 32768) + lane;
-    auto frag = [&](int kind, int c, int u) -> uint4 { return tl[(kind * 8 + c * 2 + u) * 64]; };
-    v16f av, gv, dv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint4 x = frag(PK_XN, c, u);
-        av = mfma(x, w1a[c][u], av);
-        gv = mfma(x, w1g[c][u], gv);
-        dv = mfma(frag(PK_DH, c, u), w2t[c][u], dv);
-      }
-    v16f hv, da, dg;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float f, d;
-      gelu_fd(gv[r], f, d);
-      hv[r] = av[r] * f;
-      da[r] = dv[r] * f;
-      dg[r] = dv[r] * av[r] * d;
-      sa += da[r], sg += dg[r];
-    }
-    const uint4 h0 = pack8(hv, 0), h1 = pack8(hv, 1), a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
+  for (int k = 0; k <= nt; ++k) {
+    arrive(k);
+    stage(k);
+    if (k == 0) continue;
+    const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_B + ((k - 1) % 3) * 16384) - 16 * 64 + lane;   // (kinds 2, 3 sit at fragment index 16..31 of a tile)
+    const uint4 *pi = packs + (((k - 1) & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
+    const uint4 h0 = pi[0 * 64], h1 = pi[1 * 64], a0 = pi[2 * 64], a1 = pi[3 * 64], g0 = pi[4 * 64], g1 = pi[5 * 64];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const uint4 x0 = frag(PK_XNT, c, 0), x1 = frag(PK_XNT, c, 1), d0 = frag(PK_DHT, c, 0), d1 = frag(PK_DHT, c, 1);
+      const uint4 x0 = tl[(PK_XNT * 8 + c * 2 + 0) * 64], x1 = tl[(PK_XNT * 8 + c * 2 + 1) * 64];
+      const uint4 d0 = tl[(PK_DHT * 8 + c * 2 + 0) * 64], d1 = tl[(PK_DHT * 8 + c * 2 + 1) * 64];
       dW2[c] = mfma(h1, d1, mfma(h0, d0, dW2[c]));
       dWa[c] = mfma(a1, x1, mfma(a0, x0, dWa[c]));
       dWg[c] = mfma(g1, x1, mfma(g0, x0, dWg[c]));
@@ -540,11 +593,6 @@ __global__ __launch_bounds__(WG_NW * 64, 1) void k_ff_wgrad(FwArgs a) {
       out[((4 + c) * 16 + r) * 64] = dWa[c][r];
       out[((8 + c) * 16 + r) * 64] = dWg[c][r];
     }
-  sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
-  if (lane < 32) {
-    float *bo = a.bpart + ((size_t)slab * NCHUNK + j) * 64;
-    bo[pj] = sa, bo[32 + pj] = sg;
-  }
 }
 // sums the slabs in order and scatters the tiles: gradient tile (which, c) of chunk j, register r, lane (i, hf) = unit rho(r, hf) of the
 // chunk, channel 32 c + i
@@ -574,10 +622,10 @@ inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 6
 inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &f) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) != hipSuccess) return -1;
     attr_set = true;
   }
-  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_NW), WG_NW * 64, 65536, st>>>(a);
+  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(a);
   const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
   k_ff_wgrad_finish<<<(total + 255) / 256, 256, 0, st>>>(f);
   return 0;
@@ -598,6 +646,7 @@ inline int launch_ff(hipStream_t st, const FfArgs &a) {
       return -1;
     attr_set = true;
   }
+  constexpr int NW = nw_of<BWD>();
   const long long groups = (a.R / 32 + NW - 1) / NW;
   k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(a);
   return 0;

@@ -338,6 +338,27 @@ __global__ void k_pad_cols(const float *__restrict__ W, float *__restrict__ Wp, 
   Wp[i] = c < cols ? W[(size_t)r * cols + c] : 0.f;
 }
 
+// to_k / to_v of all blocks side by side: Wkv (2 depth x 128 rows, 522 -> 528 columns, zero padded) so that the keys and values of
+// every block come from ONE product over the context tokens (the context is the same for all blocks), and their gradients back
+struct KvPtrs {
+  const float *p[2 * DFX_MAX_DEPTH];
+};
+struct KvMutPtrs {
+  float *p[2 * DFX_MAX_DEPTH];
+};
+__global__ void k_pack_kv(KvPtrs src, float *__restrict__ dst, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * C * CTXP) return;
+  const int c = idx % CTXP, row = idx / CTXP;
+  dst[idx] = c < CTX ? src.p[row / C][(size_t)(row % C) * CTX + c] : 0.f;
+}
+__global__ void k_unpack_kv(const float *__restrict__ src, KvMutPtrs dst, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * C * CTX) return;
+  const int c = idx % CTX, row = idx / CTX;
+  dst.p[row / C][(size_t)(row % C) * CTX + c] = src[(size_t)row * CTXP + c];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // cross attention to the 4 part tokens (attention.py:179-204), forward with saved probabilities, and backward
 // block = 32 points of one shape x 8 heads; k, v of the shape in LDS
@@ -972,6 +993,8 @@ struct TrainWs {
   // weight-stationary feed-forward gradients (k_ff_wgrad): per-slab partial tiles
   float *ffw_part, *ffw_bpart;
   int ffw_slabs;
+  // keys / values of all blocks in one product: packed weights (and transposed), k | v of every block side by side, their gradients
+  float *wkv, *wkvT, *kv, *dkv, *dwkv;
 };
 
 constexpr int WG_SLAB = 2048;   // rows per k_wgrad slab (64 for the few-row products over the context tokens / the batch)
@@ -1049,12 +1072,17 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.at_part = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
   w.at_sum = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
   {
-    const size_t groups = (R / 32 + dfx::ffused::NW - 1) / dfx::ffused::NW, a = groups * 3 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
+    const size_t groups = (R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD, a = groups * 3 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
     w.cpart = c.take<float>(a > b ? a : b);
   }
   w.ffw_slabs = dfx::ffused::wgrad_slabs((long long)(R / 32));
   w.ffw_part = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
   w.ffw_bpart = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
+  w.wkv = c.take<float>((size_t)2 * depth * C * CTXP);
+  w.wkvT = c.take<float>((size_t)2 * depth * C * CTXP);
+  w.dwkv = c.take<float>((size_t)2 * depth * C * CTXP);
+  w.kv = c.take<float>(BJ * 2 * depth * C);
+  w.dkv = c.take<float>(BJ * 2 * depth * C);
   return c.off;
 }
 
@@ -1392,24 +1420,22 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
   if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
   k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
+  const int LDKV = 2 * wt->depth * C;
+  if (ff_fused(bf, dropout_p, R, N)) {   // keys and values of every block: one product over the B x 4 context tokens
+    KvPtrs kp{};
+    for (int i = 0; i < wt->depth; ++i) kp.p[2 * i] = wt->blk[i].to_k, kp.p[2 * i + 1] = wt->blk[i].to_v;
+    k_pack_kv<<<(2 * wt->depth * C * CTXP + 255) / 256, 256, 0, st>>>(kp, w.wkv, 2 * wt->depth);
+    if ((rc = lin(st, w.ctx, CTXP, w.wkv, nullptr, w.kv, LDKV, BJ, LDKV, CTXP))) return rc;
+  }
   for (int i = 0; i < wt->depth; ++i) {
     const dfx_block_weights &bw = wt->blk[i];
     BlockAct &a = w.blk[i];
     float *hout = i + 1 < wt->depth ? w.blk[i + 1].hin : w.hfin;
     const bool fused = ff_fused(bf, dropout_p, R, N);
-    if (!fused) {
-      if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
-      else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
-      if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C, nullptr, 0, bf))) return rc;
-    }
-    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_k, w.wpad, C, CTX, CTXP);
-    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.k, C, BJ, C, CTXP))) return rc;
-    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_v, w.wpad, C, CTX, CTXP);
-    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
     if (fused) {
       // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
       // q, P, att, xn2, xn3, [a | g], hid never exist in memory
-      dfx::afused::k_attn_fold<<<B, 256, 0, st>>>(a.k, a.v, bw.to_q, bw.to_out_w, w.at_frags[i]);
+      dfx::afused::k_attn_fold<<<B, 256, 0, st>>>(w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, LDKV, bw.to_q, bw.to_out_w, w.at_frags[i]);
       dfx::afused::AttnArgs aa{};
       aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
       aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
@@ -1421,6 +1447,15 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
       continue;
     }
+    if (!fused) {
+      if (bf) k_ln_fwd<true><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+      else k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(a.hin, bw.norm2_w, bw.norm2_b, a.xn2, a.st2, R);
+      if ((rc = lin(st, a.xn2, C, bw.to_q, nullptr, a.q, C, R, C, C, nullptr, 0, bf))) return rc;
+    }
+    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_k, w.wpad, C, CTX, CTXP);
+    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.k, C, BJ, C, CTXP))) return rc;
+    k_pad_cols<<<(C * CTXP + 255) / 256, 256, 0, st>>>(bw.to_v, w.wpad, C, CTX, CTXP);
+    if ((rc = lin(st, w.ctx, CTXP, w.wpad, nullptr, a.v, C, BJ, C, CTXP))) return rc;
     if (bf) k_attn_fwd<true><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
     else k_attn_fwd<false><<<dim3(N / 32, B), 256, 0, st>>>(a.q, a.k, a.v, w.valid, a.p, a.att, N);
     if (dropout_p > 0.f) {   // h1 = dropout(att Wo^T + bo) + hin   (attention.py:177: to_out = Sequential(Linear, Dropout))
@@ -1476,7 +1511,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R;
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
-      const int groups = (int)((R / 32 + dfx::ffused::NW - 1) / dfx::ffused::NW);
+      const int groups = (int)((R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD);
       k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
       // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide
       {
@@ -1491,15 +1526,10 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       dfx::afused::k_attn_bwd_param<<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
       const int np = dfx::afused::dx_groups(R);
       dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
-      dfx::afused::UnfoldArgs ua{w.at_part, a.k, a.v, bw.to_q, bw.to_out_w, w.dk, w.dv, mut(gw.to_q), mut(gw.to_out_w), w.at_sum, B, w.at_split};
-      {
-        static bool attr_set = false;
-        if (!attr_set) {
-          DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dfx::afused::k_attn_unfold_kv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C * (C + 1) * sizeof(float))));
-          attr_set = true;
-        }
-      }
-      dfx::afused::k_attn_unfold_kv<<<B, 512, C * (C + 1) * sizeof(float), st>>>(ua);
+      const int LDKV = 2 * wt->depth * C;
+      dfx::afused::UnfoldArgs ua{w.at_part, w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
+                                 mut(gw.to_q), mut(gw.to_out_w), w.at_sum, B, w.at_split, LDKV};
+      dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B), 256, 0, st>>>(ua);
       dfx::afused::k_attn_unfold_w<<<C, 1024, 0, st>>>(ua);
       k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
     } else {
@@ -1531,6 +1561,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = lin(st, w.dq, C, w.wT, nullptr, w.dh2, C, R, C, C, nullptr, 0, bf))) return rc;
     if ((rc = ln_bwd(st, w, w.dh2, a.hin, a.st2, bw.norm2_w, w.dh, w.dh, mut(gw.norm2_w), mut(gw.norm2_b), R))) return rc;
     }
+    if (fused) continue;   // (keys / values of all blocks: one pair of products behind the loop)
     // keys / values of the 4 context tokens
     if ((rc = wgrad(st, w, w.dk, C, w.ctx, CTXP, mut(gw.to_k), nullptr, C, CTXP, CTX, BJ))) return rc;
     if ((rc = wgrad(st, w, w.dv, C, w.ctx, CTXP, mut(gw.to_v), nullptr, C, CTXP, CTX, BJ))) return rc;
@@ -1539,6 +1570,15 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = lin(st, w.dk, C, w.wT, nullptr, w.dctx, CTXP, BJ, CTXP, C, w.dctx, CTXP))) return rc;
     transpose(st, bw.to_v, w.wT, C, CTX);
     if ((rc = lin(st, w.dv, C, w.wT, nullptr, w.dctx, CTXP, BJ, CTXP, C, w.dctx, CTXP))) return rc;
+  }
+  if (ff_fused(bf, dropout_p, R, N)) {   // d Wk, d Wv of every block and d ctx from the side-by-side key / value gradients
+    const int n2 = 2 * wt->depth, LDKV = n2 * C;
+    if ((rc = wgrad(st, w, w.dkv, LDKV, w.ctx, CTXP, w.dwkv, nullptr, LDKV, CTXP, CTXP, BJ))) return rc;
+    KvMutPtrs gp{};
+    for (int i = 0; i < wt->depth; ++i) gp.p[2 * i] = mut(grads->blk[i].to_k), gp.p[2 * i + 1] = mut(grads->blk[i].to_v);
+    k_unpack_kv<<<(n2 * C * CTX + 255) / 256, 256, 0, st>>>(w.dwkv, gp, n2);
+    transpose(st, w.wkv, w.wkvT, LDKV, CTXP);                                  // (528 rows of 2 depth x 128)
+    if ((rc = lin(st, w.dkv, LDKV, w.wkvT, nullptr, w.dctx, CTXP, BJ, CTXP, LDKV))) return rc;
   }
   // pre_norm, proj_in
   if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
