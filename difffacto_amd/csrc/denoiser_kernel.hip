@@ -1833,7 +1833,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
   DFX_HIP_TRY(hipMemsetAsync(workspace2, 0, 2 * sizeof(double), st));
   const long long total = (long long)B * N;
   long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 64) blocks = 64;   // every wavefront ends with two float64 atomics on the same two addresses: 256 of them, not 16384 (100 us of serialised L2 atomics)
   k_masked_mse<<<(int)blocks, 256, 0, st>>>(target, pred, flags, workspace2, N, total);
   k_mse_finish<<<1, 1, 0, st>>>(workspace2, loss, flags != nullptr, (double)B * 3.0 * N);
   return check_launch("masked_mse");

@@ -543,6 +543,188 @@ __global__ void k_mse_bwd(const float *__restrict__ target, const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The two ends of the network as one pass each way (fused training path): nothing of width 128 is written that the next kernel
+// only reads back.  32 lanes per point (lane l = channels 4 l .. 4 l + 3), 8 points per 256-thread step, like k_ln_fwd.
+//   stem   hin = pre_norm(W_in xin + b_in)                          backward: recomputes h0 from xin; d W_in, d b_in, d gamma, d beta
+//   head   eps = W_out post_norm(hfin) + b_out  -> (B, 3, N)        backward: recomputes the LayerNorm; dh, d W_out, d b_out, d gamma, d beta
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int STEM_ROWS = 512, HEAD_ROWS = 128;   // points per block of the backward kernels (rows of their partial sums; the stem's partial is 8 KiB)
+__device__ __forceinline__ float sum32(float v) {
+  for (int o = 16; o; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+struct StemW {   // this lane's four rows of W_in (13 columns) and bias
+  float w[4][13], b[4];
+};
+__device__ __forceinline__ void stem_load(StemW &sw, const float *__restrict__ W, const float *__restrict__ b, int l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int k = 0; k < 13; ++k) sw.w[e][k] = W[(4 * l + e) * 13 + k];
+    sw.b[e] = b[4 * l + e];
+  }
+}
+__device__ __forceinline__ void stem_row(const StemW &sw, const float *__restrict__ xrow, float (&x)[13], v4f &h0, float &mu, float &rstd) {
+  const v4f a = *reinterpret_cast<const v4f *>(xrow), b = *reinterpret_cast<const v4f *>(xrow + 4), c = *reinterpret_cast<const v4f *>(xrow + 8);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = a[k], x[4 + k] = b[k], x[8 + k] = c[k];
+  x[12] = xrow[12];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = sw.b[e];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) t = fmaf(sw.w[e][k], x[k], t);
+    h0[e] = t;
+  }
+  mu = sum32(h0[0] + h0[1] + h0[2] + h0[3]) * (1.0f / C);
+  const v4f d = {h0[0] - mu, h0[1] - mu, h0[2] - mu, h0[3] - mu};
+  rstd = 1.0f / sqrtf(sum32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / C) + LN_EPS);
+}
+__global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ xin, const float *__restrict__ W, const float *__restrict__ b,
+                                                   const float *__restrict__ g, const float *__restrict__ be, float *__restrict__ hin, long long R) {
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  StemW sw;
+  stem_load(sw, W, b, l);
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l], bv = reinterpret_cast<const v4f *>(be)[l];
+  for (long long r = (long long)blockIdx.x * 8 + grp; r < R; r += (long long)gridDim.x * 8) {
+    float x[13], mu, rstd;
+    v4f h0;
+    stem_row(sw, xin + r * XIN, x, h0, mu, rstd);
+    v4f o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (h0[e] - mu) * rstd * gv[e] + bv[e];
+    reinterpret_cast<v4f *>(hin + r * C)[l] = o;
+  }
+}
+// part[block] = [d W_in (128 x 13) | d b_in (128) | d gamma (128) | d beta (128)] = 2048 floats
+__global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ W,
+                                                   const float *__restrict__ b, const float *__restrict__ g, float *__restrict__ part, long long R) {
+  __shared__ float red[4][2048];
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  StemW sw;
+  stem_load(sw, W, b, l);
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l];
+  float dw[4][13], db[4], dg[4], dbe[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int k = 0; k < 13; ++k) dw[e][k] = 0.f;
+    db[e] = dg[e] = dbe[e] = 0.f;
+  }
+#pragma unroll 2
+  for (int it = 0; it < STEM_ROWS / 8; ++it) {
+    const long long r = (long long)blockIdx.x * STEM_ROWS + it * 8 + grp;
+    if (r >= R) break;
+    float x[13], mu, rstd;
+    v4f h0;
+    stem_row(sw, xin + r * XIN, x, h0, mu, rstd);
+    const v4f dv = reinterpret_cast<const v4f *>(dy + r * C)[l];
+    v4f xh, dyg;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = (h0[e] - mu) * rstd;
+      dyg[e] = dv[e] * gv[e];
+      s1 += dyg[e], s2 += dyg[e] * xh[e];
+      dg[e] += dv[e] * xh[e], dbe[e] += dv[e];
+    }
+    s1 = sum32(s1) * (1.0f / C), s2 = sum32(s2) * (1.0f / C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = rstd * (dyg[e] - s1 - xh[e] * s2);   // gradient at h0
+      db[e] += d0;
+#pragma unroll
+      for (int k = 0; k < 13; ++k) dw[e][k] = fmaf(d0, x[k], dw[e][k]);
+    }
+  }
+  // eight row groups -> four LDS rows (groups 4..7 first, groups 0..3 add theirs), then a fixed-order sum
+#pragma unroll
+  for (int half = 1; half >= 0; --half) {
+    if ((grp >> 2) == half) {
+      float *rd = red[grp & 3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) rd[(4 * l + e) * 13 + k] = (half ? 0.f : rd[(4 * l + e) * 13 + k]) + dw[e][k];
+        rd[1664 + 4 * l + e] = (half ? 0.f : rd[1664 + 4 * l + e]) + db[e];
+        rd[1792 + 4 * l + e] = (half ? 0.f : rd[1792 + 4 * l + e]) + dg[e];
+        rd[1920 + 4 * l + e] = (half ? 0.f : rd[1920 + 4 * l + e]) + dbe[e];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2048; i += 256) part[(size_t)blockIdx.x * 2048 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+__device__ __forceinline__ void ln_row(const float *__restrict__ xrow, int l, v4f &xh, float &rstd) {
+  const v4f v = reinterpret_cast<const v4f *>(xrow)[l];
+  const float mu = sum32(v[0] + v[1] + v[2] + v[3]) * (1.0f / C);
+  const v4f d = {v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};
+  rstd = 1.0f / sqrtf(sum32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / C) + LN_EPS);
+  xh = d * rstd;
+}
+__global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ hfin, const float *__restrict__ g, const float *__restrict__ be,
+                                                   const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ eps, int N, long long R) {
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l], bv = reinterpret_cast<const v4f *>(be)[l];
+  const v4f w0 = reinterpret_cast<const v4f *>(W)[l], w1 = reinterpret_cast<const v4f *>(W + C)[l], w2 = reinterpret_cast<const v4f *>(W + 2 * C)[l];
+  for (long long r = (long long)blockIdx.x * 8 + grp; r < R; r += (long long)gridDim.x * 8) {
+    v4f xh;
+    float rstd;
+    ln_row(hfin + r * C, l, xh, rstd);
+    const v4f hn = xh * gv + bv;
+    const float s0 = sum32(hn[0] * w0[0] + hn[1] * w0[1] + hn[2] * w0[2] + hn[3] * w0[3]);
+    const float s1 = sum32(hn[0] * w1[0] + hn[1] * w1[1] + hn[2] * w1[2] + hn[3] * w1[3]);
+    const float s2 = sum32(hn[0] * w2[0] + hn[1] * w2[1] + hn[2] * w2[2] + hn[3] * w2[3]);
+    if (l < 3) eps[((r / N) * 3 + l) * N + (r % N)] = (l == 0 ? s0 : l == 1 ? s1 : s2) + bias[l];
+  }
+}
+// part[block] = [d W_out (3 x 128) | d gamma (128) | d beta (128) | d b_out (3) | 0 x 29] = 672 floats
+constexpr int HEAD_PART = 672;
+__global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps, const float *__restrict__ hfin, const float *__restrict__ g,
+                                                   const float *__restrict__ be, const float *__restrict__ W, float *__restrict__ dh,
+                                                   float *__restrict__ part, int N, long long R) {
+  __shared__ float red[8][HEAD_PART];
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l], bv = reinterpret_cast<const v4f *>(be)[l];
+  const v4f w0 = reinterpret_cast<const v4f *>(W)[l], w1 = reinterpret_cast<const v4f *>(W + C)[l], w2 = reinterpret_cast<const v4f *>(W + 2 * C)[l];
+  v4f a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, dg = a0, dbe = a0;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int it = 0; it < HEAD_ROWS / 8; ++it) {
+    const long long r = (long long)blockIdx.x * HEAD_ROWS + it * 8 + grp;
+    if (r >= R) break;
+    const long long bb = r / N;
+    const int n = (int)(r % N);
+    const float d0 = deps[(bb * 3 + 0) * N + n], d1 = deps[(bb * 3 + 1) * N + n], d2 = deps[(bb * 3 + 2) * N + n];
+    v4f xh;
+    float rstd;
+    ln_row(hfin + r * C, l, xh, rstd);
+    const v4f hn = xh * gv + bv;
+    const v4f dhn = d0 * w0 + d1 * w1 + d2 * w2;
+    a0 += d0 * hn, a1 += d1 * hn, a2 += d2 * hn;
+    b0 += d0, b1 += d1, b2 += d2;
+    dg += dhn * xh, dbe += dhn;
+    const v4f dyg = dhn * gv;
+    const float s1 = sum32(dyg[0] + dyg[1] + dyg[2] + dyg[3]) * (1.0f / C);
+    const float s2 = sum32(dyg[0] * xh[0] + dyg[1] * xh[1] + dyg[2] * xh[2] + dyg[3] * xh[3]) * (1.0f / C);
+    reinterpret_cast<v4f *>(dh + r * C)[l] = rstd * (dyg - s1 - xh * s2);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[grp][4 * l + e] = a0[e], red[grp][C + 4 * l + e] = a1[e], red[grp][2 * C + 4 * l + e] = a2[e];
+    red[grp][3 * C + 4 * l + e] = dg[e], red[grp][4 * C + 4 * l + e] = dbe[e];
+  }
+  if (l == 0) red[grp][5 * C] = b0, red[grp][5 * C + 1] = b1, red[grp][5 * C + 2] = b2;
+  if (l < 29) red[grp][5 * C + 3 + l] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < HEAD_PART; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][i];
+    part[(size_t)blockIdx.x * HEAD_PART + i] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight gradient: dW (O, I) = dY^T X over R rows, db = column sums of dY
 // grid (ceil(I/64), ceil(O/64), nslab); one wavefront per block; part[slab][O][I] (+ bpart[slab][O] from blockIdx.x == 0)
 // ---------------------------------------------------------------------------------------------------------------
@@ -676,10 +858,12 @@ __global__ void k_sumsq(const float *__restrict__ g, long long n, double *__rest
   __syncthreads();
   if (threadIdx.x == 0) acc_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// one wavefront: lane l adds parts l, l + 64, .. in order, then a fixed xor tree over the lanes
 __global__ void k_sumsq_finish(const double *__restrict__ acc_part, int n, double *__restrict__ total /* += */) {
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += acc_part[i];
-  *total += s;
+  for (int i = threadIdx.x; i < n; i += 64) s += acc_part[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) *total += s;
 }
 // p, m, v updated in place; grads scaled by clip = min(1, max_norm / (norm + 1e-6)) read from the device
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
@@ -1417,9 +1601,14 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   else DFX_HIP_TRY(hipMemsetAsync(w.valid, 0x3f, sizeof(float) * BJ, st));   // any non-zero value = keep
   // proj_in + pre_norm
   k_build_xin<<<(int)((R + 255) / 256), 256, 0, st>>>(x, anchors, variances, assignment, w.xin, N, R);
-  k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
-  if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
-  k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
+  const bool fused_ends = ff_fused(bf, dropout_p, R, N);
+  if (fused_ends) {
+    k_stem_fwd<<<2048, 256, 0, st>>>(w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, R);
+  } else {
+    k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
+    if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
+    k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
+  }
   const int LDKV = 2 * wt->depth * C;
   if (ff_fused(bf, dropout_p, R, N)) {   // keys and values of every block: one product over the B x 4 context tokens
     KvPtrs kp{};
@@ -1470,8 +1659,12 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     else k_geglu_fwd<false><<<(int)((R * FH / 4 + 255) / 256), 256, 0, st>>>(a.ag, a.hid, FH, R * FH, dff);
     if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C, bf))) return rc;
   }
-  k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
-  k_eps_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hn, wt->proj_out_w, wt->proj_out_b, eps, N, R);
+  if (fused_ends) {
+    k_head_fwd<<<2048, 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, wt->proj_out_b, eps, N, R);
+  } else {
+    k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
+    k_eps_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hn, wt->proj_out_w, wt->proj_out_b, eps, N, R);
+  }
   return dfx::check_launch("denoiser_train_forward");
 }
 
@@ -1491,13 +1684,20 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   const long long R = (long long)B * N;
   const int BJ = B * J;
   // proj_out, post_norm
-  {
+  const bool fused_ends = ff_fused(bf, dropout_p, R, N);
+  if (fused_ends) {
+    const int nb = (int)((R + HEAD_ROWS - 1) / HEAD_ROWS);
+    k_head_bwd<<<nb, 256, 0, st>>>(d_eps, w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, w.dh, w.part, N, R);
+    k_sum_parts<<<3 * C / 32, 1024, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, HEAD_PART);
+    k_sum_parts_multi<<<2 * C / 32, 1024, 0, st>>>(w.part + 3 * C, SumOuts{{mut(grads->post_norm_w), mut(grads->post_norm_b), nullptr, nullptr}}, nb, C, HEAD_PART);
+    k_sum_parts<<<1, 1024, 0, st>>>(w.part + 5 * C, mut(grads->proj_out_b), nb, 3, HEAD_PART);
+  } else {
     const int nb = (int)((R + EPSB_ROWS - 1) / EPSB_ROWS);
     k_eps_bwd<<<nb, 128, 0, st>>>(d_eps, w.hn, wt->proj_out_w, w.dh2, w.part, N, R);
     k_sum_parts<<<3 * C / 32, 1024, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, 4 * C);
     k_sum_parts<<<1, 1024, 0, st>>>(w.part + 3 * C, mut(grads->proj_out_b), nb, 3, 4 * C);
   }
-  if ((rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
+  if (!fused_ends && (rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
   DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));
   for (int i = wt->depth - 1; i >= 0; --i) {
     const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
@@ -1581,8 +1781,15 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = lin(st, w.dkv, LDKV, w.wkvT, nullptr, w.dctx, CTXP, BJ, CTXP, LDKV))) return rc;
   }
   // pre_norm, proj_in
-  if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
-  if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
+  if (fused_ends) {
+    const int nb = (int)((R + STEM_ROWS - 1) / STEM_ROWS);
+    k_stem_bwd<<<nb, 256, 0, st>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, w.part, R);
+    k_sum_parts<<<C * 13 / 32, 1024, 0, st>>>(w.part, mut(grads->proj_in_w), nb, C * 13, 2048);
+    k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.part + C * 13, SumOuts{{mut(grads->proj_in_b), mut(grads->pre_norm_w), mut(grads->pre_norm_b), nullptr}}, nb, C, 2048);
+  } else {
+    if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
+    if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
+  }
   // context -> part codes, (mean, var), time embedding MLP
   k_ctx_bwd<<<(B * CTX + 255) / 256, 256, 0, st>>>(w.dctx, d_ctx_code, d_ctx_mv, w.dte_out, B);
   if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;
@@ -1839,7 +2046,7 @@ int dfx_grad_sumsq_accumulate(const float *g, long long n, double *workspace1024
   long long nb = (n + 255) / 256;
   if (nb > 1024) nb = 1024;
   k_sumsq<<<(int)nb, 256, 0, dfx::as_stream(stream)>>>(g, n, workspace1024);
-  k_sumsq_finish<<<1, 1, 0, dfx::as_stream(stream)>>>(workspace1024, (int)nb, sumsq);
+  k_sumsq_finish<<<1, 64, 0, dfx::as_stream(stream)>>>(workspace1024, (int)nb, sumsq);
   return dfx::check_launch("grad_sumsq");
 }
 
