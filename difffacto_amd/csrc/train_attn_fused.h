@@ -39,6 +39,8 @@ namespace afused {
 using ffused::k_nat;
 using ffused::k_reg;
 using ffused::ln_rows;
+using ffused::load_rows;
+using ffused::rows_to_acc;
 using ffused::xhalf;
 using ffused::LN_EPS;
 using ffused::mfma;
@@ -176,7 +178,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_fwd_fused(AttnArgs a) {
   for (int j = 0; j < J; ++j) vmask |= (a.valid[s * J + j] != 0.f ? 1u : 0u) << j;
   uint4 xn[4][2];
   float mu, rstd;
-  ln_rows(a.h + row * C, hf, gb, xn, mu, rstd);
+  v16f hacc[4];   // h in the accumulator layout, from the same read
+  {
+    v8f x[4][2];
+    load_rows(a.h + row * C, hf, x);
+    ln_rows(x, hf, gb, xn, mu, rstd);
+    rows_to_acc(x, hacc);
+  }
   v16f sim = zero16();
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -189,10 +197,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_fwd_fused(AttnArgs a) {
     v16f acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int ch = 32 * ct + 8 * q + 4 * hf;
-      const v4f t = *reinterpret_cast<const v4f *>(a.h + row * C + ch), b = *reinterpret_cast<const v4f *>(gb + 2 * C + ch);
+      const v4f b = *reinterpret_cast<const v4f *>(gb + 2 * C + 32 * ct + 8 * q + 4 * hf);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[4 * q + m] = t[m] + b[m];
+      for (int m = 0; m < 4; ++m) acc[4 * q + m] = hacc[ct][4 * q + m] + b[m];
     }
     acc = mfma(fr[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc);
     acc = mfma(fr[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc);
@@ -228,13 +235,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_dx(AttnArgs a) {
   v16f P = zero16();
   uint4 db[4][2];
   row_frags(a.dh1 + row * C, hf, db);   // (requested before the LayerNorm arithmetic needs its own loads)
+  v16f dy[4], xh[4];
   {
     uint4 xn[4][2];
-    ln_rows(a.h + row * C, hf, gb, xn, mu, rstd);
+    v8f x[4][2];
+    load_rows(a.h + row * C, hf, x);
+    ln_rows(x, hf, gb, xn, mu, rstd);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) P = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn[c][u], P);
+      for (int u = 0; u < 2; ++u) {
+        x[c][u] = (x[c][u] - mu) * rstd;
+        P = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn[c][u], P);
+      }
+    rows_to_acc(x, xh);   // xhat in the accumulator layout for the LayerNorm backward, from the same read
   }
   softmax_regs(P, vmask);
   v16f ds = zero16();
@@ -245,7 +259,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_dx(AttnArgs a) {
   softmax_bwd_regs(P, ds);
   const uint4 d0 = pack8(ds, 0), d1 = pack8(ds, 1);
   // dxn2 (accumulator layout: register r of tile ct = channel 32 ct + rho(r, hf)) and the LayerNorm backward
-  v16f dy[4], xh[4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -254,10 +267,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_dx(AttnArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = 32 * ct + 8 * q + 4 * hf;
-      const v4f x = *reinterpret_cast<const v4f *>(a.h + row * C + ch), g = *reinterpret_cast<const v4f *>(gb + ch);
+      const v4f g = *reinterpret_cast<const v4f *>(gb + ch);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        xh[ct][4 * q + m] = (x[m] - mu) * rstd;
         const float dg = dy[ct][4 * q + m] * g[m];
         s1 += dg;
         s2 = fmaf(dg, xh[ct][4 * q + m], s2);

@@ -127,8 +127,7 @@ __device__ __forceinline__ void load16(v16f &v, const float *src) {
 }
 // This lane's row of h in the B-operand layout (8 consecutive channels 32 c + 16 u + 8 hf .. per (c, u)), LayerNorm statistics
 // (two passes like torch) and the normalised, affine row as bf16 fragments.  gb = LDS table [gamma(128) | beta(128)].
-__device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
-  v8f x[4][2];
+__device__ __forceinline__ void load_rows(const float *__restrict__ hrow, int hf, v8f (&x)[4][2]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -137,6 +136,25 @@ __device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, 
       const v4f lo = *reinterpret_cast<const v4f *>(p), hi = *reinterpret_cast<const v4f *>(p + 4);
       x[c][u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
+}
+// The same row in the accumulator layout (register r of tile c = channel 32 c + rho(r, hf)) without reading it again: the two
+// half-waves of a point hold complementary channel sets in either layout, and v_permlane32_swap trades the halves of two registers
+// in one instruction: (x[u][m], x[u][4 + m]) -> (d[8 u + m], d[8 u + 4 + m]).  The same call converts back.
+__device__ __forceinline__ void rows_to_acc(const v8f (&x)[4][2], v16f (&d)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float lo = x[c][u][m], hi = x[c][u][4 + m];   // (copies: a bit_cast applied to a vector-element expression reads element 0)
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        d[c][8 * u + m] = __builtin_bit_cast(float, r0);
+        d[c][8 * u + 4 + m] = __builtin_bit_cast(float, r1);
+      }
+}
+__device__ __forceinline__ void ln_rows(const v8f (&x)[4][2], int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -173,6 +191,11 @@ __device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, 
       }
       xn[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
     }
+}
+__device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
+  v8f x[4][2];
+  load_rows(hrow, hf, x);
+  ln_rows(x, hf, gb, xn, mu, rstd);
 }
 
 // x * sigmoid(k(x)), k(x) = x (c1 + c3 x^2); returns gelu and d gelu / dx
@@ -250,9 +273,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // B operand of the products over the channels: xn3 = LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   uint4 xn[4][2];
   float mu, rstd;
-  ln_rows(a.h1 + row * C, hf, gbs, xn, mu, rstd);
-  uint4 dhb[4][2];
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
+  {
+    v8f x[4][2];
+    load_rows(a.h1 + row * C, hf, x);
+    ln_rows(x, hf, gbs, xn, mu, rstd);
+    if (!BWD) rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
+  }
+  uint4 dhb[4][2];
   if (BWD) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -298,11 +326,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       v16f b2;
       load16(b2, a.b2p + hf * 64 + c * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4f t = *reinterpret_cast<const v4f *>(a.h1 + row * C + 32 * c + 8 * q + 4 * hf);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[c][4 * q + m] = t[m] + b2[4 * q + m];
-      }
+      for (int r = 0; r < 16; ++r) acc[c][r] += b2[r];
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's loads and stores are done: the loop counts only LDS-DMA pieces (+ the backward's tile stores)
@@ -481,7 +505,10 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   const int cl = wave & (WG_CHUNKS - 1);
   const bool consumer = wave >= WG_CHUNKS;
 #endif
-  const int cg = blockIdx.x % (NCHUNK / WG_CHUNKS), slab = blockIdx.x / (NCHUNK / WG_CHUNKS), j = cg * WG_CHUNKS + cl;
+  // workgroup ids are dealt round-robin over the 8 XCDs: with the slab index in the low bits the four workgroups that stream the same
+  // slab (one per chunk group) share an XCD, i.e. one L2 — the slab leaves HBM once instead of four times (nslab is a multiple of 8
+  // for all but tiny inputs)
+  const int cg = blockIdx.x / a.nslab, slab = blockIdx.x % a.nslab, j = cg * WG_CHUNKS + cl;
   const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
   const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
   // iteration k requests [xn3 | dh] of tile k + 2 and [xn3^T | dh^T] of tile k + 1: two + two 1 KiB pieces per wavefront
