@@ -57,11 +57,20 @@ enum { F_AS = 0, F_MS = 1, F_MST = 2, F_AST = 3, NSETS = 4 };
 constexpr int SET_U4 = 4 * 2 * 64, SHAPE_U4 = NSETS * SET_U4;   // 8 KiB per set, 32 KiB per shape
 
 // ---- fold: (k, v, Wq, Wo) -> fragments of A_s, M_s and their transposes; one workgroup per shape ----
-__global__ __launch_bounds__(256) void k_attn_fold(const float *__restrict__ k, const float *__restrict__ v, int ldkv,
-                                                    const float *__restrict__ wq, const float *__restrict__ wo,
-                                                    uint4 *__restrict__ frags) {
+// grid (B, depth): all blocks of the network in one launch (their keys / values sit side by side in one buffer, row stride ldkv)
+constexpr int FOLD_MAX_DEPTH = 8;
+struct FoldArgs {
+  const float *kv;                      // (B J, ldkv): block i's keys at column 2 i C, values at (2 i + 1) C
+  int ldkv;
+  const float *wq[FOLD_MAX_DEPTH], *wo[FOLD_MAX_DEPTH];
+  uint4 *frags[FOLD_MAX_DEPTH];
+};
+__global__ __launch_bounds__(256) void k_attn_fold(FoldArgs a) {
   __shared__ float As[HJ][C + 1], Ms[C][HJ + 1];
-  const int s = blockIdx.x, t = threadIdx.x;
+  const int s = blockIdx.x, t = threadIdx.x, blk = blockIdx.y, ldkv = a.ldkv;
+  const float *__restrict__ k = a.kv + 2 * blk * C, *__restrict__ v = a.kv + (2 * blk + 1) * C;
+  const float *__restrict__ wq = a.wq[blk], *__restrict__ wo = a.wo[blk];
+  uint4 *__restrict__ frags = a.frags[blk];
   for (int idx = t; idx < HJ * C; idx += 256) {
     const int m = idx / C, c = idx % C, hd = m >> 2, j = m & 3;
     const float *kk = k + ((size_t)s * J + j) * ldkv + hd * HD;

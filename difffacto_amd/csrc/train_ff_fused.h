@@ -97,7 +97,7 @@ struct FfArgs {
   const float *h1;       // (R, 128) input of the sub-block (behind the attention)
   float *h2;             // forward: (R, 128) output (may alias h1)
   const float *dh;       // backward: (R, 128) gradient at the block output
-  uint4 *pk;             // backward: [R / 32][4][4][2][64] the tile's xn3 / dh as MFMA fragments and their transposes, for k_ff_wgrad
+  uint4 *pk;             // backward: [R / 32][2][4][2][64] the tile's xn3 / dh as MFMA fragments, for k_ff_wgrad
   float *dh1;            // backward: (R, 128) gradient at h1 = dh + LN3'(W1^T d[a | g])
   float *cpart;          // backward: [workgroups][3][128] column sums for d gamma3, d beta3, d b2
   long long R;           // multiple of 32
@@ -212,9 +212,10 @@ __device__ __forceinline__ float gelu_f(float x) {
 }
 
 constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
-// per 32-point tile, for k_ff_wgrad: four sets of fragments [4 c][2 u][64 lanes] (8 KiB each)
+// per 32-point tile, for k_ff_wgrad: two sets of fragments [4 c][2 u][64 lanes] (8 KiB each) in memory; k_ff_wgrad derives the
+// transposed sets (PK_XNT, PK_DHT: channels on the lanes, points along the registers) in LDS
 enum { PK_XN = 0, PK_DH = 1, PK_XNT = 2, PK_DHT = 3 };
-constexpr int PK_TILE_U4 = 4 * 8 * 64;   // 32 KiB
+constexpr int PK_TILE_U4 = 2 * 8 * 64;   // 16 KiB
 constexpr int NW_BWD = 8;   // wavefronts per workgroup, backward (256 points, one workgroup per CU: three 40 KiB chunk buffers)
 #ifndef DFX_FF_NW_FWD
 #define DFX_FF_NW_FWD 4
@@ -295,29 +296,13 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    // the tile for k_ff_wgrad: xn3 and dh as they are (B-operand fragments, points on the lanes) and turned around (channels on the
-    // lanes, points along the registers) by the matrix unit itself — a product with a 0/1 selection matrix, exact
+    // the tile for k_ff_wgrad: xn3 and dh as bf16 B-operand fragments (points on the lanes), 16 KiB of whole 1 KiB stores
     if (live) {
-      uint4 sel[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        __bf16 o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(pj == 16 * u + 8 * hf + e ? 1.0f : 0.0f);
-        sel[u] = *reinterpret_cast<const uint4 *>(o);
-      }
       uint4 *pk = a.pk + (size_t)((row - pj) / 32) * PK_TILE_U4 + lane;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
         pk[(PK_DH * 8 + c * 2 + 0) * 64] = dhb[c][0], pk[(PK_DH * 8 + c * 2 + 1) * 64] = dhb[c][1];
-        v16f z, t;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        t = mfma(xn[c][1], sel[1], mfma(xn[c][0], sel[0], z));
-        pk[(PK_XNT * 8 + c * 2 + 0) * 64] = pack8(t, 0), pk[(PK_XNT * 8 + c * 2 + 1) * 64] = pack8(t, 1);
-        t = mfma(dhb[c][1], sel[1], mfma(dhb[c][0], sel[0], z));
-        pk[(PK_DHT * 8 + c * 2 + 0) * 64] = pack8(t, 0), pk[(PK_DHT * 8 + c * 2 + 1) * 64] = pack8(t, 1);
       }
     }
   } else {
@@ -482,16 +467,17 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 struct FwArgs {
   const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
   const float *b1;       // (1024)
-  const uint4 *pk;       // [R / 32][4][4][2][64]
+  const uint4 *pk;       // [R / 32][2][4][2][64]
   float *part;           // [nslab][NCHUNK][12][16][64] fp32 gradient tiles in accumulator layout
   float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
   long long ntiles;      // R / 32
   int nslab;
 };
 constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chunk, on the same SIMD
-// LDS: the tile halves travel in separate rings of three 16 KiB slots, two tiles ahead of their reader (L2 latency under load is
-// longer than one tile's arithmetic): [xn3 | dh] of tile k for the producers, [xn3^T | dh^T] of tile k - 1 for the consumers
-constexpr int WG_RING_A = 0, WG_RING_B = 3 * 16384, WG_RING = 6 * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
+// LDS: the tiles ([xn3 | dh] fragments, 16 KiB) travel in a ring of three slots, two tiles ahead of the producers (L2 latency under load
+// is longer than one tile's arithmetic); the consumers turn tile k around (two MFMAs with a 0/1 selection matrix per 32 x 32 tile, exact)
+// into one of two 16 KiB slots while they multiply tile k - 1
+constexpr int WG_RING_A = 0, WG_RING_T = 3 * 16384, WG_RING = 5 * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
 __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 3 tiles x 32 KiB | 2 x 4 chunks x 6 KiB of hid / da / dg fragments
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -511,23 +497,18 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   const int cg = blockIdx.x / a.nslab, slab = blockIdx.x % a.nslab, j = cg * WG_CHUNKS + cl;
   const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
   const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
-  // iteration k requests [xn3 | dh] of tile k + 2 and [xn3^T | dh^T] of tile k + 1: two + two 1 KiB pieces per wavefront
+  // iteration k requests tile k + 2: two 1 KiB pieces per wavefront
   auto stage = [&](int k) {
     if (k + 2 < nt) {
       const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
 #pragma unroll
       for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
     }
-    if (k + 1 < nt && k + 1 >= 0) {
-      const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 1) * PK_TILE_U4) + 16384;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_B + ((k + 1) % 3) * 16384 + (wave * 2 + q) * 1024);
-    }
   };
   // top of iteration k: everything requested before iteration k - 1 has landed (loads complete in order; the last iterations request
-  // less or nothing: drain)
+  // nothing: drain)
   auto arrive = [&](int k) {
-    if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -536,7 +517,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // fragments (24 MFMAs + the GEGLU arithmetic, weights in registers), the consumer multiplies tile k - 1's fragments with the
   // transposed tile (24 MFMAs into its 192 accumulator registers) — so the matrix pipe of the SIMD works through the producer's VALU
   // stretch, and neither role needs more than 256 registers.
-  stage(-2), stage(-1);   // tiles 0, 1 for the producers, tile 0 for the consumers
+  stage(-2), stage(-1);   // tiles 0, 1
   if (!consumer) {
     uint4 w1a[4][2], w1g[4][2], w2t[4][2];
     {
@@ -595,11 +576,31 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dW2[c][r] = 0.f, dWa[c][r] = 0.f, dWg[c][r] = 0.f;
+  uint4 sel[2];   // selection matrices: B[k][n] = (n == 16 u + k), this lane's eight k = 8 hf .. 8 hf + 7 of column n = lane & 31
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    __bf16 o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(pj == 16 * u + 8 * (lane >> 5) + e ? 1.0f : 0.0f);
+    sel[u] = *reinterpret_cast<const uint4 *>(o);
+  }
   for (int k = 0; k <= nt; ++k) {
     arrive(k);
     stage(k);
+    if (k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
+      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
+      uint4 *to = reinterpret_cast<uint4 *>(fw_smem + WG_RING_T + (k & 1) * 16384) + lane;
+      v16f z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind) {
+        const v16f t = mfma(tl[(kind * 8 + cl * 2 + 1) * 64], sel[1], mfma(tl[(kind * 8 + cl * 2 + 0) * 64], sel[0], z));
+        to[(kind * 8 + cl * 2 + 0) * 64] = pack8(t, 0), to[(kind * 8 + cl * 2 + 1) * 64] = pack8(t, 1);
+      }
+    }
     if (k == 0) continue;
-    const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_B + ((k - 1) % 3) * 16384) - 16 * 64 + lane;   // (kinds 2, 3 sit at fragment index 16..31 of a tile)
+    const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_T + ((k - 1) & 1) * 16384) - 16 * 64 + lane;   // (index the slot by PK_XNT, PK_DHT)
     const uint4 *pi = packs + (((k - 1) & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
     const uint4 h0 = pi[0 * 64], h1 = pi[1 * 64], a0 = pi[2 * 64], a1 = pi[3 * 64], g0 = pi[4 * 64], g1 = pi[5 * 64];
 #pragma unroll

@@ -1615,6 +1615,10 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     for (int i = 0; i < wt->depth; ++i) kp.p[2 * i] = wt->blk[i].to_k, kp.p[2 * i + 1] = wt->blk[i].to_v;
     k_pack_kv<<<(2 * wt->depth * C * CTXP + 255) / 256, 256, 0, st>>>(kp, w.wkv, 2 * wt->depth);
     if ((rc = lin(st, w.ctx, CTXP, w.wkv, nullptr, w.kv, LDKV, BJ, LDKV, CTXP))) return rc;
+    dfx::afused::FoldArgs fo{};
+    fo.kv = w.kv, fo.ldkv = LDKV;
+    for (int i = 0; i < wt->depth; ++i) fo.wq[i] = wt->blk[i].to_q, fo.wo[i] = wt->blk[i].to_out_w, fo.frags[i] = w.at_frags[i];
+    dfx::afused::k_attn_fold<<<dim3(B, wt->depth), 256, 0, st>>>(fo);
   }
   for (int i = 0; i < wt->depth; ++i) {
     const dfx_block_weights &bw = wt->blk[i];
@@ -1624,7 +1628,6 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if (fused) {
       // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
       // q, P, att, xn2, xn3, [a | g], hid never exist in memory
-      dfx::afused::k_attn_fold<<<B, 256, 0, st>>>(w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, LDKV, bw.to_q, bw.to_out_w, w.at_frags[i]);
       dfx::afused::AttnArgs aa{};
       aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
       aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
