@@ -52,9 +52,15 @@ using ffused::v8bf;
 using ffused::v8f;
 
 constexpr int C = 128, J = 4, HEADS = 8, HD = 16, HJ = HEADS * J;
-// fragment sets per shape: tile t (4), unit u (2), lane (64) uint4 each
-enum { F_AS = 0, F_MS = 1, F_MST = 2, F_AST = 3, NSETS = 4 };
-constexpr int SET_U4 = 4 * 2 * 64, SHAPE_U4 = NSETS * SET_U4;   // 8 KiB per set, 32 KiB per shape
+using ffused::F_AS;
+using ffused::F_AST;
+using ffused::F_MS;
+using ffused::F_MST;
+using ffused::NSETS;
+using ffused::SET_U4;
+using ffused::SHAPE_U4;
+using ffused::softmax_regs;
+using ffused::zero16;
 
 // ---- fold: (k, v, Wq, Wo) -> fragments of A_s, M_s and their transposes; one workgroup per shape ----
 // grid (B, depth): all blocks of the network in one launch (their keys / values sit side by side in one buffer, row stride ldkv)
@@ -135,21 +141,6 @@ __device__ __forceinline__ void row_frags(const float *__restrict__ row, int hf,
     }
 }
 
-// masked softmax over the four keys of each head, primary layout: registers 4 g .. 4 g + 3 = keys of head 2 g + hf
-__device__ __forceinline__ void softmax_regs(v16f &sim, unsigned vmask) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float sj[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;   // masked_fill_(~mask, -finfo.max)
-    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = expf(sj[j] - m), den += sj[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sim[4 * g + j] = sj[j] / den;
-  }
-}
 // softmax backward in the same layout: dsim = P (dP - sum_j P dP)
 __device__ __forceinline__ void softmax_bwd_regs(const v16f &P, v16f &dP) {
 #pragma unroll
@@ -160,13 +151,6 @@ __device__ __forceinline__ void softmax_bwd_regs(const v16f &P, v16f &dP) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dP[4 * g + j] = P[4 * g + j] * (dP[4 * g + j] - dot);
   }
-}
-
-__device__ __forceinline__ v16f zero16() {
-  v16f z;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) z[r] = 0.f;
-  return z;
 }
 
 constexpr int NW = 4;   // wavefronts per workgroup: small workgroups, several per CU — these kernels are bound by memory latency

@@ -101,7 +101,19 @@ struct FfArgs {
   float *dh1;            // backward: (R, 128) gradient at h1 = dh + LN3'(W1^T d[a | g])
   float *cpart;          // backward: [workgroups][3][128] column sums for d gamma3, d beta3, d b2
   long long R;           // multiple of 32
+  // forward with the attention sub-block in front (train_attn_fused.h; at_frags != nullptr): h1 = hin + M_s softmax(A_s LN2(hin)) + b_o is
+  // computed here from hin and written out (the backward reads it), instead of being read back from a kernel of its own
+  const uint4 *at_frags;   // [B][4 sets][4][2][64] folded (A_s, M_s) fragments of this block
+  const float *valid;      // (B, 4)
+  const float *g2, *b2n, *bo;
+  const float *hin;        // (R, 128)
+  float *h1_out;           // (R, 128)
+  int N;                   // points per shape
 };
+
+// fragment sets of the folded attention per shape (written by afused::k_attn_fold): tile t (4), unit u (2), lane (64) uint4 each
+enum { F_AS = 0, F_MS = 1, F_MST = 2, F_AST = 3, NSETS = 4 };
+constexpr int SET_U4 = 4 * 2 * 64, SHAPE_U4 = NSETS * SET_U4;   // 8 KiB per set, 32 KiB per shape
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 constexpr float LN_EPS = 1e-5f;
@@ -153,6 +165,41 @@ __device__ __forceinline__ void rows_to_acc(const v8f (&x)[4][2], v16f (&d)[4]) 
         d[c][8 * u + m] = __builtin_bit_cast(float, r0);
         d[c][8 * u + 4 + m] = __builtin_bit_cast(float, r1);
       }
+}
+__device__ __forceinline__ void acc_to_rows(const v16f (&d)[4], v8f (&x)[4][2]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float lo = d[c][8 * u + m], hi = d[c][8 * u + 4 + m];
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        x[c][u][m] = __builtin_bit_cast(float, r0);
+        x[c][u][4 + m] = __builtin_bit_cast(float, r1);
+      }
+}
+__device__ __forceinline__ v16f zero16() {
+  v16f z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// masked softmax over the four keys of each head, accumulator layout: registers 4 g .. 4 g + 3 = keys of head 2 g + hf
+__device__ __forceinline__ void softmax_regs(v16f &sim, unsigned vmask) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = (vmask >> j) & 1u ? sim[4 * g + j] : -3.402823466e38f;   // masked_fill_(~mask, -finfo.max)
+    const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = expf(sj[j] - m), den += sj[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sim[4 * g + j] = sj[j] / den;
+  }
 }
 __device__ __forceinline__ void ln_rows(const v8f (&x)[4][2], int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
   float s = 0.f;
@@ -267,15 +314,58 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // landed as well, and the stream would never run ahead
   float *b1s = reinterpret_cast<float *>(ff_smem + NBUF * BUF_BYTES);
   float *gbs = b1s + B1P_FLOATS;
+  float *gb2 = gbs + 2 * C;   // forward only: LayerNorm2 affine | to_out bias
   for (int i = threadIdx.x; i < B1P_FLOATS; i += NW * 64) b1s[i] = a.b1p[i];
   for (int i = threadIdx.x; i < 2 * C; i += NW * 64) gbs[i] = i < C ? a.g3[i] : a.b3[i - C];
+  if (!BWD && a.at_frags)
+    for (int i = threadIdx.x; i < 3 * C; i += NW * 64) gb2[i] = i < C ? a.g2[i] : i < 2 * C ? a.b2n[i - C] : a.bo[i - 2 * C];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first NBUF - 1 chunks have landed (one-off)
   __syncthreads();
   // B operand of the products over the channels: xn3 = LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   uint4 xn[4][2];
   float mu, rstd;
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
-  {
+  if (!BWD && a.at_frags) {
+    // attention sub-block in registers: h1 = hin + M_s softmax(A_s LN2(hin)) + b_o, then straight on to LayerNorm3
+    v8f x[4][2];
+    load_rows(a.hin + row * C, hf, x);
+    const int s = (int)((row - pj) / a.N);
+    const uint4 *fr = a.at_frags + (size_t)s * SHAPE_U4 + lane;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+    v16f sim = zero16();
+    {
+      uint4 xn2[4][2];
+      float mu2, rstd2;
+      ln_rows(x, hf, gb2, xn2, mu2, rstd2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sim = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], sim);
+    }
+    softmax_regs(sim, vmask);
+    const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
+    rows_to_acc(x, acc);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f b = *reinterpret_cast<const v4f *>(gb2 + 2 * C + 32 * ct + 8 * q + 4 * hf);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[ct][4 * q + m] += b[m];
+      }
+      acc[ct] = mfma(fr[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
+      acc[ct] = mfma(fr[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<v4f *>(a.h1_out + row * C + 32 * ct + 8 * q + 4 * hf) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+      }
+    }
+    acc_to_rows(acc, x);   // h1 in the B-operand layout for LayerNorm3
+    ln_rows(x, hf, gbs, xn, mu, rstd);
+  } else {
     v8f x[4][2];
     load_rows(a.h1 + row * C, hf, x);
     ln_rows(x, hf, gbs, xn, mu, rstd);
@@ -667,7 +757,7 @@ inline void launch_pack(hipStream_t st, const PackArgs &a) {
 }
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) {
-  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C) * 4;
+  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C + (BWD ? 0 : 3 * C)) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

@@ -1273,6 +1273,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
 // Fused feed-forward kernels (train_ff_fused.h) for bf16 products without dropout; dfx_debug_train_fused(0) restores the
 // layer-by-layer path (A/B timing, and the reference for the fused path's own test).
 bool g_ff_fused = true;
+bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the attention forward as a kernel of its own)
 inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return g_ff_fused && bf && dropout_p == 0.f && R % 32 == 0 && N % 32 == 0; }
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
@@ -1628,14 +1629,19 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if (fused) {
       // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
       // q, P, att, xn2, xn3, [a | g], hid never exist in memory
-      dfx::afused::AttnArgs aa{};
-      aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
-      aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
-      dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
       dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
+      if (g_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
+        fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
+        fa.hin = a.hin, fa.h1_out = a.h1, fa.N = N;
+      } else {
+        dfx::afused::AttnArgs aa{};
+        aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
+        aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
+        dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
+      }
       if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
       continue;
     }
@@ -2007,7 +2013,7 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
-void dfx_debug_train_fused(int on) { g_ff_fused = on != 0; }
+void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
 
 int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream) {
   DFX_REQUIRE(out && n >= 4 && n % 4 == 0 && p > 0.f && p < 1.f, "debug_dropout_factors: bad argument");
