@@ -60,6 +60,7 @@ using ffused::NSETS;
 using ffused::SET_U4;
 using ffused::SHAPE_U4;
 using ffused::softmax_regs;
+using ffused::softmax_bwd_regs;
 using ffused::zero16;
 
 // ---- fold: (k, v, Wq, Wo) -> fragments of A_s, M_s and their transposes; one workgroup per shape ----
@@ -139,18 +140,6 @@ __device__ __forceinline__ void row_frags(const float *__restrict__ row, int hf,
       const v8f t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       f[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(t, v8bf));
     }
-}
-
-// softmax backward in the same layout: dsim = P (dP - sum_j P dP)
-__device__ __forceinline__ void softmax_bwd_regs(const v16f &P, v16f &dP) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dot = fmaf(P[4 * g + j], dP[4 * g + j], dot);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dP[4 * g + j] = P[4 * g + j] * (dP[4 * g + j] - dot);
-  }
 }
 
 constexpr int NW = 4;   // wavefronts per workgroup: small workgroups, several per CU — these kernels are bound by memory latency

@@ -109,6 +109,9 @@ struct FfArgs {
   const float *hin;        // (R, 128)
   float *h1_out;           // (R, 128)
   int N;                   // points per shape
+  // backward with the attention's input gradient behind it (at_frags != nullptr): dh_in = dh1 + LN2'(A_s^T dsim) leaves through dh_in
+  // (may alias dh: a wavefront reads its rows of dh before it writes them) and cpart gets three more rows (d gamma2, d beta2, d b_o)
+  float *dh_in;
 };
 
 // fragment sets of the folded attention per shape (written by afused::k_attn_fold): tile t (4), unit u (2), lane (64) uint4 each
@@ -199,6 +202,17 @@ __device__ __forceinline__ void softmax_regs(v16f &sim, unsigned vmask) {
     for (int j = 0; j < 4; ++j) sj[j] = expf(sj[j] - m), den += sj[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) sim[4 * g + j] = sj[j] / den;
+  }
+}
+// softmax backward in the same layout: dsim = P (dP - sum_j P dP)
+__device__ __forceinline__ void softmax_bwd_regs(const v16f &P, v16f &dP) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dot = fmaf(P[4 * g + j], dP[4 * g + j], dot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dP[4 * g + j] = P[4 * g + j] * (dP[4 * g + j] - dot);
   }
 }
 __device__ __forceinline__ void ln_rows(const v8f (&x)[4][2], int hf, const float *gb, uint4 (&xn)[4][2], float &mu, float &rstd) {
@@ -314,10 +328,10 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // landed as well, and the stream would never run ahead
   float *b1s = reinterpret_cast<float *>(ff_smem + NBUF * BUF_BYTES);
   float *gbs = b1s + B1P_FLOATS;
-  float *gb2 = gbs + 2 * C;   // forward only: LayerNorm2 affine | to_out bias
+  float *gb2 = gbs + 2 * C;   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
   for (int i = threadIdx.x; i < B1P_FLOATS; i += NW * 64) b1s[i] = a.b1p[i];
   for (int i = threadIdx.x; i < 2 * C; i += NW * 64) gbs[i] = i < C ? a.g3[i] : a.b3[i - C];
-  if (!BWD && a.at_frags)
+  if (a.at_frags)
     for (int i = threadIdx.x; i < 3 * C; i += NW * 64) gb2[i] = i < C ? a.g2[i] : i < 2 * C ? a.b2n[i - C] : a.bo[i - 2 * C];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first NBUF - 1 chunks have landed (one-off)
   __syncthreads();
@@ -500,8 +514,10 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   s1 *= (1.0f / C), s2 *= (1.0f / C);
   constexpr int TROW = 36;   // floats per tile row: 16-byte aligned rows, conflict-free column reads
   float *tt = reinterpret_cast<float *>(ff_smem) + wave * 32 * TROW;
-  float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][3][128]
+  float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][NQ][128]
+  const int NQ = a.at_frags ? 6 : 3;
   const float keep = live ? 1.f : 0.f;
+  // (gb2 sits behind the chunk buffers: untouched by the tiles)
   auto colsum = [&](const v16f &v, int which, int c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) tt[rho(r, hf) * TROW + pj] = v[r];
@@ -512,8 +528,9 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       t += (x[0] + x[1]) + (x[2] + x[3]);
     }
     t += xhalf(t);
-    if (hf == 0) cred[(wave * 3 + which) * C + 32 * c + pj] = t * keep;
+    if (hf == 0) cred[(wave * NQ + which) * C + 32 * c + pj] = t * keep;
   };
+  v16f d1[4];   // dh1 in the accumulator layout
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     v16f dv, gx;
@@ -528,6 +545,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         dv[r] = d[m];
         gx[r] = acc[c][r] * xh[c][r];
         o[m] = d[m] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
+        d1[c][r] = o[m];
       }
       if (live) *reinterpret_cast<v4f *>(a.dh1 + row * C + ch) = o;
     }
@@ -535,12 +553,86 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     colsum(acc[c], 1, c);
     colsum(dv, 2, c);
   }
+  if (a.at_frags) {
+    // ---- the attention sub-block's input gradient on the same rows (afused::k_attn_bwd_dx's arithmetic): recompute LN2 / sim / P from hin,
+    // dP = M_s^T dh1, softmax backward, dxn2 = A_s^T dsim, LayerNorm2 backward: dh_in = dh1 + ... ; column sums for d gamma2, d beta2, d b_o ----
+    const int s = (int)((row - pj) / a.N);
+    const uint4 *fr = a.at_frags + (size_t)s * SHAPE_U4 + lane;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+    float mu2, rstd2;
+    v16f P = zero16(), ds = zero16();
+    {
+      v8f x[4][2];
+      uint4 xn2[4][2];
+      load_rows(a.hin + row * C, hf, x);
+      ln_rows(x, hf, gb2, xn2, mu2, rstd2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          x[c][u] = (x[c][u] - mu2) * rstd2;
+          P = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], P);
+        }
+      rows_to_acc(x, xh);   // xhat2 in the accumulator layout (xhat3 is done with)
+    }
+    softmax_regs(P, vmask);
+    {
+      v8f x[4][2];
+      acc_to_rows(d1, x);   // dh1 as the B operand
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          ds = mfma(fr[F_MST * SET_U4 + (c * 2 + u) * 64], __builtin_bit_cast(uint4, __builtin_convertvector(x[c][u], v8bf)), ds);
+    }
+    softmax_bwd_regs(P, ds);
+    const uint4 q0 = pack8(ds, 0), q1 = pack8(ds, 1);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = mfma(fr[F_AST * SET_U4 + (c * 2 + 1) * 64], q1, mfma(fr[F_AST * SET_U4 + (c * 2 + 0) * 64], q0, zero16()));   // dxn2
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f g = *reinterpret_cast<const v4f *>(gb2 + 32 * c + 8 * q + 4 * hf);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float dg = acc[c][4 * q + m] * g[m];
+          t1 += dg;
+          t2 = fmaf(dg, xh[c][4 * q + m], t2);
+        }
+      }
+    }
+    t1 += xhalf(t1), t2 += xhalf(t2);
+    t1 *= (1.0f / C), t2 *= (1.0f / C);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v16f gx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = 32 * c + 8 * q + 4 * hf;
+        const v4f g = *reinterpret_cast<const v4f *>(gb2 + ch);
+        v4f o;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int r = 4 * q + m;
+          gx[r] = acc[c][r] * xh[c][r];
+          o[m] = d1[c][r] + rstd2 * (acc[c][r] * g[m] - t1 - xh[c][r] * t2);
+        }
+        if (live) *reinterpret_cast<v4f *>(a.dh_in + row * C + ch) = o;
+      }
+      colsum(gx, 3, c);
+      colsum(acc[c], 4, c);
+      colsum(d1[c], 5, c);
+    }
+  }
   __syncthreads();
-  if (threadIdx.x < 3 * C) {
+  for (int i = threadIdx.x; i < NQ * C; i += NW * 64) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += cred[(w * 3 + threadIdx.x / C) * C + threadIdx.x % C];
-    a.cpart[(size_t)blockIdx.x * 3 * C + threadIdx.x] = t;
+    for (int w = 0; w < NW; ++w) t += cred[(w * NQ + i / C) * C + i % C];
+    a.cpart[(size_t)blockIdx.x * NQ * C + i] = t;
   }
 }
 
@@ -757,7 +849,7 @@ inline void launch_pack(hipStream_t st, const PackArgs &a) {
 }
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) {
-  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C + (BWD ? 0 : 3 * C)) * 4;
+  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C + 3 * C) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

@@ -1256,7 +1256,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.at_part = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
   w.at_sum = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
   {
-    const size_t groups = (R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD, a = groups * 3 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
+    const size_t groups = (R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD, a = groups * 6 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
     w.cpart = c.take<float>(a > b ? a : b);
   }
   w.ffw_slabs = dfx::ffused::wgrad_slabs((long long)(R / 32));
@@ -1719,9 +1719,17 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R;
+      const bool dx_in_ff = g_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
+      if (dx_in_ff) {
+        fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
+        fa.hin = a.hin, fa.dh_in = w.dh, fa.N = N;
+      }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
       const int groups = (int)((R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD);
-      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
+      const int nq = dx_in_ff ? 6 : 3;
+      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, nq * C);
+      if (dx_in_ff)
+        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart + 3 * C, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, groups, C, nq * C);
       // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide
       {
         dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part, w.ffw_bpart, R / 32, w.ffw_slabs};
@@ -1734,13 +1742,13 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       aa.h = a.hin, aa.dh1 = w.dh2, aa.dh = w.dh, aa.part = w.at_part, aa.cpart = w.cpart, aa.N = N, aa.split = w.at_split, aa.R = R;
       dfx::afused::k_attn_bwd_param<<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
       const int np = dfx::afused::dx_groups(R);
-      dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
+      if (!dx_in_ff) dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
       const int LDKV = 2 * wt->depth * C;
       dfx::afused::UnfoldArgs ua{w.at_part, w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
                                  mut(gw.to_q), mut(gw.to_out_w), w.at_sum, B, w.at_split, LDKV};
       dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B), 256, 0, st>>>(ua);
       dfx::afused::k_attn_unfold_w<<<C, 1024, 0, st>>>(ua);
-      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
+      if (!dx_in_ff) k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
     } else {
     if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
