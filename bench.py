@@ -276,6 +276,34 @@ def t100_line(params, names, sampler, valid, B, N, precision, dev, launches=5):
         return {"error": repr(e)[:200]}
 
 
+def small_batch_line(params, names, sampler, N, precision, dev, T):
+    """Latency side of the same kernel family (SURVEY.md §8(d) config 2, B = 1): one T-step chain for ONE shape and for four, HIP-event
+    time of the chain launch; the co-operative kernel takes these sizes, bit-identical to the pipelined one (tested)."""
+    from difffacto_amd.engine import DenoiserEngine
+    try:
+        out = {"num_timesteps": T}
+        eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=precision, device=dev)
+        for B in (1, 4):
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(98)
+            valid = torch.ones(B, 4, device=dev)
+            lat = sampler.sample_latents(torch.randn(B, 256, 4, device=dev, generator=gen), torch.randn(B, 32, device=dev, generator=gen),
+                                         valid, K=1, npoints=N)
+            ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
+            eng.sample_chain(ctx, lat["seg_mask"], seed=1)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            eng.sample_chain(ctx, lat["seg_mask"], seed=2)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b)
+            out[f"B{B}"] = {"ms_per_chain": ms, "shapes_per_s": B / ms * 1e3}
+        eng.close()
+        return out
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -422,6 +450,7 @@ def main():
         if world == 1 and not args.no_parity:
             res["parity"] = parity_block(Wnp, N)
             res["t100"] = t100_line(params, names, sampler, valid, B, N, args.precision, dev)
+            res["small_batch"] = small_batch_line(params, names, sampler, N, args.precision, dev, T)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(Wnp, N)
         if world == 1 and not args.no_train_line and args.precision == "bf16":
