@@ -427,8 +427,9 @@ int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
 /* Dropout factors (0 or 1/(1-p)) of n consecutive elements of a site: 2 i = behind to_out of block i over (B N, 128),
  * 2 i + 1 = behind the GEGLU of block i over (B N, 512), 1000 = time_embed over (B, 1024).  n % 4 == 0. */
 int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream);
-/* Debug / A-B switch: 0 routes the bf16 training path through the layer-by-layer feed-forward kernels instead of the fused
- * ones (default 1; the fused path applies to DFX_PREC_BF16 with dropout_p == 0). */
+/* Debug / A-B switch: 0 routes the bf16 training path through the layer-by-layer kernels instead of the fused ones (default 1;
+ * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
+ * kernels of their own instead of inside the feed-forward kernels. */
 void dfx_debug_train_fused(int on);
 /* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
  * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.

@@ -194,6 +194,38 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
     assert abs(fused["loss"] - layer["loss"]) < 1e-3 * abs(layer["loss"]) and e_eps < 5e-3
 
 
+def test_attention_inside_the_feed_forward_kernels_matches_the_separate_attention_kernels():
+    """dfx_debug_train_fused(2) runs the attention forward and its input gradient as kernels of their own (k_attn_fwd_fused,
+    k_attn_bwd_dx); the default folds them into k_ff<false>'s prologue / k_ff<true>'s epilogue.  Same device functions on the same
+    values: eps and the gradients agree to fp32 rounding of the column-sum order (measured: identical eps, gradients 1.6e-7)."""
+    from difffacto_amd import _ffi, synth
+    B, N = 3, 160
+    rng = np.random.Generator(np.random.PCG64(4242))
+    W = synth.make_denoiser_weights(7)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=13, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    inside = _run(c, True, precision="bf16")
+    _ffi.lib().dfx_debug_train_fused(2)
+    try:
+        apart = _run(c, True, precision="bf16")
+    finally:
+        _ffi.lib().dfx_debug_train_fused(1)
+    e_eps = np.abs(inside["eps"] - apart["eps"]).max()
+    worst = 0.0
+    for k, gr in apart["grads"].items():
+        worst = max(worst, np.abs(inside["grads"][k] - gr).max() / max(np.abs(gr).max(), 1e-30))
+    print(f"attention inside vs beside the feed-forward kernels: eps max-abs {e_eps:.1e}, gradients worst max-norm {worst:.1e}")
+    assert e_eps < 1e-5 and worst < 1e-4
+
+
 def test_dropout_factors_and_replayed_mask_parity():
     """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
     seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the
