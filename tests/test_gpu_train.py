@@ -226,6 +226,30 @@ def test_attention_inside_the_feed_forward_kernels_matches_the_separate_attentio
     assert e_eps < 1e-5 and worst < 1e-4
 
 
+def test_fused_training_step_is_bit_reproducible():
+    """No atomics anywhere in the fused path (column sums through LDS tiles in fixed order, per-slab / per-shape partials summed in
+    order): two runs of the same iteration give bit-identical eps and gradients."""
+    from difffacto_amd import synth
+    B, N = 4, 1024
+    rng = np.random.Generator(np.random.PCG64(99))
+    W = synth.make_denoiser_weights(2)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=21, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    a = _run(c, True, precision="bf16")
+    b = _run(c, True, precision="bf16")
+    assert np.array_equal(a["eps"], b["eps"])
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+
+
 def test_dropout_factors_and_replayed_mask_parity():
     """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
     seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the
