@@ -80,12 +80,16 @@ def train_iteration(Wnp, B, N, iters=4):
         del P, a, noise, opt
         torch.cuda.empty_cache()
         out["stage1"] = stage1_iteration(B, N, iters)
+        torch.cuda.empty_cache()
+        # BASELINE configs[4] is a bf16 configuration: the same step with bf16 operands for the PointNetV2 trunk's products as well
+        # (module.train_precision = "bf16"; the default keeps the encoder in exact fp32)
+        out["stage1"]["encoder_bf16_ms"] = stage1_iteration(B, N, iters, encoder_precision="bf16")["ms"]
         return out
     except Exception as e:   # secondary line: never fail the headline measurement
         return {"error": repr(e)[:200]}
 
 
-def stage1_iteration(B, N, iters=4):
+def stage1_iteration(B, N, iters=4, encoder_precision="f32"):
     """The whole stage-1 training iteration of configs/train_chair_stage1.py (PointNetV2 part encoder in train mode + prior loss
     through the latent flows + denoiser + clip + Adam) through the drop-in modules (examples/train_stage1.py)."""
     import numpy as np
@@ -102,6 +106,7 @@ def stage1_iteration(B, N, iters=4):
                              rescale_timesteps=False, model_mean_type="epsilon", learn_variance=True, loss_type='mse', include_anchors=False,
                              precision="bf16")
     enc, diff = enc.cuda().train(), diff.cuda().train()
+    enc.encoder.train_precision = encoder_precision
     opt = training.Adam(list(enc.parameters()) + list(diff.model.parameters()), lr=1e-4, max_norm=10.0)
     rng = np.random.Generator(np.random.PCG64(0))
     cu = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()

@@ -2,7 +2,7 @@
 # Per-kernel time of the whole stage-1 training step (GPU box): tools/prof_stage1_kernels.sh [out.csv]   (kernel-trace only)
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$(realpath -m ${1:-$R/gpurun_out/stage1_kernel_stats.csv})
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kst1
-rocprofv3 --kernel-trace --stats -d /tmp/kst1 --output-format csv -- python $R/examples/train_stage1.py --iters 8 --batch 128 > /tmp/kst1.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kst1 --output-format csv -- python $R/examples/train_stage1.py --iters 8 --batch 128 $STAGE1_ARGS > /tmp/kst1.log 2>&1
 F=$(find /tmp/kst1 -name "*kernel_stats.csv" | head -1)
 mkdir -p $(dirname $OUT); cp $F $OUT
 python - "$OUT" <<'PY'
