@@ -17,7 +17,8 @@
 //     dA_s[(h, j)][c] = sum_p dsim[(h, j)][p] xn2[c][p]         d Wq[d][c] = 1/4 sum_{s, j} k_{s, j}[d] dA_s[(h(d), j)][c]
 //     dM_s[c][(h, j)] = sum_p dh1[c][p] P[(h, j)][p]            d k_{s, j}[d] = 1/4 sum_c dA_s[(h(d), j)][c] Wq[d][c]      (same for Wo, v)
 // Sums over points are MFMA products with the points on the K axis, i.e. operands with the points along a lane's registers,
-// while everything computed per point has the points along the lanes.  Two kernels therefore:
+// while everything computed per point has the points along the lanes.  Two kernels therefore (the first one, and the forward, also exist
+// inside the feed-forward kernels — train_ff_fused.h, FfArgs::at_frags — which is what the training path runs by default):
 //   k_attn_bwd_dx     points on the lanes ("primary" layout, like the feed-forward kernel): dP = M_s^T dh1, softmax backward,
 //                     dxn2 = A_s^T dsim, LayerNorm2 backward, dh out; the column sums for d gamma2, d beta2, d bo leave through a
 //                     per-wave LDS tile that turns 32 points x 32 channels around

@@ -1,22 +1,25 @@
-// Fused GEGLU feed-forward of a transformer block for the TRAINING path (train_kernels.hip, bf16 matrix products, dropout off):
+// Fused GEGLU feed-forward of a transformer block for the TRAINING path (train_kernels.hip, bf16 matrix products, dropout off), with the
+// block's LayerNorms and — optionally, FfArgs::at_frags — its attention sub-block in the same kernels:
 //
-//   forward    h2 = h1 + W2 (a * gelu(g)) + b2,   [a | g] = W1 xn3 + b1                      (attention.py:50-57, 77-94)
-//   backward   given dh2:  hid = a * gelu(g),  d[a | g],  dxn3 = W1^T d[a | g]               (a, g recomputed from xn3)
+//   forward    [h1 = hin + M_s softmax(A_s LN2(hin)) + b_o]   h2 = h1 + W2 (a * gelu(g)) + b2,   [a | g] = W1 LN3(h1) + b1
+//   backward   given dh2:  d[a | g], dxn3 = W1^T d[a | g],  dh1 = dh2 + LN3'(dxn3)   [dh_in = dh1 + LN2'(A_s^T dsim)]      (attention.py:50-57, 77-94,
+//              column sums for the LayerNorm / bias gradients; the tile's xn3 / dh as bf16 fragments for k_ff_wgrad               179-204, 296-306)
+//   k_ff_wgrad dW1, db1, dW2 by a weight-stationary recompute of hid and d[a | g]
 //
 // Same structure as the sampling kernel: one wavefront = 32 points, channels on the MFMA M axis, points on the lanes, the
 // 1024-wide [a | g] and the 512-wide hidden activation live in accumulator registers one 32-unit chunk at a time and never
-// touch HBM in the forward.  The layer-by-layer path wrote [a | g] (2 KB / point), hid (1 KB), d hid (2 KB) and d[a | g]
-// (2 KB) per block and read each of them back once or twice: ~22 KB per point and block; this path moves 1.3 KB (forward)
-// + 1.5 KB (backward: dh1 and, for the weight-gradient kernel, the tile's xn3 / dh as bf16 MFMA fragments in both orientations).
-// The weight gradients come from a second, weight-stationary kernel (k_ff_wgrad below) that recomputes hid and d[a | g] from
-// those fragments instead of reading them back: a sum over the points needs the points on the K axis of the MFMA, i.e. along
-// the registers, and here they are on the lanes.
+// touch HBM.  The layer-by-layer path wrote [a | g] (2 KB / point), hid (1 KB), d hid (2 KB) and d[a | g] (2 KB) per block and read
+// each of them back once or twice: ~22 KB per point and block; these kernels move ~1.5 KB (forward: hin in, h1 and h2 out) + ~4.5 KB
+// (backward: h1, dh twice each, hin in; dh1, dh_in, 0.5 KB of fragments out).
+// A sum over the points (weight gradients) needs the points on the K axis of the MFMA, i.e. along the registers, and here they are on
+// the lanes: hence the second kernel, which recomputes hid and d[a | g] in the transposed orientation from the fragments.
 //
 // Weights: per optimiser step the block's W1 / W2 are re-packed (k_ff_pack) as bf16 MFMA A-fragments, 24 tiles of 32 x 32 per
 // hidden chunk (48 KiB): W1a, W1g (K = channels, natural order: the B operand comes from memory), W2 (K = hidden units in the
 // accumulator-register order of the GELU output), W2^T (rows = hidden units, K = channels) and W1a^T, W1g^T (rows = channels,
-// K = hidden units in register order).  A workgroup (8 wavefronts, 256 points) streams the chunks L2 -> LDS with LDS-DMA through
-// three buffers, two chunks ahead of the compute, counted s_waitcnt vmcnt and one barrier per chunk.
+// K = hidden units in register order).  A workgroup (forward: 4 wavefronts = 128 points, two workgroups per CU; backward: 8 = 256
+// points) streams the chunks L2 -> LDS with LDS-DMA through three buffers, two chunks ahead of the compute, counted s_waitcnt vmcnt
+// and one barrier per chunk.
 //
 // GELU: g * sigmoid(g (c1 + c3 g^2)) in fp32 with the hardware exp2 / rcp (max abs error 2.7e-4 against the erf form, the same
 // form as the direct sampling kernel) and its exact derivative  s + g s (1 - s) (c1 + 3 c3 g^2).
@@ -638,13 +641,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Weight gradients of the feed-forward, weight-stationary:  dW1 = d[a | g]^T xn3 (1024 x 128),  dW2 = dh^T hid (128 x 512),
-// d b1 = column sums of d[a | g].  One wavefront owns ONE 32-unit chunk of the hidden layer for a slab of rows: its W1a / W1g /
-// W2 fragments (96 registers) and its twelve 32 x 32 gradient tiles (192 accumulator registers) stay in registers while the
-// slab's 32-point tiles stream by (32 KiB each, written by k_ff<true>, L2 -> LDS with LDS-DMA, shared by the workgroup's four
-// wavefronts = four chunks).  Per tile and wavefront, everything with the chunk's units on the lanes and the 32 points along
-// the registers (the transposed orientation: activations as the A operand, weights as B):
-//     a^T, g^T = xn3 W1^T + b1 (16 MFMAs)   d hid^T = dh W2 (8)   GEGLU forward / backward on the registers
-//     dW2^T chunk += hid^T dh (8)   dW1a += da^T xn3 (8)   dW1g += dg^T xn3 (8)            K = the 32 points
+// d b1 = column sums of d[a | g].  A 32-unit chunk of the hidden layer for a slab of rows belongs to TWO wavefronts on one SIMD: the
+// producer keeps the chunk's W1a / W1g / W2 fragments (96 registers), the consumer its twelve 32 x 32 gradient tiles (192 accumulator
+// registers), while the slab's 32-point tiles stream by (16 KiB each, written by k_ff<true>, L2 -> LDS with LDS-DMA, shared by the
+// workgroup's four chunks).  Everything with the chunk's units on the lanes and the 32 points along the registers (the transposed
+// orientation: activations as the A operand, weights as B):
+//     producer   a^T, g^T = xn3 W1^T + b1 (16 MFMAs)   d hid^T = dh W2 (8)   GEGLU forward / backward on the registers -> 6 fragments in LDS
+//     consumer   xn3^T, dh^T of the tile by selection-matrix MFMAs (4 per consumer)   dW2^T chunk += hid^T dh (8)   dW1a += da^T xn3 (8)
+//                dW1g += dg^T xn3 (8)            K = the 32 points
 // Partials per (slab, chunk) are summed by k_ff_wgrad_finish in slab order.
 struct FwArgs {
   const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
