@@ -17,9 +17,9 @@
 // Weights: per optimiser step the block's W1 / W2 are re-packed (k_ff_pack) as bf16 MFMA A-fragments, 24 tiles of 32 x 32 per
 // hidden chunk (48 KiB): W1a, W1g (K = channels, natural order: the B operand comes from memory), W2 (K = hidden units in the
 // accumulator-register order of the GELU output), W2^T (rows = hidden units, K = channels) and W1a^T, W1g^T (rows = channels,
-// K = hidden units in register order).  A workgroup (forward: 4 wavefronts = 128 points, two workgroups per CU; backward: 8 = 256
-// points) streams the chunks L2 -> LDS with LDS-DMA through three buffers, two chunks ahead of the compute, counted s_waitcnt vmcnt
-// and one barrier per chunk.
+// K = hidden units in register order).  A workgroup (4 wavefronts = 128 points, two workgroups per CU: one's row loads and stores run
+// under the other's chunk loop) streams the chunks L2 -> LDS with LDS-DMA through three buffers — forward: whole chunks (24 KiB), two
+// ahead of the compute, one barrier per chunk; backward: two items per chunk (stage_item), two barriers — with counted s_waitcnt vmcnt.
 //
 // GELU: g * sigmoid(g (c1 + c3 g^2)) in fp32 with the hardware exp2 / rcp (max abs error 2.7e-4 against the erf form, the same
 // form as the direct sampling kernel) and its exact derivative  s + g s (1 - s) (c1 + 3 c3 g^2).
@@ -39,7 +39,7 @@ constexpr int C = 128, FH = 512, NCHUNK = FH / 32;
 constexpr int TILES = 24;                         // tiles per chunk in the pack
 constexpr int TILE_U4 = 128;                      // uint4 per tile (2 units x 64 lanes)
 constexpr int CHUNK_U4 = TILES * TILE_U4;         // 3072 uint4 = 48 KiB
-constexpr int FWD_TILES = 12, BWD_TILES = 20;     // forward: tiles 0..11; backward: tiles 0..7 and 12..23
+constexpr int FWD_TILES = 12, BWD_TILES = 12;     // LDS slot size in tiles.  forward: tiles 0..11 of a chunk; backward: see stage_item
 enum { T_W1A = 0, T_W1G = 4, T_W2 = 8, T_W2T = 12, T_W1AT = 16, T_W1GT = 20 };
 
 __host__ __device__ inline int rho(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
@@ -280,7 +280,7 @@ constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
 // transposed sets (PK_XNT, PK_DHT: channels on the lanes, points along the registers) in LDS
 enum { PK_XN = 0, PK_DH = 1, PK_XNT = 2, PK_DHT = 3 };
 constexpr int PK_TILE_U4 = 2 * 8 * 64;   // 16 KiB
-constexpr int NW_BWD = 8;   // wavefronts per workgroup, backward (256 points, one workgroup per CU: three 40 KiB chunk buffers)
+constexpr int NW_BWD = 4;   // wavefronts per workgroup, backward: 128 points; the chunk streams in two items through three 24 KiB slots (79 KiB: two workgroups per CU)
 #ifndef DFX_FF_NW_FWD
 #define DFX_FF_NW_FWD 4
 #endif
@@ -304,9 +304,28 @@ __device__ __forceinline__ void stage_chunk(const uint4 *frags, int j, unsigned 
   }
 }
 
-// LDS tile index of pack tile t
+// Backward: a chunk streams as two items through a ring of three 24 KiB slots — item 2 j = [W1a | W1g | W2^T] of chunk j (tiles 0..7 and
+// 12..15: GEMM1 and the d hid product), item 2 j + 1 = [W1a^T | W1g^T] (tiles 16..23: the dxn3 product) — so that a workgroup fits into
+// half a CU's LDS.  Wave w copies pieces w, w + 4, ..: six per even item, four per odd one.
+__device__ __forceinline__ void stage_item(const uint4 *frags, int item, unsigned lds_slot, int wave, unsigned voff) {
+  const char *src = reinterpret_cast<const char *>(frags + (size_t)(item >> 1) * CHUNK_U4);
+  if (item & 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = k * NW_BWD + wave;
+      dma1k(src + (32 + p) * 1024, voff, lds_slot + p * 1024);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int p = k * NW_BWD + wave;
+      dma1k(src + (p < 16 ? p : p + 8) * 1024, voff, lds_slot + p * 1024);
+    }
+  }
+}
+// LDS tile index of pack tile t (backward: within its item's slot)
 template <bool BWD>
-__device__ __forceinline__ constexpr int lt(int t) { return BWD && t >= 12 ? t - 4 : t; }
+__device__ __forceinline__ constexpr int lt(int t) { return !BWD ? t : t >= 16 ? t - 16 : t >= 12 ? t - 4 : t; }
 
 template <bool BWD>
 __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
@@ -322,9 +341,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   if (!live) row = a.R - 32;   // a workgroup's trailing wavefronts past the end recompute the last tile and store nothing
   row += pj;
 
-  constexpr int PIECES = (BWD ? BWD_TILES : FWD_TILES) * 2 / NW;   // LDS-DMA instructions per wave and chunk
-  stage_chunk<BWD>(a.frags, 0, lds0, wave, voff);
-  if (NBUF > 2) stage_chunk<BWD>(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
+  constexpr int PIECES = FWD_TILES * 2 / NW;   // forward: LDS-DMA instructions per wave and chunk
+  if (BWD) {
+    stage_item(a.frags, 0, lds0, wave, voff);
+    stage_item(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
+  } else {
+    stage_chunk<BWD>(a.frags, 0, lds0, wave, voff);
+    if (NBUF > 2) stage_chunk<BWD>(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
+  }
 
   // b1 of all chunks and LayerNorm3's affine -> LDS: inside the loop every operand must come from LDS — vector-memory loads
   // complete in order, so a global load issued behind a chunk's LDS-DMA pieces could only be consumed after those pieces had
@@ -425,8 +449,13 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 
 #pragma unroll 1
   for (int j = 0; j < NCHUNK; ++j) {
-    if (j + NBUF - 1 < NCHUNK) stage_chunk<BWD>(a.frags, j + NBUF - 1, lds0 + ((j + NBUF - 1) % NBUF) * BUF_BYTES, wave, voff);   // slot of chunk j - 1: every wave is past it
-    const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (j % NBUF) * BUF_BYTES) + lane;
+    // forward: chunk j + 2 -> the slot of chunk j - 1 (every wave is past it); backward: item 2 j + 2 -> the slot of item 2 j - 1
+    if (!BWD) {
+      if (j + NBUF - 1 < NCHUNK) stage_chunk<BWD>(a.frags, j + NBUF - 1, lds0 + ((j + NBUF - 1) % NBUF) * BUF_BYTES, wave, voff);
+    } else if (2 * j + 2 < 2 * NCHUNK) {
+      stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
+    }
+    const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (BWD ? (2 * j) % 3 : j % NBUF) * BUF_BYTES) + lane;
     auto frag = [&](int t, int u) -> uint4 { return fr[(lt<BWD>(t) * 2 + u) * 64]; };
     // ---- [a | g] = b1 + W1 xn3 ----
     v16f av, gv;
@@ -467,20 +496,34 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         da[r] = dhid[r] * f;
         dg[r] = dhid[r] * av[r] * d;
       }
-      // ---- dxn3 += W1a^T da + W1g^T dg ----
       const uint4 a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
+      // ---- item boundary: item 2 j + 1 must have landed (loads complete in order: only the six pieces of item 2 j + 2, requested at the
+      // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3 ----
+      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
+      const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
+      auto frag2 = [&](int t, int u) -> uint4 { return fr2[(lt<BWD>(t) * 2 + u) * 64]; };
+      // ---- dxn3 += W1a^T da + W1g^T dg ----
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        acc[ct] = mfma(frag(T_W1AT + ct, 0), a0, acc[ct]);
-        acc[ct] = mfma(frag(T_W1AT + ct, 1), a1, acc[ct]);
-        acc[ct] = mfma(frag(T_W1GT + ct, 0), g0, acc[ct]);
-        acc[ct] = mfma(frag(T_W1GT + ct, 1), g1, acc[ct]);
+        acc[ct] = mfma(frag2(T_W1AT + ct, 0), a0, acc[ct]);
+        acc[ct] = mfma(frag2(T_W1AT + ct, 1), a1, acc[ct]);
+        acc[ct] = mfma(frag2(T_W1GT + ct, 0), g0, acc[ct]);
+        acc[ct] = mfma(frag2(T_W1GT + ct, 1), g1, acc[ct]);
       }
     }
     // chunk j + 1 must have landed: loads complete in order, so "at most PIECES outstanding" leaves only chunk j + 2's pieces
     // (whatever the order between loads and the backward's stores); no new pieces in the last two iterations -> drain
-    if (NBUF > 2 && j + 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (BWD) {   // item 2 j + 2 must have landed; the four pieces of item 2 j + 3 may still be out
+      if (2 * j + 3 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (NBUF > 2 && j + 2 < NCHUNK) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   }
   if (!BWD) {
