@@ -1,0 +1,52 @@
+"""Random shapes through the fused bf16 training path against the layer-by-layer bf16 kernels and the bit-reproducibility of the fused
+path: python tools/fuzz_train_fused.py [cases]   (GPU box; prints one line per case, exits non-zero on a violated bound)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from difffacto_amd import synth, _ffi
+from test_gpu_train import _run
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rng = np.random.Generator(np.random.PCG64(20260929))
+bad = 0
+for case in range(ncases):
+    B = int(rng.integers(1, 7))
+    N = 32 * int(rng.integers(8, 70)) if case % 4 else 32 * int(rng.integers(8, 12))   # R = B N >= 256 for the bf16 kernels
+    all_valid = bool(rng.integers(0, 2))
+    W = synth.make_denoiser_weights(int(rng.integers(0, 1000)))
+    pc, mean, logvar, valid = synth.make_latents(B, seed=int(rng.integers(0, 1000)), all_valid=all_valid)
+    if case % 5 == 0:
+        valid[0] = [1, 0, 0, 0]   # a shape with a single part
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid if case % 3 else None, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32) if case % 2 else None)
+    if B * N < 256:
+        continue
+    f1 = _run(c, True, precision="bf16")
+    f2 = _run(c, True, precision="bf16")
+    _ffi.lib().dfx_debug_train_fused(0)
+    try:
+        lay = _run(c, True, precision="bf16")
+    finally:
+        _ffi.lib().dfx_debug_train_fused(1)
+    repro = np.array_equal(f1["eps"], f2["eps"]) and all(np.array_equal(f1["grads"][k], f2["grads"][k]) for k in f1["grads"])
+    taken = any(not np.array_equal(f1["grads"][k], lay["grads"][k]) for k in lay["grads"])
+    e_eps = np.abs(f1["eps"] - lay["eps"]).max()
+    worst, wname = 0.0, ""
+    for k, gr in lay["grads"].items():
+        e = np.abs(f1["grads"][k] - gr).max() / max(np.abs(gr).max(), 1e-30)
+        if not np.isfinite(e) or e > worst:
+            worst, wname = e, k
+    ok = repro and taken and np.isfinite(worst) and worst < 2e-2 and e_eps < 5e-3
+    bad += not ok
+    print(f"case {case:2d} B={B} N={N:5d} valid={'given' if c['valid'] is not None else 'none'} flags={'yes' if c['flags'] is not None else 'no'}: "
+          f"eps {e_eps:.1e}, worst gradient {worst:.1e} ({wname}), reproducible {repro}, fused path {'taken' if taken else 'NOT taken'}  {'ok' if ok else 'FAIL'}")
+print("violations:", bad)
+sys.exit(1 if bad else 0)
