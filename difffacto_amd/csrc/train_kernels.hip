@@ -994,28 +994,33 @@ __global__ void k_pn_rows(const float *__restrict__ x, float *__restrict__ X8, l
   reinterpret_cast<v4f *>(X8 + r * 8)[0] = v4f{x[r * 3], x[r * 3 + 1], x[r * 3 + 2], 0.f};
   reinterpret_cast<v4f *>(X8 + r * 8)[1] = v4f{0.f, 0.f, 0.f, 0.f};
 }
-// pooled[b][a][c] = max_n y[b, n, c] attn[b, n, a] scale  (pointnet.py:194-198), with the arg max for the backward.
-// Block = 64 channels x 4 point phases (thread (c, ph) walks n = ph, ph + 4, ...), grid (Cc / 64, B); the four phases are
-// merged through LDS keeping the FIRST maximum (lowest n) like the serial scan.
-template <int A>
-__global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ y, const float *__restrict__ attn, float *__restrict__ pooled,
-                                                   int32_t *__restrict__ arg, int N, int Cc, float scale) {
-  __shared__ float sb[4][A][64];
-  __shared__ int si[4][A][64];
+// pooled[b][a][c] = max_n y[b, n, c] attn[b, n, a] scale  (pointnet.py:194-198), with the arg max for the backward.  y = the last
+// layer's BatchNorm output is formed HERE from z (k_bn_apply's arithmetic, no ReLU behind this layer): the 512-channel tensor is
+// read once instead of read, written and read again.
+// Block = 64 channels x PH point phases (thread (c, ph) walks n = ph, ph + PH, ...), grid (Cc / 64, B); the phases are merged
+// through LDS keeping the FIRST maximum (lowest n) like the serial scan.
+template <int A, int PH>
+__global__ __launch_bounds__(64 * PH) void k_pool_fwd(const float *__restrict__ z, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                       const float *__restrict__ g, const float *__restrict__ be, const float *__restrict__ attn,
+                                                       float *__restrict__ pooled, int32_t *__restrict__ arg, int N, int Cc, float scale) {
+  __shared__ float sb[PH][A][64];
+  __shared__ int si[PH][A][64];
   const int b = blockIdx.y, cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float best[A];
   int bi[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) best[a] = -3.402823466e38f, bi[a] = 0;
-  if (c < Cc)
-    for (int n = ph; n < N; n += 4) {
-      const float v = y[((size_t)b * N + n) * Cc + c];
+  if (c < Cc) {
+    const float mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
+    for (int n = ph; n < N; n += PH) {
+      const float v = (z[((size_t)b * N + n) * Cc + c] - mu) * rs * gv + bv;
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
         if (w > best[a]) best[a] = w, bi[a] = n;
       }
     }
+  }
 #pragma unroll
   for (int a = 0; a < A; ++a) sb[ph][a][cl] = best[a], si[ph][a][cl] = bi[a];
   __syncthreads();
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ y, c
       float m = sb[0][a][cl];
       int mi = si[0][a][cl];
 #pragma unroll
-      for (int q = 1; q < 4; ++q) {
+      for (int q = 1; q < PH; ++q) {
         const float v = sb[q][a][cl];
         const int vi = si[q][a][cl];
         if (v > m || (v == m && vi < mi)) m = v, mi = vi;
@@ -1453,7 +1458,7 @@ size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int /*zdim: the heads 
 
 // y = [relu] BN_train(z) over R rows; leaves mean / rstd behind and updates the running statistics when momentum >= 0
 int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, const float *g, const float *b, float *run_mean,
-           float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu) {
+           float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu, bool apply = true) {
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
   k_col_stats<0><<<grid, 256, 0, st>>>(z, nullptr, w.pb.part, R, Cc);
@@ -1464,6 +1469,7 @@ int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, c
   k_bn_rstd<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, rstd, run_mean, run_var, 1.0f / (float)R,
                                               R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
   const long long total = R * Cc;
+  if (!apply) return dfx::check_launch("train: bn_fwd");   // (the consumer forms y itself: k_pool_fwd)
   if (relu) k_bn_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(z, mean, rstd, g, b, y, total, Cc);
   else k_bn_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(z, mean, rstd, g, b, y, total, Cc);
   return dfx::check_launch("train: bn_fwd");
@@ -1853,10 +1859,10 @@ int dfx_pointnet_v2_train_forward(const dfx_pointnet_v2_weights *wt, void *works
     const int K = PN_C[l], Co = PN_C[l + 1];
     if ((rc = lin(st, in, K, l == 0 ? w.wpad : wt->conv_w[l], wt->conv_b[l], w.z[l], Co, R, Co, K))) return rc;
     if ((rc = bn_fwd(st, w, w.z[l], R, Co, wt->bn_w[l], wt->bn_b[l], mut(wt->bn_mean[l]), mut(wt->bn_var[l]), momentum, wt->bn_eps,
-                     w.mean[l], w.rstd[l], w.y[l], l < 3))) return rc;
+                     w.mean[l], w.rstd[l], w.y[l], l < 3, l < 3))) return rc;
   }
   const float scale = wt->reweight_by_anchor ? (float)A : 1.0f;
-  k_pool_fwd<4><<<dim3(512 / 64, B), 256, 0, st>>>(w.y[3], attn, w.pooled, w.arg, N, 512, scale);
+  k_pool_fwd<4, 16><<<dim3(512 / 64, B), 1024, 0, st>>>(w.z[3], w.mean[3], w.rstd[3], wt->bn_w[3], wt->bn_b[3], attn, w.pooled, w.arg, N, 512, scale);
   const int hc[3] = {512, 256, 128};
   for (int k = 0; k < 2; ++k) {
     const float *in = w.pooled;
