@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ d
   }
 }
 // pass 2: dz = gamma rstd (gm - d beta / R - xhat d gamma / R)
-template <bool RELU>
+template <bool RELU, bool ZERO_DY = false>
 __global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ z,
                                const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
                                const float *__restrict__ dbeta, const float *__restrict__ dgamma, float *__restrict__ dz, float invR,
@@ -975,7 +975,9 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__rest
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const int c = (int)(i % Cc);
-  const v4f dv = *reinterpret_cast<const v4f *>(dy + i), zv = *reinterpret_cast<const v4f *>(z + i);
+  const v4f zv = *reinterpret_cast<const v4f *>(z + i);
+  v4f dv = {0.f, 0.f, 0.f, 0.f};
+  if (!ZERO_DY) dv = *reinterpret_cast<const v4f *>(dy + i);
   v4f yv = {1.f, 1.f, 1.f, 1.f};
   if (RELU) yv = *reinterpret_cast<const v4f *>(y + i);
   v4f o;
@@ -1038,6 +1040,84 @@ __global__ __launch_bounds__(64 * PH) void k_pool_fwd(const float *__restrict__ 
       pooled[((size_t)b * A + a) * Cc + c] = m, arg[((size_t)b * A + a) * Cc + c] = mi;
     }
   }
+}
+// The gradient behind the max-pool is zero except at the arg-max points (at most A per shape and channel), so the BatchNorm in front
+// of the pool needs no pass over a dense dy: its column sums come from the B x A entries per channel (k_pool_bwd_stats), its dz is the
+// dense "mean" part (k_bn_bwd_apply<false, true>: gm = 0) with the A entries per (shape, channel) recomputed in full afterwards
+// (k_pool_bwd_fix: the dense formula with gm = the sum of the parts that share the point, in part order like k_pool_bwd's +=).
+template <int A>
+__device__ __forceinline__ void pool_entries(const float *__restrict__ dpooled, const int32_t *__restrict__ arg, const float *__restrict__ attn,
+                                             int b, int c, int N, int Cc, float scale, int (&n)[A], float (&gm)[A]) {
+  float val[A];
+  int pt[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    pt[a] = arg[((size_t)b * A + a) * Cc + c];
+    val[a] = dpooled[((size_t)b * A + a) * Cc + c] * attn[((size_t)b * N + pt[a]) * A + a] * scale;
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) {   // n[a] = the point if part a is the first that selected it (else -1: skip), gm[a] = the point's total
+    bool first = true;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+      if (q < a && pt[q] == pt[a]) first = false;
+      if (q >= a && pt[q] == pt[a]) t += val[q];
+    }
+    n[a] = first ? pt[a] : -1;
+    gm[a] = t;
+  }
+}
+// d beta[c] = sum gm, d gamma[c] = sum gm xhat over the entries; block = 32 channels x 32 shape phases, summed in phase order
+template <int A>
+__global__ __launch_bounds__(1024) void k_pool_bwd_stats(const float *__restrict__ dpooled, const int32_t *__restrict__ arg,
+                                                         const float *__restrict__ attn, const float *__restrict__ z,
+                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         float *__restrict__ dbeta, float *__restrict__ dgamma, int B, int N, int Cc, float scale) {
+  __shared__ float rb[32][32], rg[32][32];
+  const int cl = threadIdx.x & 31, bq = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  float sb = 0.f, sg = 0.f;
+  if (c < Cc) {
+    const float mu = mean[c], rs = rstd[c];
+    for (int b = bq; b < B; b += 32) {
+      int n[A];
+      float gm[A];
+      pool_entries<A>(dpooled, arg, attn, b, c, N, Cc, scale, n, gm);
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        if (n[a] >= 0) {
+          const float xh = (z[((size_t)b * N + n[a]) * Cc + c] - mu) * rs;
+          sb += gm[a], sg += gm[a] * xh;
+        }
+    }
+  }
+  rb[bq][cl] = sb, rg[bq][cl] = sg;
+  __syncthreads();
+  if (bq == 0 && c < Cc) {
+    float tb = rb[0][cl], tg = rg[0][cl];
+    for (int q = 1; q < 32; ++q) tb += rb[q][cl], tg += rg[q][cl];
+    dbeta[c] = tb, dgamma[c] = tg;
+  }
+}
+// the entries of dz: g rstd (gm - d beta / R - xhat d gamma / R), one thread per (shape, channel)
+template <int A>
+__global__ __launch_bounds__(256) void k_pool_bwd_fix(const float *__restrict__ dpooled, const int32_t *__restrict__ arg,
+                                                       const float *__restrict__ attn, const float *__restrict__ z,
+                                                       const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
+                                                       const float *__restrict__ dbeta, const float *__restrict__ dgamma, float *__restrict__ dz,
+                                                       int N, int Cc, float scale, float invR) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cc) return;
+  int n[A];
+  float gm[A];
+  pool_entries<A>(dpooled, arg, attn, b, c, N, Cc, scale, n, gm);
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+    if (n[a] >= 0) {
+      const size_t o = ((size_t)b * N + n[a]) * Cc + c;
+      const float xh = (z[o] - mean[c]) * rstd[c];
+      dz[o] = g[c] * rstd[c] * (gm[a] - dbeta[c] * invR - xh * dgamma[c] * invR);
+    }
 }
 // dy (zero-initialised) [b, arg, c] += d pooled[b][a][c] attn[b, arg, a] scale; one thread per (b, c): no atomics
 template <int A>
@@ -1914,13 +1994,21 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *work
       dcur = w.dh[0];
     }
   }
-  // max-pool: the gradient goes to the arg-max point of every (shape, part, channel)
-  DFX_HIP_TRY(hipMemsetAsync(w.dA, 0, sizeof(float) * (size_t)R * 512, st));
-  k_pool_bwd<4><<<dim3(2, B), 256, 0, st>>>(w.dpooled, w.arg, attn, w.dA, N, 512, wt->reweight_by_anchor ? (float)A : 1.0f);
+  // max-pool: the gradient goes to the arg-max point of every (shape, part, channel) — and the last BatchNorm's backward works from
+  // those entries, no dense dy
   float *dy = w.dA, *dz = w.dB;
+  {
+    const float scale = wt->reweight_by_anchor ? (float)A : 1.0f;
+    k_pool_bwd_stats<4><<<512 / 32, 1024, 0, st>>>(w.dpooled, w.arg, attn, w.z[3], w.mean[3], w.rstd[3], mut(grads->bn_b[3]), mut(grads->bn_w[3]), B, N, 512, scale);
+    const long long total = R * 512;
+    k_bn_bwd_apply<false, true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(nullptr, nullptr, w.z[3], w.mean[3], w.rstd[3], wt->bn_w[3], grads->bn_b[3],
+                                                                                 grads->bn_w[3], dz, 1.0f / (float)R, total, 512);
+    k_pool_bwd_fix<4><<<dim3(2, B), 256, 0, st>>>(w.dpooled, w.arg, attn, w.z[3], w.mean[3], w.rstd[3], wt->bn_w[3], grads->bn_b[3], grads->bn_w[3], dz, N, 512,
+                                                  scale, 1.0f / (float)R);
+  }
   for (int l = 3; l >= 0; --l) {
     const int K = PN_C[l], Co = PN_C[l + 1];
-    if ((rc = bn_bwd(st, w, dy, w.y[l], w.z[l], R, Co, wt->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), l < 3))) return rc;
+    if (l < 3 && (rc = bn_bwd(st, w, dy, w.y[l], w.z[l], R, Co, wt->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true))) return rc;
     if ((rc = wgrad(st, w.pb, dz, Co, l == 0 ? w.X8 : w.y[l - 1], K, mut(grads->conv_w[l]), mut(grads->conv_b[l]), Co, K, l == 0 ? 3 : K, R))) return rc;
     if (l > 0) {
       transpose(st, wt->conv_w[l], w.wT, Co, K);   // (K, Co)
