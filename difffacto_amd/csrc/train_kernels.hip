@@ -941,22 +941,25 @@ __global__ void k_bn_apply(const float *__restrict__ z, const float *__restrict_
   }
   *reinterpret_cast<v4f *>(y + i) = o;
 }
-// backward, pass 1: gm = RELU ? dy (y > 0) : dy;  column sums of gm (d beta) and gm xhat (d gamma) -> part[slab][2][Cc]
+// backward, pass 1: gm = RELU ? dy (y > 0) : dy;  column sums of gm (d beta) and gm xhat (d gamma) -> part[slab][2][Cc].
+// The ReLU mask is re-derived from z (k_bn_apply's arithmetic: y > 0) instead of reading y: one tensor less per pass.
 template <bool RELU>
-__global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ z,
+__global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ dy, const float *__restrict__ z,
                                                       const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                      const float *__restrict__ g, const float *__restrict__ be,
                                                       float *__restrict__ part, long long R, int Cc) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float sb = 0.f, sg = 0.f;
   if (c < Cc) {
-    const float mu = mean[c], rs = rstd[c];
+    const float mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
     const long long r1 = ((long long)blockIdx.y + 1) * BN_SLAB < R ? ((long long)blockIdx.y + 1) * BN_SLAB : R;
     for (long long r = (long long)blockIdx.y * BN_SLAB + rgp; r < r1; r += 4) {
       float gm = dy[r * Cc + c];
-      if (RELU && !(y[r * Cc + c] > 0.f)) gm = 0.f;
+      const float zv = z[r * Cc + c];
+      if (RELU && !((zv - mu) * rs * gv + bv > 0.f)) gm = 0.f;
       sb += gm;
-      sg += gm * (z[r * Cc + c] - mu) * rs;
+      sg += gm * (zv - mu) * rs;
     }
   }
   red[0][rgp][cl] = sb, red[1][rgp][cl] = sg;
@@ -968,7 +971,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ d
 }
 // pass 2: dz = gamma rstd (gm - d beta / R - xhat d gamma / R)
 template <bool RELU, bool ZERO_DY = false>
-__global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ z,
+__global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ be, const float *__restrict__ z,
                                const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
                                const float *__restrict__ dbeta, const float *__restrict__ dgamma, float *__restrict__ dz, float invR,
                                long long total, int Cc) {
@@ -978,12 +981,10 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__rest
   const v4f zv = *reinterpret_cast<const v4f *>(z + i);
   v4f dv = {0.f, 0.f, 0.f, 0.f};
   if (!ZERO_DY) dv = *reinterpret_cast<const v4f *>(dy + i);
-  v4f yv = {1.f, 1.f, 1.f, 1.f};
-  if (RELU) yv = *reinterpret_cast<const v4f *>(y + i);
   v4f o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float gm = (RELU && !(yv[e] > 0.f)) ? 0.f : dv[e];
+    const float gm = (RELU && !((zv[e] - mean[c + e]) * rstd[c + e] * g[c + e] + be[c + e] > 0.f)) ? 0.f : dv[e];   // (the mask from z, like pass 1)
     const float xh = (zv[e] - mean[c + e]) * rstd[c + e];
     o[e] = g[c + e] * rstd[c + e] * (gm - dbeta[c + e] * invR - xh * dgamma[c + e] * invR);
   }
@@ -1555,17 +1556,17 @@ int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, c
   return dfx::check_launch("train: bn_fwd");
 }
 // dz from dy (gradient at the output of [relu] BN); d gamma, d beta written
-int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *y, const float *z, long long R, int Cc, const float *g,
+int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *be, const float *z, long long R, int Cc, const float *g,
            const float *mean, const float *rstd, float *dz, float *dgamma, float *dbeta, bool relu) {
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
-  if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
-  else k_bn_bwd_part<false><<<grid, 256, 0, st>>>(dy, y, z, mean, rstd, w.pb.part, R, Cc);
+  if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, z, mean, rstd, g, be, w.pb.part, R, Cc);
+  else k_bn_bwd_part<false><<<grid, 256, 0, st>>>(dy, z, mean, rstd, g, be, w.pb.part, R, Cc);
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part + Cc, dgamma, ns, Cc, 2 * Cc);
   const long long total = R * Cc;
-  if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
-  else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, y, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
+  if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
+  else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
   return dfx::check_launch("train: bn_bwd");
 }
 int check_pn(const dfx_pointnet_v2_weights *wt, const void *ws, size_t ws_bytes, int B, int N, const char *what) {
@@ -1979,7 +1980,7 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *work
       const float *in = l == 0 ? w.pooled : w.hy[k][l - 1];
       const float *dz = dcur;
       if (l < 2) {   // through relu + BatchNorm over the B rows
-        if ((rc = bn_bwd(st, w, dcur, w.hy[k][l], w.hz[k][l], B, A * cout, wt->head_bn_w[k][l], w.hmean[k][l], w.hrstd[k][l], w.dh[1],
+        if ((rc = bn_bwd(st, w, dcur, wt->head_bn_b[k][l], w.hz[k][l], B, A * cout, wt->head_bn_w[k][l], w.hmean[k][l], w.hrstd[k][l], w.dh[1],
                          mut(grads->head_bn_w[k][l]), mut(grads->head_bn_b[k][l]), true))) return rc;
         dz = w.dh[1];
       }
@@ -2008,7 +2009,7 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *work
   }
   for (int l = 3; l >= 0; --l) {
     const int K = PN_C[l], Co = PN_C[l + 1];
-    if (l < 3 && (rc = bn_bwd(st, w, dy, w.y[l], w.z[l], R, Co, wt->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true))) return rc;
+    if (l < 3 && (rc = bn_bwd(st, w, dy, wt->bn_b[l], w.z[l], R, Co, wt->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true))) return rc;
     if ((rc = wgrad(st, w.pb, dz, Co, l == 0 ? w.X8 : w.y[l - 1], K, mut(grads->conv_w[l]), mut(grads->conv_b[l]), Co, K, l == 0 ? 3 : K, R))) return rc;
     if (l > 0) {
       transpose(st, wt->conv_w[l], w.wT, Co, K);   // (K, Co)
