@@ -123,6 +123,8 @@ struct AttnArgs {
   float *dh;              // backward out: gradient at h
   float *part;            // param kernel: [B * split][2][32][128]  (dA_s, dM_s^T)
   float *cpart;           // dx kernel: [workgroups][3][128]        (d gamma2, d beta2, d bo)
+  const uint4 *pk2;       // param kernel, optional: [R / 32][2][4][2][64] xn2 / dh1 of every tile as bf16 fragments (written by k_ff<true>);
+                          // h and dh1 are then not read
   int N, split;           // points per shape (multiple of 32); workgroups per shape in the param kernel
   long long R;
 };
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_dx(AttnArgs a) {
 
 // ---- backward, parameter side: dA_s, dM_s per shape ----
 // grid = B * split workgroups; workgroup (s, k) walks the row tiles k * per .. (k + 1) * per of shape s, NW at a time
+template <bool PACKED>
 __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float gb[2 * C];
   __shared__ __attribute__((aligned(16))) float red[2 * HJ * C];   // cross-wave sum of dA_s | dM_s^T (32 KiB)
@@ -351,7 +354,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
     asm volatile("" : "+v"(fr));   // the fragments are the same for every tile of the shape: hoisted out of the loop they would cost 64 registers (spilled)
     v16f PT = zero16(), dsT = zero16();
     uint4 xn[4][2];
-    {
+    const uint4 *pk = PACKED ? a.pk2 + (size_t)((row - pj) / 32) * (2 * 8 * 64) + lane : nullptr;
+    if (PACKED) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xn[c][u] = pk[(c * 2 + u) * 64];
+    } else {
       float mu, rstd;
       ln_rows(a.h + row * C, hf, gb, xn, mu, rstd);
     }
@@ -372,7 +381,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
     {
       const uint4 pt0 = pack8(PT, 0), pt1 = pack8(PT, 1);        // A of dM_s^T: [(h, j)][points in register order]
       uint4 db[4][2];
-      row_frags(a.dh1 + row * C, hf, db);
+      if (PACKED) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) db[c][u] = pk[(8 + c * 2 + u) * 64];
+      } else {
+        row_frags(a.dh1 + row * C, hf, db);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma unroll

@@ -115,6 +115,8 @@ struct FfArgs {
   // backward with the attention's input gradient behind it (at_frags != nullptr): dh_in = dh1 + LN2'(A_s^T dsim) leaves through dh_in
   // (may alias dh: a wavefront reads its rows of dh before it writes them) and cpart gets three more rows (d gamma2, d beta2, d b_o)
   float *dh_in;
+  uint4 *pk2;              // with at_frags: [R / 32][2][4][2][64] the tile's xn2 and dh1 as bf16 fragments for k_attn_bwd_param (which
+                           // needs nothing else of them); dh1 itself is then not written
 };
 
 // fragment sets of the folded attention per shape (written by afused::k_attn_fold): tile t (4), unit u (2), lane (64) uint4 each
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         o[m] = d[m] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
         d1[c][r] = o[m];
       }
-      if (live) *reinterpret_cast<v4f *>(a.dh1 + row * C + ch) = o;
+      if (live && !a.at_frags) *reinterpret_cast<v4f *>(a.dh1 + row * C + ch) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
     }
     colsum(gx, 0, c);
     colsum(acc[c], 1, c);
@@ -609,6 +611,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
     float mu2, rstd2;
     v16f P = zero16(), ds = zero16();
+    // this tile's xn2 | dh1 fragments for k_attn_bwd_param: a wave-uniform base (scalar registers) + the lane
+    uint4 *pk2p = a.pk2 + (size_t)__builtin_amdgcn_readfirstlane((int)((row - pj) / 32)) * (2 * 8 * 64);
     {
       v8f x[4][2];
       uint4 xn2[4][2];
@@ -618,9 +622,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          x[c][u] = (x[c][u] - mu2) * rstd2;
+          if (live) pk2p[(c * 2 + u) * 64 + lane] = xn2[c][u];
           P = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], P);
         }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) x[c][u] = (x[c][u] - mu2) * rstd2;
       rows_to_acc(x, xh);   // xhat2 in the accumulator layout (xhat3 is done with)
     }
     softmax_regs(P, vmask);
@@ -630,8 +639,11 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-          ds = mfma(fr[F_MST * SET_U4 + (c * 2 + u) * 64], __builtin_bit_cast(uint4, __builtin_convertvector(x[c][u], v8bf)), ds);
+        for (int u = 0; u < 2; ++u) {
+          const uint4 db = __builtin_bit_cast(uint4, __builtin_convertvector(x[c][u], v8bf));
+          ds = mfma(fr[F_MST * SET_U4 + (c * 2 + u) * 64], db, ds);
+          if (live) pk2p[(8 + c * 2 + u) * 64 + lane] = db;
+        }
     }
     softmax_bwd_regs(P, ds);
     const uint4 q0 = pack8(ds, 0), q1 = pack8(ds, 1);

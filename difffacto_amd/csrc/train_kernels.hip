@@ -1810,6 +1810,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.dh_in = w.dh, fa.N = N;
+        fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
       const int groups = (int)((R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD);
@@ -1827,7 +1828,9 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       dfx::afused::AttnArgs aa{};
       aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
       aa.h = a.hin, aa.dh1 = w.dh2, aa.dh = w.dh, aa.part = w.at_part, aa.cpart = w.cpart, aa.N = N, aa.split = w.at_split, aa.R = R;
-      dfx::afused::k_attn_bwd_param<<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
+      aa.pk2 = dx_in_ff ? reinterpret_cast<const uint4 *>(w.dq) : nullptr;
+      if (dx_in_ff) dfx::afused::k_attn_bwd_param<true><<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
+      else dfx::afused::k_attn_bwd_param<false><<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
       const int np = dfx::afused::dx_groups(R);
       if (!dx_in_ff) dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
       const int LDKV = 2 * wt->depth * C;
