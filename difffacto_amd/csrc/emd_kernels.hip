@@ -10,11 +10,24 @@
 // the best) with DPP-free shuffles; the merge keeps the reference's result (first maximum in index order, :152-178).
 // GetMax's data race (several bidders within 1e-6 of the maximum all write max_idx, :195-199) is resolved
 // deterministically: the largest bidder index wins (integer atomicMax) — the oracle uses the same rule.
+// The auction's own state (assignment both ways, bids, increments, the unassigned list: 28 B per point) lives in LDS too when it fits
+// (STATE_LDS: n <= 2816, with the bidders' own coordinates 56 B per point; at the evaluation size n = 2048 that is 112 KiB): an iteration is five phases separated by
+// barriers, each a dependent read-modify-write of that state — through L2 every phase cost a global-memory round trip (11.7 us per
+// iteration), in LDS a few hundred cycles.
 #include "dfx_common.h"
 
 namespace {
 
 constexpr int EMD_THREADS = 1024;
+constexpr int EMD_STATE_LDS_MAX_N = 2688;   // 60 B per point <= 157.5 KiB
+bool g_emd_state_global = false;            // debug: keep the auction state in global memory whatever n
+
+#ifdef DFX_EMD_PROBE   // tools/ubench/emd_phase_probe.hip: cycles per phase of the U == 1 iterations, seen by wavefront 0
+__device__ long long g_emd_probe[24];   // 0..7 phases of U == 1 | 8..11 cycles, 12..15 count of iterations with U = 1, 2..8, 9..16, > 16 | 16 kernel
+#define EMD_T(i) do { if (U == 1 && wave == 0) { const long long t_ = clock64(); if (lane == 0 && blockIdx.x == 0) g_emd_probe[i] += t_ - tp_; tp_ = clock64(); } } while (0)
+#else
+#define EMD_T(i) do { } while (0)
+#endif
 
 struct Best {
   float best, better;
@@ -32,51 +45,118 @@ __device__ __forceinline__ Best merge(const Best &a, const Best &b) {
   return r;
 }
 
+// lane i receives lane ((i + R) mod 16) of its row of 16 (DPP row_ror: no LDS round trip, unlike ds_bpermute)
+template <int R>
+__device__ __forceinline__ Best row_ror(const Best &m) {
+  const int a = __float_as_int(m.best), b = __float_as_int(m.better), c = m.idx;
+  Best t;
+  t.best = __int_as_float(__builtin_amdgcn_update_dpp(a, a, 0x120 + R, 0xF, 0xF, false));
+  t.better = __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x120 + R, 0xF, 0xF, false));
+  t.idx = __builtin_amdgcn_update_dpp(c, c, 0x120 + R, 0xF, 0xF, false);
+  return t;
+}
+
+__device__ __forceinline__ Best lane_of(const Best &m, int l) {
+  Best t;
+  t.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.best), l));
+  t.better = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.better), l));
+  t.idx = __builtin_amdgcn_readlane(m.idx, l);
+  return t;
+}
+
+// every lane ends with the merge over the whole wavefront: four rotations inside the rows of 16, then the four rows
+__device__ __forceinline__ Best wave_merge(Best m) {
+  m = merge(m, row_ror<1>(m)), m = merge(m, row_ror<2>(m)), m = merge(m, row_ror<4>(m)), m = merge(m, row_ror<8>(m));
+  return merge(merge(lane_of(m, 0), lane_of(m, 16)), merge(lane_of(m, 32), lane_of(m, 48)));
+}
+
+template <bool STATE_LDS>
 __global__ __launch_bounds__(EMD_THREADS) void k_emd(const float *__restrict__ xyz1, const float *__restrict__ xyz2, float eps,
                                                     int iters, float *__restrict__ dist, int32_t *__restrict__ assignment,
                                                     int32_t *__restrict__ wsi, float *__restrict__ wsf, int n) {
-  extern __shared__ float lds[];   // x2[n] y2[n] z2[n] price[n]
-  float *X2 = lds, *Y2 = lds + n, *Z2 = lds + 2 * n, *price = lds + 3 * n;
-  __shared__ int cnt;
+  extern __shared__ __align__(16) float lds[];   // (16-byte aligned: a ds_read_b128 off its alignment stalls) {x2, y2, z2, price}[n]  [ | as ass_inv bid max_idx list0 (int) | bid_inc max_inc (float) | x1[n] y1[n] z1[n] | list1 ]
+  float4 *T = reinterpret_cast<float4 *>(lds);   // a target and its price in one 16-byte LDS read
+  __shared__ int cnt[2];
+  __shared__ Best wbest[EMD_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *A = xyz1 + (size_t)b * n * 3, *Bp = xyz2 + (size_t)b * n * 3;
-  int32_t *as = assignment + (size_t)b * n;
-  int32_t *ass_inv = wsi + (size_t)b * 4 * n, *bid = ass_inv + n, *max_idx = bid + n, *list = max_idx + n;
-  float *bid_inc = wsf + (size_t)b * 2 * n, *max_inc = bid_inc + n;
+  int32_t *as_out = assignment + (size_t)b * n;
+  int32_t *sl = reinterpret_cast<int32_t *>(lds + 4 * n);
+  int32_t *as = STATE_LDS ? sl : as_out;
+  int32_t *ass_inv = STATE_LDS ? sl + n : wsi + (size_t)b * 5 * n, *bid = ass_inv + n, *max_idx = bid + n, *list0 = max_idx + n;
+  float *bid_inc = STATE_LDS ? reinterpret_cast<float *>(sl + 5 * n) : wsf + (size_t)b * 2 * n, *max_inc = bid_inc + n;
+  float *XA = reinterpret_cast<float *>(sl + 7 * n);   // STATE_LDS: xyz1 as x[n] y[n] z[n] (a bid starts with its point's coordinates)
+  int32_t *list1 = STATE_LDS ? sl + 10 * n : list0 + n;
   for (int k = tid; k < n; k += EMD_THREADS) {
-    X2[k] = Bp[k * 3], Y2[k] = Bp[k * 3 + 1], Z2[k] = Bp[k * 3 + 2], price[k] = 0.f;
+    T[k] = make_float4(Bp[k * 3], Bp[k * 3 + 1], Bp[k * 3 + 2], 0.f);
     as[k] = -1, ass_inv[k] = -1, max_idx[k] = -1, max_inc[k] = 0.f;   // emd_module.py:28-37 (max_increments starts at 0)
+    list0[k] = k;
+    if (STATE_LDS) XA[k] = A[k * 3], XA[n + k] = A[k * 3 + 1], XA[2 * n + k] = A[k * 3 + 2];
   }
+  if (tid == 0) cnt[0] = n, cnt[1] = 0;
   __syncthreads();
+  // The unassigned list is kept from one iteration to the next instead of being rebuilt by a scan over all n points (the reference's
+  // calc_unass_* kernels, :29-100): what is unassigned after Assign = this iteration's losing bidders + the owners the winners
+  // displaced.  (The order of the list does not matter: bids only read prices, and GetMax / Assign resolve by value.)
+#ifdef DFX_EMD_PROBE
+  long long ti_ = 0, tk_ = clock64();
+  int cls_ = 0;
+#endif
   for (int it = 0; it < iters; ++it) {
     const bool last = it == iters - 1;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    for (int j = tid; j < n; j += EMD_THREADS)
-      if (as[j] == -1) list[atomicAdd(&cnt, 1)] = j;
-    __syncthreads();
-    const int U = cnt;
+    const int c = it & 1, U = cnt[c];
     if (U == 0) break;
-    // ---- Bid: one wavefront per unassigned point ----
-    for (int u = wave; u < U; u += EMD_THREADS / 64) {
-      const int j = list[u];
-      const float x1 = A[j * 3], y1 = A[j * 3 + 1], z1 = A[j * 3 + 2];
+    const int32_t *list = c ? list1 : list0;
+    int32_t *nlist = c ? list0 : list1;
+    int *ncnt = &cnt[c ^ 1];
+#ifdef DFX_EMD_PROBE
+    long long tp_ = clock64();
+    if (tid == 0 && blockIdx.x == 0 && it > 0) {
+      g_emd_probe[8 + cls_] += tp_ - ti_, g_emd_probe[12 + cls_] += 1;
+    }
+    ti_ = tp_, cls_ = U == 1 ? 0 : U <= 8 ? 1 : U <= 16 ? 2 : 3;
+#endif
+    if (tid == 0) *ncnt = 0;   // (read by everyone at the start of the previous iteration; filled after this iteration's first barrier)
+    // ---- Bid: G wavefronts per unassigned point, G = 16 / (points per round) — the tail of an auction is thousands of iterations with a
+    // handful of unassigned points, and one wavefront walking all n targets for its point (n / 64 dependent steps) was the iteration's
+    // length; the partial (best, second best, first index) triples of a point's wavefronts are merged through LDS (the merge keeps the
+    // reference's result whatever the split: first maximum in index order, :152-178) ----
+    constexpr int NWAVES = EMD_THREADS / 64;
+    int G = 1;
+    while (G < NWAVES && U * (2 * G) <= NWAVES) G *= 2;   // (U is workgroup-uniform)
+    const int per_round = NWAVES / G, grp = wave / G, wg = wave % G;
+    for (int u0 = 0; u0 < U; u0 += per_round) {   // (one round when G > 1)
+      const int u = u0 + grp;
       Best m{-1e9f, -1e9f, -1};
-      for (int k = lane; k < n; k += 64) {
+      int j = 0;
+      if (u < U) {
+        j = list[u];
+        const float x1 = STATE_LDS ? XA[j] : A[j * 3], y1 = STATE_LDS ? XA[n + j] : A[j * 3 + 1], z1 = STATE_LDS ? XA[2 * n + j] : A[j * 3 + 2];
+        EMD_T(0);
+        // (VALU-bound while many points bid — four wavefronts per SIMD each walking all targets: branch-free running (best, second best,
+        // first index of the best), the strides every lane has in full unrolled by four)
+        auto eval = [&](int k) {
 #pragma clang fp contract(off)
-        const float dx = X2[k] - x1, dy = Y2[k] - y1, dz = Z2[k] - z1;
-        const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        const float d = (float)(3.0 - (double)sqrtf(s) - (double)price[k]);   // `3.0` is a double literal in the reference (:151)
-        if (d > m.best) m.better = m.best, m.best = d, m.idx = k;
-        else if (d > m.better) m.better = d;
+          const float4 t = T[k];
+          const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
+          const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          const float d = (float)(3.0 - (double)sqrtf(s) - (double)t.w);   // `3.0` is a double literal in the reference (:151)
+          m.better = fmaxf(m.better, fminf(m.best, d));   // = (d > best ? best : d > better ? d : better)
+          m.idx = d > m.best ? k : m.idx;
+          m.best = fmaxf(m.best, d);
+        };
+        const int stride = G * 64, full = n >> (6 + __builtin_ctz(G));
+        int k = wg * 64 + lane, t = 0;
+        for (; t + 4 <= full; t += 4, k += 4 * stride) eval(k), eval(k + stride), eval(k + 2 * stride), eval(k + 3 * stride);
+        for (; t < full; ++t, k += stride) eval(k);
+        if (k < n) eval(k);
+        EMD_T(1);
+        m = wave_merge(m);
+        EMD_T(2);
       }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        Best t;
-        t.best = __shfl_xor(m.best, o, 64), t.better = __shfl_xor(m.better, o, 64), t.idx = __shfl_xor(m.idx, o, 64);
-        m = merge(m, t);
-      }
-      if (lane == 0) {
+      if (G > 1) {
+        if (lane == 0) wbest[wave] = m;
+      } else if (u < U && lane == 0) {
 #pragma clang fp contract(off)
         const float inc = m.best - m.better + eps;
         bid[j] = m.idx;
@@ -85,6 +165,50 @@ __global__ __launch_bounds__(EMD_THREADS) void k_emd(const float *__restrict__ x
       }
     }
     __syncthreads();
+    EMD_T(3);
+    if (G > 1) {
+      // ---- at most 8 bidders: wavefront 0 finishes the iteration alone, one lane per bidder — merge of the partials, GetMax and Assign
+      // follow each other inside one wavefront (its LDS / memory operations complete in order), no workgroup barrier between them ----
+      if (wave == 0) {
+        int j = -1, k = -1;
+        float inc = 0.f;
+        // partial q of bidder u sits in lane q * per_round + u of row 0: rotations by multiples of per_round merge a bidder's G partials
+        Best m{-1e9f, -1e9f, -1};
+        if (lane < NWAVES && lane % per_round < U) m = wbest[(lane % per_round) * G + lane / per_round];
+        if (per_round <= 1) m = merge(m, row_ror<1>(m));
+        if (per_round <= 2) m = merge(m, row_ror<2>(m));
+        if (per_round <= 4) m = merge(m, row_ror<4>(m));
+        m = merge(m, row_ror<8>(m));
+        if (lane < U) {
+#pragma clang fp contract(off)
+          j = list[lane], k = m.idx, inc = m.best - m.better + eps;
+          atomicMax(reinterpret_cast<int *>(max_inc) + k, __float_as_int(inc));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        EMD_T(4);
+        if (lane < U) {
+          const float mi = max_inc[k];
+          if ((double)inc - 1e-6 <= (double)mi && (double)mi <= (double)inc + 1e-6) atomicMax(max_idx + k, j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        EMD_T(5);
+        if (lane < U) {
+          if (last || max_idx[k] == j) {
+            const int prev = ass_inv[k];
+            if (!last && prev != -1) as[prev] = -1, nlist[atomicAdd(ncnt, 1)] = prev;
+            ass_inv[k] = j;
+            as[j] = k;
+            if (!last) T[k].w += inc, max_inc[k] = -1e9f, max_idx[k] = -1;
+          } else {
+            nlist[atomicAdd(ncnt, 1)] = j;
+          }
+        }
+        EMD_T(6);
+      }
+      __syncthreads();
+      EMD_T(7);
+      continue;
+    }
     // ---- GetMax ----
     for (int u = tid; u < U; u += EMD_THREADS) {
       const int j = list[u], k = bid[j];
@@ -97,25 +221,27 @@ __global__ __launch_bounds__(EMD_THREADS) void k_emd(const float *__restrict__ x
       const int j = list[u], k = bid[j];
       if (last || max_idx[k] == j) {
         const int prev = ass_inv[k];
-        if (!last && prev != -1) as[prev] = -1;
+        if (!last && prev != -1) as[prev] = -1, nlist[atomicAdd(ncnt, 1)] = prev;
         ass_inv[k] = j;
         as[j] = k;
-        if (!last) price[k] += bid_inc[j], max_inc[k] = -1e9f;
+        // (max_idx: the winner's target forgets this round's bidder index — the reference's separate pass :203-223 clears exactly the
+        // winners' targets; a loser of the same target compares its own index with j or with -1: it loses either way)
+        if (!last) T[k].w += bid_inc[j], max_inc[k] = -1e9f, max_idx[k] = -1;
+      } else {
+        nlist[atomicAdd(ncnt, 1)] = j;
       }
     }
     __syncthreads();
-    if (!last)
-      for (int u = tid; u < U; u += EMD_THREADS) {   // winners' targets: forget this round's bidder index
-        const int k = bid[list[u]];
-        if (as[list[u]] == k) max_idx[k] = -1;
-      }
-    __syncthreads();
   }
+#ifdef DFX_EMD_PROBE
+  if (tid == 0 && blockIdx.x == 0) g_emd_probe[16] = clock64() - tk_;
+#endif
   __syncthreads();
   for (int j = tid; j < n; j += EMD_THREADS) {
 #pragma clang fp contract(off)
     const int k = as[j];
-    const float dx = A[j * 3] - X2[k], dy = A[j * 3 + 1] - Y2[k], dz = A[j * 3 + 2] - Z2[k];
+    if (STATE_LDS) as_out[j] = k;
+    const float dx = A[j * 3] - T[k].x, dy = A[j * 3 + 1] - T[k].y, dz = A[j * 3 + 2] - T[k].z;
     dist[(size_t)b * n + j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
   }
 }
@@ -135,7 +261,7 @@ __global__ void k_emd_grad(const float *__restrict__ xyz1, const float *__restri
 
 extern "C" {
 
-size_t dfx_emd_workspace_bytes(int B, int n) { return (size_t)(B > 0 ? B : 0) * (size_t)(n > 0 ? n : 0) * 6 * 4; }
+size_t dfx_emd_workspace_bytes(int B, int n) { return (size_t)(B > 0 ? B : 0) * (size_t)(n > 0 ? n : 0) * 7 * 4; }
 
 int dfx_emd_forward_f32(const float *xyz1, const float *xyz2, float *dist, int32_t *assignment, void *workspace, int B, int n,
                         float eps, int iters, dfx_stream_t stream) {
@@ -143,17 +269,22 @@ int dfx_emd_forward_f32(const float *xyz1, const float *xyz2, float *dist, int32
   if (B == 0) return DFX_OK;
   DFX_REQUIRE(n <= 8192, "emd_forward: n = %d > 8192 (the targets of one cloud live in LDS)", n);
   DFX_REQUIRE(xyz1 && xyz2 && dist && assignment && workspace, "emd_forward: null pointer");
-  const int lds_bytes = n * 16;
   static bool attr = false;
   if (!attr) {
-    DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_emd), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+    DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_emd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+    DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_emd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EMD_STATE_LDS_MAX_N * 60));
     attr = true;
   }
   int32_t *wsi = static_cast<int32_t *>(workspace);
-  float *wsf = reinterpret_cast<float *>(wsi + (size_t)B * 4 * n);
-  k_emd<<<B, EMD_THREADS, lds_bytes, dfx::as_stream(stream)>>>(xyz1, xyz2, eps, iters, dist, assignment, wsi, wsf, n);
+  float *wsf = reinterpret_cast<float *>(wsi + (size_t)B * 5 * n);
+  if (n <= EMD_STATE_LDS_MAX_N && !g_emd_state_global)   // targets + prices (16 B), the auction state (32 B) and the bidders (12 B) per point in LDS
+    k_emd<true><<<B, EMD_THREADS, n * 60, dfx::as_stream(stream)>>>(xyz1, xyz2, eps, iters, dist, assignment, wsi, wsf, n);
+  else
+    k_emd<false><<<B, EMD_THREADS, n * 16, dfx::as_stream(stream)>>>(xyz1, xyz2, eps, iters, dist, assignment, wsi, wsf, n);
   return dfx::check_launch("emd_forward");
 }
+
+void dfx_debug_emd_state_global(int on) { g_emd_state_global = on != 0; }
 
 int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad_dist, const int32_t *assignment,
                          float *grad_xyz1, int B, int n, dfx_stream_t stream) {

@@ -431,6 +431,8 @@ int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long
  * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
  * kernels of their own instead of inside the feed-forward kernels. */
 void dfx_debug_train_fused(int on);
+/* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
+void dfx_debug_emd_state_global(int on);
 /* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
  * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
  * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */
