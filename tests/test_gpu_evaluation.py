@@ -45,3 +45,19 @@ def test_pairwise_and_all_metrics_vs_bruteforce():
     # 1-NNA on two identical sets: every cloud's nearest neighbour (leave-one-out) is its twin in the other set -> accuracy 0
     res_same = ev.compute_all_metrics(R.clone(), R, batch_size=4)
     assert float(res_same["1-NN-CD-acc"]) == 0.0 and float(res_same["lgan_cov-CD"]) == 1.0 and float(res_same["lgan_mmd-CD"]) == 0.0
+
+
+def test_pairwise_launch_size_does_not_change_the_matrices(monkeypatch):
+    """The all-pairs matrices go to the kernels PAIRS_PER_LAUNCH pairs at a time: any launch size gives the same numbers (masks too)."""
+    from difffacto_amd import evaluation as ev
+    g = torch.Generator(device="cuda").manual_seed(5)
+    S, R = torch.rand(5, 96, 3, device="cuda", generator=g), torch.rand(7, 96, 3, device="cuda", generator=g)
+    ms, mr = (torch.rand(5, 96, device="cuda", generator=g) > 0.3).float(), (torch.rand(7, 96, device="cuda", generator=g) > 0.3).float()
+    whole = ev._pairwise_EMD_CD_(S, R, batch_size=32, mask_sample=ms, mask_ref=mr)
+    monkeypatch.setattr(ev, "PAIRS_PER_LAUNCH", 1)
+    for bs in (1, 4, 9):
+        part = ev._pairwise_EMD_CD_(S, R, batch_size=bs, mask_sample=ms, mask_ref=mr)
+        assert torch.equal(part[1], whole[1])                       # the auction: bit-identical per pair
+        assert torch.allclose(part[0], whole[0], rtol=1e-6, atol=0)   # Chamfer means: torch reductions
+    paired = ev.EMD_CD(S, R[:5], batch_size=2, reduced=False)
+    assert torch.equal(paired["MMD-EMD"], torch.diagonal(ev._pairwise_EMD_CD_(S, R[:5], batch_size=2)[1]))

@@ -102,3 +102,9 @@ with torch.no_grad():
     ms = timeit(lambda: enc(x, attn), iters=10)
 fl = 2 * 128 * 2048 * (3 * 128 + 128 * 128 + 128 * 256 + 256 * 512) + 2 * 2 * 128 * 4 * (512 * 256 + 256 * 128 + 128 * 256)
 print(f"PointNetV2 forward (trunk rows = 262144, masked max-pool, grouped heads): {ms * 1e3:9.1f} us  {fl / (ms * 1e-3) / 1e12:6.1f} TFLOP/s fp32")
+# a whole chip of auctions: the evaluator (difffacto_amd/evaluation.py) sends the all-pairs matrices out PAIRS_PER_LAUNCH pairs at a time
+from difffacto_amd.evaluation import PAIRS_PER_LAUNCH  # noqa: E402
+a, b = torch.rand(PAIRS_PER_LAUNCH, 2048, 3, device=dev), torch.rand(PAIRS_PER_LAUNCH, 2048, 3, device=dev)
+ms = timeit(lambda: emd(a, b), iters=2, warmup=1)
+print(f"EMD auction, {PAIRS_PER_LAUNCH} pairs per launch (one workgroup per pair, one per compute unit): {ms:9.1f} ms = {PAIRS_PER_LAUNCH / ms * 1e3:7.0f} pairs/s "
+      f"(32 pairs per launch as the reference batches them: see the line above)")
