@@ -3,17 +3,21 @@
 // GetMax :188-201, Assign :203-223} + CalcDist :225-234; backward :286-316; bound in emd_module.py:17-51).
 //
 // The reference launches seven kernels per auction iteration (70 000 launches at the evaluation setting of 10 000
-// iterations).  Here ONE persistent workgroup (16 wavefronts) runs the whole auction of one cloud pair: the targets'
-// coordinates and prices stay in LDS (16 B per point: n <= 8192 in 128 KiB), the four phases are separated by workgroup
-// barriers, and the loop ends as soon as nothing is unassigned (after that no reference kernel changes any state).
-// Bids: one wavefront per unassigned point, lanes scan the targets strided and merge (best, second best, first index of
-// the best) with DPP-free shuffles; the merge keeps the reference's result (first maximum in index order, :152-178).
-// GetMax's data race (several bidders within 1e-6 of the maximum all write max_idx, :195-199) is resolved
-// deterministically: the largest bidder index wins (integer atomicMax) — the oracle uses the same rule.
-// The auction's own state (assignment both ways, bids, increments, the unassigned list: 28 B per point) lives in LDS too when it fits
-// (STATE_LDS: n <= 2816, with the bidders' own coordinates 56 B per point; at the evaluation size n = 2048 that is 112 KiB): an iteration is five phases separated by
-// barriers, each a dependent read-modify-write of that state — through L2 every phase cost a global-memory round trip (11.7 us per
-// iteration), in LDS a few hundred cycles.
+// iterations).  Here ONE persistent workgroup (16 wavefronts) runs the whole auction of one cloud pair, and the loop ends as
+// soon as nothing is unassigned (after that no reference kernel changes any state).
+//   LDS (n <= 2688, 60 B per point; 120 KiB at the evaluation size n = 2048): the targets with their prices as 16-byte records
+//   (one ds_read_b128 per evaluated pair), the bidders' coordinates, both assignments, the bids and TWO unassigned lists — the
+//   list is carried from one iteration to the next (losers + displaced owners) instead of being rebuilt by a scan over n points.
+//   Larger n (<= 8192): only the targets in LDS, the state in the caller's workspace (every phase then pays an L2 round trip).
+//   Bid: a wavefront per unassigned point, lanes strided over the targets, branch-free running (best, second best, first index),
+//   merged over the wavefront by DPP rotations + 4 readlanes (the merge keeps the reference's result: first maximum in index
+//   order, :152-178).  The scan is VALU-bound (correctly rounded sqrtf + the reference's double-precision `3.0 - d - price`).
+//   Tail (<= 8 unassigned, 85 % of the iterations): 8 wavefronts share the bidders' scans, wavefront 0 merges their partials and
+//   does GetMax and Assign in registers, one lane per bidder — two workgroup barriers per iteration.
+//   GetMax's data race (several bidders within 1e-6 of the maximum all write max_idx, :195-199) is resolved deterministically:
+//   the largest bidder index wins — the oracle uses the same rule.
+// 117 ms -> 63 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
+// shuffles, 8 barriers); a pair owns a compute unit, so throughput comes from launching >= 256 pairs (evaluation.py: 1024).
 #include "dfx_common.h"
 
 namespace {
@@ -34,18 +38,17 @@ struct Best {
   int idx;
 };
 
-// a then b, where every index in a is smaller than every index in b is NOT required: ties take the smaller index
+// Merge of two (best, second best, first index of the best) triples over disjoint target sets; ties take the smaller index, a triple
+// that has seen nothing (idx -1) loses them.  Branch-free (the auction's tail is a chain of these): bitwise | and & on purpose.
 __device__ __forceinline__ Best merge(const Best &a, const Best &b) {
+  const bool bw = (b.best > a.best) | ((b.best == a.best) & ((unsigned)b.idx < (unsigned)a.idx));
   Best r;
-  if (b.best > a.best || (b.best == a.best && b.idx >= 0 && (a.idx < 0 || b.idx < a.idx))) {
-    r.best = b.best, r.idx = b.idx, r.better = fmaxf(a.best, b.better);
-  } else {
-    r.best = a.best, r.idx = a.idx, r.better = fmaxf(a.better, b.best);
-  }
+  r.best = bw ? b.best : a.best, r.idx = bw ? b.idx : a.idx;
+  r.better = fmaxf(fmaxf(a.better, b.better), fminf(a.best, b.best));   // the loser's best or one of the second bests
   return r;
 }
 
-// lane i receives lane ((i + R) mod 16) of its row of 16 (DPP row_ror: no LDS round trip, unlike ds_bpermute)
+// lane i receives lane ((i - R) mod 16) of its row of 16 (DPP row_ror: no LDS round trip, unlike ds_bpermute)
 template <int R>
 __device__ __forceinline__ Best row_ror(const Best &m) {
   const int a = __float_as_int(m.best), b = __float_as_int(m.better), c = m.idx;
@@ -116,99 +119,118 @@ __global__ __launch_bounds__(EMD_THREADS) void k_emd(const float *__restrict__ x
     }
     ti_ = tp_, cls_ = U == 1 ? 0 : U <= 8 ? 1 : U <= 16 ? 2 : 3;
 #endif
-    if (tid == 0) *ncnt = 0;   // (read by everyone at the start of the previous iteration; filled after this iteration's first barrier)
-    // ---- Bid: G wavefronts per unassigned point, G = 16 / (points per round) — the tail of an auction is thousands of iterations with a
-    // handful of unassigned points, and one wavefront walking all n targets for its point (n / 64 dependent steps) was the iteration's
-    // length; the partial (best, second best, first index) triples of a point's wavefronts are merged through LDS (the merge keeps the
-    // reference's result whatever the split: first maximum in index order, :152-178) ----
+    if (tid == 0) *ncnt = 0;   // (read by everyone at the start of the previous iteration; filled after this iteration's first barrier;
+                               // tid 0 is lane 0 of wavefront 0, which also stores the count of the <= 8 bidder path: same lane, program order)
     constexpr int NWAVES = EMD_THREADS / 64;
-    int G = 1;
-    while (G < NWAVES && U * (2 * G) <= NWAVES) G *= 2;   // (U is workgroup-uniform)
-    const int per_round = NWAVES / G, grp = wave / G, wg = wave % G;
-    for (int u0 = 0; u0 < U; u0 += per_round) {   // (one round when G > 1)
-      const int u = u0 + grp;
+    // ---- Bid (:102-186): a wavefront walks the targets for one unassigned point, lanes strided, keeping (best, second best, first index
+    // of the best); the lanes' triples are merged with the reference's result (first maximum in index order, :152-178) ----
+    auto bid_scan = [&](int j, int first, int stride_log2) {
       Best m{-1e9f, -1e9f, -1};
-      int j = 0;
-      if (u < U) {
-        j = list[u];
-        const float x1 = STATE_LDS ? XA[j] : A[j * 3], y1 = STATE_LDS ? XA[n + j] : A[j * 3 + 1], z1 = STATE_LDS ? XA[2 * n + j] : A[j * 3 + 2];
-        EMD_T(0);
-        // (VALU-bound while many points bid — four wavefronts per SIMD each walking all targets: branch-free running (best, second best,
-        // first index of the best), the strides every lane has in full unrolled by four)
-        auto eval = [&](int k) {
+      const float x1 = STATE_LDS ? XA[j] : A[j * 3], y1 = STATE_LDS ? XA[n + j] : A[j * 3 + 1], z1 = STATE_LDS ? XA[2 * n + j] : A[j * 3 + 2];
+      EMD_T(0);
+      // (VALU-bound: branch-free update, the strides every lane has in full unrolled by four)
+      auto eval = [&](int k) {
 #pragma clang fp contract(off)
-          const float4 t = T[k];
-          const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
-          const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          const float d = (float)(3.0 - (double)sqrtf(s) - (double)t.w);   // `3.0` is a double literal in the reference (:151)
-          m.better = fmaxf(m.better, fminf(m.best, d));   // = (d > best ? best : d > better ? d : better)
-          m.idx = d > m.best ? k : m.idx;
-          m.best = fmaxf(m.best, d);
-        };
-        const int stride = G * 64, full = n >> (6 + __builtin_ctz(G));
-        int k = wg * 64 + lane, t = 0;
-        for (; t + 4 <= full; t += 4, k += 4 * stride) eval(k), eval(k + stride), eval(k + 2 * stride), eval(k + 3 * stride);
-        for (; t < full; ++t, k += stride) eval(k);
-        if (k < n) eval(k);
-        EMD_T(1);
-        m = wave_merge(m);
-        EMD_T(2);
-      }
-      if (G > 1) {
+        const float4 t = T[k];
+        const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
+        const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float d = (float)(3.0 - (double)sqrtf(s) - (double)t.w);   // `3.0` is a double literal in the reference (:151)
+        m.better = fmaxf(m.better, fminf(m.best, d));   // = (d > best ? best : d > better ? d : better)
+        m.idx = d > m.best ? k : m.idx;
+        m.best = fmaxf(m.best, d);
+      };
+      const int stride = 1 << stride_log2, full = n >> stride_log2;
+      int k = first + lane, t = 0;
+      for (; t + 4 <= full; t += 4, k += 4 * stride) eval(k), eval(k + stride), eval(k + 2 * stride), eval(k + 3 * stride);
+      for (; t < full; ++t, k += stride) eval(k);
+      if (k < n) eval(k);
+      EMD_T(1);
+      m = wave_merge(m);
+      EMD_T(2);
+      return m;
+    };
+    if (U <= 8) {
+      // ---- the tail of an auction: thousands of iterations with a handful of unassigned points.  The iteration is as long as the
+      // instructions its wavefronts issue (four SIMDs; a merge over a wavefront costs as much as two targets per lane; one wavefront
+      // alone on a SIMD issues dependent instructions at half the rate two reach), so the bids use EIGHT wavefronts — two per SIMD:
+      // G = 8, 4, 2, 1 wavefronts per bidder for U = 1, 2, 3-4, 5-8 — and wavefront 0
+      // finishes the iteration alone, one lane per bidder: merge of the partials, GetMax and Assign follow each other in registers /
+      // in program order, no workgroup barrier between them ----
+      const int lp = U == 1 ? 0 : U == 2 ? 1 : U <= 4 ? 2 : 3, P = 1 << lp, lg = 3 - lp, G = 1 << lg;   // P = 1, 2, 4, 8 >= U; G = 8 / P
+      if (wave < U * G) {
+        const Best m = bid_scan(list[wave >> lg], (wave & (G - 1)) * 64, 6 + lg);
         if (lane == 0) wbest[wave] = m;
-      } else if (u < U && lane == 0) {
-#pragma clang fp contract(off)
-        const float inc = m.best - m.better + eps;
-        bid[j] = m.idx;
-        bid_inc[j] = inc;
-        atomicMax(reinterpret_cast<int *>(max_inc) + m.idx, __float_as_int(inc));   // inc > 0 vs stored 0 / -1e9: int order = float order
       }
-    }
-    __syncthreads();
-    EMD_T(3);
-    if (G > 1) {
-      // ---- at most 8 bidders: wavefront 0 finishes the iteration alone, one lane per bidder — merge of the partials, GetMax and Assign
-      // follow each other inside one wavefront (its LDS / memory operations complete in order), no workgroup barrier between them ----
+      __syncthreads();
+      EMD_T(3);
       if (wave == 0) {
-        int j = -1, k = -1;
-        float inc = 0.f;
-        // partial q of bidder u sits in lane q * per_round + u of row 0: rotations by multiples of per_round merge a bidder's G partials
+        // partial q of bidder u sits in lane q * P + u of row 0: rotations to the LEFT by P, 2P, .. < 8 (lane i receives lane i + s) merge
+        // a bidder's partials into lane u
         Best m{-1e9f, -1e9f, -1};
-        if (lane < NWAVES && lane % per_round < U) m = wbest[(lane % per_round) * G + lane / per_round];
-        if (per_round <= 1) m = merge(m, row_ror<1>(m));
-        if (per_round <= 2) m = merge(m, row_ror<2>(m));
-        if (per_round <= 4) m = merge(m, row_ror<4>(m));
-        m = merge(m, row_ror<8>(m));
+        if ((lane & (P - 1)) < U && (lane >> lp) < G) m = wbest[(lane & (P - 1)) * G + (lane >> lp)];
+        if (P <= 1) m = merge(m, row_ror<15>(m));
+        if (P <= 2) m = merge(m, row_ror<14>(m));
+        if (P <= 4) m = merge(m, row_ror<12>(m));
+        int j = -1, k = -2 - lane;
+        float inc = 0.f;
         if (lane < U) {
 #pragma clang fp contract(off)
           j = list[lane], k = m.idx, inc = m.best - m.better + eps;
-          atomicMax(reinterpret_cast<int *>(max_inc) + k, __float_as_int(inc));
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         EMD_T(4);
-        if (lane < U) {
-          const float mi = max_inc[k];
-          if ((double)inc - 1e-6 <= (double)mi && (double)mi <= (double)inc + 1e-6) atomicMax(max_idx + k, j);
+        // GetMax among at most 8 lanes, in registers (max_inc / max_idx are scratch of one iteration — every target that receives bids has
+        // a winner, which puts them back to -1e9 / -1, and every increment is > 0 —, so this path neither reads nor writes them):
+        // the target's largest increment, then the largest bidder index within 1e-6 of it (:195-199 with the race resolved as in the oracle)
+        float mi = inc;
+        for (int v = 0; v < U; ++v) {
+          const int kv = __builtin_amdgcn_readlane(k, v);
+          const float iv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), v));
+          mi = kv == k ? fmaxf(mi, iv) : mi;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const int cj = ((double)inc - 1e-6 <= (double)mi && (double)mi <= (double)inc + 1e-6) ? j : -1;
+        int wj = cj;
+        for (int v = 0; v < U; ++v) {
+          const int kv = __builtin_amdgcn_readlane(k, v), cv = __builtin_amdgcn_readlane(cj, v);
+          wj = kv == k ? max(wj, cv) : wj;
+        }
         EMD_T(5);
+        int push = -1;   // the point this lane leaves unassigned: itself when it lost, the owner it displaced when it won
         if (lane < U) {
-          if (last || max_idx[k] == j) {
+          if (last || wj == j) {
             const int prev = ass_inv[k];
-            if (!last && prev != -1) as[prev] = -1, nlist[atomicAdd(ncnt, 1)] = prev;
+            if (!last && prev != -1) as[prev] = -1, push = prev;
             ass_inv[k] = j;
             as[j] = k;
-            if (!last) T[k].w += inc, max_inc[k] = -1e9f, max_idx[k] = -1;
+            if (!last) T[k].w += inc;
           } else {
-            nlist[atomicAdd(ncnt, 1)] = j;
+            push = j;
           }
         }
+        const unsigned long long pm = __ballot(push >= 0);
+        if (push >= 0) nlist[__popcll(pm & ((1ull << lane) - 1))] = push;
+        if (lane == 0) *ncnt = __popcll(pm);
         EMD_T(6);
       }
       __syncthreads();
       EMD_T(7);
       continue;
     }
+    // ---- more than 8 bidders: one wavefront per bidder, 16 at a time ----
+    for (int u0 = 0; u0 < U; u0 += NWAVES) {
+      const int u = u0 + wave;
+      if (u < U) {
+        const int j = list[u];
+        const Best m = bid_scan(j, 0, 6);
+        if (lane == 0) {
+#pragma clang fp contract(off)
+          const float inc = m.best - m.better + eps;
+          bid[j] = m.idx;
+          bid_inc[j] = inc;
+          atomicMax(reinterpret_cast<int *>(max_inc) + m.idx, __float_as_int(inc));   // inc > 0 vs stored 0 / -1e9: int order = float order
+        }
+      }
+    }
+    __syncthreads();
     // ---- GetMax ----
     for (int u = tid; u < U; u += EMD_THREADS) {
       const int j = list[u], k = bid[j];

@@ -268,8 +268,8 @@ void oracle_chamfer_grad(int b, int n, int m, const float *xyz1, const float *xy
  *     max_idx: a data race in the reference; here the LARGEST bidder index wins (stated deviation, ties are rare);
  *   - the last iteration assigns every still-unassigned bidder to its bid without evicting (:209-211).
  * Iterations stop early once nothing is unassigned (no kernel changes any state after that). */
-void oracle_emd_forward(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
-                        int32_t *assignment) {
+static void emd_forward_impl(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
+                             int32_t *assignment, int32_t *unassigned) {
   int32_t *ass_inv = (int32_t *)malloc(sizeof(int32_t) * n), *bid = (int32_t *)malloc(sizeof(int32_t) * n),
           *max_idx = (int32_t *)malloc(sizeof(int32_t) * n);
   float *price = (float *)malloc(sizeof(float) * n), *bid_inc = (float *)malloc(sizeof(float) * n),
@@ -298,6 +298,11 @@ void oracle_emd_forward(int b, int n, const float *xyz1, const float *xyz2, floa
         bid_inc[j] = best - better + eps;
         if (bid_inc[j] > max_inc[best_i]) max_inc[best_i] = bid_inc[j];
       }
+      if (unassigned) {   /* (tests: how many points bid in iteration `it` of the first pair) */
+        int u = 0;
+        for (int j = 0; j < n; ++j) u += as[j] == -1;
+        if (bi == 0) unassigned[it] = u;
+      }
       if (!any) break;
       for (int j = 0; j < n; ++j) {   /* GetMax: ascending j, the largest matching bidder index stays */
         if (as[j] != -1) continue;
@@ -324,6 +329,17 @@ void oracle_emd_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     }
   }
   free(ass_inv); free(bid); free(max_idx); free(price); free(bid_inc); free(max_inc);
+}
+
+void oracle_emd_forward(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
+                        int32_t *assignment) {
+  emd_forward_impl(b, n, xyz1, xyz2, eps, iters, dist, assignment, NULL);
+}
+
+/* the same auction; unassigned[it] = number of bidders of iteration it of the first pair (0 from convergence on; caller zero-fills) */
+void oracle_emd_forward_trace(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
+                              int32_t *assignment, int32_t *unassigned) {
+  emd_forward_impl(b, n, xyz1, xyz2, eps, iters, dist, assignment, unassigned);
 }
 
 /* NmDistanceGradKernel :286-301: grad_xyz1[j] += 2 grad_dist[j] (x1_j - x2_assignment[j]); grad_xyz2 stays zero */

@@ -167,6 +167,16 @@ def emd_forward(xyz1, xyz2, eps, iters):
     return dist, assignment
 
 
+def emd_unassigned_per_iteration(xyz1, xyz2, eps, iters):
+    """How many points bid in each iteration of the first pair's auction (0 once it has converged) — lets a test check that it stops
+    the auction inside the tail."""
+    xyz1, xyz2 = _c(xyz1, _F), _c(xyz2, _F)
+    B, n, _ = xyz1.shape
+    dist, assignment, hist = np.zeros((B, n), _F), np.zeros((B, n), _I), np.zeros(iters, _I)
+    lib().oracle_emd_forward_trace(B, n, _p(xyz1), _p(xyz2), ctypes.c_float(eps), int(iters), _p(dist), _p(assignment), _p(hist))
+    return hist
+
+
 def emd_backward(xyz1, xyz2, grad_dist, assignment):
     xyz1, xyz2, grad_dist, assignment = _c(xyz1, _F), _c(xyz2, _F), _c(grad_dist, _F), _c(assignment, _I)
     B, n, _ = xyz1.shape

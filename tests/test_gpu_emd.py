@@ -53,3 +53,33 @@ def test_emd_backward_vs_oracle():
     ref = o.emd_backward(a, b, w.cpu().numpy(), asg.cpu().numpy())
     assert np.abs(x1.grad.cpu().numpy() - ref).max() < 1e-6
     assert float(x2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("state_global", [0, 1])
+def test_emd_tail_iterations_and_ties_bit_exact(state_global):
+    """The auction's tail (<= 8 unassigned points: a separate path of the kernel — eight wavefronts share the scans, one finishes the
+    iteration in registers) stopped at many different iterations, so that the last, non-evicting iteration (:209-211) falls on 1, 2,
+    .. bidders as well as on many; ragged n; and lattice clouds: exact ties between targets (first index wins), equal increments on
+    one target (largest bidder index wins) and coincident points (distance 0).  With the state in LDS and in the workspace."""
+    from difffacto_amd import _ffi
+    from difffacto_amd.metrics import emdFunction
+    from oracle import pointnet2 as o
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = []
+    for n in (257, 96):
+        a, b = _clouds(1, n, n)
+        cases += [(a, b, it) for it in (1, 2, 3, 17, 40, 80, 120, 160, 200, 250, 300, 400, 600, 900)]
+    lat = (rng.integers(0, 5, (2, 200, 3)) / 4).astype(np.float32)
+    cases += [(lat[:1], lat[1:], it) for it in (5, 50, 500, 3000)] + [(lat[:1], lat[:1].copy(), 50)]
+    _ffi.lib().dfx_debug_emd_state_global(state_global)
+    try:
+        tails = 0
+        for a, b, it in cases:
+            d_ref, as_ref = o.emd_forward(a, b, 0.002, it)
+            d, asg = emdFunction.apply(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 0.002, it)
+            assert np.array_equal(asg.cpu().numpy(), as_ref), (a.shape, it)
+            assert np.array_equal(d.cpu().numpy(), d_ref), (a.shape, it)
+            tails += 0 < int(o.emd_unassigned_per_iteration(a, b, 0.002, it)[-1]) <= 8
+        assert tails >= 6   # the sweep does stop inside the tail (the last iteration has 1..8 bidders)
+    finally:
+        _ffi.lib().dfx_debug_emd_state_global(0)
