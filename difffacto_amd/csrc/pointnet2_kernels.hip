@@ -468,6 +468,9 @@ int dfx_gather_points_grad_f32(const float *grad_out, const int32_t *idx, float 
 
 int dfx_fps_max_resident(void) { return 1024 * 16; }
 
+namespace { int g_fps_nt = 0, g_fps_ppt = 0; }
+void dfx_debug_fps_shape(int threads, int points_per_thread) { g_fps_nt = threads, g_fps_ppt = points_per_thread; }
+
 int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, int B, int N, int M,
                                     dfx_stream_t stream) {
   DFX_REQUIRE(B >= 0 && N >= 0 && M >= 0, "fps: negative size");
@@ -483,11 +486,28 @@ int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, 
     const size_t sh = 2 * 16 * sizeof(unsigned long long) + ((LDSC) ? (size_t)N * 12 : 0);                     \
     fps_resident_kernel<NT, PPT, LDSC><<<B, NT, sh, st>>>(xyz, idx, N, M, log2bs);                             \
   } while (0)
-  if (N <= 512) DFX_FPS_LAUNCH(256, 2, true);
-  else if (N <= 2048) DFX_FPS_LAUNCH(256, 8, true);
-  else if (N <= 4096) DFX_FPS_LAUNCH(512, 8, true);
-  else if (N <= 8192) DFX_FPS_LAUNCH(1024, 8, true);
-  else if (N <= 16384) DFX_FPS_LAUNCH(1024, 16, false);
+  // Workgroup shape: the selection loop is a chain of M dependent arg-max reductions whose length is the instructions the wavefronts
+  // issue per step — 11 per point, plus ~70 per WAVEFRONT for the two reduction levels —, so: as few wavefronts as keep two per SIMD
+  // busy (one alone issues dependent instructions at half the rate), more points per thread (`tools/sweep_fps_shape.py`).
+  int nt = 0, ppt = 0;
+  if (g_fps_nt && (long long)g_fps_nt * g_fps_ppt >= N) nt = g_fps_nt, ppt = g_fps_ppt;   // debug / sweep override
+  else if (N <= 512) nt = 256, ppt = 2;
+  else if (N <= 1024) nt = 256, ppt = 4;
+  else if (N <= 2048) nt = 256, ppt = 8;
+  else if (N <= 4096) nt = 512, ppt = 8;
+  else if (N <= 8192) nt = 512, ppt = 16;
+  else if (N <= 16384) nt = 1024, ppt = 16;
+  const bool ldsc = N <= 8192;
+#define DFX_FPS_CASE(NT, PPT)                                                                  \
+  if (nt == NT && ppt == PPT) {                                                                \
+    if (ldsc) DFX_FPS_LAUNCH(NT, PPT, true);                                                   \
+    else DFX_FPS_LAUNCH(NT, PPT, false);                                                       \
+  } else
+  DFX_FPS_CASE(256, 2) DFX_FPS_CASE(256, 4) DFX_FPS_CASE(256, 8) DFX_FPS_CASE(256, 16) DFX_FPS_CASE(256, 32)
+  DFX_FPS_CASE(512, 2) DFX_FPS_CASE(512, 4) DFX_FPS_CASE(512, 8) DFX_FPS_CASE(512, 16)
+  DFX_FPS_CASE(1024, 2) DFX_FPS_CASE(1024, 4) DFX_FPS_CASE(1024, 8) DFX_FPS_CASE(1024, 16)
+  if (nt) return dfx::set_error(DFX_ERR_INVALID_ARG, "fps: no kernel for %d threads x %d points per thread", nt, ppt);
+#undef DFX_FPS_CASE
   else {
     DFX_REQUIRE(tmp, "fps: N=%d > %d needs the (B,N) float scratch `tmp`", N, dfx_fps_max_resident());
     fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, tmp, idx, N, M, log2bs);

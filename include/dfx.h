@@ -433,6 +433,9 @@ int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long
 void dfx_debug_train_fused(int on);
 /* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
 void dfx_debug_emd_state_global(int on);
+/* Debug / sweep: workgroup shape of the register-resident FPS kernel (threads in {256, 512, 1024} x points per thread in {2..32},
+ * used when threads * points >= N; 0, 0 = automatic). */
+void dfx_debug_fps_shape(int threads, int points_per_thread);
 /* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
  * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
  * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */
