@@ -19,6 +19,7 @@
 // 117 ms -> 63 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
 // shuffles, 8 barriers); a pair owns a compute unit, so throughput comes from launching >= 256 pairs (evaluation.py: 1024).
 #include "dfx_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -47,6 +48,22 @@ __device__ __forceinline__ Best merge(const Best &a, const Best &b) {
   r.better = fmaxf(fmaxf(a.better, b.better), fminf(a.best, b.best));   // the loser's best or one of the second bests
   return r;
 }
+
+// Correctly rounded sqrtf (what sqrtf() is, and what the reference's CUDA sqrtf is) with the compiler's range handling moved out of
+// the way: v_sqrt_f32 is within 1 ulp, the two residuals pick between the result and its neighbours.  The compiler's expansion
+// also rescales inputs below 2^-96 (the residuals would lose bits there) and patches 0 / inf through a class test — 7 of its 16
+// instructions; here 0, inf and NaN fall through the residual tests unchanged (their neighbours give NaN or zero residuals), and a
+// scan that met an input in (0, 2^-96) is redone with the library function (`tiny`: running minimum of bits(s) - 1, unsigned).
+__device__ __forceinline__ float sqrt_rn_normal(float s, unsigned &tiny) {
+  tiny = min(tiny, (unsigned)(__float_as_int(s) - 1));
+  const float r = __builtin_amdgcn_sqrtf(s);
+  const float rd = __int_as_float(__float_as_int(r) - 1), ru = __int_as_float(__float_as_int(r) + 1);
+  const float e1 = fmaf(-rd, r, s), e2 = fmaf(-ru, r, s);
+  float q = e1 <= 0.f ? rd : r;
+  q = e2 > 0.f ? ru : q;
+  return q;
+}
+constexpr unsigned EMD_TINY = 0x0f800000u - 1u;   // bits(2^-96) - 1
 
 // lane i receives lane ((i - R) mod 16) of its row of 16 (DPP row_ror: no LDS round trip, unlike ds_bpermute)
 template <int R>
@@ -129,21 +146,30 @@ __global__ __launch_bounds__(EMD_THREADS) void k_emd(const float *__restrict__ x
       const float x1 = STATE_LDS ? XA[j] : A[j * 3], y1 = STATE_LDS ? XA[n + j] : A[j * 3 + 1], z1 = STATE_LDS ? XA[2 * n + j] : A[j * 3 + 2];
       EMD_T(0);
       // (VALU-bound: branch-free update, the strides every lane has in full unrolled by four)
-      auto eval = [&](int k) {
+      unsigned tiny = 0xffffffffu;
+      auto scan = [&](auto lib) {
+        auto eval = [&](int k) {
 #pragma clang fp contract(off)
-        const float4 t = T[k];
-        const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
-        const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        const float d = (float)(3.0 - (double)sqrtf(s) - (double)t.w);   // `3.0` is a double literal in the reference (:151)
-        m.better = fmaxf(m.better, fminf(m.best, d));   // = (d > best ? best : d > better ? d : better)
-        m.idx = d > m.best ? k : m.idx;
-        m.best = fmaxf(m.best, d);
+          const float4 t = T[k];
+          const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
+          const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          const float r = decltype(lib)::value ? sqrtf(s) : sqrt_rn_normal(s, tiny);
+          const float d = (float)(3.0 - (double)r - (double)t.w);   // `3.0` is a double literal in the reference (:151)
+          m.better = __builtin_amdgcn_fmed3f(m.best, m.better, d);   // best >= better: the median = (d > best ? best : d > better ? d : better)
+          m.idx = d > m.best ? k : m.idx;
+          m.best = fmaxf(m.best, d);
+        };
+        const int stride = 1 << stride_log2, full = n >> stride_log2;
+        int k = first + lane, t = 0;
+        for (; t + 4 <= full; t += 4, k += 4 * stride) eval(k), eval(k + stride), eval(k + 2 * stride), eval(k + 3 * stride);
+        for (; t < full; ++t, k += stride) eval(k);
+        if (k < n) eval(k);
       };
-      const int stride = 1 << stride_log2, full = n >> stride_log2;
-      int k = first + lane, t = 0;
-      for (; t + 4 <= full; t += 4, k += 4 * stride) eval(k), eval(k + stride), eval(k + 2 * stride), eval(k + 3 * stride);
-      for (; t < full; ++t, k += stride) eval(k);
-      if (k < n) eval(k);
+      scan(std::false_type{});
+      if (__builtin_expect(__any(tiny < EMD_TINY), 0)) {   // a squared distance in (0, 2^-96): once more with the library's sqrtf
+        m = Best{-1e9f, -1e9f, -1};
+        scan(std::true_type{});
+      }
       EMD_T(1);
       m = wave_merge(m);
       EMD_T(2);

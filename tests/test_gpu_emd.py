@@ -71,6 +71,12 @@ def test_emd_tail_iterations_and_ties_bit_exact(state_global):
         cases += [(a, b, it) for it in (1, 2, 3, 17, 40, 80, 120, 160, 200, 250, 300, 400, 600, 900)]
     lat = (rng.integers(0, 5, (2, 200, 3)) / 4).astype(np.float32)
     cases += [(lat[:1], lat[1:], it) for it in (5, 50, 500, 3000)] + [(lat[:1], lat[:1].copy(), 50)]
+    # squared distances in (0, 2^-96) (the kernel's square root takes its library path for such a scan), alone and mixed with ordinary ones
+    a, b = _clouds(1, 130, 3)
+    mixed_a, mixed_b = a.copy(), b.copy()
+    mixed_a[0, :40] *= np.float32(1e-17)
+    mixed_b[0, 20:70] *= np.float32(1e-17)
+    cases += [(a * np.float32(1e-16), b * np.float32(1e-16), 30), (mixed_a, mixed_b, 40), (mixed_a, mixed_b, 700)]
     _ffi.lib().dfx_debug_emd_state_global(state_global)
     try:
         tails = 0
