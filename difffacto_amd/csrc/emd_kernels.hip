@@ -16,7 +16,7 @@
 //   does GetMax and Assign in registers, one lane per bidder — two workgroup barriers per iteration.
 //   GetMax's data race (several bidders within 1e-6 of the maximum all write max_idx, :195-199) is resolved deterministically:
 //   the largest bidder index wins — the oracle uses the same rule.
-// 117 ms -> 63 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
+// 117 ms -> 58 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
 // shuffles, 8 barriers); a pair owns a compute unit, so throughput comes from launching >= 256 pairs (evaluation.py: 1024).
 #include "dfx_common.h"
 #include <type_traits>
