@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "dfx_common.h"
+#include <type_traits>
 #include "mfma_linear.h"
 
 using namespace dfx::lin;
@@ -173,52 +174,87 @@ __device__ __forceinline__ v16f relu16(v16f a) {
   return a;
 }
 
-// one output tile of a register-chained layer: acc = b + sum over the input tiles (nin of them, <= 4)
-__device__ __forceinline__ v16f chain_tile(const v16f (&in)[4], int nin, const float *wp, int ot, int lane, const float *b,
-                                           int hf) {
-  v16f acc = bias_tile(b, ot, hf);
-  const v4f *w = reinterpret_cast<const v4f *>(wp) + (size_t)ot * (nin * 4) * 64 + lane;
+// Weight fragments of the register-chained layers: group s = (output tile ot, input tile t) = 4 x 64 float4, consecutive in s
+// = ot * nin + t.  They come from L2 (every wavefront of the grid reads the same few KiB), ~600 cycles away: the group of step
+// s + 1 is requested before the 16 MFMAs (1024 matrix-pipe cycles) of step s start, across output tiles and across layers — the
+// compiler on its own kept two fragments in flight, one group of 4 MFMAs ahead, and drained the queue at every input tile.
+__device__ __forceinline__ void load_group(const v4f *w, v4f (&u)[4]) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t < nin) {
-      v4f u[4];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) u[r4] = w[(t * 4 + r4) * 64];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u[r4][e], in[t][4 * r4 + e], acc, 0, 0, 0);
-    }
-  }
-  return acc;
+  for (int r4 = 0; r4 < 4; ++r4) u[r4] = w[r4 * 64];
 }
 
-// max over the 32 lanes of each half-wave (row_shr butterflies stay inside a row of 16; the last step crosses rows)
+__device__ __forceinline__ void mfma_group(const v4f (&u)[4], const v16f &x, v16f &acc) {
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u[r4][e], x[4 * r4 + e], acc, 0, 0, 0);
+}
+
+// max over the 32 lanes of each half-wave, left in lanes 16..31 / 48..63: DPP permutes inside the rows of 16 (no LDS-crossbar
+// round trips: 80 of them per output tile before), then row 0 -> 1 and row 2 -> 3 by row_bcast:15
 __device__ __forceinline__ float half_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64));
-  v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64));
-  v = fmaxf(v, __shfl_xor(v, 8, 64));
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  auto step = [](float x, auto ctrl, auto rmask) {
+    const int xi = __float_as_int(x);
+    return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl)::value, decltype(rmask)::value, 0xf, false)));
+  };
+  v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+  v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3
   return v;
 }
 
-// last layer: one output tile at a time -> ReLU -> max over this tile's neighbours -> atomic max across tiles
-__device__ __forceinline__ void pooled_last_layer(const FusedArgs &a, const v16f (&hin)[4], int nin, int li, int lane, bool valid,
-                                                  int b, int m) {
+// One output tile of a register-chained layer: acc += sum over the nin input tiles, the fragments of the step after each one
+// requested first.  Two fragment sets used alternately (a copy "cur = next" would make every step wait for the loads it has
+// just issued); `wa` holds step s0's fragments on entry and the fragments of step s0 + nin on exit (for odd nin after one copy).
+template <int NIN>   // the number of input tiles at compile time (0: run time — every `t < nin` is then a branch whose merge makes the
+                     // compiler wait for ALL outstanding loads, the prefetched ones included)
+__device__ __forceinline__ void chain_steps(const v16f (&in)[4], int nin_rt, const v4f *w, int s0, int S, const v4f *after, v16f &acc,
+                                            v4f (&wa)[4], v4f (&wb)[4]) {
+  const int nin = NIN ? NIN : nin_rt;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < nin) {
+      v4f(&use)[4] = (t & 1) ? wb : wa;
+      v4f(&pre)[4] = (t & 1) ? wa : wb;
+      const int s = s0 + t;
+      // behind a layer's last step: the first group of the next layer (or, after the very last one, any valid group: an
+      // unconditional request keeps the outstanding-load count the same on every path, so the waits can be counted ones)
+      load_group(s + 1 < S ? w + (size_t)(s + 1) * 256 : (after ? after : w), pre);
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the requests behind 12 of the 16 MFMAs to save registers)
+      mfma_group(use, in[t], acc);
+    }
+  if (nin & 1) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) wa[r4] = wb[r4];
+  }
+}
+
+// last layer: one output tile at a time -> ReLU -> max over this tile's neighbours -> atomic max across tiles.
+// `wa` holds the fragments of the layer's first group on entry.
+template <int NIN>
+__device__ __forceinline__ void pooled_last_layer(const FusedArgs &a, const v16f (&hin)[4], int nin_rt, int li, int lane, bool valid,
+                                                  int b, int m, v4f (&wa)[4], v4f (&wb)[4]) {
+  const int nin = NIN ? NIN : nin_rt;
   const int j = lane & 31, hf = lane >> 5;
+  const v4f *w = reinterpret_cast<const v4f *>(a.wp[li]) + lane;
+  const int S = a.nt[li] * nin;
   for (int ot = 0; ot < a.nt[li]; ++ot) {
-    const v16f y = relu16(chain_tile(hin, nin, a.wp[li], ot, lane, a.b[li], hf));
+    v16f acc = bias_tile(a.b[li], ot, hf);
+    chain_steps<NIN>(hin, nin, w, ot * nin, S, nullptr, acc, wa, wb);
+    const v16f y = relu16(acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = half_max(valid ? y[r] : 0.f);   // padding neighbours contribute 0 <= the true maximum
       const int c = 32 * ot + rho(r, hf);
-      if (j == 0 && c < a.cout)   // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
+      if (j == 16 && c < a.cout)   // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
         atomicMax(reinterpret_cast<unsigned *>(a.out) + ((size_t)b * a.cout + c) * a.M + m, __float_as_uint(v) & 0x7fffffffu);
     }
   }
 }
 
+template <int N0, int N1>   // tiles of the first / middle layer's output at compile time (0: run time)
 __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
   const int lane = threadIdx.x & 63, j = lane & 31, hf = lane >> 5;
   const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -230,16 +266,21 @@ __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
   const int nb = tl * 32 + j;
   const bool valid = nb < a.ns;
   const int pid = valid ? (a.idx ? a.idx[((size_t)b * a.M + m) * a.ns + nb] : nb) : 0;
-  const int nx = a.use_xyz ? 3 : 0, C0 = nx + a.C;
+  const int nx = a.use_xyz ? 3 : 0, C0 = nx + a.C, nt0 = N0 ? N0 : a.nt[0];
+  v4f wa[4], wb[4];
+  load_group(reinterpret_cast<const v4f *>(a.wp[1]) + lane, wa);   // first group of the second layer: under the gathers
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) wb[r4] = wa[r4];
 
   // ---- layer 0: B operand straight from the gathers, channel k = 8 u + 2 e + hf ----
   v16f h0[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    if (t < a.nt[0]) h0[t] = bias_tile(a.b[0], t, hf);
+    if (t < nt0) h0[t] = bias_tile(a.b[0], t, hf);
   const v4f *w0 = reinterpret_cast<const v4f *>(a.wp[0]) + lane;
-  for (int u = 0; u < a.U0; ++u) {
-    float x[4];
+  // (the gathers are two dependent trips to memory — index, then coordinate / feature — and the compiler issues them where they are
+  // used: the operands of K unit u + 1 are requested before the MFMAs of unit u, two register sets used alternately)
+  auto operands = [&](int u, float (&x)[4], v4f (&wv)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = 8 * u + 2 * e + hf;
@@ -256,25 +297,50 @@ __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < a.nt[0]) {
-        const v4f wv = w0[((size_t)t * a.U0 + u) * 64];
+      if (t < nt0) wv[t] = w0[((size_t)t * a.U0 + u) * 64];
+  };
+  auto unit = [&](const float (&x)[4], const v4f (&wv)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], x[e], h0[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t)
+      if (t < nt0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][e], x[e], h0[t], 0, 0, 0);
       }
+  };
+  {
+    float xa[4], xb[4];
+    v4f va[4], vb[4];
+    operands(0, xa, va);
+    int u = 0;
+    for (; u + 1 < a.U0; u += 2) {
+      operands(u + 1, xb, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      unit(xa, va);
+      operands(min(u + 2, a.U0 - 1), xa, va);
+      __builtin_amdgcn_sched_barrier(0);
+      unit(xb, vb);
+    }
+    if (u < a.U0) unit(xa, va);   // odd number of units: the last one's operands were requested by the last pair (or above)
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    if (t < a.nt[0]) h0[t] = relu16(h0[t]);
+    if (t < nt0) h0[t] = relu16(h0[t]);
 
   // ---- optional middle layer (register-chained), then the pooled last layer ----
   if (a.L == 3) {
     v16f h1[4];
+    const v4f *w1 = reinterpret_cast<const v4f *>(a.wp[1]) + lane, *w2 = reinterpret_cast<const v4f *>(a.wp[2]) + lane;
+    const int nin = N0 ? N0 : a.nt[0], nt1 = N1 ? N1 : a.nt[1], S = nt1 * nin;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < a.nt[1]) h1[t] = relu16(chain_tile(h0, a.nt[0], a.wp[1], t, lane, a.b[1], hf));
-    pooled_last_layer(a, h1, a.nt[1], 2, lane, valid, b, m);
+    for (int ot = 0; ot < 4; ++ot)
+      if (ot < nt1) {
+        v16f acc = bias_tile(a.b[1], ot, hf);
+        chain_steps<N0>(h0, nin, w1, ot * nin, S, w2, acc, wa, wb);
+        h1[ot] = relu16(acc);
+      }
+    pooled_last_layer<N1>(a, h1, nt1, 2, lane, valid, b, m, wa, wb);
   } else {
-    pooled_last_layer(a, h0, a.nt[0], 1, lane, valid, b, m);
+    pooled_last_layer<N0>(a, h0, a.nt[0], 1, lane, valid, b, m, wa, wb);
   }
 }
 
@@ -475,7 +541,14 @@ int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz
     a.tiles_per_centre = (ns + 31) >> 5;
     a.total_tiles = (long long)B * M * a.tiles_per_centre;
     DFX_REQUIRE(a.total_tiles / 4 + 1 < 0x7fffffffLL, "sa_forward: too many tiles");
-    k_sa_fused<<<(int)((a.total_tiles + 3) / 4), 256, 0, st>>>(a);
+    const int grid = (int)((a.total_tiles + 3) / 4), n0 = a.nt[0], n1 = a.L == 3 ? a.nt[1] : 0;
+    // the channel widths of the reference's encoders at compile time (64-64-128, 128-128-256, 32-32-64, two-layer 64 / 128); others at run time
+    if (a.L == 3 && n0 == 2 && n1 == 2) k_sa_fused<2, 2><<<grid, 256, 0, st>>>(a);
+    else if (a.L == 3 && n0 == 4 && n1 == 4) k_sa_fused<4, 4><<<grid, 256, 0, st>>>(a);
+    else if (a.L == 3 && n0 == 1 && n1 == 1) k_sa_fused<1, 1><<<grid, 256, 0, st>>>(a);
+    else if (a.L == 2 && n0 == 2) k_sa_fused<2, 0><<<grid, 256, 0, st>>>(a);
+    else if (a.L == 2 && n0 == 4) k_sa_fused<4, 0><<<grid, 256, 0, st>>>(a);
+    else k_sa_fused<0, 0><<<grid, 256, 0, st>>>(a);
     return dfx::check_launch("sa_forward (fused)");
   }
   const long long rows = (long long)B * M * ns;
