@@ -233,32 +233,56 @@ __device__ __forceinline__ void chain_steps(const v16f (&in)[4], int nin_rt, con
 
 // last layer: one output tile at a time -> ReLU -> max over this tile's neighbours -> atomic max across tiles.
 // `wa` holds the fragments of the layer's first group on entry.
-template <int NIN>
+// COMBINE (the tiles of a centre all sit in one workgroup: 1, 2 or 4 tiles per centre): the four wavefronts leave their 32 channel
+// maxima of the output tile in LDS, the first wavefront of each centre merges them and stores — no atomics (they cost SA1 270 us of
+// 1550: 16.8 M read-modify-writes in L2) and no zero-fill of `out`.  Otherwise: atomic max across tiles into the zero-filled output.
+template <int NIN, bool COMBINE>
 __device__ __forceinline__ void pooled_last_layer(const FusedArgs &a, const v16f (&hin)[4], int nin_rt, int li, int lane, bool valid,
-                                                  int b, int m, v4f (&wa)[4], v4f (&wb)[4]) {
+                                                  bool store, int b, int m, v4f (&wa)[4], v4f (&wb)[4]) {
   const int nin = NIN ? NIN : nin_rt;
-  const int j = lane & 31, hf = lane >> 5;
+  const int j = lane & 31, hf = lane >> 5, wave = threadIdx.x >> 6;
   const v4f *w = reinterpret_cast<const v4f *>(a.wp[li]) + lane;
   const int S = a.nt[li] * nin;
+  __shared__ unsigned red[2][4][32];
   for (int ot = 0; ot < a.nt[li]; ++ot) {
     v16f acc = bias_tile(a.b[li], ot, hf);
     chain_steps<NIN>(hin, nin, w, ot * nin, S, nullptr, acc, wa, wb);
     const v16f y = relu16(acc);
+    unsigned mine = 0;   // COMBINE: lane 16 + r (48 + r) keeps the maximum of accumulator register r = channel rho(r, hf) of the tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = half_max(valid ? y[r] : 0.f);   // padding neighbours contribute 0 <= the true maximum
-      const int c = 32 * ot + rho(r, hf);
-      if (j == 16 && c < a.cout)   // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
-        atomicMax(reinterpret_cast<unsigned *>(a.out) + ((size_t)b * a.cout + c) * a.M + m, __float_as_uint(v) & 0x7fffffffu);
+      // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
+      const unsigned bits = __float_as_uint(v) & 0x7fffffffu;
+      if (COMBINE) {
+        mine = (lane & 15) == r ? bits : mine;
+      } else {
+        const int c = 32 * ot + rho(r, hf);
+        if (j == 16 && c < a.cout && store) atomicMax(reinterpret_cast<unsigned *>(a.out) + ((size_t)b * a.cout + c) * a.M + m, bits);
+      }
+    }
+    if (COMBINE) {
+      if (j >= 16) red[ot & 1][wave][rho(lane & 15, hf)] = mine;
+      __syncthreads();   // (one per output tile: the buffer of tile ot + 2 is written after the barrier of ot + 1, behind the reads of ot)
+      if (wave % a.tiles_per_centre == 0 && lane < 32) {
+        unsigned u = red[ot & 1][wave][lane];
+        for (int q = 1; q < a.tiles_per_centre; ++q) u = max(u, red[ot & 1][wave + q][lane]);
+        const int c = 32 * ot + lane;
+        if (store && c < a.cout) reinterpret_cast<unsigned *>(a.out)[((size_t)b * a.cout + c) * a.M + m] = u;
+      }
     }
   }
 }
 
-template <int N0, int N1>   // tiles of the first / middle layer's output at compile time (0: run time)
+template <int N0, int N1, bool COMBINE>   // tiles of the first / middle layer's output at compile time (0: run time)
 __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
   const int lane = threadIdx.x & 63, j = lane & 31, hf = lane >> 5;
-  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= a.total_tiles) return;
+  long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool store = tile < a.total_tiles;
+  if (!store) {
+    if (!COMBINE) return;
+    tile = a.total_tiles - 1;   // (the workgroup's barriers need every wavefront: the spare ones redo the last tile and store nothing)
+  }
   const int tl = tile % a.tiles_per_centre;
   const long long bm = tile / a.tiles_per_centre;
   const int m = bm % a.M;
@@ -338,9 +362,9 @@ __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
         chain_steps<N0>(h0, nin, w1, ot * nin, S, w2, acc, wa, wb);
         h1[ot] = relu16(acc);
       }
-    pooled_last_layer<N1>(a, h1, nt1, 2, lane, valid, b, m, wa, wb);
+    pooled_last_layer<N1, COMBINE>(a, h1, nt1, 2, lane, valid, store, b, m, wa, wb);
   } else {
-    pooled_last_layer<N0>(a, h0, a.nt[0], 1, lane, valid, b, m, wa, wb);
+    pooled_last_layer<N0, COMBINE>(a, h0, a.nt[0], 1, lane, valid, store, b, m, wa, wb);
   }
 }
 
@@ -532,7 +556,6 @@ int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz
   hipStream_t st = dfx::as_stream(stream);
   const int Cout = h->ch[h->L];
   if (h->fused_ok && !force_general) {
-    DFX_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * M, st));
     FusedArgs a{};
     a.xyz = xyz, a.new_xyz = new_xyz, a.feat = features, a.idx = idx, a.out = out;
     a.L = h->L, a.U0 = h->kpad[0] >> 3, a.cout = Cout;
@@ -542,13 +565,20 @@ int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz
     a.total_tiles = (long long)B * M * a.tiles_per_centre;
     DFX_REQUIRE(a.total_tiles / 4 + 1 < 0x7fffffffLL, "sa_forward: too many tiles");
     const int grid = (int)((a.total_tiles + 3) / 4), n0 = a.nt[0], n1 = a.L == 3 ? a.nt[1] : 0;
-    // the channel widths of the reference's encoders at compile time (64-64-128, 128-128-256, 32-32-64, two-layer 64 / 128); others at run time
-    if (a.L == 3 && n0 == 2 && n1 == 2) k_sa_fused<2, 2><<<grid, 256, 0, st>>>(a);
-    else if (a.L == 3 && n0 == 4 && n1 == 4) k_sa_fused<4, 4><<<grid, 256, 0, st>>>(a);
-    else if (a.L == 3 && n0 == 1 && n1 == 1) k_sa_fused<1, 1><<<grid, 256, 0, st>>>(a);
-    else if (a.L == 2 && n0 == 2) k_sa_fused<2, 0><<<grid, 256, 0, st>>>(a);
-    else if (a.L == 2 && n0 == 4) k_sa_fused<4, 0><<<grid, 256, 0, st>>>(a);
-    else k_sa_fused<0, 0><<<grid, 256, 0, st>>>(a);
+    const bool combine = a.tiles_per_centre == 1 || a.tiles_per_centre == 2 || a.tiles_per_centre == 4;   // a centre's tiles in one workgroup
+    if (!combine) DFX_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * M, st));
+    // the channel widths of the reference's encoders at compile time (64-64-128, 128-128-256, two-layer 64 / 128); others at run time
+#define DFX_SA_CASE(A, B_)                                                       \
+  do {                                                                           \
+    if (combine) k_sa_fused<A, B_, true><<<grid, 256, 0, st>>>(a);              \
+    else k_sa_fused<A, B_, false><<<grid, 256, 0, st>>>(a);                     \
+  } while (0)
+    if (a.L == 3 && n0 == 2 && n1 == 2) DFX_SA_CASE(2, 2);
+    else if (a.L == 3 && n0 == 4 && n1 == 4) DFX_SA_CASE(4, 4);
+    else if (a.L == 2 && n0 == 2) DFX_SA_CASE(2, 0);
+    else if (a.L == 2 && n0 == 4) DFX_SA_CASE(4, 0);
+    else DFX_SA_CASE(0, 0);
+#undef DFX_SA_CASE
     return dfx::check_launch("sa_forward (fused)");
   }
   const long long rows = (long long)B * M * ns;

@@ -136,3 +136,36 @@ def test_native_mlp_tracks_parameter_updates():
         _, ref = mod(xyz, None)
     _close(b, ref.detach())
     assert not torch.allclose(a, b)
+
+
+@pytest.mark.parametrize("B,N,npoint,nsample,mlp", [
+    (1, 300, 3, 64, [4, 64, 64, 128]),       # 6 tiles: the last workgroup has two spare wavefronts (they take part in its barriers)
+    (2, 400, 37, 96, [4, 64, 64, 128]),      # 3 tiles per centre: a centre straddles workgroups -> atomic max into the zero-filled output
+    (2, 400, 50, 40, [4, 64, 64, 128]),      # 2 tiles per centre, the second one mostly padding
+    (2, 400, 33, 128, [4, 128, 128, 256]),   # 4 tiles per centre = one workgroup
+    (3, 256, 21, 16, [4, 32, 32, 64]),       # run-time tile counts (1, 1), one tile per centre
+    (2, 256, 19, 64, [4, 64, 96, 64]),       # run-time tile counts (2, 3): odd number of input tiles -> the fragment sets swap by a copy
+    (2, 256, 30, 64, [4, 64, 128]),          # two layers
+    (2, 256, 30, 32, [4, 128, 256]),         # two layers, 4 input tiles
+    (1, 200, 10, 70, [9, 64, 64, 100]),      # 12 + 3 input channels (two K units), ragged output width
+])
+def test_fused_set_abstraction_variants_vs_general(B, N, npoint, nsample, mlp):
+    """Every code path of the fused kernel's output stage and weight pipeline (compile-time / run-time tile counts, LDS merge of a
+    centre's tiles / atomics, spare wavefronts) against the layer-by-layer path of the same library and the torch layers."""
+    from difffacto_amd.pointnet2_ops.pointnet2_modules import PointnetSAModule
+    from difffacto_amd import _ffi
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + nsample))
+    xyz = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)).cuda()
+    feats = torch.from_numpy(rng.standard_normal((B, mlp[0], N)).astype(np.float32)).cuda()
+    mod = _randomize(PointnetSAModule(npoint=npoint, radius=0.6, nsample=nsample, mlp=list(mlp)), nsample)
+    with torch.no_grad():
+        new_xyz = mod._centres(xyz)
+        out_f = mod._forward_native(0, xyz, new_xyz, feats)
+        assert _ffi.lib().dfx_shared_mlp_is_fused(mod._native(0).handle()) == 1
+        out_g = mod._forward_native(0, xyz, new_xyz, feats, force_general=True)
+        again = mod._forward_native(0, xyz, new_xyz, feats)
+    with torch.enable_grad():
+        _, out_t = mod(xyz, feats)
+    assert torch.equal(out_f, again)
+    _close(out_f, out_g)
+    _close(out_f, out_t.detach())
