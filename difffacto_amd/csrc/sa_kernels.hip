@@ -370,28 +370,40 @@ __global__ __launch_bounds__(256) void k_sa_fused(FusedArgs a) {
 
 // PointNetV2 pooling (pointnet.py:194-198): pooled[b][j][c] = max_n Y[b N + n][c] * attn[b][n][j] * scale
 // (points outside part j contribute 0 * x = 0, exactly as in the reference)
+// One workgroup = one cloud x 64 channels, its 16 wavefronts take the points n = p, p + 16, ... (a wavefront reads 256 contiguous
+// bytes per point; one thread per (cloud, channel) walking all N points alone — 1 wavefront per SIMD, a dependent load per point —
+// ran at 0.63 TB/s: 853 of the 2000 us of the encoder's forward); the 16 partial maxima meet in LDS.  max is exact: any order.
 template <int A>
-__global__ void k_masked_max(const float *__restrict__ Y, const float *__restrict__ attn, float *__restrict__ pooled, int N, int C,
-                             int ld, float scale, long long total) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int c = t % C;
-  const long long b = t / C;
+__global__ __launch_bounds__(1024) void k_masked_max(const float *__restrict__ Y, const float *__restrict__ attn, float *__restrict__ pooled,
+                                                   int N, int C, int ld, float scale) {
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  const long long b = blockIdx.y;
+  __shared__ float red[16][A][64];
   float mx[A];
 #pragma unroll
   for (int j = 0; j < A; ++j) mx[j] = -3.402823466e38f;
-  const float *y = Y + b * N * ld + c;
-  const float *w = attn + b * N * A;
-  for (int n = 0; n < N; ++n) {
-    const float v = y[(size_t)n * ld];
+  if (c < C) {
+    const float *y = Y + b * N * ld + c;
+    const float *w = attn + b * N * A;
+#pragma unroll 4
+    for (int n = ph; n < N; n += 16) {
+      const float v = y[(size_t)n * ld];
 #pragma unroll
-    for (int j = 0; j < A; ++j) {
+      for (int j = 0; j < A; ++j) {
 #pragma clang fp contract(off)
-      mx[j] = fmaxf(mx[j], v * w[n * A + j] * scale);
+        mx[j] = fmaxf(mx[j], v * w[n * A + j] * scale);
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < A; ++j) pooled[(b * A + j) * C + c] = mx[j];
+  for (int j = 0; j < A; ++j) red[ph][j][lane] = mx[j];
+  __syncthreads();
+  if (ph < A && c < C) {
+    float m = red[0][ph][lane];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) m = fmaxf(m, red[p][ph][lane]);
+    pooled[(b * A + ph) * C + c] = m;
+  }
 }
 
 inline int nblk(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
@@ -707,9 +719,8 @@ int dfx_pointnet_v2_forward_f32(dfx_pointnet_v2 *h, const float *x, const float 
     h->ws_floats = nP + nH1 + nH2;
   }
   float *P = h->ws, *H1 = P + nP, *H2 = H1 + nH1;
-  const long long tot = (long long)B * 512;
   switch (A) {
-#define DFX_CASE(a) case a: k_masked_max<a><<<nblk(tot), 256, 0, st>>>(Y, attn, P, N, 512, ld, h->scale, tot); break;
+#define DFX_CASE(a) case a: k_masked_max<a><<<dim3(512 / 64, B), 1024, 0, st>>>(Y, attn, P, N, 512, ld, h->scale); break;
     DFX_CASE(1) DFX_CASE(2) DFX_CASE(3) DFX_CASE(4) DFX_CASE(5) DFX_CASE(6) DFX_CASE(7) DFX_CASE(8)
 #undef DFX_CASE
   }
