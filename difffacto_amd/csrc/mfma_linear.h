@@ -157,19 +157,19 @@ static __global__ __launch_bounds__(256) void k_lin_wide(LinArgs a) {
 // The same tile with the weights resident in LDS.  k_lin_wide's five loads per K step all have the fragment shape (32 rows x 32
 // bytes: 32 cache lines per instruction), four of them for weights that every wavefront of the grid re-reads: at 262 144 rows the
 // kernel sits on the texture-address path at ~43 % of the matrix peak whatever the prefetch distance.  Here a workgroup of eight
-// wavefronts stages its 128-channel weight block ONCE, fragment-ready ([tile][K step][lane] float4: K / 2 KiB, K <= 272), and walks over
+// wavefronts stages its 128-channel weight block ONCE, fragment-ready ([tile][K step][lane] float4: K / 2 KiB for 128 channels, K <= 272; 64-channel blocks up to K = 544), and walks over
 // row tiles of 256 with it: per K step one global load (the activations, one step ahead) and four conflict-free ds_read_b128.
-template <int EPI>
+template <int EPI, int NT>   // NT = 4: 128 channels per block, K <= 272; NT = 2: 64 channels, K <= 544 (the block fits LDS either way)
 static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
   static_assert(EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID, "plain epilogues only");
   extern __shared__ __align__(16) float lin_smem[];
   v4f *wl = reinterpret_cast<v4f *>(lin_smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
-  const int n0 = blockIdx.x * 128, g = blockIdx.z, U = a.K >> 3;
+  const int n0 = blockIdx.x * (32 * NT), g = blockIdx.z, U = a.K >> 3;
   auto ld = [](const float *p) { return *reinterpret_cast<const v4f *>(p); };
   {
     const float *wbase = a.W + g * a.w_gs;
-    for (int e = threadIdx.x; e < 4 * U * 64; e += 512) {
+    for (int e = threadIdx.x; e < NT * U * 64; e += 512) {
       const int l = e & 63, tu = e >> 6, u = tu % U, t = tu / U;
       wl[e] = ld(wbase + (size_t)(n0 + 32 * t + (l & 31)) * a.K + 8 * u + 4 * (l >> 5));
     }
@@ -182,24 +182,24 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
     if (m0 >= a.M) continue;
     const int mrow = min(m0 + j, a.M - 1);
     const float *xp = a.X + g * a.x_gs + (size_t)mrow * a.ldx + 4 * hf;
-    v16f acc[4];
+    v16f acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    auto operands = [&](int u, v4f &xv, v4f (&wv)[4]) {
+    auto operands = [&](int u, v4f &xv, v4f (&wv)[NT]) {
       xv = ld(xp + 8 * u);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wv[t] = wlane[(t * U + u) * 64];
+      for (int t = 0; t < NT; ++t) wv[t] = wlane[(t * U + u) * 64];
     };
-    auto step = [&](const v4f &xv, const v4f (&wv)[4]) {
+    auto step = [&](const v4f &xv, const v4f (&wv)[NT]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], xv[s], acc[t], 0, 0, 0);
     };
     {
-      v4f xa, xb, wa[4], wb[4];
+      v4f xa, xb, wa[NT], wb[NT];
       operands(0, xa, wa);
       int u = 0;
       for (; u + 1 < U; u += 2) {
@@ -217,7 +217,7 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
     float *yp = a.Y + g * a.y_gs + (size_t)m * a.ldy;
     const float *rp = EPI == EPI_RESID ? a.R + (size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr : nullptr;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + 32 * t + 8 * q + 4 * hf;
@@ -239,16 +239,19 @@ inline void launch(hipStream_t st, int groups, const LinArgs &a) {
   constexpr bool plain = (EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID);
   if constexpr (plain) {
     if (a.N % 128 == 0 && a.M >= 512 && a.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (a.y_gs % 4) == 0) {
-      if (a.K % 8 == 0 && a.K <= 272 && a.M >= 8192 && a.ldx % 4 == 0) {   // enough row tiles per workgroup to pay for staging the weights
-        const size_t lds = (size_t)a.K / 8 * 4096;
+      if (a.K % 8 == 0 && a.K <= 544 && a.M >= 8192 && a.ldx % 4 == 0) {   // enough row tiles per workgroup to pay for staging the weights
+        const bool narrow = a.K > 272;   // 64-channel blocks when the 128-channel one would not fit
+        const size_t lds = (size_t)a.K / 8 * (narrow ? 2048 : 4096);
         static bool attr = false;
         if (!attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lin_wide_lds<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 4096);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 4096);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 2048);
           attr = true;
         }
-        const int cols = a.N / 128, per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 1024) / lds));
+        const int cols = a.N / (narrow ? 64 : 128), per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 1024) / lds));
         const int rows = (int)std::min<long long>((a.M + 255) / 256, std::max(1, 256 * per_cu / (cols * groups)));
-        k_lin_wide_lds<EPI><<<dim3(cols, rows, groups), 512, lds, st>>>(a);
+        if (narrow) k_lin_wide_lds<EPI, 2><<<dim3(cols, rows, groups), 512, lds, st>>>(a);
+        else k_lin_wide_lds<EPI, 4><<<dim3(cols, rows, groups), 512, lds, st>>>(a);
         return;
       }
       dim3 grid(a.N / 128, (a.M + 127) / 128, groups);

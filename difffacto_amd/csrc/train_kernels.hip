@@ -726,12 +726,22 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient: dW (O, I) = dY^T X over R rows, db = column sums of dY
-// grid (ceil(I/64), ceil(O/64), nslab); one wavefront per block; part[slab][O][I] (+ bpart[slab][O] from blockIdx.x == 0)
+// grid (ceil(I/64), ceil(O/64), nslab); part[slab][O][I] (+ bpart[slab][O] from blockIdx.x == 0).  NW wavefronts per block share
+// the tile: each takes a quarter of the slab's rows and the accumulators meet in LDS (fixed order: bit-reproducible) — the products
+// over all 262 144 points had 2 wavefronts per SIMD, each waiting ~2 us for operands that come from HBM (40 % of the matrix peak);
+// four times the wavefronts for the same number of partial tiles.
 // ---------------------------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
-                                           float *__restrict__ pp, float *__restrict__ bp, int O, int I, long long r0, long long r1) {
-  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
-  const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+                                           float *__restrict__ pp, float *__restrict__ bp, int O, int I, long long r0, long long r1,
+                                           int bx, int by) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  if (NW > 1) {   // this wavefront's share of the rows (an even number: rows go two per MFMA)
+    const long long q = ((r1 - r0 + NW - 1) / NW + 1) & ~1ll;
+    r0 = r0 + wave * q < r1 ? r0 + wave * q : r1;
+    r1 = r0 + q < r1 ? r0 + q : r1;
+  }
+  const int i0 = bx * 64, o0 = by * 64;
   const bool oa = o0 + j < O, ob = o0 + 32 + j < O, ia = i0 + j < I, ib = i0 + 32 + j < I;
   const float *py = dY + o0 + j, *px = X + i0 + j;
   v16f acc[2][2];
@@ -742,25 +752,46 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
-  long long r = r0;
-  for (; r + 8 <= r1; r += 8) {
+  // eight rows (16 loads, 16 MFMAs) per block; the loads of block q + 1 are issued before the MFMAs of block q (two register sets
+  // used alternately; the request behind the last block re-reads it, so that every path has the same number of loads in flight)
+  struct Rows {
     float ya[4], yb[4], xa[4], xb[4];
+  };
+  auto load8 = [&](long long r, Rows &w) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long rr = r + 2 * u + hf;
-      ya[u] = oa ? py[rr * ldy] : 0.f;
-      yb[u] = ob ? py[rr * ldy + 32] : 0.f;
-      xa[u] = ia ? px[rr * ldx] : 0.f;
-      xb[u] = ib ? px[rr * ldx + 32] : 0.f;
+      w.ya[u] = oa ? py[rr * ldy] : 0.f;
+      w.yb[u] = ob ? py[rr * ldy + 32] : 0.f;
+      w.xa[u] = ia ? px[rr * ldx] : 0.f;
+      w.xb[u] = ib ? px[rr * ldx + 32] : 0.f;
     }
+  };
+  auto mm8 = [&](const Rows &w) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], xa[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], xb[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[u], xa[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[u], xb[u], acc[1][1], 0, 0, 0);
-      bs0 += ya[u], bs1 += yb[u];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.ya[u], w.xa[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.ya[u], w.xb[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.yb[u], w.xa[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.yb[u], w.xb[u], acc[1][1], 0, 0, 0);
+      bs0 += w.ya[u], bs1 += w.yb[u];
     }
+  };
+  const long long nfull = (r1 - r0) / 8;
+  long long r = r0 + 8 * nfull;
+  if (nfull > 0) {
+    Rows wa, wb;
+    load8(r0, wa);
+    long long q = 0;
+    for (; q + 1 < nfull; q += 2) {
+      load8(r0 + 8 * (q + 1), wb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm8(wa);
+      load8(r0 + 8 * (q + 2 < nfull ? q + 2 : nfull - 1), wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mm8(wb);
+    }
+    if (q < nfull) mm8(wa);
   }
   for (; r < r1; r += 2) {
     const long long rr = r + hf;
@@ -772,6 +803,35 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xa, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
     bs0 += ya, bs1 += yb;
+  }
+  if (NW > 1) {   // wavefronts 2, 3 -> 0, 1, then 1 -> 0 (two 17 KiB slots)
+    __shared__ float red[2][4096 + 128];
+    auto put = [&](float *d) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 16; ++rg) d[((a * 2 + b) * 16 + rg) * 64 + lane] = acc[a][b][rg];
+      d[4096 + lane] = bs0, d[4096 + 64 + lane] = bs1;
+    };
+    auto add = [&](const float *d) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 16; ++rg) acc[a][b][rg] += d[((a * 2 + b) * 16 + rg) * 64 + lane];
+      bs0 += d[4096 + lane], bs1 += d[4096 + 64 + lane];
+    };
+    if (wave >= 2) put(red[wave - 2]);
+    __syncthreads();
+    if (wave < 2) add(red[wave]);
+    __syncthreads();
+    if (wave == 1) put(red[0]);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red[0]);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -785,7 +845,7 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
         if (o < O) pp[(size_t)o * I + i] = acc[a][b][rg];
       }
     }
-  if (bp && blockIdx.x == 0) {
+  if (bp && bx == 0) {
     bs0 += __shfl_xor(bs0, 32), bs1 += __shfl_xor(bs1, 32);
     if (hf == 0) {
       if (oa) bp[o0 + j] = bs0;
@@ -793,12 +853,22 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
     }
   }
 }
-__global__ __launch_bounds__(64) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+__global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                                float *__restrict__ part, float *__restrict__ bpart, int O, int I,
                                                long long R, int rows_per_slab) {
-  const long long r0 = (long long)blockIdx.z * rows_per_slab;
+  // Every 64 x 64 tile of a slab reads the slab's dY / X strips again (dY I / 64 times, X O / 64 times: 4.3 GB for the 512 x 256
+  // product over 262 144 rows).  Workgroups go to the 8 XCDs round-robin by their linear id, each XCD with its own L2: a slab's tiles
+  // are given ids of ONE residue mod 8, so that the re-reads hit that XCD's L2 instead of HBM.
+  const int tiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  int slab = lin / tiles, t = lin % tiles;
+  if (gridDim.z % 8 == 0) {
+    const int q = lin >> 3;
+    slab = (q / tiles) * 8 + (lin & 7), t = q % tiles;
+  }
+  const long long r0 = (long long)slab * rows_per_slab;
   const long long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
-  wgrad_tile(dY, ldy, X, ldx, part + (size_t)blockIdx.z * O * I, bpart ? bpart + (size_t)blockIdx.z * O : nullptr, O, I, r0, r1);
+  wgrad_tile<4>(dY, ldy, X, ldx, part + (size_t)slab * O * I, bpart ? bpart + (size_t)slab * O : nullptr, O, I, r0, r1, t % gridDim.x, t / gridDim.x);
 }
 // Up to four independent few-row products in one launch (blockIdx.z = group): operands at uniform group strides, results
 // through pointer tables (the per-part flows' parameters are separate tensors); all R rows in one slab, written directly
@@ -808,7 +878,7 @@ struct Ptr4 {
 __global__ __launch_bounds__(64) void k_wgrad_g4(const float *__restrict__ dY, int ldy, long long dy_gs, const float *__restrict__ X,
                                                   int ldx, long long x_gs, Ptr4 dW, Ptr4 db, int O, int I, long long R) {
   const int g = blockIdx.z;
-  wgrad_tile(dY + g * dy_gs, ldy, X + g * x_gs, ldx, dW.p[g], db.p[g], O, I, 0, R);
+  wgrad_tile<1>(dY + g * dy_gs, ldy, X + g * x_gs, ldx, dW.p[g], db.p[g], O, I, 0, R, blockIdx.x, blockIdx.y);
 }
 struct CPtr4 {
   const float *p[4];
@@ -1448,10 +1518,10 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
       ns = (int)((R + slab - 1) / slab);
     }
     if (ns == 1 && I_valid == I) {   // one slab: the "partial" tile is the result (few-row products: heads, flows, time embedding)
-      k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, 1), 64, 0, st>>>(dY, ldy, X, ldx, dW, db, O, I, R, slab);
+      k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, 1), 256, 0, st>>>(dY, ldy, X, ldx, dW, db, O, I, R, slab);
       return dfx::check_launch("train: wgrad");
     }
-    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 64, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
+    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 256, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
   }
   if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 1024, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
   else k_wgrad_finish<<<(O * I_valid + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
