@@ -49,16 +49,38 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
     }
   };
   auto ld = [](const float *p) { return *reinterpret_cast<const v4f *>(p); };
-  int k = 0;
-  for (; k + 32 <= a.K; k += 32) {   // 4 K-blocks of 8 per trip: 8-12 loads in flight ahead of 16-32 MFMAs
+  // 4 K-blocks of 8 per trip (8-12 loads, 16-32 MFMAs); the loads of trip t + 1 are issued before the MFMAs of trip t (two register
+  // sets used alternately; the request behind the last trip re-reads it: the same number of loads in flight on every path) — the
+  // few-row calls of the flows are one dependent chain of trips per wavefront, ~1.2 us of memory latency each
+  struct Trip {
     v4f xv[4], wv[4], uv[4];
+  };
+  auto load_trip = [&](int k, Trip &t) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      xv[u] = ld(xp + k + 8 * u), wv[u] = ld(wp + k + 8 * u);
-      uv[u] = DUAL ? ld(wq + k + 8 * u) : v4f{0.f, 0.f, 0.f, 0.f};
+      t.xv[u] = ld(xp + k + 8 * u), t.wv[u] = ld(wp + k + 8 * u);
+      t.uv[u] = DUAL ? ld(wq + k + 8 * u) : v4f{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  auto run_trip = [&](const Trip &t) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) block(xv[u], wv[u], uv[u]);
+    for (int u = 0; u < 4; ++u) block(t.xv[u], t.wv[u], t.uv[u]);
+  };
+  const int ntrip = a.K / 32;
+  int k = 32 * ntrip;
+  if (ntrip > 0) {
+    Trip ta, tb;
+    load_trip(0, ta);
+    int t = 0;
+    for (; t + 1 < ntrip; t += 2) {
+      load_trip(32 * (t + 1), tb);
+      __builtin_amdgcn_sched_barrier(0);
+      run_trip(ta);
+      load_trip(32 * min(t + 2, ntrip - 1), ta);
+      __builtin_amdgcn_sched_barrier(0);
+      run_trip(tb);
+    }
+    if (t < ntrip) run_trip(ta);
   }
   for (; k < a.K; k += 8) block(ld(xp + k), ld(wp + k), DUAL ? ld(wq + k) : v4f{0.f, 0.f, 0.f, 0.f});
   const int m = m0 + j;

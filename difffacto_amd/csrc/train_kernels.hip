@@ -875,10 +875,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dY, int
 struct Ptr4 {
   float *p[4];
 };
-__global__ __launch_bounds__(64) void k_wgrad_g4(const float *__restrict__ dY, int ldy, long long dy_gs, const float *__restrict__ X,
+__global__ __launch_bounds__(256) void k_wgrad_g4(const float *__restrict__ dY, int ldy, long long dy_gs, const float *__restrict__ X,
                                                   int ldx, long long x_gs, Ptr4 dW, Ptr4 db, int O, int I, long long R) {
   const int g = blockIdx.z;
-  wgrad_tile<1>(dY + g * dy_gs, ldy, X + g * x_gs, ldx, dW.p[g], db.p[g], O, I, 0, R, blockIdx.x, blockIdx.y);
+  wgrad_tile<4>(dY + g * dy_gs, ldy, X + g * x_gs, ldx, dW.p[g], db.p[g], O, I, 0, R, blockIdx.x, blockIdx.y);
 }
 struct CPtr4 {
   const float *p[4];
@@ -2166,17 +2166,17 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
     const size_t hm = (size_t)(H > ZD ? H : ZD);
     const long long wt_gs = (long long)(hm * hm);
     // net_s_t.4: s_t = h2 W3^T + b3   (the four parts per launch)
-    k_wgrad_g4<<<dim3((H + 63) / 64, (ZD + 63) / 64, NPART), 64, 0, st>>>(w.dst, ZD, gsZ, w.h2[l], H, gsH, gw[2], gb[2], ZD, H, B);
+    k_wgrad_g4<<<dim3((H + 63) / 64, (ZD + 63) / 64, NPART), 256, 0, st>>>(w.dst, ZD, gsZ, w.h2[l], H, gsH, gw[2], gb[2], ZD, H, B);
     k_transpose_g4<<<dim3((H + 31) / 32, (ZD + 31) / 32, NPART), 256, 0, st>>>(wp[2], w.wT, wt_gs, ZD, H);
     if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, w.dst, ZD, gsZ, nullptr, nullptr, w.wT, wt_gs, w.dh2, H, gsH, B, H, ZD))) return rc;
     k_relu_mask<<<(int)(((long long)Rf * H + 255) / 256), 256, 0, st>>>(w.dh2, w.h2[l], (long long)Rf * H);
     // net_s_t.2
-    k_wgrad_g4<<<dim3((H + 63) / 64, (H + 63) / 64, NPART), 64, 0, st>>>(w.dh2, H, gsH, w.h1[l], H, gsH, gw[1], gb[1], H, H, B);
+    k_wgrad_g4<<<dim3((H + 63) / 64, (H + 63) / 64, NPART), 256, 0, st>>>(w.dh2, H, gsH, w.h1[l], H, gsH, gw[1], gb[1], H, H, B);
     k_transpose_g4<<<dim3((H + 31) / 32, (H + 31) / 32, NPART), 256, 0, st>>>(wp[1], w.wT, wt_gs, H, H);
     if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, w.dh2, H, gsH, nullptr, nullptr, w.wT, wt_gs, w.dh1, H, gsH, B, H, H))) return rc;
     k_relu_mask<<<(int)(((long long)Rf * H + 255) / 256), 256, 0, st>>>(w.dh1, w.h1[l], (long long)Rf * H);
     // net_s_t.0: input = the conditioning half of x; its gradient is added to the pass-through gradient already in dx
-    k_wgrad_g4<<<dim3((ZH + 63) / 64, (H + 63) / 64, NPART), 64, 0, st>>>(w.dh1, H, gsH, w.xs[l] + xc, ZD, gsZ, gw[0], gb[0], H, ZH, B);
+    k_wgrad_g4<<<dim3((ZH + 63) / 64, (H + 63) / 64, NPART), 256, 0, st>>>(w.dh1, H, gsH, w.xs[l] + xc, ZD, gsZ, gw[0], gb[0], H, ZH, B);
     k_transpose_g4<<<dim3((ZH + 31) / 32, (H + 31) / 32, NPART), 256, 0, st>>>(wp[0], w.wT, wt_gs, H, ZH);
     if ((rc = lin_g4<dfx::lin::EPI_RESID>(st, w.dh1, H, gsH, nullptr, nullptr, w.wT, wt_gs, dx + xc, ZD, gsZ, B, ZH, H, dx + xc, ZD, gsZ))) return rc;
     float *t = dy;
