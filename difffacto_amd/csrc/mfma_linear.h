@@ -260,7 +260,10 @@ template <int EPI>
 inline void launch(hipStream_t st, int groups, const LinArgs &a) {
   constexpr bool plain = (EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID);
   if constexpr (plain) {
-    if (a.N % 128 == 0 && a.M >= 512 && a.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (a.y_gs % 4) == 0) {
+    // (the wide tile only when its grid gives every CU a workgroup: a wavefront's K loop is one dependent chain, 16 MFMAs per step
+    // there against 4 in k_lin — the aligner's 512-row layers ran as 8-32 workgroups of the wide kernel, 54 us per call)
+    if (a.N % 128 == 0 && a.M >= 512 && (long long)(a.N / 128) * ((a.M + 127) / 128) * groups >= 256 && a.ldy % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (a.y_gs % 4) == 0) {
       if (a.K % 8 == 0 && a.K <= 544 && a.M >= 8192 && a.ldx % 4 == 0) {   // enough row tiles per workgroup to pay for staging the weights
         const bool narrow = a.K > 272;   // 64-channel blocks when the 128-channel one would not fit
         const size_t lds = (size_t)a.K / 8 * (narrow ? 2048 : 4096);
