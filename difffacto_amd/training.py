@@ -593,6 +593,35 @@ def linear_lr(epoch, start_epoch, end_epoch, start_lr, end_lr):
     return start_lr * f
 
 
+class _PinnedRing:
+    """Small host arrays go to the device through a ring of pinned buffers with a non-blocking copy: `tensor.to(device)` from pageable
+    memory makes the host wait until everything queued on the stream before the copy has run — in the middle of a training step that
+    is a full drain of the encoder's forward, and the device then idles while the host catches up with the denoiser's launches."""
+
+    def __init__(self, slots=4):
+        self.slots, self.buf, self.ev, self.i = slots, {}, {}, 0
+
+    def to_device(self, array, device):
+        src = torch.from_numpy(array)
+        key = (tuple(src.shape), src.dtype)
+        if key not in self.buf:
+            self.buf[key] = [torch.empty(src.shape, dtype=src.dtype).pin_memory() for _ in range(self.slots)]
+            self.ev[key] = [None] * self.slots
+        k = self.i % self.slots
+        self.i += 1
+        if self.ev[key][k] is not None:
+            self.ev[key][k].synchronize()      # the copy that last used this slot (several steps ago) has long run
+        self.buf[key][k].copy_(src)
+        out = self.buf[key][k].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(out.device))
+        self.ev[key][k] = ev
+        return out
+
+
+_pinned = _PinnedRing()
+
+
 def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None, overlap_prior=True):
     """The training forward of the reference's agent for stage 1 (AnchorDiffAE.forward, anchor_gen.py:970-1020): the encoder's
     training forward (part codes, prior loss, ground-truth anchors per point, ctx), one timestep per shape, and the denoiser's
@@ -612,7 +641,7 @@ def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diff
         encoder.prior_loss_stream = None
     variance_pp = torch.exp(logvar_pp)
     if t is None:
-        t = torch.from_numpy(np.random.choice(diffusion.num_timesteps, size=(B,))).to(device)
+        t = _pinned.to_device(np.random.choice(diffusion.num_timesteps, size=(B,)), device)   # (host-drawn like the reference's sampler)
     dp = pcds.get("dp_present", None)
     flags = None
     if dp is not None:
