@@ -1371,7 +1371,6 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   uint4 (*s_xn)[64] = reinterpret_cast<uint4 (*)[64]>(pipe_smem + CL_XN);
   uint4 (*s_hid)[2][64] = reinterpret_cast<uint4 (*)[2][64]>(pipe_smem + CL_HID);
   uint4 *s_at = reinterpret_cast<uint4 *>(pipe_smem + CL_AT);
-  uint4 *s_w2 = reinterpret_cast<uint4 *>(pipe_smem + CL_W2);
   float *s_hs = reinterpret_cast<float *>(pipe_smem + CL_HS);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
