@@ -190,20 +190,28 @@ __device__ __forceinline__ void mfma_group(const v4f (&u)[4], const v16f &x, v16
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u[r4][e], x[4 * r4 + e], acc, 0, 0, 0);
 }
 
-// max over the 32 lanes of each half-wave, left in lanes 16..31 / 48..63: DPP permutes inside the rows of 16 (no LDS-crossbar
-// round trips: 80 of them per output tile before), then row 0 -> 1 and row 2 -> 3 by row_bcast:15
-__device__ __forceinline__ float half_max(float v) {
-  auto step = [](float x, auto ctrl, auto rmask) {
-    const int xi = __float_as_int(x);
-    return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl)::value, decltype(rmask)::value, 0xf, false)));
-  };
-  v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
-  v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
-  v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
-  v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
-  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3
-  return v;
+// max over the 32 lanes of each half-wave for the 16 accumulator registers of a tile, left in lanes 16..31 / 48..63: DPP permutes inside
+// the rows of 16 (no LDS-crossbar round trips: 80 ds_bpermute per output tile before), then row 0 -> 1 and row 2 -> 3 by row_bcast:15.
+// Written as ONE asm block of v_max_f32 with the permute as operand modifier: from `fmaxf(x, update_dpp(x))` hipcc makes a
+// v_mov_b32_dpp + v_max_f32 pair per step.  A DPP read needs two wait states behind the VALU write of its source: inside the block
+// a register's steps are 16 instructions apart; the leading s_nop covers what the compiler put in front of it.
+#define DFX_DPPMAX(n, ctrl) "v_max_f32_dpp %" #n ", %" #n ", %" #n " " ctrl "\n"
+#define DFX_DPPMAX16(ctrl)                                                                                                          \
+  DFX_DPPMAX(0, ctrl) DFX_DPPMAX(1, ctrl) DFX_DPPMAX(2, ctrl) DFX_DPPMAX(3, ctrl) DFX_DPPMAX(4, ctrl) DFX_DPPMAX(5, ctrl)          \
+  DFX_DPPMAX(6, ctrl) DFX_DPPMAX(7, ctrl) DFX_DPPMAX(8, ctrl) DFX_DPPMAX(9, ctrl) DFX_DPPMAX(10, ctrl) DFX_DPPMAX(11, ctrl)        \
+  DFX_DPPMAX(12, ctrl) DFX_DPPMAX(13, ctrl) DFX_DPPMAX(14, ctrl) DFX_DPPMAX(15, ctrl)
+__device__ __forceinline__ void half_max16(float (&f)[16]) {
+  asm volatile("s_nop 1\n"
+               DFX_DPPMAX16("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               DFX_DPPMAX16("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               DFX_DPPMAX16("row_half_mirror row_mask:0xf bank_mask:0xf")
+               DFX_DPPMAX16("row_mirror row_mask:0xf bank_mask:0xf")
+               DFX_DPPMAX16("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]),
+                 "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
 }
+#undef DFX_DPPMAX16
+#undef DFX_DPPMAX
 
 // One output tile of a register-chained layer: acc += sum over the nin input tiles, the fragments of the step after each one
 // requested first.  Two fragment sets used alternately (a copy "cur = next" would make every step wait for the loads it has
@@ -249,9 +257,13 @@ __device__ __forceinline__ void pooled_last_layer(const FusedArgs &a, const v16f
     chain_steps<NIN>(hin, nin, w, ot * nin, S, nullptr, acc, wa, wb);
     const v16f y = relu16(acc);
     unsigned mine = 0;   // COMBINE: lane 16 + r (48 + r) keeps the maximum of accumulator register r = channel rho(r, hf) of the tile
+    float pooled[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pooled[r] = valid ? y[r] : 0.f;   // padding neighbours contribute 0 <= the true maximum
+    half_max16(pooled);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float v = half_max(valid ? y[r] : 0.f);   // padding neighbours contribute 0 <= the true maximum
+      const float v = pooled[r];
       // post-ReLU values are >= 0: their bit patterns order like unsigned integers (sign bit masked: -0)
       const unsigned bits = __float_as_uint(v) & 0x7fffffffu;
       if (COMBINE) {
