@@ -115,6 +115,36 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return readlane_u64(v, 63);
 }
 
+// The arg-max in two single-word reductions instead of one over 64-bit (distance, key) pairs: first the largest distance (floats
+// >= 0), then the largest key among the candidates that have it — the same winner as the u64 maximum, but every step is ONE
+// v_max with the lane permute as operand modifier (a 64-bit step is two DPP moves, a 64-bit compare and two selects, and hipcc makes a
+// mov + max pair even of a 32-bit one); the selection loop is a chain of M such reductions.  Inline asm: a DPP read needs two wait
+// states behind the VALU write of its source, which the assembler does not insert — hence the s_nop in front of every step.
+#define DFX_DPP1(op, ctrl) "s_nop 1\n " op " %0, %0, %0 " ctrl "\n"
+#define DFX_ROW_STEPS(op)                                                                                                  \
+  DFX_DPP1(op, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") DFX_DPP1(op, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+  DFX_DPP1(op, "row_half_mirror row_mask:0xf bank_mask:0xf") DFX_DPP1(op, "row_mirror row_mask:0xf bank_mask:0xf")
+#define DFX_WAVE_STEPS(op) DFX_ROW_STEPS(op) DFX_DPP1(op, "row_bcast:15 row_mask:0xa bank_mask:0xf") DFX_DPP1(op, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+__device__ __forceinline__ float wave_max_f32(float v) {   // wave-uniform
+  asm volatile(DFX_WAVE_STEPS("v_max_f32_dpp") "s_nop 1\n" : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  asm volatile(DFX_WAVE_STEPS("v_max_u32_dpp") "s_nop 1\n" : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float row0_max_f32(float v) {   // maximum of lanes 0..15, wave-uniform
+  asm volatile(DFX_ROW_STEPS("v_max_f32_dpp") "s_nop 1\n" : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+__device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
+  asm volatile(DFX_ROW_STEPS("v_max_u32_dpp") "s_nop 1\n" : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+}
+#undef DFX_WAVE_STEPS
+#undef DFX_ROW_STEPS
+#undef DFX_DPP1
+
 // Register-resident variant: N <= NT*PPT.  LDS holds the cloud as SoA for the winner lookup when
 // COORDS_LDS (N*12 bytes), else the 3 winner coordinates come from global (L2-resident).
 template <int NT, int PPT, bool COORDS_LDS>
@@ -177,21 +207,27 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
       y1 = ds[old * 3 + 1];
       z1 = ds[old * 3 + 2];
     }
-    unsigned long long best = 0ull;
+    float m = 0.f;   // distances are >= 0 and absent / skipped points carry 0
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
       const float d2 = fminf(d, tmp[i]);
       tmp[i] = d2;
-      const unsigned long long v = ((unsigned long long)__float_as_uint(d2) << 32) | nkey[i];
-      best = v > best ? v : best;
+      m = fmaxf(m, d2);
     }
-    best = wave_max_u64(best);
+    const float M = wave_max_f32(m);
+    unsigned k = 0u;   // the largest key among this lane's points at the wavefront's largest distance (key 0: none / not a candidate)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) k = max(k, tmp[i] == M ? nkey[i] : 0u);
+    const unsigned K = wave_max_u32(k);
     unsigned long long *slot = slots + (j & 1) * 16;
-    if (lane == 0) slot[wave] = best;
+    if (lane == 0) slot[wave] = ((unsigned long long)__float_as_uint(M) << 32) | K;
     __syncthreads();
-    unsigned long long v = lane < NW ? slot[lane] : 0ull;
-    v = readlane_u64(row_max_u64(v), 0);
+    const unsigned long long sv = lane < NW ? slot[lane] : 0ull;
+    const float sd = __uint_as_float((unsigned)(sv >> 32));
+    const float M2 = row0_max_f32(sd);
+    const unsigned K2 = row0_max_u32(sd == M2 ? (unsigned)sv : 0u);
+    const unsigned long long v = ((unsigned long long)__float_as_uint(M2) << 32) | K2;
     old = fps_unpack(v, log2bs);
     if (tid == 0) out[j] = old;
   }
@@ -486,16 +522,17 @@ int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, 
     const size_t sh = 2 * 16 * sizeof(unsigned long long) + ((LDSC) ? (size_t)N * 12 : 0);                     \
     fps_resident_kernel<NT, PPT, LDSC><<<B, NT, sh, st>>>(xyz, idx, N, M, log2bs);                             \
   } while (0)
-  // Workgroup shape: the selection loop is a chain of M dependent arg-max reductions whose length is the instructions the wavefronts
-  // issue per step — 11 per point, plus ~70 per WAVEFRONT for the two reduction levels —, so: as few wavefronts as keep two per SIMD
-  // busy (one alone issues dependent instructions at half the rate), more points per thread (`tools/sweep_fps_shape.py`).
+  // Workgroup shape: the selection loop is a chain of M dependent arg-max reductions whose length is the instructions a wavefront
+  // issues per step — ~8 per point plus the two reduction levels; every size takes the fastest shape of `tools/sweep_fps_shape.py`
+  // (with the 64-bit reductions, ~70 instructions per wavefront, fewer and fatter wavefronts won: 512 x 16 at N = 8192; with the
+  // single-word ones the per-wavefront cost is small again and 1024 x 8 is back in front).
   int nt = 0, ppt = 0;
   if (g_fps_nt && (long long)g_fps_nt * g_fps_ppt >= N) nt = g_fps_nt, ppt = g_fps_ppt;   // debug / sweep override
   else if (N <= 512) nt = 256, ppt = 2;
   else if (N <= 1024) nt = 256, ppt = 4;
-  else if (N <= 2048) nt = 256, ppt = 8;
+  else if (N <= 2048) nt = 512, ppt = 4;
   else if (N <= 4096) nt = 512, ppt = 8;
-  else if (N <= 8192) nt = 512, ppt = 16;
+  else if (N <= 8192) nt = 1024, ppt = 8;
   else if (N <= 16384) nt = 1024, ppt = 16;
   const bool ldsc = N <= 8192;
 #define DFX_FPS_CASE(NT, PPT)                                                                  \
