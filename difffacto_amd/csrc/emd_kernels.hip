@@ -10,13 +10,13 @@
 //   list is carried from one iteration to the next (losers + displaced owners) instead of being rebuilt by a scan over n points.
 //   Larger n (<= 8192): only the targets in LDS, the state in the caller's workspace (every phase then pays an L2 round trip).
 //   Bid: a wavefront per unassigned point, lanes strided over the targets, branch-free running (best, second best, first index),
-//   merged over the wavefront by DPP rotations + 4 readlanes (the merge keeps the reference's result: first maximum in index
+//   merged over the wavefront by three single-word DPP reductions (the merge keeps the reference's result: first maximum in index
 //   order, :152-178).  The scan is VALU-bound (correctly rounded sqrtf + the reference's double-precision `3.0 - d - price`).
 //   Tail (<= 8 unassigned, 85 % of the iterations): 8 wavefronts share the bidders' scans, wavefront 0 merges their partials and
 //   does GetMax and Assign in registers, one lane per bidder — two workgroup barriers per iteration.
 //   GetMax's data race (several bidders within 1e-6 of the maximum all write max_idx, :195-199) is resolved deterministically:
 //   the largest bidder index wins — the oracle uses the same rule.
-// 117 ms -> 58 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
+// 117 ms -> 54 ms for 32 pairs x 2048 points x 10 000 iterations over the round (state through L2, one wavefront per bid, LDS
 // shuffles, 8 barriers); a pair owns a compute unit, so throughput comes from launching >= 256 pairs (evaluation.py: 1024).
 #include "dfx_common.h"
 #include <type_traits>
@@ -85,9 +85,32 @@ __device__ __forceinline__ Best lane_of(const Best &m, int l) {
 }
 
 // every lane ends with the merge over the whole wavefront: four rotations inside the rows of 16, then the four rows
-__device__ __forceinline__ Best wave_merge(Best m) {
-  m = merge(m, row_ror<1>(m)), m = merge(m, row_ror<2>(m)), m = merge(m, row_ror<4>(m)), m = merge(m, row_ror<8>(m));
-  return merge(merge(lane_of(m, 0), lane_of(m, 16)), merge(lane_of(m, 32), lane_of(m, 48)));
+// Three single-word reductions instead of a tree of triple merges (87 instructions): the largest value; the smallest index among the
+// lanes that have it; the second largest = the winner lane's own second best against everybody else's best.  Every step is ONE
+// v_max / v_min with the lane permute as operand modifier (inline asm: hipcc makes a mov + op pair of each; a DPP read needs two wait
+// states behind the VALU write of its source, hence the s_nop in front of every step).  (The merge of the <= 8 partials in wavefront 0
+// stays a tree of `merge`: its steps depend on the number of bidders, and as separate asm statements they were no faster.)
+#define DFX_DPP1(op, ctrl) "s_nop 1\n " op " %0, %0, %0 " ctrl "\n"
+#define DFX_WAVE_STEPS(op)                                                                                                       \
+  DFX_DPP1(op, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") DFX_DPP1(op, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")   \
+  DFX_DPP1(op, "row_half_mirror row_mask:0xf bank_mask:0xf") DFX_DPP1(op, "row_mirror row_mask:0xf bank_mask:0xf")                \
+  DFX_DPP1(op, "row_bcast:15 row_mask:0xa bank_mask:0xf") DFX_DPP1(op, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
+__device__ __forceinline__ float wave_max_f32(float v) {   // wave-uniform
+  asm volatile(DFX_WAVE_STEPS("v_max_f32_dpp") : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  asm volatile(DFX_WAVE_STEPS("v_min_u32_dpp") : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef DFX_WAVE_STEPS
+#undef DFX_DPP1
+__device__ __forceinline__ Best wave_merge(const Best &m) {
+  Best r;
+  r.best = wave_max_f32(m.best);
+  r.idx = (int)wave_min_u32(m.best == r.best ? (unsigned)m.idx : 0xffffffffu);   // (a lane that has seen nothing carries idx -1: it loses)
+  r.better = wave_max_f32((m.best == r.best) & (m.idx == r.idx) ? m.better : m.best);
+  return r;
 }
 
 template <bool STATE_LDS>

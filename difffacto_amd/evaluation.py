@@ -20,7 +20,7 @@ def emd_approx(sample, ref):
 
 
 # One workgroup of the auction kernel serves one pair of clouds and owns a compute unit while it runs (its state fills most of the
-# 160 KiB of LDS): a launch of the reference's `batch_size` (32) pairs would leave 7/8 of the chip idle for the 58 ms an auction
+# 160 KiB of LDS): a launch of the reference's `batch_size` (32) pairs would leave 7/8 of the chip idle for the 54 ms an auction
 # takes.  The pairs are independent, so they go to the kernels this many at a time whatever `batch_size` says (never fewer than it).
 PAIRS_PER_LAUNCH = 1024
 
