@@ -735,7 +735,7 @@ template <int NW>
 __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                            float *__restrict__ pp, float *__restrict__ bp, int O, int I, long long r0, long long r1,
                                            int bx, int by) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
   if (NW > 1) {   // this wavefront's share of the rows (an even number: rows go two per MFMA)
     const long long q = ((r1 - r0 + NW - 1) / NW + 1) & ~1ll;
     r0 = r0 + wave * q < r1 ? r0 + wave * q : r1;
@@ -757,14 +757,17 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
   struct Rows {
     float ya[4], yb[4], xa[4], xb[4];
   };
+  // (row base in scalar registers + a per-lane 32-bit offset that never changes: with the row index per lane the address arithmetic
+  // was most of the 9 VALU instructions per MFMA of this kernel)
+  // Columns past the edge are not predicated either: they are read from the last valid column instead, and what they contribute
+  // lands only in rows / columns of the tile (and bias sums) that are never stored.
+  const unsigned offy = (unsigned)(hf * ldy + min(o0 + j, O - 1)), offy2 = (unsigned)(hf * ldy + min(o0 + 32 + j, O - 1));
+  const unsigned offx = (unsigned)(hf * ldx + min(i0 + j, I - 1)), offx2 = (unsigned)(hf * ldx + min(i0 + 32 + j, I - 1));
   auto load8 = [&](long long r, Rows &w) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long long rr = r + 2 * u + hf;
-      w.ya[u] = oa ? py[rr * ldy] : 0.f;
-      w.yb[u] = ob ? py[rr * ldy + 32] : 0.f;
-      w.xa[u] = ia ? px[rr * ldx] : 0.f;
-      w.xb[u] = ib ? px[rr * ldx + 32] : 0.f;
+      const float *ry = dY + (r + 2 * u) * ldy, *rx = X + (r + 2 * u) * ldx;
+      w.ya[u] = ry[offy], w.yb[u] = ry[offy2], w.xa[u] = rx[offx], w.xb[u] = rx[offx2];
     }
   };
   auto mm8 = [&](const Rows &w) {
