@@ -76,15 +76,7 @@ __device__ __forceinline__ Best row_ror(const Best &m) {
   return t;
 }
 
-__device__ __forceinline__ Best lane_of(const Best &m, int l) {
-  Best t;
-  t.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.best), l));
-  t.better = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.better), l));
-  t.idx = __builtin_amdgcn_readlane(m.idx, l);
-  return t;
-}
-
-// every lane ends with the merge over the whole wavefront: four rotations inside the rows of 16, then the four rows
+// The merge over the whole wavefront, wave-uniform.
 // Three single-word reductions instead of a tree of triple merges (87 instructions): the largest value; the smallest index among the
 // lanes that have it; the second largest = the winner lane's own second best against everybody else's best.  Every step is ONE
 // v_max / v_min with the lane permute as operand modifier (inline asm: hipcc makes a mov + op pair of each; a DPP read needs two wait
@@ -109,7 +101,7 @@ __device__ __forceinline__ Best wave_merge(const Best &m) {
   Best r;
   r.best = wave_max_f32(m.best);
   r.idx = (int)wave_min_u32(m.best == r.best ? (unsigned)m.idx : 0xffffffffu);   // (a lane that has seen nothing carries idx -1: it loses)
-  r.better = wave_max_f32((m.best == r.best) & (m.idx == r.idx) ? m.better : m.best);
+  r.better = wave_max_f32(((m.best == r.best) & (m.idx == r.idx)) ? m.better : m.best);
   return r;
 }
 
