@@ -5,7 +5,7 @@
 //                     minimum wins, also across its 512-point tiles, :137), and symmetrically dist2 / idx2
 //   backward :173-201 grad_xyz1[i] += 2 g1[i] (x1_i - x2_idx1[i]);  grad_xyz2[idx1[i]] -= the same   (atomicAdd)
 // Squared distances use the mul,fma,fma evaluation order stated in oracle/pointnet2.c.
-// Mapping: one thread per query point, the other cloud streams through LDS in SoA tiles (stride-1, conflict-free);
+// Mapping: one or two query points per thread, the other cloud streams through LDS in tiles of 16-byte records (broadcast reads);
 // HBM traffic = both clouds once per 256-query workgroup (L2-resident), outputs once.  Bound: VALU (N*M fma chains).
 #include "dfx_common.h"
 
@@ -18,44 +18,50 @@ __device__ __forceinline__ float sq3(float a, float b, float c) {
   return t;
 }
 
-constexpr int CD_TILE = 2048;
+constexpr int CD_TILE = 1024;   // 16 KiB of records: eight workgroups per CU
 
+// Q query points per thread (2 whenever that still leaves every CU a workgroup: one LDS read and one loop step per two distances —
+// 4.19 -> 4.44 T pair-distances/s at 128 x 2048 x 2048, 5.3 T at 1024 clouds), the reference cloud through LDS as 16-byte records (one broadcast ds_read_b128 per
+// reference point instead of three ds_read_b32), the first reference point taken outside the loop (the reference's "k == 0 or closer"
+// test, chamfer.cu:137, is then the plain strict '<').
+template <int Q>
 __global__ void __launch_bounds__(256) chamfer_nn_kernel(const float *__restrict__ query, const float *__restrict__ ref,
                                                          float *__restrict__ dist, int32_t *__restrict__ idx, int n,
                                                          int m, int wg_per_cloud) {
-  __shared__ float sx[CD_TILE], sy[CD_TILE], sz[CD_TILE];
+  __shared__ float4 sp[CD_TILE];
   const int b = blockIdx.x / wg_per_cloud;
-  const int j = (blockIdx.x % wg_per_cloud) * 256 + threadIdx.x;
-  const float *Q = query + (size_t)b * n * 3;
+  const int j0 = (blockIdx.x % wg_per_cloud) * (256 * Q) + threadIdx.x;
+  const float *Qp = query + (size_t)b * n * 3;
   const float *R = ref + (size_t)b * m * 3;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (j < n) {
-    qx = Q[j * 3 + 0]; qy = Q[j * 3 + 1]; qz = Q[j * 3 + 2];
+  float qx[Q], qy[Q], qz[Q], best[Q];
+  int besti[Q];
+  const float r0x = R[0], r0y = R[1], r0z = R[2];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = min(j0 + 256 * q, n - 1);   // (threads past the end work on the last point and store nothing)
+    qx[q] = Qp[j * 3 + 0], qy[q] = Qp[j * 3 + 1], qz[q] = Qp[j * 3 + 2];
+    best[q] = sq3(r0x - qx[q], r0y - qy[q], r0z - qz[q]), besti[q] = 0;
   }
-  float best = 0.f;
-  int besti = 0;
   for (int base = 0; base < m; base += CD_TILE) {
     const int cnt = min(CD_TILE, m - base);
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt * 3; i += 256) {
-      const float v = R[(size_t)base * 3 + i];
-      const int k = i / 3, c = i - 3 * k;
-      (c == 0 ? sx : (c == 1 ? sy : sz))[k] = v;
-    }
+    for (int k = threadIdx.x; k < cnt; k += 256) sp[k] = make_float4(R[(size_t)(base + k) * 3], R[(size_t)(base + k) * 3 + 1], R[(size_t)(base + k) * 3 + 2], 0.f);
     __syncthreads();
-    if (j < n) {
-      for (int k = 0; k < cnt; ++k) {
-        const float d = sq3(sx[k] - qx, sy[k] - qy, sz[k] - qz);
-        if ((base + k) == 0 || d < best) {
-          best = d;
-          besti = base + k;
-        }
+#pragma unroll 4
+    for (int k = base == 0 ? 1 : 0; k < cnt; ++k) {
+      const float4 r = sp[k];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float d = sq3(r.x - qx[q], r.y - qy[q], r.z - qz[q]);
+        const bool c = d < best[q];
+        best[q] = c ? d : best[q], besti[q] = c ? base + k : besti[q];
       }
     }
   }
-  if (j < n) {
-    dist[(size_t)b * n + j] = best;
-    idx[(size_t)b * n + j] = besti;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = j0 + 256 * q;
+    if (j < n) dist[(size_t)b * n + j] = best[q], idx[(size_t)b * n + j] = besti[q];
   }
 }
 
@@ -89,9 +95,17 @@ int dfx_chamfer_forward_f32(const float *xyz1, const float *xyz2, float *dist1, 
   DFX_REQUIRE(N > 0 && M > 0, "chamfer_forward: empty cloud");
   DFX_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2, "chamfer_forward: null pointer");
   hipStream_t st = dfx::as_stream(stream);
-  const int w1 = (N + 255) / 256, w2 = (M + 255) / 256;
-  chamfer_nn_kernel<<<B * w1, 256, 0, st>>>(xyz1, xyz2, dist1, idx1, N, M, w1);
-  chamfer_nn_kernel<<<B * w2, 256, 0, st>>>(xyz2, xyz1, dist2, idx2, M, N, w2);
+  auto run = [&](const float *q, const float *r, float *d, int32_t *ix, int n, int m) {
+    if ((long long)B * ((n + 511) / 512) >= 256) {   // a workgroup per CU even with two query points per thread
+      const int w = (n + 511) / 512;
+      chamfer_nn_kernel<2><<<B * w, 256, 0, st>>>(q, r, d, ix, n, m, w);
+    } else {
+      const int w = (n + 255) / 256;
+      chamfer_nn_kernel<1><<<B * w, 256, 0, st>>>(q, r, d, ix, n, m, w);
+    }
+  };
+  run(xyz1, xyz2, dist1, idx1, N, M);
+  run(xyz2, xyz1, dist2, idx2, M, N);
   return dfx::check_launch("chamfer_forward");
 }
 
