@@ -298,10 +298,21 @@ __global__ void __launch_bounds__(BQ_WAVES *WAVE) ball_query_kernel(const float 
   int32_t *I = idx + (size_t)b * M * nsample;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   if (CLOUD_LDS) {
-    for (int i = tid; i < N * 3; i += BQ_WAVES * WAVE) {  // coalesced AoS read -> SoA LDS
-      const float v = X[i];
-      const int k = i / 3, c = i - 3 * k;
-      (c == 0 ? sx : (c == 1 ? sy : sz))[k] = v;
+    // coalesced AoS read -> SoA LDS, eight loads in flight per thread (one load, one wait, one LDS write per trip made the fill a chain
+    // of 24 memory latencies in front of every workgroup's work)
+    constexpr int NT = BQ_WAVES * WAVE;
+    for (int i0 = tid; i0 < N * 3; i0 += 8 * NT) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = X[min(i0 + u * NT, N * 3 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * NT;
+        if (i < N * 3) {
+          const int k = i / 3, c = i - 3 * k;
+          (c == 0 ? sx : (c == 1 ? sy : sz))[k] = v[u];
+        }
+      }
     }
     __syncthreads();
   }
@@ -313,15 +324,16 @@ __global__ void __launch_bounds__(BQ_WAVES *WAVE) ball_query_kernel(const float 
     // four chunks of 64 points per step: their 12 LDS reads and distance tests are independent, and a step without any hit (the
     // common one: ~9 of 2048 points fall inside r = 0.2) costs one test of the OR of the four ballots; hits are recorded chunk by
     // chunk in index order exactly as before (slots past nsample are not written, the first hit is the first in index order)
-    auto test = [&](int k) {
-      if (k >= N) return false;
+    auto test = [&](int k) {   // (branch-free: past the end the last point is read and the result masked — a predicate per chunk
+                               // put every chunk's reads behind their own exec-mask branch and wait)
+      const int kc = min(k, N - 1);
       float x, y, z;
       if (CLOUD_LDS) {
-        x = sx[k]; y = sy[k]; z = sz[k];
+        x = sx[kc]; y = sy[kc]; z = sz[kc];
       } else {
-        x = X[k * 3 + 0]; y = X[k * 3 + 1]; z = X[k * 3 + 2];
+        x = X[kc * 3 + 0]; y = X[kc * 3 + 1]; z = X[kc * 3 + 2];
       }
-      return sq3(nx - x, ny - y, nz - z) < radius2;
+      return (sq3(nx - x, ny - y, nz - z) < radius2) & (k < N);
     };
     for (int base = 0; base < N && cnt < nsample; base += 4 * WAVE) {
       bool hit[4];
