@@ -190,10 +190,20 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
   const int n0 = blockIdx.x * (32 * NT), g = blockIdx.z, U = a.K >> 3;
   auto ld = [](const float *p) { return *reinterpret_cast<const v4f *>(p); };
   {
+    // (eight loads in flight per thread: one load, one wait, one LDS write per trip made the staging a chain of 16-68 memory latencies
+    // in front of every workgroup's work)
     const float *wbase = a.W + g * a.w_gs;
-    for (int e = threadIdx.x; e < NT * U * 64; e += 512) {
-      const int l = e & 63, tu = e >> 6, u = tu % U, t = tu / U;
-      wl[e] = ld(wbase + (size_t)(n0 + 32 * t + (l & 31)) * a.K + 8 * u + 4 * (l >> 5));
+    const int total = NT * U * 64;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 512) {
+      v4f v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = min(e0 + q * 512, total - 1), l = e & 63, tu = e >> 6, u = tu % U, t = tu / U;
+        v[q] = ld(wbase + (size_t)(n0 + 32 * t + (l & 31)) * a.K + 8 * u + 4 * (l >> 5));
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (e0 + q * 512 < total) wl[e0 + q * 512] = v[q];
     }
   }
   __syncthreads();
