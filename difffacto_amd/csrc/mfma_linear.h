@@ -7,6 +7,7 @@
 #pragma once
 #include "dfx_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace dfx {
 namespace lin {
@@ -228,7 +229,7 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], xv[s], acc[t], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], wv[t][s], acc[t], 0, 0, 0);   // rows on the M axis
     };
     {
       v4f xa, xb, wa[NT], wb[NT];
@@ -244,25 +245,30 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
       }
       if (u < U) step(xa, wa);
     }
-    const int m = m0 + j;
-    if (m >= a.M) continue;
-    float *yp = a.Y + g * a.y_gs + (size_t)m * a.ldy;
-    const float *rp = EPI == EPI_RESID ? a.R + (size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr : nullptr;
+    // Rows on the MFMA's M axis (accumulator registers), channels on the lanes: a store instruction writes 32 consecutive channels
+    // = one full 128-byte line of two rows.  (With the channels in the registers — the orientation of k_lin_wide — a store was 16 bytes
+    // per lane at the row stride: 32 lines touched per instruction, each a quarter written: 10 % of the kernel in
+    // tools/ubench/mfma_f32_feed.hip.)
+    float *ybase = a.Y + g * a.y_gs;
+    auto epilogue = [&](auto full) {   // full: all 32 rows of the tile exist (every tile but the last one of a ragged M): no per-store mask
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 32 * t + j;
+        const float bias = bp ? bp[n] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + 32 * t + 8 * q + 4 * hf;
-        v4f v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float y = acc[t][4 * q + e] + (bp ? bp[n + e] : 0.f);
-          if (EPI == EPI_RELU) y = fmaxf(y, 0.f);
-          if (EPI == EPI_RESID) y += rp[n + e];
-          v[e] = y;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          if (decltype(full)::value || m < a.M) {
+            float y = acc[t][r] + bias;
+            if (EPI == EPI_RELU) y = fmaxf(y, 0.f);
+            if (EPI == EPI_RESID) y += a.R[(size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr + n];
+            ybase[(size_t)m * a.ldy + n] = y;
+          }
         }
-        *reinterpret_cast<v4f *>(yp + n) = v;
       }
+    };
+    if (m0 + 32 <= a.M) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
   }
 }
 
