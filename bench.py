@@ -19,8 +19,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver only supports dmabuf IPC: RCCL's intra-node transport needs this before the HIP runtime starts (the driver's
+# environment exports it already; a bare `python -m torch.distributed.run bench.py` gets it here)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -315,12 +319,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="shapes per GPU (shipped val batch_size=128)")
+    ap.add_argument("--total-shapes", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3]: 1024 shapes over the node): the JOB is this many shapes, block-partitioned "
+                         "over the ranks (overrides --batch; scaling = 'strong')")
     ap.add_argument("--npoints", type=int, default=2048)
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-line", action="store_true", help="skip the secondary training-iteration measurement")
-    ap.add_argument("--debug-flags", type=int, default=0, help="timing ablations (invalid results)")
     ap.add_argument("--force-direct", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (HIP vs PyTorch-CPU oracle, T=100, 2 shapes)")
     ap.add_argument("--dump-clouds", default=None, help="rank 0 writes the last step's gathered clouds (shapes, N, 3) to this .npy")
@@ -347,9 +353,16 @@ def main():
     from difffacto_amd.engine import DenoiserEngine
     from difffacto_amd.parallel import broadcast_params, gather_clouds
 
-    B, N, T = args.batch, args.npoints, args.timesteps
+    N, T = args.npoints, args.timesteps
+    # The JOB: `total` shapes, block-partitioned over the ranks (parallel.shard_range).  Weak scaling (default): --batch shapes per
+    # GPU, total = world * batch.  Strong scaling (--total-shapes S): total = S whatever the world size, rank r takes its block.
+    from difffacto_amd.parallel import shard_range
+    total = args.total_shapes if args.total_shapes > 0 else args.batch * world
+    lo, hi = shard_range(total, rank, world)
+    B = hi - lo
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    assert B >= 1, f"rank {rank} has no shape: --total-shapes {total} < world size {world}"
     from difffacto_amd import _ffi
-    _ffi.lib().dfx_debug_flags(args.debug_flags)
     _ffi.lib().dfx_debug_force_direct(int(args.force_direct))
     names = [n for n, _ in synth.denoiser_param_shapes()]
     lat_shapes = [("encoder." + n, s) for n, s in synth.latent_param_shapes()]
@@ -362,34 +375,34 @@ def main():
         Wnp = None
         params = {k: torch.empty(s, dtype=torch.float32, device=dev)
                   for k, s in list(synth.denoiser_param_shapes()) + lat_shapes}
-    bcast_ms = 0.0
+    bcast_ms, bcast_bytes, world_seen = 0.0, 0, None
     if dist is not None:
+        from difffacto_amd.parallel import describe_world
+        world_seen = describe_world(dev)          # backend, world size and device of every rank as the process group reports them
+        assert world_seen["world_size"] == world
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         broadcast_params(params, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
+        bcast_bytes = 4 * sum(int(v.numel()) for v in params.values())
     eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=args.precision, device=dev)
     from difffacto_amd.latents import LatentSampler
     sampler = LatentSampler({k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")},
                             noise_scale=100.0, device=dev)          # configs/gen_chair.py:14-31
 
-    # Synthetic part-presence patterns, resident in HBM.  The JOB is `world * B` shapes, block-partitioned over the ranks
-    # (rank r owns global shapes [r B, (r + 1) B), parallel.shard_range): every per-shape input — presence pattern, latent
-    # draws, the chain's Philox stream (keyed by the global point id through shape_offset) — is a function of the GLOBAL
-    # shape index only, so the generated clouds do not depend on the number of GPUs.
-    from difffacto_amd.parallel import shard_range
-    lo, hi = shard_range(B * world, rank, world)
-    assert hi - lo == B
-    valid = torch.from_numpy(synth.make_latents(B * world, seed=1000)[3][lo:hi].copy()).to(dev)
+    # Synthetic part-presence patterns, resident in HBM.  Rank r owns global shapes [lo, hi): every per-shape input — presence
+    # pattern, latent draws, the chain's Philox stream (keyed by the global point id through shape_offset) — is a function of the
+    # GLOBAL shape index only, so the generated clouds do not depend on the number of GPUs.
+    valid = torch.from_numpy(synth.make_latents(total, seed=1000)[3][lo:hi].copy()).to(dev)
     gen = torch.Generator(device=dev)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def one_step(i, timed):
         gen.manual_seed(1234 + i)                                        # the whole job's draws, then this rank's block
-        w = torch.randn(B * world, 256, 4, device=dev, generator=gen)[lo:hi]    # part_encoders.py:1054
-        an = torch.randn(B * world, 32, device=dev, generator=gen)[lo:hi]       # :1065 (K = 1 noise per shape)
+        w = torch.randn(total, 256, 4, device=dev, generator=gen)[lo:hi]    # part_encoders.py:1054
+        an = torch.randn(total, 32, device=dev, generator=gen)[lo:hi]       # :1065 (K = 1 noise per shape)
         lat = sampler.sample_latents(w, an, valid, K=1, npoints=N)
         ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
         if timed:
@@ -398,7 +411,7 @@ def main():
         if timed:
             ev[i][1].record()
         if dist is not None:
-            pred = gather_clouds(pred, dst=0, sizes=[B] * world)   # block partition: sizes known, no size exchange / host sync
+            pred = gather_clouds(pred, dst=0, sizes=sizes)   # block partition: sizes known, no size exchange / host sync
         return pred
 
     for i in range(args.warmup):
@@ -424,24 +437,24 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
-        assert out is not None and (args.debug_flags or torch.isfinite(out).all())
-        assert out.shape[0] == B * world, (out.shape, B, world)
+        assert out is not None and torch.isfinite(out).all()
+        assert out.shape[0] == total, (out.shape, total)
         if args.dump_clouds:
             np.save(args.dump_clouds, out.cpu().numpy())
-        total_shapes = B * world * args.steps
-        value = total_shapes / dt
+        value = total * args.steps / dt
         F = flops_per_step(N) * T * B                      # algorithmic FLOPs per launch (one rank)
         achieved = F / (kern_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         res = {
             "metric": "generated shapes/sec (2048 pts, 1000-step DDPM)",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.total_shapes > 0 else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"gen_chair decode: {B} shapes/GPU x {N} pts x 4 parts, T={T} DDPM steps, "
                                    f"random-init flows + part aligner + denoiser (depth 5, inner 128), in-kernel Philox noise",
                        "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
-                       "weights_bcast_ms": bcast_ms},
+                       "total_shapes": total, "weights_bcast_ms": bcast_ms, "weights_bcast_bytes": bcast_bytes},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(T, B, N), "kernel": "k_denoise_pipe (persistent T-step chain)", "kernel_ms": kern_ms,
                          "flops_per_launch": F},
@@ -452,6 +465,10 @@ def main():
             res["roofline"]["sustained_mfma_tflops_random_operands"] = SUSTAINED_BF16_TFLOPS
             res["roofline"]["frac_of_sustained"] = achieved / SUSTAINED_BF16_TFLOPS
         res["config"]["shapes_gathered"] = int(out.shape[0])
+        if world_seen is not None:   # what the process group itself reports: the SCALE record shows the collective library saw N ranks
+            res["config"].update({"backend": world_seen["backend"], "world_size_seen": world_seen["world_size"],
+                                  "rank_devices": world_seen["devices"], "visible_gpus": torch.cuda.device_count(),
+                                  "gather": os.environ.get("DFX_GATHER", "gather"), "shapes_per_rank": sizes})
         if world == 1 and not args.no_parity:
             res["parity"] = parity_block(Wnp, N)
             res["t100"] = t100_line(params, names, sampler, valid, B, N, args.precision, dev)

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdfx.so")
 DFX_PREC_F32 = 0
 DFX_PREC_BF16 = 1
 DFX_MAX_DEPTH = 8
+DFX_ABI_VERSION = 2   # include/dfx.h: the argument lists this binding was written against
 
 
 class DfxLibraryError(RuntimeError):
@@ -66,6 +67,7 @@ class PointNetV2Weights(ctypes.Structure):
 _I, _F, _P, _U64, _SZ, _D = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_double
 SIGNATURES = {
     "dfx_version": (_I, []),
+    "dfx_abi_version": (_I, []),
     "dfx_last_error": (ctypes.c_char_p, []),
     "dfx_gather_points_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfx_gather_points_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -131,7 +133,6 @@ SIGNATURES = {
     "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
     "dfx_debug_pipe_waves": (None, [_I]),
-    "dfx_debug_flags": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),
     "dfx_set_event_timing": (None, [_I]),
     "dfx_last_kernel_ms": (_F, []),
@@ -162,6 +163,9 @@ def lib():
                 raise DfxLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        if L.dfx_abi_version() != DFX_ABI_VERSION:
+            raise DfxLibraryError(f"{LIB_PATH} has ABI version {L.dfx_abi_version()}, this binding expects {DFX_ABI_VERSION}: "
+                                  "rebuild it (python -m difffacto_amd.build --force)")
         _lib = L
     return _lib
 

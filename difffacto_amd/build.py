@@ -29,7 +29,7 @@ def sources():
 
 
 def _deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "dfx.h")]
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
 def needs_build():

@@ -56,7 +56,6 @@ struct KParams {
   float ddim_xdc[DDIM_MAX_STEPS];
   unsigned long long *trace;  // debug: s_memtime stamps of waves 0 and 4 of workgroup 0 at every slot boundary
   int trace_cap;
-  int debug;  // reserved (dfx_debug_flags)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -1652,7 +1651,6 @@ __global__ void k_mse_finish(const double *acc, float *loss, int has_flags, doub
 bool g_force_direct = false;
 int g_force_nw = 0;       // debug: wavefronts per workgroup of the pipelined kernel (0 = by batch size)
 int g_num_cus = 256;
-int g_debug = 0;
 unsigned long long *g_trace = nullptr;
 int g_trace_cap = 0;
 
@@ -1663,7 +1661,6 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   p.part = v.part;
   p.cpart = v.cpart;
   p.as_ms = v.as_ms;
-  p.debug = g_debug;
   p.trace = g_trace;
   p.trace_cap = g_trace_cap;
   constexpr int NW = 4;
@@ -1696,14 +1693,14 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
   const bool coop = bf16 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
   if (pipe || coop) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<8>::L_TOTAL));
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<4>::L_TOTAL));
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg<2>::L_TOTAL));
-      DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_denoise_coop), hipFuncAttributeMaxDynamicSharedMemorySize, CL_TOTAL));
-      attr_set = true;
-    }
+    static PerDeviceOnce attrs;
+    DFX_HIP_TRY(attrs.run([] {
+      hipError_t e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<8>), PipeCfg<8>::L_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<4>), PipeCfg<4>::L_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<2>), PipeCfg<2>::L_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop), CL_TOTAL);
+      return e;
+    }));
   }
   EventTimer tm;
   tm.begin(st);
@@ -1840,7 +1837,6 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
 void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1) ? nw : 0; }
-void dfx_debug_flags(int flags) { g_debug = flags; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);
   g_trace_cap = capacity;

@@ -2,11 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 
 #include "../../include/dfx.h"
+#include "../../include/dfx_debug.h"   // test / tuning hooks (not part of the drop-in ABI)
 
 namespace dfx {
 
@@ -34,6 +36,28 @@ inline int check_launch(const char *what) {
   do {                                                                   \
     if (!(cond)) return dfx::set_error(DFX_ERR_INVALID_ARG, __VA_ARGS__); \
   } while (0)
+
+// Kernels that need more than 64 KiB of dynamic LDS carry a per-function attribute that HIP keeps PER DEVICE: a guard per launch
+// site, keyed by the current device (one bit each), set before the first launch there.  Thread-safe without a lock: the
+// attribute call is idempotent, so two host threads racing on a device's first call both make it and both then launch correctly.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done[4] = {};   // 256 devices
+  template <class F>
+  hipError_t run(F &&set_attributes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<unsigned long long> &word = done[(dev >> 6) & 3];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (word.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = set_attributes();
+    if (e == hipSuccess) word.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
+inline hipError_t set_max_lds(const void *kernel, int bytes) {
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 // Optional HIP-event timing of the hot-path launches (bench.py's roofline leg).
 struct EventTimer {

@@ -47,6 +47,7 @@ void EventTimer::end() {
 extern "C" {
 
 int dfx_version(void) { return 100; }
+int dfx_abi_version(void) { return DFX_ABI_VERSION; }
 
 const char *dfx_last_error(void) { return dfx::err_buf(); }
 

@@ -332,12 +332,12 @@ int dfx_emd_forward_f32(const float *xyz1, const float *xyz2, float *dist, int32
   if (B == 0) return DFX_OK;
   DFX_REQUIRE(n <= 8192, "emd_forward: n = %d > 8192 (the targets of one cloud live in LDS)", n);
   DFX_REQUIRE(xyz1 && xyz2 && dist && assignment && workspace, "emd_forward: null pointer");
-  static bool attr = false;
-  if (!attr) {
-    DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_emd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-    DFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_emd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EMD_STATE_LDS_MAX_N * 60));
-    attr = true;
-  }
+  static dfx::PerDeviceOnce attrs;
+  DFX_HIP_TRY(attrs.run([] {
+    hipError_t e = dfx::set_max_lds(reinterpret_cast<const void *>(k_emd<false>), 8192 * 16);
+    if (e == hipSuccess) e = dfx::set_max_lds(reinterpret_cast<const void *>(k_emd<true>), EMD_STATE_LDS_MAX_N * 60);
+    return e;
+  }));
   int32_t *wsi = static_cast<int32_t *>(workspace);
   float *wsf = reinterpret_cast<float *>(wsi + (size_t)B * 5 * n);
   if (n <= EMD_STATE_LDS_MAX_N && !g_emd_state_global)   // targets + prices (16 B), the auction state (32 B) and the bidders (12 B) per point in LDS

@@ -283,12 +283,12 @@ inline void launch(hipStream_t st, int groups, const LinArgs &a) {
       if (a.K % 8 == 0 && a.K <= 544 && a.M >= 8192 && a.ldx % 4 == 0) {   // enough row tiles per workgroup to pay for staging the weights
         const bool narrow = a.K > 272;   // 64-channel blocks when the 128-channel one would not fit
         const size_t lds = (size_t)a.K / 8 * (narrow ? 2048 : 4096);
-        static bool attr = false;
-        if (!attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 34 * 4096);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 2048);
-          attr = true;
-        }
+        static PerDeviceOnce attrs;   // (a failure here surfaces as the launch error the caller's check_launch reports)
+        (void)attrs.run([] {
+          hipError_t e = set_max_lds(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 4>), 34 * 4096);
+          if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_lin_wide_lds<EPI, 2>), 68 * 2048);
+          return e;
+        });
         const int cols = a.N / (narrow ? 64 : 128), per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 1024) / lds));
         const int rows = (int)std::min<long long>((a.M + 255) / 256, std::max(1, 256 * per_cu / (cols * groups)));
         if (narrow) k_lin_wide_lds<EPI, 2><<<dim3(cols, rows, groups), 512, lds, st>>>(a);

@@ -889,11 +889,8 @@ __global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishArgs a) {
 }
 inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
 inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &f) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) != hipSuccess) return -1;
-    attr_set = true;
-  }
+  static PerDeviceOnce attrs;
+  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_wgrad), WG_LDS); }) != hipSuccess) return -1;
   k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(a);
   const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
   k_ff_wgrad_finish<<<(total + 255) / 256, 256, 0, st>>>(f);
@@ -909,12 +906,8 @@ inline void launch_pack(hipStream_t st, const PackArgs &a) {
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) {
   constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C + 3 * C) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ff<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return -1;
-    attr_set = true;
-  }
+  static PerDeviceOnce attrs;
+  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff<BWD>), LDS); }) != hipSuccess) return -1;
   constexpr int NW = nw_of<BWD>();
   const long long groups = (a.R / 32 + NW - 1) / NW;
   k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(a);

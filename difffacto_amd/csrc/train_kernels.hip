@@ -14,6 +14,9 @@
 //   dW = dY^T X, db    -> k_wgrad: one wavefront owns a 64 x 64 tile of dW and a slab of rows, two rows per
 //                         v_mfma_f32_32x32x2_f32 (lane (j, hf) feeds dY[r + hf][o0 + j] and X[r + hf][i0 + j]: 128-byte
 //                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
+#include <mutex>
+#include <unordered_map>
+
 #include "dfx_common.h"
 #include "gemm_bf16.h"
 #include "train_attn_fused.h"
@@ -998,6 +1001,15 @@ __global__ void k_bn_rstd(const float *__restrict__ ssq, const float *__restrict
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
   }
 }
+// BatchNorm affine y = (z - mu) rs g + b: ONE definition with the contraction pinned off, shared by the forward (k_bn_apply), the
+// pooling (k_pool_fwd) and the two backward passes that re-derive the ReLU mask from z instead of reading a stored y — the sign of a
+// value within an ulp of 0 must not depend on how a particular kernel's multiply-adds were fused.
+__device__ __forceinline__ float bn_affine(float z, float mu, float rs, float g, float b) {
+#pragma clang fp contract(off)
+  const float xh = (z - mu) * rs;
+  const float sc = xh * g;
+  return sc + b;
+}
 template <bool RELU>
 __global__ void k_bn_apply(const float *__restrict__ z, const float *__restrict__ mean, const float *__restrict__ rstd,
                            const float *__restrict__ g, const float *__restrict__ b, float *__restrict__ y, long long total, int Cc) {
@@ -1009,7 +1021,7 @@ __global__ void k_bn_apply(const float *__restrict__ z, const float *__restrict_
   v4f o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    o[e] = (zv[e] - mu[e]) * rs[e] * gv[e] + bv[e];
+    o[e] = bn_affine(zv[e], mu[e], rs[e], gv[e], bv[e]);
     if (RELU) o[e] = fmaxf(o[e], 0.f);
   }
   *reinterpret_cast<v4f *>(y + i) = o;
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ d
     for (long long r = (long long)blockIdx.y * BN_SLAB + rgp; r < r1; r += 4) {
       float gm = dy[r * Cc + c];
       const float zv = z[r * Cc + c];
-      if (RELU && !((zv - mu) * rs * gv + bv > 0.f)) gm = 0.f;
+      if (RELU && !(bn_affine(zv, mu, rs, gv, bv) > 0.f)) gm = 0.f;
       sb += gm;
       sg += gm * (zv - mu) * rs;
     }
@@ -1057,7 +1069,7 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__rest
   v4f o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float gm = (RELU && !((zv[e] - mean[c + e]) * rstd[c + e] * g[c + e] + be[c + e] > 0.f)) ? 0.f : dv[e];   // (the mask from z, like pass 1)
+    const float gm = (RELU && !(bn_affine(zv[e], mean[c + e], rstd[c + e], g[c + e], be[c + e]) > 0.f)) ? 0.f : dv[e];   // (the mask from z, like pass 1)
     const float xh = (zv[e] - mean[c + e]) * rstd[c + e];
     o[e] = g[c + e] * rstd[c + e] * (gm - dbeta[c + e] * invR - xh * dgamma[c + e] * invR);
   }
@@ -1089,7 +1101,7 @@ __global__ __launch_bounds__(64 * PH) void k_pool_fwd(const float *__restrict__ 
   if (c < Cc) {
     const float mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
     for (int n = ph; n < N; n += PH) {
-      const float v = (z[((size_t)b * N + n) * Cc + c] - mu) * rs * gv + bv;
+      const float v = bn_affine(z[((size_t)b * N + n) * Cc + c], mu, rs, gv, bv);
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
@@ -1433,7 +1445,14 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
 // layer-by-layer path (A/B timing, and the reference for the fused path's own test).
 bool g_ff_fused = true;
 bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the attention forward as a kernel of its own)
-inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return g_ff_fused && bf && dropout_p == 0.f && R % 32 == 0 && N % 32 == 0; }
+// The switches are sampled ONCE per step, by the forward, and recorded per workspace on the host: the backward follows the record,
+// not the switches, so toggling dfx_debug_train_fused between a forward and its backward (the A/B tests do) cannot pair a fused
+// backward with the activations of a layer-by-layer forward.
+struct PathRecord { bool fused, attn_in_ff; int prec; float dropout_p; int B, N; };
+std::mutex g_path_mu;
+std::unordered_map<const void *, PathRecord> g_path;   // keyed by workspace pointer (a handful per process)
+thread_local bool t_ff_fused = true, t_attn_in_ff = true;   // what the call in progress on this thread uses
+inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return t_ff_fused && bf && dropout_p == 0.f && R % 32 == 0 && N % 32 == 0; }
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
 thread_local int g_prec = DFX_PREC_F32;
@@ -1745,6 +1764,12 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_forward: precision %d", precision);
   DFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "denoiser_train_forward: dropout_p %g", (double)dropout_p);
   g_prec = precision;
+  t_ff_fused = g_ff_fused, t_attn_in_ff = g_attn_in_ff;
+  {
+    std::lock_guard<std::mutex> lk(g_path_mu);
+    if (g_path.size() > 4096) g_path.clear();
+    g_path[workspace] = PathRecord{t_ff_fused, t_attn_in_ff, precision, dropout_p, B, N};
+  }
   const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
@@ -1793,7 +1818,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
-      if (g_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
+      if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.h1_out = a.h1, fa.N = N;
       } else {
@@ -1845,6 +1870,16 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_backward: precision %d", precision);
   DFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "denoiser_train_backward: dropout_p %g", (double)dropout_p);
   g_prec = precision;
+  {
+    std::lock_guard<std::mutex> lk(g_path_mu);
+    const auto it = g_path.find(workspace);
+    DFX_REQUIRE(it != g_path.end(), "denoiser_train_backward: no forward has filled this workspace");
+    const PathRecord &r = it->second;
+    DFX_REQUIRE(r.prec == precision && r.dropout_p == dropout_p && r.B == B && r.N == N,
+                "denoiser_train_backward: the forward of this workspace ran with precision %d, dropout %g, B %d, N %d", r.prec,
+                (double)r.dropout_p, r.B, r.N);
+    t_ff_fused = r.fused, t_attn_in_ff = r.attn_in_ff;
+  }
   const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(d_eps && grads, "denoiser_train_backward: null tensor");
   hipStream_t st = dfx::as_stream(stream);
@@ -1879,7 +1914,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R;
-      const bool dx_in_ff = g_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
+      const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.dh_in = w.dh, fa.N = N;

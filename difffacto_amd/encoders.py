@@ -21,7 +21,6 @@ import weakref
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _ffi
 from .latents import LatentSampler
@@ -142,17 +141,15 @@ class PointNetV2(nn.Module):
                         mod.num_batches_tracked += 1
             self.__dict__["_ver"] = None      # the running statistics changed under the eval handle's feet
             return m, v
-        # eval-mode statistics with autograd, CPU tensors, B = 1: the module's own torch layers
-        h = x.transpose(1, 2)
-        for i in (1, 2, 3):
-            h = F.relu(getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h)))
-        h = self.bn4(self.conv4(h))
-        wx = h.unsqueeze(-1) * attn_weight.unsqueeze(1)
-        if self.reweight_by_anchor:
-            wx = wx * A
-        pooled = wx.max(dim=2)[0]                                  # (B, 512, A)
-        z = pooled.transpose(1, 2).reshape(B, -1, 1)
-        return self.mlp_m(z).reshape(B, A, -1), self.mlp_v(z).reshape(B, A, -1)
+        # No second implementation behind the native one: what libdfx does not run raises, like every other
+        # unsupported option of this module.
+        if not x.is_cuda:
+            raise RuntimeError("PointNetV2: CPU not supported")
+        if not self.training:
+            _unsupported("PointNetV2 in eval() mode with autograd enabled (running-statistics BatchNorm has no native backward): "
+                         "wrap the call in torch.no_grad(), or call .train() for the stage-1 training step")
+        _unsupported(f"PointNetV2.train() needs batch >= 2 (BatchNorm batch statistics), num_anchors == 4 and zdim % 4 == 0; "
+                     f"got B={B}, num_anchors={A}, zdim={self.zdim}")
 
 
 class CouplingLayer(nn.Module):

@@ -69,12 +69,40 @@ def gather_clouds(pred, dst=0, sizes=None):
     if pred.shape[0] < bmax:
         pad = torch.cat([pred, pred.new_zeros((bmax - pred.shape[0],) + tuple(pred.shape[1:]))])
     pad = pad.contiguous()
+    if _gather_mode() == "all_gather":
+        # fallback (DFX_GATHER=all_gather): every rank receives every block (N x the bytes of the rooted gather — 3 MB per 128 shapes,
+        # irrelevant next to a T-step chain); for a collective library whose rooted gather misbehaves
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        return torch.cat([b[:n] for b, n in zip(bufs, sizes)]).to(out_device) if rank == dst else None
     if rank == dst:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.gather(pad, gather_list=bufs, dst=dst)
         return torch.cat([b[:n] for b, n in zip(bufs, sizes)]).to(out_device)
     dist.gather(pad, gather_list=None, dst=dst)
     return None
+
+
+def _gather_mode():
+    import os
+    mode = os.environ.get("DFX_GATHER", "gather")
+    if mode not in ("gather", "all_gather"):
+        raise ValueError(f"DFX_GATHER={mode!r}: expected 'gather' or 'all_gather'")
+    return mode
+
+
+def describe_world(device=None):
+    """What the process group actually looks like, for the bench line of an N > 1 run: backend, world size as torch.distributed sees
+    it, and every rank's device index (one small all_gather).  Proof that the collective library saw N ranks on N devices."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "devices": [torch.cuda.current_device() if torch.cuda.is_available() else -1]}
+    world = dist.get_world_size()
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    mine = torch.tensor([torch.cuda.current_device() if on_gpu else -1], dtype=torch.int64,
+                        device=device if (on_gpu and dist.get_backend() != "gloo") else "cpu")
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return {"backend": dist.get_backend(), "world_size": world, "devices": [int(g.item()) for g in got]}
 
 
 def allreduce_gradients(params, average=True, bucket=None):

@@ -37,6 +37,11 @@ extern "C" {
 typedef void *dfx_stream_t;
 
 int dfx_version(void);
+/* Bumped whenever an existing entry point changes its argument list (round 2 inserted `shape_offset` into the four sampling
+ * calls: 2).  Bindings compare dfx_abi_version() with the DFX_ABI_VERSION they were written against at load time (_ffi.py does)
+ * instead of shifting arguments silently. */
+#define DFX_ABI_VERSION 2
+int dfx_abi_version(void);
 const char *dfx_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -397,7 +402,7 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
  *   included); factors come from Philox4x32-10 keyed by dropout_seed with counter (element group, site) and are
  *   regenerated by the backward (pass the same p and seed); torch's own CUDA dropout stream is launch-geometry dependent
  *   and not reproducible, so this is libdfx's contract, checked against torch autograd by replaying the factors
- *   (dfx_debug_dropout_factors).
+ *   (dfx_debug_dropout_factors, include/dfx_debug.h).
  *   x (B,3,N); t (B,) int32; ctx_code (B,256,4) and ctx_mv (B,6,4) = the two tensors of the reference's ctx list;
  *   anchors, variances (B,N,3) per point (the caller's gather, as at anchored_diffusion.py:261); valid (B,4) 0/1 or
  *   NULL; assignment (B,N) int32; eps (B,3,N).
@@ -423,35 +428,6 @@ int dfx_grad_sumsq_accumulate(const float *g, long long n, double *workspace1024
 int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const double *sumsq,
                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       dfx_stream_t stream);
-
-/* Dropout factors (0 or 1/(1-p)) of n consecutive elements of a site: 2 i = behind to_out of block i over (B N, 128),
- * 2 i + 1 = behind the GEGLU of block i over (B N, 512), 1000 = time_embed over (B, 1024).  n % 4 == 0. */
-int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream);
-/* Debug / A-B switch: 0 routes the bf16 training path through the layer-by-layer kernels instead of the fused ones (default 1;
- * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
- * kernels of their own instead of inside the feed-forward kernels. */
-void dfx_debug_train_fused(int on);
-/* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
-void dfx_debug_emd_state_global(int on);
-/* Debug / sweep: workgroup shape of the register-resident FPS kernel (threads in {256, 512, 1024} x points per thread in {2..32},
- * used when threads * points >= N; 0, 0 = automatic). */
-void dfx_debug_fps_shape(int threads, int points_per_thread);
-/* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
- * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
- * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */
-int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *B, int ldb, int b_bf16, const float *bias,
-                        const float *resid, float *C, float *db, float *workspace, size_t workspace_floats, int M, int N, int K,
-                        dfx_stream_t stream);
-/* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
-void dfx_debug_force_direct(int on);
-/* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
- * 32-point tile per workgroup, eight wavefronts on it); 0 = chosen from the batch size.  All variants are bit-identical. */
-void dfx_debug_pipe_waves(int nw);
-/* Reserved for experiments (timing ablations are compile-time macros in denoiser_kernel.hip). */
-void dfx_debug_flags(int flags);
-/* Slot-boundary clock stamps of two wavefronts of workgroup 0 (device buffer of 2*capacity uint64; NULL = off).
- * Only effective in a library built with -DDFX_TRACE (tools/trace_slots.py builds one). */
-void dfx_debug_trace(void *device_buf, int capacity);
 
 /* Name + average duration bookkeeping for bench.py: duration in ms of the last dfx_sample_chain /
  * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */

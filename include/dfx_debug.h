@@ -1,0 +1,45 @@
+/* libdfx test and tuning hooks — NOT part of the drop-in ABI of include/dfx.h.
+ *
+ * Nothing here replaces a reference interface: these are the switches tests/ and tools/ use to run two implementations of the
+ * same entry point against each other (A/B), to sweep a launch shape, or to replay random factors into the oracle.  They are
+ * process-global and not thread-safe; a product binding never includes this header.  Results are valid under
+ * every setting (all variants are parity-tested against each other); only the choice of kernel changes.
+ */
+#ifndef DFX_DEBUG_H
+#define DFX_DEBUG_H
+#include "dfx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dropout factors (0 or 1/(1-p)) of n consecutive elements of a site: 2 i = behind to_out of block i over (B N, 128),
+ * 2 i + 1 = behind the GEGLU of block i over (B N, 512), 1000 = time_embed over (B, 1024).  n % 4 == 0. */
+int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream);
+/* Debug / A-B switch: 0 routes the bf16 training path through the layer-by-layer kernels instead of the fused ones (default 1;
+ * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
+ * kernels of their own instead of inside the feed-forward kernels. */
+void dfx_debug_train_fused(int on);
+/* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
+void dfx_debug_emd_state_global(int on);
+/* Debug / sweep: workgroup shape of the register-resident FPS kernel (threads in {256, 512, 1024} x points per thread in {2..32},
+ * used when threads * points >= N; 0, 0 = automatic). */
+void dfx_debug_fps_shape(int threads, int points_per_thread);
+/* Test hook for the bf16 product kernels of the training path (csrc/gemm_bf16.h): tn = 0: C (M,N) = A (M,K) B (N,K)^T + bias +
+ * resid; tn = 1: C (M,N) = A (K,M)^T B (K,N) and db (M) = column sums of A, workspace >= (K/64 + 1) (M N + M) floats.
+ * a_bf16 / b_bf16: the operand is stored as bf16 (lda / ldb in elements).  N % 128 == 0 (and M % 128 == 0 for tn = 1). */
+int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *B, int ldb, int b_bf16, const float *bias,
+                        const float *resid, float *C, float *db, float *workspace, size_t workspace_floats, int M, int N, int K,
+                        dfx_stream_t stream);
+/* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
+void dfx_debug_force_direct(int on);
+/* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
+ * 32-point tile per workgroup, eight wavefronts on it); 0 = chosen from the batch size.  All variants are bit-identical. */
+void dfx_debug_pipe_waves(int nw);
+/* Slot-boundary clock stamps of two wavefronts of workgroup 0 (device buffer of 2*capacity uint64; NULL = off).
+ * Only effective in a library built with -DDFX_TRACE (tools/trace_slots.py builds one). */
+void dfx_debug_trace(void *device_buf, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_DEBUG_H */

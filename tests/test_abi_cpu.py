@@ -16,10 +16,19 @@ def built_lib():
     return build.build(verbose=False)
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "dfx.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(dfx_[a-z0-9_]+)\s*\(", src)))
+def _declared_symbols(headers=("dfx.h", "dfx_debug.h")):
+    """dfx.h = the drop-in ABI; dfx_debug.h = test / tuning hooks (A/B switches, sweeps), kept out of the product header."""
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(dfx_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_product_header_has_no_debug_switches():
+    assert not [n for n in _declared_symbols(("dfx.h",)) if n.startswith("dfx_debug")]
+    assert all(n.startswith("dfx_debug") for n in _declared_symbols(("dfx_debug.h",)))
 
 
 def test_header_symbols_exported(built_lib):
@@ -34,7 +43,7 @@ def test_ffi_signatures_cover_header(built_lib):
     from difffacto_amd import _ffi
     assert sorted(_ffi.SIGNATURES) == _declared_symbols()
     L = _ffi.lib()
-    assert L.dfx_version() >= 100
+    assert L.dfx_version() >= 100 and L.dfx_abi_version() == _ffi.DFX_ABI_VERSION
     assert L.dfx_chain_num_snapshots(100, 10) == 10
     assert L.dfx_chain_num_snapshots(10, 3) == 3
     assert L.dfx_fps_max_resident() >= 8192

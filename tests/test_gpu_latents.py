@@ -153,8 +153,9 @@ def test_generate_end_to_end():
 
 
 def test_pointnet_v2_matches_reference_golden():
-    """PointNetV2.forward (pointnet.py:187-213, eval): native kernels vs the reference class's output, and vs the module's
-    own torch layers at the shipped size (B = 16, N = 2048)."""
+    """PointNetV2.forward (pointnet.py:187-213, eval): native kernels vs the reference class's output, and vs the numpy
+    oracle (pinned to the same golden) at the shipped size (B = 16, N = 2048)."""
+    from oracle import pointnet_v2 as opv
     g = np.load(os.path.join(GOLDEN, "pointnet_v2_B3_N200.npz"))
     enc = _mirror()
     x, attn = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["attn"]).cuda()
@@ -163,11 +164,30 @@ def test_pointnet_v2_matches_reference_golden():
     _close(m, g["m"], 2e-5)
     _close(v, g["v"], 2e-5)
     rng = np.random.Generator(np.random.PCG64(3))
-    x = torch.from_numpy(rng.uniform(-1, 1, size=(16, 2048, 3)).astype(np.float32)).cuda()
-    attn = torch.eye(4, device="cuda")[torch.from_numpy(rng.integers(0, 4, size=(16, 2048))).cuda()]
+    xn = rng.uniform(-1, 1, size=(16, 2048, 3)).astype(np.float32)
+    an = np.eye(4, dtype=np.float32)[rng.integers(0, 4, size=(16, 2048))]
     with torch.no_grad():
-        m, v = enc.encoder(x, attn)
-    with torch.enable_grad():
-        mt, vt = enc.encoder(x, attn)
-    _close(m, mt.detach().cpu().numpy(), 2e-5)
-    _close(v, vt.detach().cpu().numpy(), 2e-5)
+        m, v = enc.encoder(torch.from_numpy(xn).cuda(), torch.from_numpy(an).cuda())
+    mo, vo = opv.forward(synth.make_pointnet_v2_weights(0), xn, an)
+    _close(m, mo, 2e-5)
+    _close(v, vo, 2e-5)
+
+
+def test_pointnet_v2_has_no_second_implementation():
+    """Every call libdfx does not run natively raises (no CPU / PyTorch fallback): CPU tensors -> the reference's
+    'CPU not supported'; eval with autograd, train() with B = 1 -> NotImplementedError."""
+    enc = _mirror().encoder
+    x, attn = torch.zeros(2, 64, 3), torch.ones(2, 64, 4)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="CPU not supported"):
+        enc(x, attn)
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="CPU not supported"):
+        enc(x, attn)
+    with torch.enable_grad(), pytest.raises(NotImplementedError, match="eval"):
+        enc(x.cuda(), attn.cuda())
+    enc.train()
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        enc(x, attn)
+    with pytest.raises(NotImplementedError, match="batch >= 2"):
+        enc(x[:1].cuda(), attn[:1].cuda())
+    m, v = enc(x.cuda(), attn.cuda())          # the native training path
+    assert m.grad_fn is not None and tuple(m.shape) == (2, 4, 256)

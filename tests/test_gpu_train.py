@@ -120,8 +120,9 @@ def test_bf16_product_kernels_against_torch(tn, M, N, K, a_bf, b_bf):
 
 def test_bf16_matrix_products_within_stated_tolerance():
     """precision="bf16": the linear layers over the B*N points run on the bf16 matrix pipe (operands rounded to bf16, fp32
-    accumulate).  Tolerance: loss 2e-3 relative, eps 3e-2 max-abs (|eps| ~ 1), every gradient 4e-2 of its max-abs in
-    max norm and 1.5e-2 in relative L2 (measured: 4e-4, 8e-3, <1.5e-2, <5e-3)."""
+    accumulate).  Measured against the fp32 autograd oracle (profiles/r02_parity_headline.txt; deterministic kernels, the same on
+    every box): loss 4.4e-7 relative, eps 2.2e-3 max-abs (|eps| ~ 1), worst gradient 5.8e-3 of its max-abs in max norm and 4.3e-3
+    in relative L2.  Gates at 3x: 1.5e-6, 6.6e-3, 1.7e-2, 1.3e-2."""
     from difffacto_amd import synth
     from oracle import train
     B, N = 2, 1024
@@ -141,14 +142,14 @@ def test_bf16_matrix_products_within_stated_tolerance():
     r = _run(c, True, precision="bf16")
     f = _run(c, True, precision="f32")
     assert any(not np.array_equal(r["grads"][k], f["grads"][k]) for k in f["grads"]), "bf16 path not taken"
-    assert abs(r["loss"] - ref["loss"]) < 2e-3 * abs(ref["loss"])
-    assert np.abs(r["eps"] - ref["eps"]).max() < 3e-2
+    assert abs(r["loss"] - ref["loss"]) < 1.5e-6 * abs(ref["loss"]), abs(r["loss"] - ref["loss"]) / abs(ref["loss"])
+    assert np.abs(r["eps"] - ref["eps"]).max() < 6.6e-3, np.abs(r["eps"] - ref["eps"]).max()
     worst_max = worst_l2 = 0.0
     for k, gr in ref["grads"].items():
         scale = max(np.abs(gr).max(), 1e-30)
         e_max = np.abs(r["grads"][k] - gr).max() / scale
         e_l2 = np.linalg.norm((r["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
-        assert e_max < 4e-2 and e_l2 < 1.5e-2, (k, e_max, e_l2)
+        assert e_max < 1.7e-2 and e_l2 < 1.3e-2, (k, e_max, e_l2)
         worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
     print(f"bf16 products: loss rel err {abs(r['loss'] - ref['loss']) / abs(ref['loss']):.1e}, eps max-abs {np.abs(r['eps'] - ref['eps']).max():.1e}, "
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
@@ -188,10 +189,11 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
         e_max = np.abs(fused["grads"][k] - gr).max() / scale
         e_l2 = np.linalg.norm((fused["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
         worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
-        assert e_max < 2e-2 and e_l2 < 1e-2, (k, e_max, e_l2)
+        assert e_max < 4.5e-3 and e_l2 < 3.9e-3, (k, e_max, e_l2)   # measured worst over the three shapes: 1.5e-3 / 1.3e-3 (x3)
     print(f"fused vs layer-by-layer FF (B={B}, N={N}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
-    assert abs(fused["loss"] - layer["loss"]) < 1e-3 * abs(layer["loss"]) and e_eps < 5e-3
+    # measured: loss 4.8e-5 relative, eps 2.4e-3 (gates at 3x)
+    assert abs(fused["loss"] - layer["loss"]) < 1.5e-4 * abs(layer["loss"]) and e_eps < 7.2e-3
 
 
 def test_attention_inside_the_feed_forward_kernels_matches_the_separate_attention_kernels():

@@ -141,3 +141,17 @@ def test_point_padding_helpers_of_the_engine():
     sp = E._pad_seg(seg, 3)
     assert sp.shape == (2, 8) and sp.is_contiguous() and torch.equal(sp[:, :5], seg)
     assert sp[0, 5:].tolist() == [2, 2, 2] and sp[1, 5:].tolist() == [1, 1, 1]      # a label that is present in that shape
+
+
+def test_pointnet_v2_rejects_cpu_tensors_in_every_mode():
+    """No torch-layer fallback behind the native part encoder: CPU tensors raise the reference op's
+    'CPU not supported' in eval / no_grad, eval / grad and train() alike."""
+    import torch
+    from difffacto_amd.encoders import PointNetV2
+    enc = PointNetV2(zdim=256, num_anchors=4, per_part_mlp=True)
+    x, attn = torch.zeros(2, 64, 3), torch.ones(2, 64, 4)
+    for train in (False, True):
+        enc.train(train)
+        for grad in (False, True):
+            with torch.set_grad_enabled(grad), pytest.raises(RuntimeError, match="CPU not supported"):
+                enc(x, attn)

@@ -69,6 +69,49 @@ def test_broadcast_and_gather_world2():
     assert sorted(res) == [(0, True, True), (1, True, True)]
 
 
+def _world_worker(rank, world, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DFX_GATHER"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = 2 * world + 2                          # ragged for world > 2
+        sizes = [b - a for a, b in (parallel.shard_range(total, r, world) for r in range(world))]
+        lo, hi = parallel.shard_range(total, rank, world)
+        mine = (torch.arange(lo, hi, dtype=torch.float32) + 0.5).view(-1, 1, 1).expand(-1, 6, 3).contiguous()
+        got = parallel.gather_clouds(mine, dst=0, sizes=sizes)
+        exp = (torch.arange(total, dtype=torch.float32) + 0.5).view(-1, 1, 1).expand(-1, 6, 3)
+        ok = torch.equal(got, exp) if rank == 0 else got is None
+        seen = parallel.describe_world("cpu")
+        ok = ok and seen == {"backend": "gloo", "world_size": world, "devices": [-1] * world}
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(4, "gather"), (4, "all_gather"), (8, "all_gather"), (8, "gather")])
+def test_gather_modes_and_world_description_beyond_two_ranks(world, mode):
+    """world sizes above 2 (only 2 had ever run), the rooted gather and its DFX_GATHER=all_gather fallback on a
+    ragged block partition, and describe_world() — the block bench.py puts into the N > 1 JSON line."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_gather_mode_rejects_unknown_value(monkeypatch):
+    monkeypatch.setenv("DFX_GATHER", "scatter")
+    with pytest.raises(ValueError):
+        parallel._gather_mode()
+
+
 def test_shard_range_partitions():
     for total in (0, 1, 7, 128, 1024):
         for world in (1, 2, 3, 8):

@@ -9,5 +9,5 @@ from difffacto_amd import build
 build.build(force=True, verbose=False, extra_flags="$C $F".split())
 PY
   echo -n "[$C $F]: "
-  python bench.py --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-train-line --debug-flags 1 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('kernel_ms %.3f' % d['roofline']['kernel_ms'])"
+  python bench.py --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-train-line 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('kernel_ms %.3f' % d['roofline']['kernel_ms'])"
 done
