@@ -258,20 +258,8 @@ __device__ __forceinline__ void load16(v16f &v, const float *src) {
   }
 }
 
-// Cross attention to the 4 part tokens (attention.py:179-204 with q/k/v folded away, see denoiser_setup.hip):
-//   sim = A_s LN2(h) + sbias;  P = softmax over the 4 keys of each head (masked);  h += M_s P + c_t
-// `rec` = this lane's view of the attention record (tiles 0..3 = A_s, 4..7 = M_s).
-template <int PREC>
-__device__ __forceinline__ void attention(v16f (&h)[4], const uint4 *rec, const float *sbias, const float *ct,
-                                          unsigned vmask) {
-  constexpr int TSTRIDE = tile_units(PREC) * 64;
-  Act<PREC> xn[4];
-  ln_to_act<PREC>(h, xn);
-  v16f sim;
-  load16(sim, sbias);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) mma_tile<PREC>(sim, rec + c * TSTRIDE, xn[c]);
-  // registers 4g..4g+3 = keys 0..3 of head 2g+hf
+// Masked softmax over the 4 keys of each head, in place (registers 4g..4g+3 = keys 0..3 of head 2g+hf; attention.py:195-198).
+__device__ __forceinline__ void softmax4(v16f &sim, unsigned vmask) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float sj[4];
@@ -288,6 +276,22 @@ __device__ __forceinline__ void attention(v16f (&h)[4], const uint4 *rec, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) sim[4 * g + j] = e[j] * inv;
   }
+}
+
+// Cross attention to the 4 part tokens (attention.py:179-204 with q/k/v folded away, see denoiser_setup.hip):
+//   sim = A_s LN2(h) + sbias;  P = softmax over the 4 keys of each head (masked);  h += M_s P + c_t
+// `rec` = this lane's view of the attention record (tiles 0..3 = A_s, 4..7 = M_s).
+template <int PREC>
+__device__ __forceinline__ void attention(v16f (&h)[4], const uint4 *rec, const float *sbias, const float *ct,
+                                          unsigned vmask) {
+  constexpr int TSTRIDE = tile_units(PREC) * 64;
+  Act<PREC> xn[4];
+  ln_to_act<PREC>(h, xn);
+  v16f sim;
+  load16(sim, sbias);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mma_tile<PREC>(sim, rec + c * TSTRIDE, xn[c]);
+  softmax4(sim, vmask);
   Act<PREC> pa;
   pa.set(sim);
 #pragma unroll
@@ -1266,6 +1270,226 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
   wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
 }
 
+// ----------------------------------------------------------------------------------------------
+// LDS-pipelined kernel, exact fp32 (v_mfma_f32_32x32x2_f32): the reference-precision sampler.  The reference computes in
+// fp32 end to end (attention.py:296-306, anchored_diffusion.py:227-395); this is that arithmetic at the structure of the bf16
+// chain kernel — one workgroup = NW wavefronts x 32 points of one shape, the residual stream in registers for the whole chain,
+// the posterior fused, and every weight streamed L2 -> LDS through the same 5-slot ring of 24 KiB records by LDS-DMA three
+// records ahead, one workgroup barrier per record.  Same device functions and the same MFMA order per accumulator as the direct
+// kernel k_denoise<DFX_PREC_F32>: the results are bit-identical (tested), so every golden of the fp32 path holds for it.
+//
+// What differs from the bf16 kernel is the balance: an fp32 MFMA is 64 cycles of matrix pipe for 4 bytes of A operand per lane
+// (the bf16 one: 32 cycles for 16 bytes), so operand delivery is a twentieth of the bf16 kernel's — one ds_read_b128 feeds four
+// MFMAs — and the fp32 VALU work (LayerNorm, softmax, erf-GELU, posterior) is ~15 % of the matrix time of one wavefront, hidden by
+// the other wavefront of the SIMD without any slot choreography.  The direct kernel takes every fragment from L2 (~600 cycles
+// away, 4 KiB tiles, two or three requests in flight per wavefront) and idles the matrix pipe 70 % of the time; here the pipe waits only
+// at the record barriers.
+//
+// Ring records (24 KiB = six fp32 tiles = 24 DMA pieces of 1 KiB; RECORDS_F32 = 2 + 2 x 17 per transformer block):
+//     k = 0      A_s tiles 0..3 | sbias piece (+16 KiB) | c_t row (+17 KiB); block constants -> their own double buffer
+//     k = 1      M_s tiles 0..3
+//     k = 2 + 2j FF record j, first half:  W1 g-rows x k-tiles 0..3 (tiles 4..7 of the packed record) | W1 a-rows x k-tiles 0, 1
+//     k = 3 + 2j FF record j, second half: W1 a-rows x k-tiles 2, 3 | W2 row tiles 0..3 x hidden chunk j-1 (tiles 8..11)
+// so g is complete after the first half and the second half ends with the MFMAs that do not feed the GELU (GEMM2 of the chunk before).
+constexpr int RECORDS_F32 = 2 + 2 * FF_STAGES;
+static_assert(tile_bytes(DFX_PREC_F32) * 6 == SLOT_BYTES && asms_bytes(DFX_PREC_F32) == 33 * 1024, "fp32 ring records");
+
+struct DmaStateF {
+  int step, b, k, seq, slot;
+};
+
+template <int NC>
+__device__ __forceinline__ void issue_pieces_f32(const KParams &p, const DmaStateF &st, int q0, unsigned voff, unsigned lds0, int s) {
+  const unsigned ring = lds0 + L_RING + st.slot * SLOT_BYTES;
+  if (st.step >= p.nsteps) {  // past the end: padding pieces keep the vmcnt bookkeeping uniform
+    dma_nk<NC>(p.d.blk[0].chunks, voff, lds0 + L_DUMMY);
+    return;
+  }
+  const BlockPack bp = block_pack(p, st.b);
+  const char *asms = reinterpret_cast<const char *>(p.as_ms) + ((size_t)s * p.d.depth + st.b) * asms_bytes(DFX_PREC_F32);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int q = q0 + j;
+    const char *src = reinterpret_cast<const char *>(bp.bconst);   // padding piece
+    unsigned dst = lds0 + L_DUMMY;
+    if (st.k == 0) {
+      if (q < 16) src = asms + q * 1024, dst = ring + q * 1024;
+      else if (q == 16) src = asms + 32 * 1024, dst = ring + 16 * 1024;
+      else if (q < 22) src = reinterpret_cast<const char *>(bp.bconst) + (q - 17) * 1024, dst = lds0 + L_BCONST + (st.seq & 1) * BCONST_BYTES + (q - 17) * 1024;
+      else if (q == 22) src = reinterpret_cast<const char *>(bp.ct + (size_t)step_t(p, st.step, s) * CT_ROW), dst = ring + 17 * 1024;
+    } else if (st.k == 1) {
+      if (q < 16) src = asms + (16 + q) * 1024, dst = ring + q * 1024;
+    } else {
+      const char *rec = reinterpret_cast<const char *>(bp.chunks) + (size_t)((st.k - 2) >> 1) * chunk_bytes(DFX_PREC_F32);
+      if (((st.k - 2) & 1) == 0) src = rec + (q < 16 ? (16 + q) * 1024 : (q - 16) * 1024);
+      else src = rec + (q < 8 ? (8 + q) * 1024 : (32 + q - 8) * 1024);
+      dst = ring + q * 1024;
+    }
+    dma1k_pinned(src, voff, dst);
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void issue_record_f32(const KParams &p, DmaStateF &st, int wave, unsigned voff, unsigned lds0, int s) {
+  issue_pieces_f32<PipeCfg<NW>::CALLS>(p, st, wave * PipeCfg<NW>::CALLS, voff, lds0, s);
+  st.slot = st.slot + 1 == NSLOT ? 0 : st.slot + 1;
+  if (++st.k == RECORDS_F32) {
+    st.k = 0;
+    ++st.seq;
+    if (++st.b == p.d.depth) {
+      st.b = 0;
+      ++st.step;
+    }
+  }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe_f32(const KParams p) {
+  constexpr int PREC = DFX_PREC_F32;
+  constexpr int PTS = PipeCfg<NW>::PTS, TS = tile_units(PREC) * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  // XCD-aware placement and tile bookkeeping: as in k_denoise_pipe
+  const int wpg = (p.N + NW * 32 - 1) / (NW * 32);
+  int bid = blockIdx.x;
+  {
+    const int per = 8 * wpg;
+    const int full = ((int)gridDim.x / per) * per;
+    if (bid < full) {
+      const int x = bid & 7, q = (bid % per) >> 3;
+      bid = (bid / per) * per + x * wpg + q;
+    }
+  }
+  const int s = __builtin_amdgcn_readfirstlane(bid / wpg);
+  int n0 = __builtin_amdgcn_readfirstlane((bid - s * wpg) * (NW * 32) + wave * 32);
+  const bool live = n0 < p.N;
+  if (!live) n0 = p.N - 32;
+  const int n = n0 + pj;
+  const unsigned long long gid = ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n;
+  const int depth = p.d.depth;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
+
+  DmaStateF dma{0, 0, 0, 0, 0};
+  issue_record_f32<NW>(p, dma, wave, voff, lds0, s);
+  issue_record_f32<NW>(p, dma, wave, voff, lds0, s);
+  issue_record_f32<NW>(p, dma, wave, voff, lds0, s);
+  {
+    float4 *winx = reinterpret_cast<float4 *>(pipe_smem + L_WINX);
+    float2 *pregb = reinterpret_cast<float2 *>(pipe_smem + L_PREGB);
+    float4 *wout = reinterpret_cast<float4 *>(pipe_smem + L_WOUT);
+    float *cp = reinterpret_cast<float *>(pipe_smem + L_CPART);
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+      winx[tid] = p.d.win_x[tid];
+      pregb[tid] = p.d.pre_gb[tid];
+      wout[tid] = p.d.wout[tid];
+    }
+    for (int i = tid; i < NCLS * INNER; i += NW * 64) cp[i] = p.cpart[(size_t)s * NCLS * INNER + i];
+  }
+  unsigned vmask;
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + PipeCfg<NW>::L_PSTATE);
+  const int pt = wave * 32 + pj;
+  {
+    PointState ps0;
+    ps0.live = live;
+    point_init(p, ps0, s, n, gid, vmask);
+    pstate_store(ps_lds, pt, PTS, ps0, true);
+  }
+  __syncthreads();
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
+
+  // record boundary: this wave's pieces of the record after next have landed, everybody is done with the slot that is refilled next
+  // (ring protocol of k_denoise_pipe), then the pieces of the record three ahead are issued
+#define DFX_RECORD(ptr)                                                                      \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    wait_vmcnt<PipeCfg<NW>::CALLS>();                                                        \
+    __builtin_amdgcn_s_barrier();                                                            \
+    issue_record_f32<NW>(p, dma, wave, voff, lds0, s);                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    ptr = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES);            \
+    cur = cur + 1 == NSLOT ? 0 : cur + 1;                                                    \
+  } while (0)
+
+  int cur = 0, seq = 0;
+  v16f h[4];
+  bool done = false;
+  for (int step = 0; step <= p.nsteps && !done; ++step) {
+    for (int b = 0; b < depth; ++b, ++seq) {
+      const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
+      if (seq > 0)  // b2 of the previous block (other block-constant buffer)
+        add_cvec(h, reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) + BCONST_B2_OFF + hf * 64);
+      if (b == 0) {
+        PointState ps;
+        ps.s = s, ps.n = n, ps.gid = gid, ps.live = live;
+        pstate_load(ps_lds, pt, PTS, ps, step > 0);
+        if (step > 0) {
+          float eps[3];
+          post_eps(h, wout, p.d.bout, eps);
+          done = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1, s));
+          if (!done) pstate_store(ps_lds, pt, PTS, ps, false);
+        }
+        if (step == p.nsteps) done = true;
+        if (!done) proj_in_prenorm(h, ps.x, reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64, winx, pregb);
+      }
+      if (done) break;
+      const uint4 *rec;
+      Act<PREC> xn[4];
+      ln_to_act<PREC>(h, xn);
+      // ---- attention: sim = sbias + A_s LN2(h);  P = softmax4;  h += M_s P + c_t ----
+      DFX_RECORD(rec);
+      const float *ct = reinterpret_cast<const float *>(rec) + 17 * 256 + hf * 64;   // (read during the NEXT record: its slot is refilled one barrier later)
+      v16f sim;
+      load16(sim, reinterpret_cast<const float *>(rec) + 16 * 256 + hf * 16);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mma_tile<PREC>(sim, rec + lane + c * TS, xn[c]);
+      softmax4(sim, vmask);
+      Act<PREC> pa;
+      pa.set(sim);
+      DFX_RECORD(rec);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], rec + lane + t * TS, pa);
+      add_cvec(h, ct);
+      ln_to_act<PREC>(h, xn);
+      // ---- feed-forward: 17 records of two halves; GEMM2 of chunk j-1 rides in the second half of record j ----
+      Act<PREC> hid;
+#pragma unroll 1
+      for (int j = 0; j < FF_STAGES; ++j) {
+        v16f a, g;
+        DFX_RECORD(rec);
+        if (j < FF_CHUNKS) {
+          load16(a, bc + j * 64 + hf * 16);
+          load16(g, bc + j * 64 + hf * 16 + 32);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mma_tile<PREC>(g, rec + lane + c * TS, xn[c]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) mma_tile<PREC>(a, rec + lane + (4 + c) * TS, xn[c]);
+        }
+        DFX_RECORD(rec);
+        if (j < FF_CHUNKS) {
+#pragma unroll
+          for (int c = 2; c < 4; ++c) mma_tile<PREC>(a, rec + lane + (c - 2) * TS, xn[c]);
+        }
+        if (j > 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], rec + lane + (2 + t) * TS, hid);
+        }
+        if (j < FF_CHUNKS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hid.x[r] = a[r] * gelu_erf(g[r]);
+        }
+      }
+    }
+  }
+#undef DFX_RECORD
+  wait_vmcnt<0>();  // drain padding DMAs before the LDS allocation is released
+}
+
 // The step boundary runs on one wavefront with nobody to hide its LDS latency behind: the same arithmetic as post_eps /
 // proj_in_prenorm (operation for operation — the results are bit-identical), with the operand reads of a whole 16-channel tile
 // issued ahead of the tile before's arithmetic (hipcc, short of registers over the whole kernel, otherwise reads one operand at a time).
@@ -1680,6 +1904,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     return base * (full * f(g_num_cus * fill_per_wg) + (rest ? f(rest * fill_per_wg) : 0.0));
   };
   const bool bf16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct;
+  const bool f32 = d->dev.prec == DFX_PREC_F32 && !g_force_direct;
   int nw = PIPE_NW;
   double best = 1e300;
   for (int c = 8; c >= 2; c >>= 1) {
@@ -1691,14 +1916,19 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long wpg = tiles(nw);
   // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
   const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
+  // the exact-fp32 chain: same tiling; ~3x the direct kernel's rate per point, so a padded small shape may still take it
+  const bool pipe_f32 = f32 && g_force_nw != 1 && wpg * nw * 32 <= 3LL * p.N;
   const bool coop = bf16 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
-  if (pipe || coop) {
+  if (pipe || coop || pipe_f32) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {
       hipError_t e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<8>), PipeCfg<8>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<4>), PipeCfg<4>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<2>), PipeCfg<2>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop), CL_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<8>), PipeCfg<8>::L_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<4>), PipeCfg<4>::L_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<2>), PipeCfg<2>::L_TOTAL);
       return e;
     }));
   }
@@ -1708,6 +1938,9 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   else if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
   else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
+  else if (pipe_f32 && nw == 8) k_denoise_pipe_f32<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
+  else if (pipe_f32 && nw == 4) k_denoise_pipe_f32<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
+  else if (pipe_f32) k_denoise_pipe_f32<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
   else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
   const int rc = check_launch("denoiser kernel");

@@ -328,7 +328,7 @@ def test_ddim_pipelined_bf16_vs_f32_and_module_api(W):
         assert sorted(k for k in out[prec] if k != "pred") == sorted({t for t in d.steps if t and t % 10 == 0} | {T})
     err = (out["f32"]["pred"] - out["bf16"]["pred"]).abs().max().item()
     print(f"ddim bf16 vs f32 (quad, 25 steps, T=100, B=4, N=256): max-abs {err:.3e}")
-    assert torch.isfinite(out["bf16"]["pred"]).all() and err < 5e-2, err
+    assert torch.isfinite(out["bf16"]["pred"]).all() and err < 2.7e-4, err   # measured 8.8e-5 (gpurun r03): gate at 3x
 
 
 # ---------------------------------------------------------------------- training-style forward (eval mode)
