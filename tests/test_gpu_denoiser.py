@@ -425,3 +425,44 @@ def test_small_batch_workgroup_sizes_are_bit_identical(W, N):
         assert torch.equal(out[nw][2], out[8][2]), nw
         assert torch.equal(out[nw][3][0], out[8][3][0]) and torch.equal(out[nw][3][1], out[8][3][1]), nw
     assert torch.equal(auto, out[8][1]) and torch.isfinite(auto).all()
+
+
+@pytest.mark.parametrize("N", [2048, 2080, 512, 96])
+def test_f32_pipelined_chain_is_bit_identical_to_the_direct_kernel(W, N):
+    """k_denoise_pipe_f32 (weights through the LDS ring, 8 / 4 / 2 wavefronts per workgroup) against the direct exact-fp32 kernel
+    that every fp32 golden was established on: same device functions, same MFMA order per accumulator -> the same bits, for the
+    chain with explicit noise (trajectory included) and with the in-kernel Philox stream, single evaluations (one t and per-shape t),
+    single steps with pred_xstart, and the DDIM chain; full, ragged (2080) and padded (96: three tiles of 32 in a 64-point tile pair)
+    last tiles."""
+    from difffacto_amd import _ffi
+    T, B = 4, 3
+    e = _engine(W, T, "f32")
+    pc, mean, logvar, va = synth.make_latents(B, seed=N + 1)
+    cx = e.prepare_shapes(*map(torch.from_numpy, (pc, mean, np.exp(logvar).astype(np.float32), va)))
+    sg = torch.from_numpy(synth.make_seg_mask(va, N))
+    g = torch.Generator().manual_seed(N)
+    xT, sn = torch.randn(B, 3, N, generator=g), torch.randn(T, B, 3, N, generator=g)
+    tt = torch.tensor([3, 0, 2], dtype=torch.int32)
+
+    def run():
+        return (e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn, ret_interval=2), e.sample_chain(cx, sg, seed=9)[0], e.eps(cx, xT, sg, 2),
+                e.p_sample(cx, xT, sg, 1, noise=sn[0], want_xstart=True), e.eps_t(cx, xT, sg, tt),
+                e.sample_chain_ddim(cx, sg, [0, 1, 3], 1.0, x_T_noise=xT, step_noise=sn[:3])[0])
+    out = {}
+    try:
+        _ffi.lib().dfx_debug_force_direct(1)
+        out[0] = run()
+        _ffi.lib().dfx_debug_force_direct(0)
+        for nw in (8, 4, 2):
+            _ffi.lib().dfx_debug_pipe_waves(nw)
+            out[nw] = run()
+    finally:
+        _ffi.lib().dfx_debug_force_direct(0)
+        _ffi.lib().dfx_debug_pipe_waves(0)
+    out["auto"] = run()
+    flat = lambda r: [r[0][0], r[0][1], r[1], r[2], r[3][0], r[3][1], r[4], r[5]]
+    ref = flat(out[0])
+    assert all(torch.isfinite(x).all() for x in ref)
+    for k in (8, 4, 2, "auto"):
+        for i, (x, y) in enumerate(zip(flat(out[k]), ref)):
+            assert torch.equal(x, y), (k, i, (x - y).abs().max().item())
