@@ -1271,6 +1271,314 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_denoise_pipe2: the bf16 chain with TWO point tiles (64 points) per wavefront — VERDICT r2 item 1(a).
+//
+// The pipelined kernel above reads every A (weight) fragment from LDS once per 32 points: eight wavefronts x 24 KiB per record,
+// ~10 % of the energy of a record on a chip that sits on its power cap (profiles/r02_energy_budget.txt).  Here a workgroup is four
+// wavefronts of 64 points (the same 256-point tile, LDS map and ring), ONE wavefront per SIMD with the whole 512-entry register
+// file: every fragment read feeds two MFMAs (tile 0, tile 1), and the b1 accumulator initialisers are read once and enter both
+// tiles' first MFMA as its C operand (dst != src C), so the LDS -> register traffic per point halves.  There is no partner
+// wavefront to run the VALU work beside the MFMAs, so the feed-forward is software-pipelined inside the wave (the r02 DFX_SWP
+// experiment, now with two tiles): for FF record j
+//     stage A   GEMM1 of chunk j   (16 fragments x 2 tiles = 32 MFMAs)  with the packed-fp16 GELU of chunk j-1 behind them (5 v_pk per MFMA)
+//     stage B   GEMM2 of chunk j-1 (8 x 2 = 16 MFMAs)                   with (a, g) of chunk j -> packed fp16 and b1 of chunk j+1 -> registers
+// Same device functions and the same MFMA order per accumulator as k_denoise_pipe: bit-identical results (tested).
+constexpr int P2_NW = 4;
+constexpr int P2_LDS = PipeCfg<P2_NW>::L_PSTATE + PSTATE_FIELDS * 256 * 4;   // the 4-wave ring map (6 DMA pieces per wave) with 256 point slots
+struct GeluRegs {
+  h2 y[8], z[8], r[8];
+};
+// operation K = stage * 8 + pair of gelu16_f16_math (same instructions in the same order per pair)
+template <int K>
+__device__ __forceinline__ void gelu_op(GeluRegs &t, const h2 (&aa)[8], const h2 (&gg)[8]) {
+  constexpr int st = K / 8, i = K % 8;
+  if (st == 0) t.z[i] = __builtin_elementwise_fma(gg[i], gg[i], h2c(-1.62f));
+  if (st == 1) t.y[i] = aa[i] * gg[i];
+  if (st == 2) t.z[i] = __builtin_elementwise_min(t.z[i], h2c(1.62f));
+  if (st == 3) t.r[i] = __builtin_elementwise_fma(t.z[i], h2c(-0.0011402554f), h2c(0.0057853916f));
+  if (st == 4) t.r[i] = __builtin_elementwise_fma(t.r[i], t.z[i], h2c(-0.0158536041f));
+  if (st == 5) t.r[i] = __builtin_elementwise_fma(t.r[i], t.z[i], h2c(0.0409006897f));
+  if (st == 6) t.r[i] = __builtin_elementwise_fma(t.r[i], t.z[i], h2c(-0.1098130657f));
+  if (st == 7) t.r[i] = __builtin_elementwise_fma(t.r[i], t.z[i], h2c(0.3885767652f));
+  if (st == 8) asm("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(t.z[i]) : "v"(gg[i]), "v"(t.r[i]));   // Phi
+  if (st == 9) t.y[i] = t.y[i] * t.z[i];
+}
+template <int K0, int N>
+__device__ __forceinline__ void gelu_ops(GeluRegs &t, const h2 (&aa)[8], const h2 (&gg)[8]) {
+  if constexpr (N > 0) {
+    gelu_op<K0>(t, aa, gg);
+    gelu_ops<K0 + 1, N - 1>(t, aa, gg);
+  }
+}
+__device__ __forceinline__ void hid_from(const GeluRegs &t, HidAct &hid) {
+  hid.f[0] = make_uint4(__builtin_bit_cast(unsigned, t.y[0]), __builtin_bit_cast(unsigned, t.y[1]), __builtin_bit_cast(unsigned, t.y[2]),
+                        __builtin_bit_cast(unsigned, t.y[3]));
+  hid.f[1] = make_uint4(__builtin_bit_cast(unsigned, t.y[4]), __builtin_bit_cast(unsigned, t.y[5]), __builtin_bit_cast(unsigned, t.y[6]),
+                        __builtin_bit_cast(unsigned, t.y[7]));
+}
+// fragment order of this kernel's records: the 16 W1 fragments (GEMM1 MFMA e: half e >> 3, index e & 7), then the 8 W2 fragments
+enum { P2_NEXT_W1 = 0, P2_NEXT_W2 = 1, P2_NEXT_AS = 2 };
+template <int NEXT>
+__device__ __forceinline__ constexpr int p2_next_frag(int i) { return NEXT == P2_NEXT_W1 ? w1_frag(i, 0) : NEXT == P2_NEXT_W2 ? w2_frag(i) : as_frag(i); }
+
+// b1 of one chunk -> registers (the C operand of both tiles' first GEMM1 MFMAs)
+__device__ __forceinline__ void load_b1(v16f &b1a, v16f &b1g, const float *b1) {
+  typedef __attribute__((address_space(3))) const float lds_cf;
+  unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1;
+  asm volatile("" : "+v"(addr));   // one base register, immediate offsets
+  const float *src = (const float *)(lds_cf *)(uintptr_t)addr;
+  load16(b1a, src);
+  load16(b1g, src + 32);
+}
+
+// One FF record for both tiles.  FIRST: record F0 (GEMM1 of chunk 0 only); LAST: record F16 (GELU + GEMM2 of chunk 15 only).
+// P enters with the record's first eight fragments and leaves with the next record's (tail prefetch, as in k_denoise_pipe).
+template <bool FIRST, bool LAST, int NEXT>
+__device__ __forceinline__ void ff2(v16f (&h)[2][4], const Act<DFX_PREC_BF16> (&xn)[2][4], v16f (&a)[2], v16f (&g)[2], h2 (&aa)[2][8],
+                                    h2 (&gg)[2][8], v16f &b1a, v16f &b1g, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next,
+                                    const float *b1_next) {
+  GeluRegs t[2];
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!LAST) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = e & 7, half = e >> 3;
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        v16f &acc = (k & 1) ? g[tl] : a[tl];
+        const v16f &c0 = (k & 1) ? b1g : b1a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[k]), xn[tl][2 * half + (k >> 2)].f[(k >> 1) & 1], e < 2 ? c0 : acc, 0, 0, 0);
+        if (tl == 1) P[k] = e + 8 < 16 ? ck[w1_frag((e + 8) & 7, (e + 8) >> 3)] : FIRST ? ck_next[p2_next_frag<NEXT>(e + 8 - 16)] : ck[w2_frag(e + 8 - 16)];
+        if constexpr (!FIRST) {
+          if (e == 0) gelu_ops<0, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 1) gelu_ops<5, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 2) gelu_ops<10, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 3) gelu_ops<15, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 4) gelu_ops<20, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 5) gelu_ops<25, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 6) gelu_ops<30, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 7) gelu_ops<35, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 8) gelu_ops<40, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 9) gelu_ops<45, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 10) gelu_ops<50, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 11) gelu_ops<55, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 12) gelu_ops<60, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 13) gelu_ops<65, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 14) gelu_ops<70, 5>(t[tl], aa[tl], gg[tl]);
+          if (e == 15) gelu_ops<75, 5>(t[tl], aa[tl], gg[tl]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) gelu_ops<0, 80>(t[tl], aa[tl], gg[tl]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (!FIRST) {
+    HidAct hid[2];
+    hid_from(t[0], hid[0]);
+    hid_from(t[1], hid[1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        h[tl][i & 3] = mma_hid(P[i], hid[tl].f[i >> 2], h[tl][i & 3]);
+        if (tl == 1) P[i] = ck_next[p2_next_frag<NEXT>(i)];
+        if constexpr (!LAST) {   // (a, g) of this chunk -> packed fp16: a got its last MFMA before g did
+          if (i < 4) {
+#pragma unroll
+            for (int q = 2 * i; q < 2 * i + 2; ++q) aa[tl][q] = pk_f16(a[tl][2 * q], a[tl][2 * q + 1]);
+          } else {
+#pragma unroll
+            for (int q = 2 * (i - 4); q < 2 * (i - 4) + 2; ++q) gg[tl][q] = pk_f16(g[tl][2 * q], g[tl][2 * q + 1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!LAST && b1_next) load_b1(b1a, b1g, b1_next);
+  } else {
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) gelu16_f16_cvt(a[tl], g[tl], aa[tl], gg[tl]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (b1_next) load_b1(b1a, b1g, b1_next);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p) {
+  constexpr int PREC = DFX_PREC_BF16;
+  constexpr int NW = P2_NW, PTS = PipeCfg<NW>::PTS * 2;
+  static_assert(PTS == 256 && P2_LDS <= 160 * 1024, "LDS budget");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const int wpg = (p.N + PTS - 1) / PTS;
+  int bid = blockIdx.x;
+  {
+    const int per = 8 * wpg;
+    const int full = ((int)gridDim.x / per) * per;
+    if (bid < full) {
+      const int x = bid & 7, q = (bid % per) >> 3;
+      bid = (bid / per) * per + x * wpg + q;
+    }
+  }
+  const int s = __builtin_amdgcn_readfirstlane(bid / wpg);
+  const int depth = p.d.depth;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
+  // the wave's two tiles are tiles 2 wave and 2 wave + 1 of the workgroup's eight (the point slots of k_denoise_pipe<8>'s waves)
+  int nn[2], ptv[2];
+  bool lv[2];
+  unsigned long long gidv[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    int n0 = __builtin_amdgcn_readfirstlane((bid - s * wpg) * PTS + (2 * wave + tl) * 32);
+    lv[tl] = n0 < p.N;
+    if (!lv[tl]) n0 = p.N - 32;
+    nn[tl] = n0 + pj;
+    ptv[tl] = (2 * wave + tl) * 32 + pj;
+    gidv[tl] = ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)nn[tl];
+  }
+
+  DmaState dma{0, 0, 0, 0, 0, nullptr};
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
+  issue_record<NW>(p, dma, wave, voff, lds0, s);
+  {
+    float4 *winx = reinterpret_cast<float4 *>(pipe_smem + L_WINX);
+    float2 *pregb = reinterpret_cast<float2 *>(pipe_smem + L_PREGB);
+    float4 *wout = reinterpret_cast<float4 *>(pipe_smem + L_WOUT);
+    float *cp = reinterpret_cast<float *>(pipe_smem + L_CPART);
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+      winx[tid] = p.d.win_x[tid];
+      pregb[tid] = p.d.pre_gb[tid];
+      wout[tid] = p.d.wout[tid];
+    }
+    for (int i = tid; i < NCLS * INNER; i += NW * 64) cp[i] = p.cpart[(size_t)s * NCLS * INNER + i];
+  }
+  unsigned vmask = 0;
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + PipeCfg<NW>::L_PSTATE);
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    PointState ps0;
+    ps0.live = lv[tl];
+    point_init(p, ps0, s, nn[tl], gidv[tl], vmask);
+    pstate_store(ps_lds, ptv[tl], PTS, ps0, true);
+  }
+  __syncthreads();
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + L_WINX) + hf * 64;
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
+
+#define DFX_RECORD2()                                                                   \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    wait_vmcnt<PipeCfg<NW>::CALLS>();                                                   \
+    __builtin_amdgcn_s_barrier();                                                       \
+    issue_record<NW>(p, dma, wave, voff, lds0, s);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane; \
+    cur = cur + 1 == NSLOT ? 0 : cur + 1;                                               \
+  } while (0)
+#define DFX_PEEK2() (reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane)
+
+  uint4 P[8];
+  int cur = 0, seq = 0;
+  v16f h[2][4];
+  bool done = false;
+  for (int step = 0; step <= p.nsteps && !done; ++step) {
+    for (int b = 0; b < depth; ++b, ++seq) {
+      const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
+      const float *b1 = bc + hf * 16;
+      const uint4 *ck;
+      Act<PREC> xn[2][4];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        if (seq > 0)
+          add_cvec(h[tl], reinterpret_cast<const float *>(pipe_smem + L_BCONST + ((seq - 1) & 1) * BCONST_BYTES) + BCONST_B2_OFF + hf * 64);
+        if (b == 0) {
+          PointState ps;
+          ps.s = s, ps.n = nn[tl], ps.gid = gidv[tl], ps.live = lv[tl];
+          pstate_load(ps_lds, ptv[tl], PTS, ps, step > 0);
+          bool dn = false;
+          if (step > 0) {
+            float eps[3];
+            post_eps<true>(h[tl], wout, p.d.bout, eps);
+            dn = step_epilogue(p, ps, eps, step - 1, step_t(p, step - 1, s));
+            if (!dn) pstate_store(ps_lds, ptv[tl], PTS, ps, false);
+          }
+          if (step == p.nsteps) dn = true;
+          if (!dn) proj_in_prenorm<true>(h[tl], ps.x, reinterpret_cast<const float *>(pipe_smem + L_CPART) + ps.sg * INNER + hf * 64, winx, pregb);
+          done = dn;   // (wave-uniform and the same for both tiles: mode / step count)
+        }
+        if (!done) ln_to_act<PREC>(h[tl], xn[tl]);
+      }
+      if (done) break;
+      // ---- attention record ----
+      DFX_RECORD2();
+      const uint4 *rec = ck;
+      {
+        if (seq == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) P[i] = rec[as_frag(i)];
+        }
+        v16f sb, sim[2];
+        load16(sb, reinterpret_cast<const float *>(rec - lane + 1024) + hf * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int tl = 0; tl < 2; ++tl)
+            sim[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), xn[tl][i >> 1].f[i & 1], i == 0 ? sb : sim[tl], 0, 0, 0);
+          P[i] = rec[ms_frag(i)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        Act<PREC> pa[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) attn_softmax(sim[tl], pa[tl], vmask);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4 *nx = DFX_PEEK2();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int tl = 0; tl < 2; ++tl)
+            h[tl][i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[i]), pa[tl].f[i >> 2], h[tl][i & 3], 0, 0, 0);
+          P[i] = nx[w1_frag(i, 0)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        add_cvec(h[tl], reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
+        ln_to_act<PREC>(h[tl], xn[tl]);
+      }
+      // ---- feed-forward ----
+      v16f a[2], g[2], b1a, b1g;
+      h2 aa[2][8], gg[2][8];
+      load_b1(b1a, b1g, b1);
+      DFX_RECORD2();
+      ff2<true, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + 64);
+#pragma unroll 1
+      for (int j = 1; j < FF_CHUNKS - 1; ++j) {
+        DFX_RECORD2();
+        ff2<false, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + (j + 1) * 64);
+      }
+      DFX_RECORD2();
+      ff2<false, false, P2_NEXT_W2>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr);
+      DFX_RECORD2();
+      ff2<false, true, P2_NEXT_AS>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr);
+    }
+  }
+#undef DFX_RECORD2
+#undef DFX_PEEK2
+  wait_vmcnt<0>();
+}
+
+// ----------------------------------------------------------------------------------------------
 // LDS-pipelined kernel, exact fp32 (v_mfma_f32_32x32x2_f32): the reference-precision sampler.  The reference computes in
 // fp32 end to end (attention.py:296-306, anchored_diffusion.py:227-395); this is that arithmetic at the structure of the bf16
 // chain kernel — one workgroup = NW wavefronts x 32 points of one shape, the residual stream in registers for the whole chain,
@@ -1912,13 +2220,15 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     const double cost = rounds_cost(tiles(c) * p.B, c == 8 ? 93.5 : c == 4 ? 88.5 : 86.5, c / (8.0 * g_num_cus));
     if (cost < best) best = cost, nw = c;
   }
-  if (g_force_nw > 1) nw = g_force_nw;
+  const bool pipe2 = bf16 && g_force_nw == 64 && tiles(8) * 256 <= 3LL * p.N;   // two tiles per wavefront (k_denoise_pipe2): 256-point workgroup tiles
+  if (g_force_nw > 1 && g_force_nw != 64) nw = g_force_nw;
+  if (pipe2) nw = 8;
   const long long wpg = tiles(nw);
   // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
   const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
   // the exact-fp32 chain: same tiling; ~3x the direct kernel's rate per point, so a padded small shape may still take it
   const bool pipe_f32 = f32 && g_force_nw != 1 && wpg * nw * 32 <= 3LL * p.N;
-  const bool coop = bf16 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
+  const bool coop = bf16 && !pipe2 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
   if (pipe || coop || pipe_f32) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {
@@ -1926,6 +2236,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<4>), PipeCfg<4>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<2>), PipeCfg<2>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop), CL_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe2), P2_LDS);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<8>), PipeCfg<8>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<4>), PipeCfg<4>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<2>), PipeCfg<2>::L_TOTAL);
@@ -1934,7 +2245,8 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   }
   EventTimer tm;
   tm.begin(st);
-  if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
+  if (pipe2) k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
+  else if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
   else if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
   else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
@@ -2069,7 +2381,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1) ? nw : 0; }
+void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1 || nw == 64) ? nw : 0; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);
   g_trace_cap = capacity;

@@ -200,7 +200,7 @@ def test_bench_line_contract_single_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline", "parity", "t100", "small_batch"):
+              "config", "roofline", "cpu_baseline", "parity", "t100", "small_batch", "f32", "sweep"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["unit"] == "shapes/s" and d["dtype"] == "bf16" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -208,7 +208,10 @@ def test_bench_line_contract_single_gpu(tmp_path):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["parity"] and d["parity"]["bf16"]["max_abs"] < 3e-3 and d["parity"]["f32"]["max_abs"] < 1e-4   # measured 9.2e-4 / 2.4e-6
-    assert "error" not in d["t100"] and d["t100"]["shapes_per_s"] > 0
+    assert "error" not in d["t100"] and d["t100"]["shapes_per_s"] > d["t100"]["wall_shapes_per_s"] > 0
+    assert "error" not in d["f32"] and d["f32"]["dtype"] == "f32" and d["f32"]["finite"] and 0 < d["f32"]["frac"] < 1
+    assert sorted(d["sweep"]) == ["gen_airplane", "gen_car", "gen_chair_B1024", "gen_lamp"]
+    assert all("error" not in v and v["finite"] and v["shapes_per_s"] > 0 for v in d["sweep"].values()) and d["sweep"]["gen_car"]["npoints"] == 8192
     assert "error" not in d["small_batch"] and d["small_batch"]["B1"]["ms_per_chain"] > 0 and d["small_batch"]["B4"]["shapes_per_s"] > 0
 
 
