@@ -13,6 +13,7 @@
 // chain register-to-register.  LayerNorm / softmax / GELU / posterior are fp32 VALU on the same
 // registers; the 4-key attention needs no q/k/v at run time (folded into A_s / M_s at prepare time).
 #include <cmath>
+#include <type_traits>
 
 #include "denoiser_internal.h"
 
@@ -1331,54 +1332,100 @@ __device__ __forceinline__ void load_b1(v16f &b1a, v16f &b1g, const float *b1) {
   load16(b1g, src + 32);
 }
 
+// GEMM1 accumulators (a, g) in ARCHITECTURAL registers.  With a 512-register budget hipcc selects the accumulator-file form for
+// every MFMA builtin, and the GELU's conversions would then pay one v_accvgpr_read per value (64 per record: a third more VALU
+// instructions).  The C/D file of an MFMA is chosen per instruction (A and B independently), so these — and only these — MFMAs are
+// inline asm: D / C = VGPRs, A = the fragment from LDS (VGPR), B = the LayerNorm output (accumulator file: nothing else reads it).
+// Hazards (guide §5.7 item 2): the inputs are written long before (ds_read + the compiler's lgkmcnt wait; xn one record earlier); D is
+// read only by the NEXT MFMA on the same accumulator as its whole C (0 states) and by the conversions of stage B, at least three
+// MFMA issues (> 96 cycles) after the accumulator's last MFMA (8-pass XDL: 12 states).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_v_init(v16f &acc, const uint4 &A, const v8bf &B, const v16f &C) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(__builtin_bit_cast(v4u, A)), "a"(B), "v"(C));
+}
+__device__ __forceinline__ void mfma_v_acc(v16f &acc, const uint4 &A, const v8bf &B) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(v4u, A)), "a"(B));
+}
+template <int E>   // the ten operations behind the E-th fragment of stage A: tile 0's GELU rides on fragments 0..7, tile 1's on 8..15
+__device__ __forceinline__ void gelu_slot(GeluRegs &t, const h2 (&aa)[2][8], const h2 (&gg)[2][8], int half_slot) {
+  constexpr int tl = E >> 3, base = (E & 7) * 10;
+  if (half_slot == 0) gelu_ops<base, 5>(t, aa[tl], gg[tl]);
+  else gelu_ops<base + 5, 5>(t, aa[tl], gg[tl]);
+}
+
+// The wave's DMA duty for the record three ahead: FF records (24 contiguous KiB) are issued one piece at a time from inside the
+// MFMA stream (two scalar bases, immediate offsets); the irregular attention record at once behind its barrier.
+struct Issuer2 {
+  const char *src;   // nullptr: nothing deferred
+  unsigned dst;
+  unsigned voff;
+  template <int Q>
+  __device__ __forceinline__ void piece() const {
+    if (src) {
+      if (Q < 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(src), "s"(dst), "i"(Q * 1024) : "memory");
+      else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(src + 4096), "s"(dst + 4096), "i"((Q - 4) * 1024) : "memory");
+    }
+  }
+};
+
 // One FF record for both tiles.  FIRST: record F0 (GEMM1 of chunk 0 only); LAST: record F16 (GELU + GEMM2 of chunk 15 only).
 // P enters with the record's first eight fragments and leaves with the next record's (tail prefetch, as in k_denoise_pipe).
 template <bool FIRST, bool LAST, int NEXT>
 __device__ __forceinline__ void ff2(v16f (&h)[2][4], const Act<DFX_PREC_BF16> (&xn)[2][4], v16f (&a)[2], v16f (&g)[2], h2 (&aa)[2][8],
                                     h2 (&gg)[2][8], v16f &b1a, v16f &b1g, const uint4 *ck, uint4 (&P)[8], const uint4 *ck_next,
-                                    const float *b1_next) {
-  GeluRegs t[2];
+                                    const float *b1_next, const Issuer2 &dma, Tracer &tr) {
+  GeluRegs t;
+  HidAct hid[2];
   __builtin_amdgcn_sched_barrier(0);
+  tr.stamp(30);
   if constexpr (!LAST) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int k = e & 7, half = e >> 3;
+    auto stage_a = [&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int k = e & 7, half = e >> 3;
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         v16f &acc = (k & 1) ? g[tl] : a[tl];
-        const v16f &c0 = (k & 1) ? b1g : b1a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(P[k]), xn[tl][2 * half + (k >> 2)].f[(k >> 1) & 1], e < 2 ? c0 : acc, 0, 0, 0);
+        if (e < 2) mfma_v_init(acc, P[k], xn[tl][2 * half + (k >> 2)].f[(k >> 1) & 1], (k & 1) ? b1g : b1a);
+        else mfma_v_acc(acc, P[k], xn[tl][2 * half + (k >> 2)].f[(k >> 1) & 1]);
         if (tl == 1) P[k] = e + 8 < 16 ? ck[w1_frag((e + 8) & 7, (e + 8) >> 3)] : FIRST ? ck_next[p2_next_frag<NEXT>(e + 8 - 16)] : ck[w2_frag(e + 8 - 16)];
-        if constexpr (!FIRST) {
-          if (e == 0) gelu_ops<0, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 1) gelu_ops<5, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 2) gelu_ops<10, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 3) gelu_ops<15, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 4) gelu_ops<20, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 5) gelu_ops<25, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 6) gelu_ops<30, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 7) gelu_ops<35, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 8) gelu_ops<40, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 9) gelu_ops<45, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 10) gelu_ops<50, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 11) gelu_ops<55, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 12) gelu_ops<60, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 13) gelu_ops<65, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 14) gelu_ops<70, 5>(t[tl], aa[tl], gg[tl]);
-          if (e == 15) gelu_ops<75, 5>(t[tl], aa[tl], gg[tl]);
+        if constexpr (!FIRST) gelu_slot<e>(t, aa, gg, tl);
+        if constexpr (!FIRST && e == 7) {
+          if (tl == 1) hid_from(t, hid[0]);
+        }
+        if (tl == 0 && e % 3 == 0 && e / 3 < 6) {   // DMA pieces behind fragments 0, 3, 6, 9, 12, 15
+          if (e == 0) dma.piece<0>();
+          if (e == 3) dma.piece<1>();
+          if (e == 6) dma.piece<2>();
+          if (e == 9) dma.piece<3>();
+          if (e == 12) dma.piece<4>();
+          if (e == 15) dma.piece<5>();
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    stage_a(std::integral_constant<int, 0>{});  stage_a(std::integral_constant<int, 1>{});  stage_a(std::integral_constant<int, 2>{});
+    stage_a(std::integral_constant<int, 3>{});  stage_a(std::integral_constant<int, 4>{});  stage_a(std::integral_constant<int, 5>{});
+    stage_a(std::integral_constant<int, 6>{});  stage_a(std::integral_constant<int, 7>{});  stage_a(std::integral_constant<int, 8>{});
+    stage_a(std::integral_constant<int, 9>{});  stage_a(std::integral_constant<int, 10>{}); stage_a(std::integral_constant<int, 11>{});
+    stage_a(std::integral_constant<int, 12>{}); stage_a(std::integral_constant<int, 13>{}); stage_a(std::integral_constant<int, 14>{});
+    stage_a(std::integral_constant<int, 15>{});
+    if constexpr (!FIRST) hid_from(t, hid[1]);
+    tr.stamp(31);
   } else {
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) gelu_ops<0, 80>(t[tl], aa[tl], gg[tl]);
+    gelu_ops<0, 80>(t, aa[0], gg[0]);
+    hid_from(t, hid[0]);
+    gelu_ops<0, 80>(t, aa[1], gg[1]);
+    hid_from(t, hid[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr (!FIRST) {
-    HidAct hid[2];
-    hid_from(t[0], hid[0]);
-    hid_from(t[1], hid[1]);
+    const float *b1q = nullptr;
+    if (!LAST && b1_next) {   // one opaque base register, immediate offsets
+      typedef __attribute__((address_space(3))) const float lds_cf;
+      unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1_next;
+      asm volatile("" : "+v"(addr));
+      b1q = (const float *)(lds_cf *)(uintptr_t)addr;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1394,10 +1441,27 @@ __device__ __forceinline__ void ff2(v16f (&h)[2][4], const Act<DFX_PREC_BF16> (&
             for (int q = 2 * (i - 4); q < 2 * (i - 4) + 2; ++q) gg[tl][q] = pk_f16(g[tl][2 * q], g[tl][2 * q + 1]);
           }
         }
+        if constexpr (!LAST) {   // b1 of the next chunk -> registers, a quarter per fragment (landed long before the next record's first MFMA)
+          if (tl == 1 && b1q) {
+            const v4f q4 = *reinterpret_cast<const v4f *>(b1q + (i < 4 ? 4 * i : 32 + 4 * (i - 4)));
+            v16f &dst = i < 4 ? b1a : b1g;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) dst[4 * (i & 3) + e4] = q4[e4];
+          }
+        }
+        if constexpr (LAST) {
+          if (tl == 0 && i < 6) {
+            if (i == 0) dma.piece<0>();
+            if (i == 1) dma.piece<1>();
+            if (i == 2) dma.piece<2>();
+            if (i == 3) dma.piece<3>();
+            if (i == 4) dma.piece<4>();
+            if (i == 5) dma.piece<5>();
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (!LAST && b1_next) load_b1(b1a, b1g, b1_next);
   } else {
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) gelu16_f16_cvt(a[tl], g[tl], aa[tl], gg[tl]);
@@ -1405,6 +1469,7 @@ __device__ __forceinline__ void ff2(v16f (&h)[2][4], const Act<DFX_PREC_BF16> (&
     if (b1_next) load_b1(b1a, b1g, b1_next);
   }
   __builtin_amdgcn_sched_barrier(0);
+  tr.stamp(32);
 }
 
 __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p) {
@@ -1474,15 +1539,35 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
   const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + L_PREGB) + hf * 64;
   const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + L_WOUT) + hf * 64;
 
-#define DFX_RECORD2()                                                                   \
+  // `defer`: the record that follows is an FF record with an MFMA stream to hide the DMA pieces in
+  Issuer2 isr{nullptr, 0u, voff};
+#ifdef DFX_TRACE
+  Tracer tr{(p.trace != nullptr && bid == 0 && wave == 0) ? p.trace : nullptr, p.trace_cap, 0};
+#else
+  Tracer tr;
+#endif
+#define DFX_RECORD2(defer)                                                              \
   do {                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    wait_vmcnt<PipeCfg<NW>::CALLS>();                                                   \
-    __builtin_amdgcn_s_barrier();                                                       \
-    issue_record<NW>(p, dma, wave, voff, lds0, s);                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
+    /* the (scalar) bookkeeping of a deferred FF record runs AHEAD of the barrier: with one wavefront per SIMD nobody */ \
+    /* covers what sits between the barrier and the first MFMA */                      \
+    isr.src = nullptr;                                                                  \
+    const bool deferred_ = (defer) && dma.k > 0 && dma.step < p.nsteps;                 \
+    if (deferred_) {                                                                    \
+      isr.src = pin_ptr(dma.ff_src);                                                    \
+      isr.dst = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + L_RING + dma.slot * SLOT_BYTES + wave * PipeCfg<NW>::CALLS * 1024); \
+      dma.ff_src += SLOT_BYTES;                                                         \
+      advance_record(p, dma);                                                           \
+    }                                                                                   \
     ck = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane; \
     cur = cur + 1 == NSLOT ? 0 : cur + 1;                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    tr.stamp(1);                                                                        \
+    wait_vmcnt<PipeCfg<NW>::CALLS>();                                                   \
+    __builtin_amdgcn_s_barrier();                                                       \
+    tr.stamp(2);                                                                        \
+    if (!deferred_) issue_record<NW>(p, dma, wave, voff, lds0, s);                      \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
   } while (0)
 #define DFX_PEEK2() (reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES) + lane)
 
@@ -1519,7 +1604,7 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
       }
       if (done) break;
       // ---- attention record ----
-      DFX_RECORD2();
+      DFX_RECORD2(false);
       const uint4 *rec = ck;
       {
         if (seq == 0) {
@@ -1537,10 +1622,12 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
           P[i] = rec[ms_frag(i)];
           __builtin_amdgcn_sched_barrier(0);
         }
+        tr.stamp(21);
         Act<PREC> pa[2];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) attn_softmax(sim[tl], pa[tl], vmask);
         __builtin_amdgcn_sched_barrier(0);
+        tr.stamp(22);
         const uint4 *nx = DFX_PEEK2();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1550,27 +1637,35 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
           P[i] = nx[w1_frag(i, 0)];
           __builtin_amdgcn_sched_barrier(0);
         }
+        tr.stamp(23);
       }
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         add_cvec(h[tl], reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
         ln_to_act<PREC>(h[tl], xn[tl]);
+        // LN3's output is read by GEMM1's MFMAs only: into the accumulator file HERE, once per block (an "a" operand whose value
+        // lives in VGPRs is otherwise copied in front of every asm MFMA: 64 v_accvgpr_write per record)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          asm volatile("" : "+a"(xn[tl][c].f[0]));
+          asm volatile("" : "+a"(xn[tl][c].f[1]));
+        }
       }
       // ---- feed-forward ----
       v16f a[2], g[2], b1a, b1g;
       h2 aa[2][8], gg[2][8];
       load_b1(b1a, b1g, b1);
-      DFX_RECORD2();
-      ff2<true, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + 64);
+      DFX_RECORD2(true);
+      ff2<true, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + 64, isr, tr);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS - 1; ++j) {
-        DFX_RECORD2();
-        ff2<false, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + (j + 1) * 64);
+        DFX_RECORD2(true);
+        ff2<false, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + (j + 1) * 64, isr, tr);
       }
-      DFX_RECORD2();
-      ff2<false, false, P2_NEXT_W2>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr);
-      DFX_RECORD2();
-      ff2<false, true, P2_NEXT_AS>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr);
+      DFX_RECORD2(true);
+      ff2<false, false, P2_NEXT_W2>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr, isr, tr);
+      DFX_RECORD2(true);
+      ff2<false, true, P2_NEXT_AS>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr, isr, tr);
     }
   }
 #undef DFX_RECORD2
