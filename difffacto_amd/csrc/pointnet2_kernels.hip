@@ -164,37 +164,49 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
   const float *ds = dataset + (size_t)blockIdx.x * N * 3;
   int32_t *out = idxs + (size_t)blockIdx.x * M;
 
-  // per-point state in registers: coordinates, running min distance, and the (constant) tie-break key
-  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  // per-point state in registers: coordinates (as PAIRS: the distance update runs on packed fp32 — v_pk_add / v_pk_mul / v_pk_fma do
+  // two points per instruction with the scalar instructions' IEEE results), running min distance, and the (constant) tie-break key
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  static_assert(PPT % 2 == 0, "points per thread come in pairs");
+  v2f px[PPT / 2], py[PPT / 2], pz[PPT / 2];
+  float tmp[PPT];
   unsigned nkey[PPT];  // low half of fps_pack(): ~key32 ; 0 marks "skipped / absent" (never wins)
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = tid + i * NT;
-    px[i] = py[i] = pz[i] = 0.f;
-    // skipped / absent points: running distance 0 and key 0 — min(d, 0) = 0 keeps both, and their packed value (0 << 32) | 0 is
-    // "no candidate" by itself: no select in the loop (the reference never reads a skipped point's temp entry)
-    tmp[i] = 0.f;
+    float x = 0.f, y = 0.f, z = 0.f;
+    // skipped / absent points: running distance -1 and key 0 — min(d, -1) = -1 keeps it, the maximum (which starts at 0) never sees it,
+    // and it never EQUALS the maximum either, so the key selection below needs no validity test (the reference never reads a skipped
+    // point's temp entry)
+    tmp[i] = -1.f;
     nkey[i] = 0u;
     if (k < N) {
-      px[i] = ds[k * 3 + 0];
-      py[i] = ds[k * 3 + 1];
-      pz[i] = ds[k * 3 + 2];
-      const float mag = sq3(px[i], py[i], pz[i]);
+      x = ds[k * 3 + 0];
+      y = ds[k * 3 + 1];
+      z = ds[k * 3 + 2];
+      const float mag = sq3(x, y, z);
       if (!(mag <= __uint_as_float(FPS_SKIP_THRESH_BITS))) {
         nkey[i] = (unsigned)(fps_pack(0.f, k, log2bs) & 0xffffffffull);
         tmp[i] = 1e10f;  // sampling.cpp:74-76
       }
       if (COORDS_LDS) {
-        sx[k] = px[i];
-        sy[k] = py[i];
-        sz[k] = pz[i];
+        sx[k] = x;
+        sy[k] = y;
+        sz[k] = z;
       }
     }
+    px[i >> 1][i & 1] = x;
+    py[i >> 1][i & 1] = y;
+    pz[i >> 1][i & 1] = z;
   }
   if (tid < 32) slots[tid] = 0ull;
   int old = 0;
   if (tid == 0) out[0] = 0;
   __syncthreads();
+  // A thread's keys fall with i when the reference's block size divides NT (k mod bs is then the same for all of a thread's points and
+  // k div bs grows with i): the largest key among the points at the maximum is the one of the SMALLEST such i — a compare + select
+  // per point, walked downwards, instead of compare + select + max.
+  const bool mono = (NT & ((1 << log2bs) - 1)) == 0;
 
   for (int j = 1; j < M; ++j) {
     float x1, y1, z1;
@@ -207,18 +219,33 @@ __global__ void __launch_bounds__(NT) fps_resident_kernel(const float *__restric
       y1 = ds[old * 3 + 1];
       z1 = ds[old * 3 + 2];
     }
-    float m = 0.f;   // distances are >= 0 and absent / skipped points carry 0
+    const v2f nx = {-x1, -x1}, ny = {-y1, -y1}, nz = {-z1, -z1};
+    float m = 0.f;   // distances are >= 0; absent / skipped points carry -1
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
-      const float d2 = fminf(d, tmp[i]);
-      tmp[i] = d2;
-      m = fmaxf(m, d2);
+    for (int i = 0; i < PPT / 2; ++i) {
+      // sq3(px - x1, py - y1, pz - z1) for two points: the same roundings as the scalar chain (sub = add of the negated value; mul;
+      // fma; fma), in three v_pk_add_f32, one v_pk_mul_f32 and two v_pk_fma_f32
+      const v2f dx = px[i] + nx, dy = py[i] + ny, dz = pz[i] + nz;
+      v2f t = dx * dx;
+      t = __builtin_elementwise_fma(dy, dy, t);
+      t = __builtin_elementwise_fma(dz, dz, t);
+      // (plain v_min_f32: through fminf hipcc first re-quiets the extracted halves with a v_max x, x each — 8 more instructions per step)
+      float da, db;
+      asm("v_min_f32 %0, %1, %2" : "=v"(da) : "v"(t[0]), "v"(tmp[2 * i]));
+      asm("v_min_f32 %0, %1, %2" : "=v"(db) : "v"(t[1]), "v"(tmp[2 * i + 1]));
+      tmp[2 * i] = da;
+      tmp[2 * i + 1] = db;
+      m = fmaxf(fmaxf(m, da), db);   // v_max3_f32
     }
     const float M = wave_max_f32(m);
-    unsigned k = 0u;   // the largest key among this lane's points at the wavefront's largest distance (key 0: none / not a candidate)
+    unsigned k = 0u;   // the largest key among this lane's points at the wavefront's largest distance (key 0: none)
+    if (mono) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) k = max(k, tmp[i] == M ? nkey[i] : 0u);
+      for (int i = PPT - 1; i >= 0; --i) k = tmp[i] == M ? nkey[i] : k;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) k = max(k, tmp[i] == M ? nkey[i] : 0u);
+    }
     const unsigned K = wave_max_u32(k);
     unsigned long long *slot = slots + (j & 1) * 16;
     if (lane == 0) slot[wave] = ((unsigned long long)__float_as_uint(M) << 32) | K;

@@ -64,3 +64,61 @@ def test_config_sweep(name):
             assert err < abs_tol, err
         else:
             assert err < rel_tol * extent, (err, extent)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_config_chain_T1000_vs_f32_and_cpu_oracle(name):
+    """VERDICT r2 ("config 3's chain leg ... exercised, not deep"): every config of the sweep at the HEADLINE chain length, T = 1000, at
+    its own point count and with latents from its own sampler (noise_scale): the bf16 pipelined chain against the exact-fp32 chain
+    (k_denoise_pipe_f32) on identical explicit noise, and the fp32 chain against the PyTorch-CPU oracle (pinned to the reference
+    goldens) on 256 points of shape 0 walked through all 1000 steps (points are independent given the shape's part tokens).
+    Weight set and normalisation as in tests/test_gpu_headline.py (proj_out scaled by 0.05: the chain is the linear expansion by
+    1 / sqrt(alpha_t), deviations relative to the cloud extent are meaningful); part variances fixed at 0.05 so that the extent
+    is O(10) for every config.  Gates = the headline test's (3x its measured values; the measured ones here are printed)."""
+    from difffacto_amd.engine import DenoiserEngine
+    from difffacto_amd.latents import LatentSampler
+    from oracle import diffusion as odf
+    from oracle import torch_cpu as tc
+    cfg = CONFIGS[name]
+    N, B, T = cfg["npoints"], 2, 1000
+    Wn = synth.make_denoiser_weights(seed=0)
+    Wn["proj_out.weight"] = (Wn["proj_out.weight"] * 0.05).astype(np.float32)
+    Wn["proj_out.bias"] = (Wn["proj_out.bias"] * 0.05).astype(np.float32)
+    W = {k: torch.from_numpy(v) for k, v in Wn.items()}
+    sampler = LatentSampler(synth.make_latent_weights(seed=0), noise_scale=cfg["noise_scale"])
+    g = torch.Generator(device="cuda").manual_seed(len(name))
+    valid = torch.from_numpy(synth.make_latents(B, seed=len(name))[3]).cuda()
+    lat = sampler.sample_latents(torch.randn(B, 256, 4, device="cuda", generator=g), torch.randn(B, 32, device="cuda", generator=g), valid,
+                                 K=1, npoints=N)
+    mean = lat["params"][:, :3].contiguous()
+    var = torch.full_like(mean, 0.05)
+    xT = torch.randn(B, 3, N, device="cuda", generator=g)
+    zs = torch.randn(T, B, 3, N, device="cuda", generator=g)
+    out = {}
+    for prec in ("f32", "bf16"):
+        eng = DenoiserEngine(W, num_timesteps=T, precision=prec)
+        ctx = eng.prepare_shapes(lat["part_code"], mean, var, lat["valid_id"])
+        out[prec], _ = eng.sample_chain(ctx, lat["seg_mask"], x_T_noise=xT, step_noise=zs)
+        eng.close()
+    assert torch.isfinite(out["bf16"]).all() and torch.isfinite(out["f32"]).all()
+    extent = float((out["f32"].amax((1, 2)) - out["f32"].amin((1, 2))).mean())
+    rel = float((out["bf16"] - out["f32"]).abs().max()) / extent
+    sub = np.arange(0, N, N // 256)
+    tt = lambda a: a.detach().cpu().contiguous()
+    seg0 = lat["seg_mask"][:1, sub].cpu().numpy()
+    anchors, variance = odf.gather_params(seg0, tt(mean[:1]).numpy(), tt(var[:1]).numpy())
+    cx = [tt(lat["part_code"][:1]), torch.cat([tt(mean[:1]), tt(var[:1])], 1)]
+    Wt = {k: v for k, v in W.items()}
+    tb = odf.Tables(T)
+    xTs, zss = xT[:1, :, sub].cpu(), zs[:, :1][:, :, :, sub].cpu()
+    with torch.no_grad():
+        x = torch.sqrt(torch.from_numpy(variance)) * xTs + torch.from_numpy(anchors)
+        for i, t in enumerate(range(T - 1, -1, -1)):
+            x, _ = tc.p_sample(tb, Wt, x, t, torch.from_numpy(anchors), cx, torch.from_numpy(variance), torch.from_numpy(seg0),
+                               tt(lat["valid_id"][:1]), zss[i])
+    ref = x.transpose(1, 2)[0]
+    rel_or = float((out["f32"][0, sub].cpu() - ref).abs().max()) / extent
+    rel_or_bf16 = float((out["bf16"][0, sub].cpu() - ref).abs().max()) / extent
+    print(f"{name} T={T} N={N} noise_scale={cfg['noise_scale']}: extent {extent:.2f}; bf16 vs f32 / extent {rel:.3e}; f32 vs CPU oracle (256 pts) "
+          f"{rel_or:.3e}; bf16 vs oracle {rel_or_bf16:.3e}")
+    assert rel < 3.6e-5 and rel_or < 1.5e-6 and rel_or_bf16 < 3.6e-5
