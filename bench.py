@@ -145,7 +145,7 @@ def measured_traffic(T, B, N):
     """Fabric-side bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes, see
     profiles/README.md), which scales linearly with the number of diffusion steps; None if not applicable."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         if d["B"] == B and d["N"] == N:
             return d["bytes_per_step"] * T
     except Exception:

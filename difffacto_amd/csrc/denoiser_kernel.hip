@@ -1694,6 +1694,38 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
 //     k = 2 + 2j FF record j, first half:  W1 g-rows x k-tiles 0..3 (tiles 4..7 of the packed record) | W1 a-rows x k-tiles 0, 1
 //     k = 3 + 2j FF record j, second half: W1 a-rows x k-tiles 2, 3 | W2 row tiles 0..3 x hidden chunk j-1 (tiles 8..11)
 // so g is complete after the first half and the second half ends with the MFMAs that do not feed the GELU (GEMM2 of the chunk before).
+// Second half of FF record j of the fp32 chain: `a` x k-tiles 2, 3 (tiles 0, 1 of the half-record) and GEMM2 of chunk j - 1 (tiles 2..5),
+// with the erf of chunk j's g BEHIND the MFMAs: g is complete since the first half, an fp32 MFMA keeps the matrix pipe busy for 64
+// cycles after its issue, and the wave spends them on the VALU — gelu_erf(g[r]) overwrites g[r], one element per NM / 16 MFMAs
+// (erff branches per lane; that only cuts basic blocks, the MFMAs in flight do not care).  Before this the two wavefronts of a SIMD
+// reached the GELU together and the pipe idled for its whole length (80 % busy).  Same MFMA order per accumulator, same GELU
+// function on the same values: bit-identical to the direct kernel.
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void ff_f32_second_half(v16f (&h)[4], const Act<DFX_PREC_F32> (&xn)[4], v16f &a, v16f &g, Act<DFX_PREC_F32> &hid,
+                                                   const uint4 *rl) {
+  constexpr int TS = tile_units(DFX_PREC_F32) * 64;
+  constexpr int T0 = LAST ? 2 : 0, T1 = FIRST ? 2 : 6;   // tiles of the half-record that carry MFMAs here
+  constexpr int NM = (T1 - T0) * 16, PER = NM / 16;
+  v4f w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int t = T0 + m / 16, r4 = (m % 16) / 4, e = m % 4;
+    if (e == 0) w = __builtin_bit_cast(v4f, rl[t * TS + r4 * 64]);
+    if (t < 2) a = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xn[2 + t].x[4 * r4 + e], a, 0, 0, 0);
+    else h[t - 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], hid.x[4 * r4 + e], h[t - 2], 0, 0, 0);
+    if constexpr (!LAST) {
+      if ((m + 1) % PER == 0) {
+        const int r = (m + 1) / PER - 1;
+        g[r] = gelu_erf(g[r]);
+      }
+    }
+  }
+  if constexpr (!LAST) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid.x[r] = a[r] * g[r];
+  }
+}
+
 constexpr int RECORDS_F32 = 2 + 2 * FF_STAGES;
 static_assert(tile_bytes(DFX_PREC_F32) * 6 == SLOT_BYTES && asms_bytes(DFX_PREC_F32) == 33 * 1024, "fp32 ring records");
 
@@ -1861,32 +1893,29 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe_f32(const KParams p
       ln_to_act<PREC>(h, xn);
       // ---- feed-forward: 17 records of two halves; GEMM2 of chunk j-1 rides in the second half of record j ----
       Act<PREC> hid;
+      v16f a, g;
+      auto first_half = [&](int j) {   // g x k-tiles 0..3, a x k-tiles 0, 1
+        load16(a, bc + j * 64 + hf * 16);
+        load16(g, bc + j * 64 + hf * 16 + 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma_tile<PREC>(g, rec + lane + c * TS, xn[c]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) mma_tile<PREC>(a, rec + lane + (4 + c) * TS, xn[c]);
+      };
+      DFX_RECORD(rec);
+      first_half(0);
+      DFX_RECORD(rec);
+      ff_f32_second_half<true, false>(h, xn, a, g, hid, rec + lane);
 #pragma unroll 1
-      for (int j = 0; j < FF_STAGES; ++j) {
-        v16f a, g;
+      for (int j = 1; j < FF_CHUNKS; ++j) {
         DFX_RECORD(rec);
-        if (j < FF_CHUNKS) {
-          load16(a, bc + j * 64 + hf * 16);
-          load16(g, bc + j * 64 + hf * 16 + 32);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) mma_tile<PREC>(g, rec + lane + c * TS, xn[c]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) mma_tile<PREC>(a, rec + lane + (4 + c) * TS, xn[c]);
-        }
+        first_half(j);
         DFX_RECORD(rec);
-        if (j < FF_CHUNKS) {
-#pragma unroll
-          for (int c = 2; c < 4; ++c) mma_tile<PREC>(a, rec + lane + (c - 2) * TS, xn[c]);
-        }
-        if (j > 0) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) mma_tile<PREC>(h[t], rec + lane + (2 + t) * TS, hid);
-        }
-        if (j < FF_CHUNKS) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hid.x[r] = a[r] * gelu_erf(g[r]);
-        }
+        ff_f32_second_half<false, false>(h, xn, a, g, hid, rec + lane);
       }
+      DFX_RECORD(rec);   // (record 16, first half: zero tiles of the packed layout — consumed to keep the ring uniform)
+      DFX_RECORD(rec);
+      ff_f32_second_half<false, true>(h, xn, a, g, hid, rec + lane);
     }
   }
 #undef DFX_RECORD

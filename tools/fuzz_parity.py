@@ -120,6 +120,10 @@ FAMILIES = [
     # and the fused training feed-forward against the layer-by-layer kernels
     ("bf16 kernels 8/4/2-wave + co-operative: bit-identical", lambda a: td.test_small_batch_workgroup_sizes_are_bit_identical(W, *a),
      lambda: (32 * ri(3, 100),)),
+    # round 3: the exact-fp32 persistent chain (k_denoise_pipe_f32, 8 / 4 / 2 wavefronts) against the direct fp32 kernel, bit for bit;
+    # the small-batch family above now includes k_denoise_pipe2 (two point tiles per wavefront) as variant 64
+    ("f32 pipelined = direct fp32 kernel: bit-identical", lambda a: td.test_f32_pipelined_chain_is_bit_identical_to_the_direct_kernel(W, *a),
+     lambda: (32 * ri(3, 100),)),
     ("fused vs layer-by-layer training FF", lambda a: tt.test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(*a),
      lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 3), n))(32 * ri(1, 40))),
 ]
