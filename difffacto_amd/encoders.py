@@ -32,10 +32,11 @@ def _unsupported(what):
 
 
 
-def _training_generation():
-    """training.Adam updates parameters through raw pointers (no torch version bump): packed-weight caches key on its counter."""
+def _training_generation(tensors):
+    """training.Adam updates parameters through raw pointers (no torch version bump): packed-weight caches key on the generation of
+    their own parameter set (training.generation_of)."""
     from . import training
-    return training.param_generation()
+    return training.generation_of(tensors)
 
 
 class PointNetV2(nn.Module):
@@ -67,7 +68,7 @@ class PointNetV2(nn.Module):
     # ---- libdfx handle, rebuilt when a parameter / buffer changes ----
     def _handle(self):
         ts = [t for t in list(self.parameters()) + list(self.buffers()) if t.dtype == torch.float32]
-        ver = (_training_generation(),) + tuple((t._version, t.data_ptr()) for t in ts)
+        ver = (_training_generation(ts),) + tuple((t._version, t.data_ptr()) for t in ts)
         if self.__dict__.get("_h") is None or self.__dict__.get("_ver") != ver:
             self._close()
             keep = []
@@ -230,7 +231,7 @@ class _StandaloneAligner:
 
     def sampler(self):
         al = self._al()
-        ver = (_training_generation(),) + tuple(p._version for p in al.parameters())
+        ver = (_training_generation(list(al.parameters())),) + tuple(p._version for p in al.parameters())
         if self._s is None or ver != self._ver:
             sd = {"part_aligner." + k: v for k, v in al.state_dict().items()}
             self._s = LatentSampler(sd, n_class=al.n_class, zdim=al.zdim, n_heads=al.n_heads, d_head=al.d_head,
@@ -288,7 +289,7 @@ class PartEncoderForTransformerDecoder(nn.Module):
     def sampler(self):
         """The libdfx handle for the current parameters (rebuilt when a parameter was modified in place or reloaded)."""
         own = [p for n, p in self.named_parameters() if not n.startswith("encoder.")]
-        ver = (_training_generation(),) + tuple(p._version for p in own) + (own[0].device,)
+        ver = (_training_generation(own),) + tuple(p._version for p in own) + (own[0].device,)
         if self._sampler is None or ver != self._ver:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.")}
             al = self.part_aligner

@@ -109,8 +109,8 @@ class TransformerNet(nn.Module):
 
     def engine(self):
         params = dict(self.named_parameters())
-        # training.Adam updates parameters through raw pointers (no version bump): its generation counter is part of the key
-        key = (self._dfx_T, self._dfx_betas, self._dfx_precision, _training.param_generation(),
+        # training.Adam updates parameters through raw pointers (no version bump): the generation of THIS module's parameters is part of the key
+        key = (self._dfx_T, self._dfx_betas, self._dfx_precision, _training.generation_of(params.values()),
                tuple((p.data_ptr(), p._version) for p in params.values()))
         if self._engine is None or key != self._engine_key:
             dev = next(self.parameters()).device

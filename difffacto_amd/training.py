@@ -444,13 +444,17 @@ def masked_mse(target, pred, flags=None):
     return MaskedMSEFn.apply(target, pred, flags)
 
 
-_PARAM_GENERATION = [0]
+def generation_of(tensors):
+    """Generation of a parameter SET: `Adam.step` updates parameters through raw pointers, which torch's in-place version counters do
+    not see, so it bumps a counter on every tensor it steps (`_dfx_gen`); caches of packed weights (modules.TransformerNet.engine,
+    encoders.PointNetV2 / the latent samplers) key on the sum over THEIR OWN parameters — stepping one parameter set (say the stage-2
+    modules) leaves the engines and handles of every other set (a frozen stage-1 denoiser, an evaluation copy) alone."""
+    return sum(getattr(t, "_dfx_gen", 0) for t in tensors)
 
 
-def param_generation():
-    """Counter bumped by every `Adam.step`: the kernels update parameters through raw pointers, which torch's in-place
-    version counters do not see; caches of packed weights (modules.TransformerNet.engine, encoders.PointNetV2) key on it."""
-    return _PARAM_GENERATION[0]
+def _bump_generation(tensors):
+    for t in tensors:
+        t._dfx_gen = getattr(t, "_dfx_gen", 0) + 1
 
 
 class Adam:
@@ -565,7 +569,7 @@ class Adam:
         lib = _ffi.lib()
         norm = self.grad_norm() if self.max_norm and self.max_norm > 0 else None
         self.step_count += 1
-        _PARAM_GENERATION[0] += 1
+        _bump_generation(self.params)
         work = self._flat_work()
         if work is None:
             self.last_step_was_flat = False

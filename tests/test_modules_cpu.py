@@ -155,3 +155,15 @@ def test_pointnet_v2_rejects_cpu_tensors_in_every_mode():
         for grad in (False, True):
             with torch.set_grad_enabled(grad), pytest.raises(RuntimeError, match="CPU not supported"):
                 enc(x, attn)
+
+
+def test_parameter_generation_is_per_parameter_set():
+    """an optimiser step on one parameter set must not invalidate the packed-weight caches of another (they key on
+    training.generation_of(their own parameters), which Adam.step bumps per stepped tensor)."""
+    import torch
+    from difffacto_amd import training
+    a, b = [torch.zeros(3), torch.zeros(2, 2)], [torch.zeros(5)]
+    assert training.generation_of(a) == 0 and training.generation_of(b) == 0
+    training._bump_generation(a)
+    training._bump_generation(a)
+    assert training.generation_of(a) == 4 and training.generation_of(b) == 0 and training.generation_of(a[:1]) == 2
