@@ -1840,12 +1840,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe_f32(const KParams p
 
   // record boundary: this wave's pieces of the record after next have landed, everybody is done with the slot that is refilled next
   // (ring protocol of k_denoise_pipe), then the pieces of the record three ahead are issued
+#ifdef DFX_TRACE   // phase stamps of waves 0 and 4 (one SIMD) of workgroup 0: tools/trace_f32.py
+  Tracer tr{(p.trace != nullptr && bid == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr, p.trace_cap, 0};
+#else
+  Tracer tr;
+#endif
 #define DFX_RECORD(ptr)                                                                      \
   do {                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                       \
+    tr.stamp(1);                                                                             \
     wait_vmcnt<PipeCfg<NW>::CALLS>();                                                        \
     __builtin_amdgcn_s_barrier();                                                            \
+    tr.stamp(2);                                                                             \
     issue_record_f32<NW>(p, dma, wave, voff, lds0, s);                                       \
+    tr.stamp(3);                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     ptr = reinterpret_cast<const uint4 *>(pipe_smem + L_RING + cur * SLOT_BYTES);            \
     cur = cur + 1 == NSLOT ? 0 : cur + 1;                                                    \
