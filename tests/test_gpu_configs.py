@@ -74,7 +74,8 @@ def test_config_chain_T1000_vs_f32_and_cpu_oracle(name):
     goldens) on 256 points of shape 0 walked through all 1000 steps (points are independent given the shape's part tokens).
     Weight set and normalisation as in tests/test_gpu_headline.py (proj_out scaled by 0.05: the chain is the linear expansion by
     1 / sqrt(alpha_t), deviations relative to the cloud extent are meaningful); part variances fixed at 0.05 so that the extent
-    is O(10) for every config.  Gates = the headline test's (3x its measured values; the measured ones here are printed)."""
+    is O(10) for every config.  Measured (profiles/r03_parity_prints.txt): bf16 vs fp32 1.5e-5 / 1.5e-5 / 1.9e-5 of the extent (airplane / car /
+    lamp), fp32 vs the CPU oracle 1.3e-6 / 8.6e-7 / 1.2e-6, bf16 vs the oracle 1.3e-5 / 1.4e-5 / 1.8e-5; gates at 3x the largest."""
     from difffacto_amd.engine import DenoiserEngine
     from difffacto_amd.latents import LatentSampler
     from oracle import diffusion as odf
@@ -121,4 +122,4 @@ def test_config_chain_T1000_vs_f32_and_cpu_oracle(name):
     rel_or_bf16 = float((out["bf16"][0, sub].cpu() - ref).abs().max()) / extent
     print(f"{name} T={T} N={N} noise_scale={cfg['noise_scale']}: extent {extent:.2f}; bf16 vs f32 / extent {rel:.3e}; f32 vs CPU oracle (256 pts) "
           f"{rel_or:.3e}; bf16 vs oracle {rel_or_bf16:.3e}")
-    assert rel < 3.6e-5 and rel_or < 1.5e-6 and rel_or_bf16 < 3.6e-5
+    assert rel < 5.8e-5 and rel_or < 4e-6 and rel_or_bf16 < 5.4e-5
