@@ -463,32 +463,75 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     v16f av, gv;
     load16(av, b1s + ((j * 2 + 0) * 2 + hf) * 16);
     load16(gv, b1s + ((j * 2 + 1) * 2 + hf) * 16);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        av = mfma(frag(T_W1A + c, u), xn[c][u], av);
-        gv = mfma(frag(T_W1G + c, u), xn[c][u], gv);
-      }
     if (!BWD) {
+      // Forward: the chunk's 24 A fragments go through a ring of eight registers (the sampling kernel's scheme): MFMA m takes P[m & 7],
+      // which is refilled in place with fragment m + 8 — GEMM2's eight W2 fragments are requested during GEMM1's second half and have
+      // landed long before the GELU is done.  One exposed LDS round trip per chunk; left to itself hipcc requested every fragment one
+      // or two MFMAs ahead of its use and waited for it (lgkmcnt(0 / 1) in front of nearly every MFMA).
+      // GEMM1 MFMA m: k-tile c = m >> 2, unit u = (m >> 1) & 1, a / g = m & 1;  GEMM2 MFMA i: row tile ct = i & 3, unit u = i >> 2
+      auto f1 = [&](int m) -> uint4 { return frag(((m & 1) ? T_W1G : T_W1A) + (m >> 2), (m >> 1) & 1); };
+      auto f2 = [&](int i) -> uint4 { return frag(T_W2 + (i & 3), i >> 2); };
+      uint4 P[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) P[i] = f1(i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if (m & 1) gv = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], gv);
+        else av = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], av);
+        P[m & 7] = m + 8 < 16 ? f1(m + 8) : f2(m + 8 - 16);
+      }
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       v16f hv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) hv[r] = av[r] * gelu_f(gv[r]);
       const uint4 h0 = pack8(hv, 0), h1 = pack8(hv, 1);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        acc[ct] = mfma(frag(T_W2 + ct, 0), h0, acc[ct]);
-        acc[ct] = mfma(frag(T_W2 + ct, 1), h1, acc[ct]);
-      }
+      for (int i = 0; i < 8; ++i) acc[i & 3] = mfma(P[i], (i >> 2) ? h1 : h0, acc[i & 3]);
     } else {
-      // ---- d hid = W2^T dh ----
+      // Backward, first burst: GEMM1 recompute (16 MFMAs) and d hid = W2^T dh (8) are independent of each other — one stream of 24
+      // MFMAs through the same ring of eight fragment registers (one exposed LDS round trip).
+      auto f1 = [&](int m) -> uint4 {
+        return m < 16 ? frag(((m & 1) ? T_W1G : T_W1A) + (m >> 2), (m >> 1) & 1) : frag(T_W2T + ((m - 16) >> 1), (m - 16) & 1);
+      };
+      uint4 P[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) P[i] = f1(i);
       v16f dhid;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dhid[r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int m = 0; m < 24; ++m) {
+        if (m >= 16) dhid = mfma(P[m & 7], dhb[(m - 16) >> 1][(m - 16) & 1], dhid);
+        else if (m & 1) gv = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], gv);
+        else av = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], av);
+        if (m + 8 < 24) P[m & 7] = f1(m + 8);
+      }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dhid = mfma(frag(T_W2T + c, u), dhb[c][u], dhid);
+      for (int m = 0; m < 16; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- item boundary: item 2 j + 1 must have landed (loads complete in order: only the six pieces of item 2 j + 2, requested at the
+      // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3.  The boundary sits in FRONT
+      // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
+      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
+      const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
+      // second burst, MFMA m: row tile ct = m & 3, operand q = m >> 2 (W1a^T unit 0, unit 1, W1g^T unit 0, unit 1: the order per accumulator)
+      auto f2 = [&](int m) -> uint4 { return fr2[(lt<BWD>(((m >> 2) < 2 ? T_W1AT : T_W1GT) + (m & 3)) * 2 + ((m >> 2) & 1)) * 64]; };
+#pragma unroll
+      for (int i = 0; i < 8; ++i) P[i] = f2(i);
+      __builtin_amdgcn_sched_barrier(0);
       // ---- GEGLU backward on the registers ----
       v16f da, dg;
 #pragma unroll
@@ -499,22 +542,20 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         dg[r] = dhid[r] * av[r] * d;
       }
       const uint4 a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
-      // ---- item boundary: item 2 j + 1 must have landed (loads complete in order: only the six pieces of item 2 j + 2, requested at the
-      // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3 ----
-      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
-      const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
-      auto frag2 = [&](int t, int u) -> uint4 { return fr2[(lt<BWD>(t) * 2 + u) * 64]; };
+      __builtin_amdgcn_sched_barrier(0);
       // ---- dxn3 += W1a^T da + W1g^T dg ----
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        acc[ct] = mfma(frag2(T_W1AT + ct, 0), a0, acc[ct]);
-        acc[ct] = mfma(frag2(T_W1AT + ct, 1), a1, acc[ct]);
-        acc[ct] = mfma(frag2(T_W1GT + ct, 0), g0, acc[ct]);
-        acc[ct] = mfma(frag2(T_W1GT + ct, 1), g1, acc[ct]);
+      for (int m = 0; m < 16; ++m) {
+        const int q = m >> 2;
+        acc[m & 3] = mfma(P[m & 7], q == 0 ? a0 : q == 1 ? a1 : q == 2 ? g0 : g1, acc[m & 3]);
+        if (m + 8 < 16) P[m & 7] = f2(m + 8);
       }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // chunk j + 1 must have landed: loads complete in order, so "at most PIECES outstanding" leaves only chunk j + 2's pieces
     // (whatever the order between loads and the backward's stores); no new pieces in the last two iterations -> drain
