@@ -193,8 +193,9 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
         assert e_max < 2e-2 and e_l2 < 1.3e-2, (k, e_max, e_l2)
     print(f"fused vs layer-by-layer FF (B={B}, N={N}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
-    # measured: loss 4.8e-5 relative, eps 2.4e-3 (gates at 3x)
-    assert abs(fused["loss"] - layer["loss"]) < 1.5e-4 * abs(layer["loss"]) and e_eps < 7.2e-3
+    # measured over the three shapes here and ~120 random ones (tools/fuzz_parity.py, r03): loss up to 1.9e-4 relative, eps up to 3.3e-3 -> 3x
+    e_loss = abs(fused["loss"] - layer["loss"]) / abs(layer["loss"])
+    assert e_loss < 6e-4 and e_eps < 1e-2, (e_loss, e_eps)
 
 
 def test_attention_inside_the_feed_forward_kernels_matches_the_separate_attention_kernels():
