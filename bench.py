@@ -503,7 +503,8 @@ def main():
                        "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
                        "total_shapes": total, "weights_bcast_ms": bcast_ms, "weights_bcast_bytes": bcast_bytes},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(T, B, N), "kernel": "k_denoise_pipe (persistent T-step chain)", "kernel_ms": kern_ms,
+                         "traffic": measured_traffic(T, B, N) if args.precision == "bf16" else None,
+                         "kernel": ("k_denoise_pipe" if args.precision == "bf16" else "k_denoise_pipe_f32") + " (persistent T-step chain)", "kernel_ms": kern_ms,
                          "flops_per_launch": F},
         }
         if args.precision == "bf16":
