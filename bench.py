@@ -40,7 +40,55 @@ def flops_per_step(N, depth=5):
     return 2 * (N * per_point + depth * 2 * 4 * 522 * 128 + 256 * 2048 + 1024 * 256)
 
 
-SUSTAINED_BF16_TFLOPS = 1630.0   # 24 x 8 x 256 MFMAs of 32768 FLOP per 988 ns record (profiles/r01_ubench_power.txt)
+def rccl_transport_summary():
+    """Version banner + distinct channel transports from this process's NCCL_DEBUG_FILE (see main()), or None."""
+    import re
+    path = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        version, via = None, {}
+        for line in open(path, errors="replace"):
+            if version is None and ("RCCL version" in line or "NCCL version" in line):
+                version = line.strip()[-120:]
+            m = re.search(r"via (\S+)", line)
+            if m:
+                via[m.group(1)] = via.get(m.group(1), 0) + 1
+        return {"banner": version, "channels_via": via}
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)[:120]}
+
+
+def _newest_profile(pattern):
+    """Newest committed profiles/rNN_<pattern> (by round number), or None."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)):
+        r = int(re.match(r"r(\d+)_", os.path.basename(f)).group(1))
+        if best is None or r > best[0]:
+            best = (r, f)
+    return best
+
+
+def power_limited_ceiling():
+    """What the chip sustains on bare MFMA streams with random bf16 operands at the 1.4 kW cap, from the newest committed run of
+    tools/ubench/pair_issue.hip (full-chip rows, TFLOP/s of EXECUTED MFMAs): bare MFMAs, + one LDS fragment refill per MFMA, + the
+    kernel's own mix (refill per MFMA + 5 packed VALU per MFMA).  Context for `frac`, not a replacement for the nominal peak."""
+    import re
+    best = _newest_profile("ubench_pair_issue.txt")
+    if best is None:
+        return None
+    rows = {}
+    for line in open(best[1]):
+        m = re.match(r"(.+?)\s+blocks\s+(\d+):.*-> (\d+) TFLOP/s", line)
+        if m and int(m.group(2)) > 1:
+            rows[m.group(1).strip()] = float(m.group(3))
+    pick = lambda k: rows.get(k)
+    return {"source": os.path.relpath(best[1], ROOT), "round": f"r{best[0]:02d}",
+            "bare_mfma_tflops": pick("C/D VGPR, B VGPR, no refill, no filler"),
+            "refill_per_mfma_tflops": pick("C/D AGPR, refill per MFMA (own A)"),
+            "kernel_mix_tflops": pick("C/D AGPR, refill per MFMA, 5 v_pk per MFMA")}
 
 
 def train_iteration(Wnp, B, N, iters=4):
@@ -142,15 +190,20 @@ def stage1_iteration(B, N, iters=4, encoder_precision="f32"):
 
 
 def measured_traffic(T, B, N):
-    """Fabric-side bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes, see
-    profiles/README.md), which scales linearly with the number of diffusion steps; None if not applicable."""
+    """Fabric-side bytes per launch from the newest committed PMC profile (profiles/rNN_traffic.json: separate rocprofv3 --pmc
+    passes of this command, see profiles/README.md — counters cannot be read from inside the run), which scales linearly with the
+    number of diffusion steps.  Returns (bytes or None, provenance or None): the bench line names the file and round it came from."""
+    best = _newest_profile("traffic.json")
+    if best is None:
+        return None, None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        d = json.load(open(best[1]))
         if d["B"] == B and d["N"] == N:
-            return d["bytes_per_step"] * T
+            return d["bytes_per_step"] * T, {"file": os.path.relpath(best[1], ROOT), "round": d.get("round", f"r{best[0]:02d}"),
+                                             "T_profiled": d.get("T_profiled"), "note": "PMC pass of an earlier run of this command, scaled by T; not measured in this run"}
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(W, N, budget_s=20.0):
@@ -209,23 +262,27 @@ def cpu_baseline(W, N, budget_s=20.0):
             "ms_per_step_per_shape": s_per_step_shape * 1e3}
 
 
-def parity_block(Wnp, N, T=100, B=2):
+def parity_block(Wnp, N, T=100, B=2, B_gpu=32):
     """BASELINE.md §3 / SURVEY.md §8(d) 'quality parity', from the same run and outside the timed region: the bf16 HIP chain
-    (the headline kernel) and the exact-fp32 HIP chain against the PyTorch-CPU oracle (oracle/torch_cpu.py, pinned to the
-    reference goldens) on IDENTICAL explicit noise, B shapes x N points, T steps: max-abs point deviation, Chamfer-L2 and
-    auction EMD (the evaluation's setting 0.002 / 10000 on unit-box-normalised clouds; libdfx's own metric kernels)."""
+    and the exact-fp32 HIP chain against the PyTorch-CPU oracle (oracle/torch_cpu.py, pinned to the reference goldens) on
+    IDENTICAL explicit noise, T steps: max-abs point deviation, Chamfer-L2 and auction EMD (the evaluation's setting 0.002 / 10000
+    on unit-box-normalised clouds; libdfx's own metric kernels).  The HIP side runs B_gpu = 32 shapes x N points — a batch at which
+    the launcher takes the HEADLINE kernels (k_denoise_pipe<8> / k_denoise_pipe_f32<8>, one workgroup per CU; the variant that ran is
+    reported per precision) — and the oracle walks the first B of them (shapes are independent)."""
     from oracle import diffusion as odf
     from oracle import torch_cpu as tc
-    from difffacto_amd.engine import DenoiserEngine
+    from difffacto_amd.engine import DenoiserEngine, last_kernel_variant
     from difffacto_amd.metrics import EMD, chamfer_l2
     try:
-        pc, mean, logvar, valid = synth.make_latents(B, seed=5)
-        var = np.exp(logvar).astype(np.float32)
-        seg = synth.make_seg_mask(valid, N)
-        anchors, variance = odf.gather_params(seg, mean, var)
+        pc_g, mean_g, logvar_g, valid_g = synth.make_latents(B_gpu, seed=5)
+        var_g = np.exp(logvar_g).astype(np.float32)
+        seg_g = synth.make_seg_mask(valid_g, N)
         g = torch.Generator().manual_seed(T)
-        xT = torch.randn(B, 3, N, generator=g)
-        zs = torch.randn(T, B, 3, N, generator=g)
+        xT_g = torch.randn(B_gpu, 3, N, generator=g)
+        zs_g = torch.randn(T, B_gpu, 3, N, generator=g)
+        pc, mean, var, valid, seg = pc_g[:B], mean_g[:B], var_g[:B], valid_g[:B], seg_g[:B]
+        xT, zs = xT_g[:B], zs_g[:, :B]
+        anchors, variance = odf.gather_params(seg, mean, var)
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
         Wt = {k: tt(v) for k, v in Wnp.items()}
         tb = odf.Tables(T)
@@ -237,8 +294,9 @@ def parity_block(Wnp, N, T=100, B=2):
                 x, _ = tc.p_sample(tb, Wt, x, t, tt(anchors), ctx, tt(variance), tt(seg), tt(valid), zs[i])
         ref = x.transpose(1, 2).contiguous().cuda()
         cpu_s = time.perf_counter() - t0
-        out = {"what": f"HIP chain vs PyTorch-CPU oracle on identical explicit noise: {B} shapes x {N} pts, T={T}; part sigma "
-                       f"~{float(np.sqrt(var).mean()):.3f}; EMD on unit-box-normalised clouds (eps 0.002, 10000 iterations)",
+        out = {"what": f"HIP chain ({B_gpu} shapes x {N} pts in the launch) vs PyTorch-CPU oracle on identical explicit noise, compared on the "
+                       f"first {B} shapes, T={T}; part sigma ~{float(np.sqrt(var).mean()):.3f}; EMD on unit-box-normalised clouds (eps 0.002, "
+                       f"10000 iterations)",
                "oracle_cpu_s": cpu_s}
 
         def emd_pair(x, y):
@@ -247,10 +305,12 @@ def parity_block(Wnp, N, T=100, B=2):
             return EMD(0.002, 10000, True)(((x - lo) / (hi - lo)).contiguous(), ((y - lo) / (hi - lo)).contiguous())
         for prec in ("bf16", "f32"):
             eng = DenoiserEngine(Wt, T, precision=prec)
-            c = eng.prepare_shapes(tt(pc), tt(mean), tt(var), tt(valid))
-            pred, _ = eng.sample_chain(c, tt(seg), x_T_noise=xT, step_noise=zs)
+            c = eng.prepare_shapes(tt(pc_g), tt(mean_g), tt(var_g), tt(valid_g))
+            pred, _ = eng.sample_chain(c, tt(seg_g), x_T_noise=xT_g, step_noise=zs_g)
+            variant = last_kernel_variant()
             eng.close()
-            out[prec] = {"max_abs": float((pred - ref).abs().max()), "mean_abs": float((pred - ref).abs().mean()),
+            pred = pred[:B].contiguous()
+            out[prec] = {"kernel_variant": variant, "max_abs": float((pred - ref).abs().max()), "mean_abs": float((pred - ref).abs().mean()),
                          "chamfer_l2": float(chamfer_l2(pred, ref).mean()), "emd": float(emd_pair(pred, ref).mean())}
         return out
     except Exception as e:   # secondary block: never fail the headline measurement
@@ -389,6 +449,12 @@ def main():
         ndev = torch.cuda.device_count()
         torch.cuda.set_device(local_rank % ndev)
         if backend == "nccl":
+            # day-one evidence of what RCCL did: its version banner and the transport of every channel ("via P2P/IPC" = xGMI peer
+            # access, "via SHM" = host bounce) go to a per-process file that rank 0 summarises into the JSON line
+            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,P2P,SHM,NET"
+                os.environ["NCCL_DEBUG_FILE"] = f"/tmp/dfx_rccl_{os.getpid()}.log"
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
         else:
             dist.init_process_group(backend)
@@ -397,7 +463,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from difffacto_amd.engine import DenoiserEngine
-    from difffacto_amd.parallel import broadcast_params, gather_clouds
+    from difffacto_amd.parallel import broadcast_params, collective_library, gather_clouds, probe_gather
 
     N, T = args.npoints, args.timesteps
     # The JOB: `total` shapes, block-partitioned over the ranks (parallel.shard_range).  Weak scaling (default): --batch shapes per
@@ -427,6 +493,7 @@ def main():
         from difffacto_amd.parallel import describe_world
         world_seen = describe_world(dev)          # backend, world size and device of every rank as the process group reports them
         assert world_seen["world_size"] == world
+        gather_info = probe_gather(dev)           # one tiny rooted gather; all ranks fall back to all_gather together if it raises
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         broadcast_params(params, src=0)
@@ -482,6 +549,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    from difffacto_amd.engine import last_kernel_variant
+    variant = last_kernel_variant()           # the kernel the timed launches took (dfx_last_kernel_variant)
+    rank_ms = None
+    if dist is not None:
+        from difffacto_amd.parallel import all_gather_floats
+        rank_ms = all_gather_floats([kern_ms, dt * 1e3 / args.steps], dev)   # per rank: chain kernel ms, wall ms per step
 
     if rank == 0:
         assert out is not None and torch.isfinite(out).all()
@@ -490,6 +563,7 @@ def main():
             np.save(args.dump_clouds, out.cpu().numpy())
         value = total * args.steps / dt
         F = flops_per_step(N) * T * B                      # algorithmic FLOPs per launch (one rank)
+        traffic, traffic_src = measured_traffic(T, B, N) if args.precision == "bf16" else (None, None)
         achieved = F / (kern_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         res = {
@@ -503,20 +577,19 @@ def main():
                        "batch_per_gpu": B, "npoints": N, "num_timesteps": T, "parallelism": f"dp{world} (independent shapes)",
                        "total_shapes": total, "weights_bcast_ms": bcast_ms, "weights_bcast_bytes": bcast_bytes},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(T, B, N) if args.precision == "bf16" else None,
-                         "kernel": ("k_denoise_pipe" if args.precision == "bf16" else "k_denoise_pipe_f32") + " (persistent T-step chain)", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": variant + " (persistent T-step chain)", "kernel_variant": variant, "kernel_ms": kern_ms,
                          "flops_per_launch": F},
         }
         if args.precision == "bf16":
-            # the same MFMA + LDS-fragment-read stream with random bf16 operands, no other work (tools/ubench/swp_law.hip
-            # power -> profiles/r01_ubench_power.txt): the chip throttles its clock on real data, this is what it sustains
-            res["roofline"]["sustained_mfma_tflops_random_operands"] = SUSTAINED_BF16_TFLOPS
-            res["roofline"]["frac_of_sustained"] = achieved / SUSTAINED_BF16_TFLOPS
+            res["roofline"]["power_limited_ceiling"] = power_limited_ceiling()
         res["config"]["shapes_gathered"] = int(out.shape[0])
         if world_seen is not None:   # what the process group itself reports: the SCALE record shows the collective library saw N ranks
             res["config"].update({"backend": world_seen["backend"], "world_size_seen": world_seen["world_size"],
                                   "rank_devices": world_seen["devices"], "visible_gpus": torch.cuda.device_count(),
-                                  "gather": os.environ.get("DFX_GATHER", "gather"), "shapes_per_rank": sizes})
+                                  "gather": gather_info["gather"], "gather_fallback": gather_info["fallback"], "shapes_per_rank": sizes,
+                                  "collective_library": collective_library(), "transport": rccl_transport_summary(),
+                                  "rank_kernel_ms": [r[0] for r in rank_ms], "rank_wall_ms_per_step": [r[1] for r in rank_ms]})
         if world == 1 and not args.no_parity:
             res["parity"] = parity_block(Wnp, N)
             res["t100"] = t100_line(params, names, B, N, args.precision, dev)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdfx.so")
 DFX_PREC_F32 = 0
 DFX_PREC_BF16 = 1
 DFX_MAX_DEPTH = 8
-DFX_ABI_VERSION = 2   # include/dfx.h: the argument lists this binding was written against
+DFX_ABI_VERSION = 3   # include/dfx.h: the argument lists this binding was written against
 
 
 class DfxLibraryError(RuntimeError):
@@ -136,6 +136,7 @@ SIGNATURES = {
     "dfx_debug_trace": (None, [_P, _I]),
     "dfx_set_event_timing": (None, [_I]),
     "dfx_last_kernel_ms": (_F, []),
+    "dfx_last_kernel_variant": (ctypes.c_char_p, []),
 }
 
 _lib = None

@@ -2377,16 +2377,18 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   }
   EventTimer tm;
   tm.begin(st);
-  if (pipe2) k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
-  else if (coop) k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
-  else if (pipe && nw == 8) k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
-  else if (pipe && nw == 4) k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
-  else if (pipe) k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
-  else if (pipe_f32 && nw == 8) k_denoise_pipe_f32<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
-  else if (pipe_f32 && nw == 4) k_denoise_pipe_f32<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
-  else if (pipe_f32) k_denoise_pipe_f32<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
-  else if (d->dev.prec == DFX_PREC_BF16) k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
-  else k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
+  const char *variant;
+  if (pipe2) variant = "k_denoise_pipe2", k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
+  else if (coop) variant = "k_denoise_coop", k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
+  else if (pipe && nw == 8) variant = "k_denoise_pipe<8>", k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
+  else if (pipe && nw == 4) variant = "k_denoise_pipe<4>", k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
+  else if (pipe) variant = "k_denoise_pipe<2>", k_denoise_pipe<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
+  else if (pipe_f32 && nw == 8) variant = "k_denoise_pipe_f32<8>", k_denoise_pipe_f32<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
+  else if (pipe_f32 && nw == 4) variant = "k_denoise_pipe_f32<4>", k_denoise_pipe_f32<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
+  else if (pipe_f32) variant = "k_denoise_pipe_f32<2>", k_denoise_pipe_f32<2><<<(int)(wpg * p.B), 2 * 64, PipeCfg<2>::L_TOTAL, st>>>(p);
+  else if (d->dev.prec == DFX_PREC_BF16) variant = "k_denoise<bf16>", k_denoise<DFX_PREC_BF16, NW><<<(int)grid, NW * 64, 0, st>>>(p);
+  else variant = "k_denoise<f32>", k_denoise<DFX_PREC_F32, NW><<<(int)grid, NW * 64, 0, st>>>(p);
+  g_last_variant = variant;
   const int rc = check_launch("denoiser kernel");
   tm.end();
   return rc;

@@ -69,5 +69,6 @@ struct EventTimer {
 };
 extern bool g_event_timing;
 extern float g_last_ms;
+extern const char *g_last_variant;   // name of the denoiser kernel the last launch() took (dfx_last_kernel_variant)
 
 }  // namespace dfx

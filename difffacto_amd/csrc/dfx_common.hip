@@ -19,6 +19,7 @@ int set_error(int code, const char *fmt, ...) {
 
 bool g_event_timing = false;
 float g_last_ms = -1.0f;
+const char *g_last_variant = "";
 
 void EventTimer::begin(hipStream_t s) {
   active = g_event_timing;
@@ -54,5 +55,7 @@ const char *dfx_last_error(void) { return dfx::err_buf(); }
 void dfx_set_event_timing(int enable) { dfx::g_event_timing = enable != 0; }
 
 float dfx_last_kernel_ms(void) { return dfx::g_last_ms; }
+
+const char *dfx_last_kernel_variant(void) { return dfx::g_last_variant; }
 
 }  // extern "C"

@@ -53,6 +53,11 @@ def _dev_f32(t, name, device):
     return t
 
 
+def last_kernel_variant():
+    """Name of the denoiser kernel the most recent launch took (``dfx_last_kernel_variant``), e.g. ``"k_denoise_pipe<8>"``."""
+    return _ffi.lib().dfx_last_kernel_variant().decode()
+
+
 class ShapeContext:
     """Per-batch static operands living in one device buffer (dfx_shape_ctx_prepare)."""
 

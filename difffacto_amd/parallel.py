@@ -83,12 +83,73 @@ def gather_clouds(pred, dst=0, sizes=None):
     return None
 
 
+_MODE_OVERRIDE = None   # set by probe_gather() when the rooted gather failed on some rank
+
+
 def _gather_mode():
     import os
+    if _MODE_OVERRIDE is not None:
+        return _MODE_OVERRIDE
     mode = os.environ.get("DFX_GATHER", "gather")
     if mode not in ("gather", "all_gather"):
         raise ValueError(f"DFX_GATHER={mode!r}: expected 'gather' or 'all_gather'")
     return mode
+
+
+def probe_gather(device=None):
+    """Day-one guard for a collective library this code has not met yet: every rank tries ONE tiny rooted gather; if it raises on
+    any rank (agreed through an all_reduce(MIN) of the success flags, so that all ranks switch together), gather_clouds() uses
+    all_gather from then on.  Returns {"gather": mode in use, "fallback": None or the first error text}.  A collective that HANGS
+    cannot be rescued from inside the process; DFX_GATHER=all_gather skips the rooted gather altogether."""
+    global _MODE_OVERRIDE
+    if not dist.is_initialized() or dist.get_world_size() == 1 or _gather_mode() == "all_gather":
+        return {"gather": _gather_mode(), "fallback": None}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    err = None
+    try:
+        t = torch.full((4,), float(rank), device=dev)
+        if rank == 0:
+            bufs = [torch.empty_like(t) for _ in range(world)]
+            dist.gather(t, gather_list=bufs, dst=0)
+            if dev != "cpu":
+                torch.cuda.synchronize()
+            if [float(b[0]) for b in bufs] != [float(r) for r in range(world)]:
+                raise RuntimeError("rooted gather returned wrong blocks")
+        else:
+            dist.gather(t, gather_list=None, dst=0)
+            if dev != "cpu":
+                torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001 - whatever the backend raises
+        err = repr(e)[:200]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        _MODE_OVERRIDE = "all_gather"
+        return {"gather": "all_gather", "fallback": err or "the rooted gather failed on another rank"}
+    return {"gather": "gather", "fallback": None}
+
+
+def all_gather_floats(values, device=None):
+    """Every rank's list of floats -> (world, len) nested list on every rank (one small all_gather): per-rank kernel times for the
+    bench line, so that a straggler GPU is visible."""
+    v = [float(x) for x in values]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [v]
+    dev = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    mine = torch.tensor(v, dtype=torch.float64, device=dev)
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return [[float(x) for x in g.cpu()] for g in got]
+
+
+def collective_library():
+    """Version of the collective library behind the "nccl" backend (RCCL on ROCm) as torch reports it, or None."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:   # noqa: BLE001 - CPU-only torch builds, missing symbol
+        return None
 
 
 def describe_world(device=None):

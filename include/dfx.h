@@ -40,7 +40,7 @@ int dfx_version(void);
 /* Bumped whenever an existing entry point changes its argument list (round 2 inserted `shape_offset` into the four sampling
  * calls: 2).  Bindings compare dfx_abi_version() with the DFX_ABI_VERSION they were written against at load time (_ffi.py does)
  * instead of shifting arguments silently. */
-#define DFX_ABI_VERSION 2
+#define DFX_ABI_VERSION 3
 int dfx_abi_version(void);
 const char *dfx_last_error(void);
 
@@ -433,6 +433,11 @@ int dfx_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
  * dfx_p_sample / dfx_denoise_eps launch measured with HIP events on `stream` when profiling is enabled. */
 void dfx_set_event_timing(int enable);
 float dfx_last_kernel_ms(void);
+/* Which kernel the last dfx_sample_chain / dfx_p_sample / dfx_denoise_eps (and their _ddim / _t forms) launched on this host
+ * thread's process: "k_denoise_pipe<8>", "k_denoise_pipe<4>", "k_denoise_pipe<2>", "k_denoise_coop", "k_denoise_pipe2",
+ * "k_denoise_pipe_f32<8|4|2>", "k_denoise<bf16>", "k_denoise<f32>" ("" before the first launch).  The choice is made from the
+ * batch shape; every variant of one precision produces the same bits.  Static storage, never NULL. */
+const char *dfx_last_kernel_variant(void);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,8 @@ import numpy as np
 import pytest
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tests/_variants.py
+
 pytestmark = pytest.mark.gpu
 
 from difffacto_amd import synth  # noqa: E402
@@ -27,7 +29,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #   f32_oracle exact-fp32 HIP chain vs the PyTorch-CPU oracle on a 256-point subset / extent (measured 4.8e-7)
 #   cd         Chamfer-L2(bf16, fp32) / extent^2                                             (measured 6.0e-11)
 #   emd        auction EMD(bf16, fp32) on the unit-box-normalised clouds                     (measured 5.0e-6)
-GATES = {"contractive": dict(bf16_f32=3.6e-5, f32_oracle=1.5e-6, cd=1.8e-10, emd=1.5e-5),
+GATES = {"contractive": dict(bf16_f32=3.6e-5, f32_oracle=5e-6,   # f32_oracle: ~10x measured (CPU BLAS summation order varies by host)
+                                cd=1.8e-10, emd=1.5e-5),
          # the random-init set is chaotic over 1000 steps (no oracle leg: fp32 rounding differences between two fp32
          # implementations grow the same way); it is kept as the worst case for the bf16 deviation
          "random-init": dict(bf16_f32=9e-4, f32_oracle=None, cd=6.5e-8, emd=2.8e-4)}   # measured 3.1e-4, 2.2e-8, 9.3e-5
@@ -47,8 +50,12 @@ def _engine(W, T, prec):
     return DenoiserEngine({k: torch.from_numpy(v) for k, v in W.items()}, num_timesteps=T, precision=prec)
 
 
-@pytest.mark.parametrize("wset", ["contractive", "random-init"])
-def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle(wset):
+@pytest.mark.parametrize("wset,nw", [("contractive", 8), ("random-init", 8), ("contractive", 0)])
+def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle(wset, nw):
+    """nw = 8: the kernels bench.py times at B = 128 — `k_denoise_pipe<8>` (bf16) and `k_denoise_pipe_f32<8>` (fp32) — FORCED
+    (at B = 8 the launcher would otherwise take the co-operative kernel / two-wavefront workgroups) and asserted through
+    dfx_last_kernel_variant; nw = 0 keeps the automatic choice covered."""
+    from _variants import forced, ran
     from difffacto_amd.metrics import EMD, chamfer_l2
     from oracle import diffusion as odf
     from oracle import torch_cpu as tc
@@ -63,10 +70,14 @@ def test_headline_T1000_N2048_bf16_pipe_vs_f32_and_oracle(wset):
     zs = torch.randn(T, B, 3, N, device="cuda", generator=g)
     args = tuple(map(torch.from_numpy, (pc, mean, var, valid)))
     out = {}
+    took = {}
     for prec in ("f32", "bf16"):
         eng = _engine(W, T, prec)
-        out[prec], _ = eng.sample_chain(eng.prepare_shapes(*args), torch.from_numpy(seg), x_T_noise=xT, step_noise=zs)
+        with forced(nw):
+            out[prec], _ = eng.sample_chain(eng.prepare_shapes(*args), torch.from_numpy(seg), x_T_noise=xT, step_noise=zs)
+            took[prec] = ran(prec, nw)
         eng.close()
+    print(f"headline[{wset}] kernels: bf16 -> {took['bf16']}, f32 -> {took['f32']}")
     assert torch.isfinite(out["bf16"]).all() and torch.isfinite(out["f32"]).all()
     extent = float((out["f32"].amax((1, 2)) - out["f32"].amin((1, 2))).mean())
     rel = float((out["bf16"] - out["f32"]).abs().max()) / extent

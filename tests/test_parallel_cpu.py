@@ -174,3 +174,53 @@ def test_linear_lr_matches_the_reference_schedule():
     for e in (0, 1, 3999, 4000, 4001, 6000, 7999, 8000, 8001, 20000):
         assert abs(linear_lr(e, start_epoch, end_epoch, start_lr, end_lr) - start_lr * lr_func(e)) < 1e-15
     assert linear_lr(6000, start_epoch, end_epoch, start_lr, end_lr) == pytest.approx(1.05e-3)
+
+
+def _probe_worker(rank, world, port, q, break_gather):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("DFX_GATHER", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if break_gather and rank == 1:
+            # a collective library whose rooted gather raises on ONE rank only: every rank must still switch, together
+            real = dist.gather
+
+            def broken(*a, **k):
+                real(*a, **k)                      # take part in the collective (the others would hang otherwise), then fail
+                raise RuntimeError("rooted gather is broken here")
+            dist.gather = broken
+        info = parallel.probe_gather("cpu")
+        dist.gather = getattr(dist, "gather")
+        lo, hi = parallel.shard_range(5, rank, world)
+        mine = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 3).contiguous()
+        if break_gather:
+            def never(*a, **k):
+                raise AssertionError("the rooted gather must not be used after the fallback")
+            dist.gather = never
+        got = parallel.gather_clouds(mine, dst=0, sizes=[3, 2])
+        ok = torch.equal(got, torch.arange(5, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 3)) if rank == 0 else got is None
+        times = parallel.all_gather_floats([10.0 + rank, 2.0 * rank], "cpu")
+        ok = ok and times == [[10.0, 0.0], [11.0, 2.0]]
+        q.put((rank, bool(ok), info["gather"], info["fallback"] is not None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_gather", [False, True])
+def test_probe_gather_falls_back_on_every_rank_together(break_gather):
+    """bench.py --gpus N probes the rooted gather once; if it raises on any rank, all ranks use all_gather (and the
+    JSON line says so); per-rank kernel times travel through one small all_gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, q, break_gather)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mode = "all_gather" if break_gather else "gather"
+    assert res == [(0, True, mode, break_gather), (1, True, mode, break_gather)]
+    assert parallel.collective_library() is None or isinstance(parallel.collective_library(), str)
