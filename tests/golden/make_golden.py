@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Generate golden vectors by running the REFERENCE's own Python model on CPU (dev container only).
 
-    python tests/golden/make_golden.py          # writes tests/golden/*.npz
+    python tests/golden/make_golden.py          # every fixture of THIS script (26 .npz, the two ddim_T40_* included)
+    python tests/golden/make_golden.py --all    # + make_golden_pins.py + make_golden_sa.py (all 34) + MANIFEST.sha256 (manifest.py)
 
 The reference (/root/reference) is imported through tools/ref_import.py (six stub modules,
 SURVEY.md §8c).  Weights are NOT stored: both sides regenerate them with
@@ -43,6 +44,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, HERE)
 
 import ref_import  # noqa: E402
 from difffacto_amd import synth  # noqa: E402
@@ -410,7 +412,7 @@ def main():
     gen_prior_loss(model, "B6", B=6, seed=95)
     if "--only-train" in sys.argv:
         return
-    if "--only-ddim" in sys.argv or "--only-latents" in sys.argv:
+    if True:   # the DDIM fixtures (also what --only-ddim / --only-latents stop after): the flag-less run regenerates EVERY fixture of this script
         from difffacto.config.config import get_cfg
         from difffacto.utils.registry import build_from_cfg, MODELS
         cfg = get_cfg()
@@ -422,7 +424,7 @@ def main():
             load_denoiser_weights(dm, W)
             gen_chain(dm, name + "_B2_N64", B=2, N=64, seed=61, all_valid=False, T=40, prefix="ddim")
         cfg.model["diffusion"].update(ddim_sampling=False)
-    if "--only-latents" in sys.argv:
+    if "--only-latents" in sys.argv or "--only-ddim" in sys.argv:
         return
     gen_eps(model, "B2_N128_mixed", B=2, N=128, seed=11, all_valid=False, ts=[0, 3, 9])
     gen_eps(model, "B2_N128_allvalid", B=2, N=128, seed=12, all_valid=True, ts=[5])
@@ -431,6 +433,13 @@ def main():
     gen_chain(model, "B3_N64_allvalid", B=3, N=64, seed=22, all_valid=True, T=10)
     gen_tables()
     gen_pn2_torch()
+    if "--all" in sys.argv:   # the other two generators + the manifest: one command regenerates all fixtures of tests/golden/
+        import make_golden_pins
+        import make_golden_sa
+        import manifest
+        make_golden_pins.main()
+        make_golden_sa.main()
+        manifest.write()
 
 
 if __name__ == "__main__":

@@ -145,8 +145,12 @@ def gen_three_nn():
         print("wrote three_nn_ref_" + tag)
 
 
-if __name__ == "__main__":
+def main():
     gen_three_nn()
     gen_fps()
     gen_chamfer()
     gen_ballquery()
+
+
+if __name__ == "__main__":
+    main()

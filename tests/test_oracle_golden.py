@@ -227,3 +227,15 @@ def test_prior_loss_oracle_matches_reference_autograd():
             assert np.abs(r["grads"][name].ravel()[g["gi/" + name]] - g[key]).max() <= 1e-4 * max(np.abs(g[key]).max(), 1e-30)
             n += 1
     assert n == 336
+
+
+def test_golden_manifest():
+    """Every committed fixture is listed in tests/golden/MANIFEST.sha256 with the hash of its array contents, nothing is missing or
+    extra; `python tests/golden/make_golden.py --all` regenerates all of them and rewrites the manifest."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("golden_manifest", os.path.join(os.path.dirname(__file__), "golden", "manifest.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    missing, extra, changed = m.diff()
+    assert not missing and not extra and not changed, (missing, extra, changed)
+    assert len(m.read()) >= 34
