@@ -1463,6 +1463,11 @@ __device__ __forceinline__ void ff2(v16f (&h)[2][4], const Act<DFX_PREC_BF16> (&
       }
     }
   } else {
+    // Stage A's MFMAs are inline asm writing VGPRs: the hazard recogniser does not see them, and on this path no stage B sits
+    // between the last MFMA (e = 15, tile 1 -> g[1]) and the conversions that read a / g.  An 8-pass XDL write needs 11 wait states
+    // before a VALU read (18 for 16 passes): 24 explicit ones, once per block, whatever order the scheduler gives the conversions.
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) gelu16_f16_cvt(a[tl], g[tl], aa[tl], gg[tl]);
     __builtin_amdgcn_sched_barrier(0);

@@ -1448,7 +1448,8 @@ bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the atte
 // The switches are sampled ONCE per step, by the forward, and recorded per workspace on the host: the backward follows the record,
 // not the switches, so toggling dfx_debug_train_fused between a forward and its backward (the A/B tests do) cannot pair a fused
 // backward with the activations of a layer-by-layer forward.
-struct PathRecord { bool fused, attn_in_ff; int prec; float dropout_p; int B, N; };
+struct PathRecord { bool fused, attn_in_ff; int prec; float dropout_p; int B, N; unsigned long long seq; };
+unsigned long long g_path_seq = 0;   // forward counter: the record with the smallest seq is the one evicted when the table is full
 std::mutex g_path_mu;
 std::unordered_map<const void *, PathRecord> g_path;   // keyed by workspace pointer (a handful per process)
 thread_local bool t_ff_fused = true, t_attn_in_ff = true;   // what the call in progress on this thread uses
@@ -1767,8 +1768,16 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   t_ff_fused = g_ff_fused, t_attn_in_ff = g_attn_in_ff;
   {
     std::lock_guard<std::mutex> lk(g_path_mu);
-    if (g_path.size() > 4096) g_path.clear();
-    g_path[workspace] = PathRecord{t_ff_fused, t_attn_in_ff, precision, dropout_p, B, N};
+    // bounded table: a record is overwritten by the next forward into the same workspace (stale addresses cost nothing); when 4096
+    // DIFFERENT workspaces have been seen, only the OLDEST record goes — never the record of a forward whose backward is pending
+    // unless more than 4096 forwards are outstanding at once
+    if (g_path.size() >= 4096 && g_path.find(workspace) == g_path.end()) {
+      auto oldest = g_path.begin();
+      for (auto it = g_path.begin(); it != g_path.end(); ++it)
+        if (it->second.seq < oldest->second.seq) oldest = it;
+      g_path.erase(oldest);
+    }
+    g_path[workspace] = PathRecord{t_ff_fused, t_attn_in_ff, precision, dropout_p, B, N, ++g_path_seq};
   }
   const bool bf = bf_store((long long)B * N);
   DFX_REQUIRE(x && t && ctx_code && ctx_mv && anchors && variances && assignment && eps, "denoiser_train_forward: null tensor");

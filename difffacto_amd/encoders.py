@@ -113,7 +113,12 @@ class PointNetV2(nn.Module):
         """x (B,N,3), attn_weight (B,N,num_anchors) -> (m, v), each (B, num_anchors, zdim)."""
         B, N, _ = x.shape
         A = self.num_anchors
-        if not self.training and not torch.is_grad_enabled():
+        # eval(): the native forward runs whenever no gradient can be asked for through it — under no_grad, and also with autograd
+        # enabled when neither an input nor a parameter requires grad (a frozen encoder called outside no_grad, like the
+        # reference's nn.Module would simply run)
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or attn_weight.requires_grad
+                                                  or any(p.requires_grad for p in self.parameters()))
+        if not self.training and not wants_grad:
             if not x.is_cuda:
                 raise RuntimeError("PointNetV2: CPU not supported")
             x = x.detach().to(torch.float32).contiguous()
@@ -147,8 +152,9 @@ class PointNetV2(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("PointNetV2: CPU not supported")
         if not self.training:
-            _unsupported("PointNetV2 in eval() mode with autograd enabled (running-statistics BatchNorm has no native backward): "
-                         "wrap the call in torch.no_grad(), or call .train() for the stage-1 training step")
+            _unsupported("PointNetV2 in eval() mode with a gradient required through it (an input or a parameter has requires_grad; "
+                         "running-statistics BatchNorm has no native backward): freeze the module (requires_grad_(False)), wrap the "
+                         "call in torch.no_grad(), or call .train() for the stage-1 training step")
         _unsupported(f"PointNetV2.train() needs batch >= 2 (BatchNorm batch statistics), num_anchors == 4 and zdim % 4 == 0; "
                      f"got B={B}, num_anchors={A}, zdim={self.zdim}")
 

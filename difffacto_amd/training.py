@@ -448,13 +448,31 @@ def generation_of(tensors):
     """Generation of a parameter SET: `Adam.step` updates parameters through raw pointers, which torch's in-place version counters do
     not see, so it bumps a counter on every tensor it steps (`_dfx_gen`); caches of packed weights (modules.TransformerNet.engine,
     encoders.PointNetV2 / the latent samplers) key on the sum over THEIR OWN parameters — stepping one parameter set (say the stage-2
-    modules) leaves the engines and handles of every other set (a frozen stage-1 denoiser, an evaluation copy) alone."""
-    return sum(getattr(t, "_dfx_gen", 0) for t in tensors)
+    modules) leaves the engines and handles of every other set (a frozen stage-1 denoiser, an evaluation copy) alone.
+    The counter also lives per STORAGE (`_STORAGE_GEN`, keyed by the storage's base address): a parameter updated through an alias
+    — a second Parameter or a view on the same memory, tensors re-wrapped after the flat re-pointing — still invalidates the caches of
+    every tensor object that shares that memory."""
+    return sum(getattr(t, "_dfx_gen", 0) + _STORAGE_GEN.get(_storage_key(t), 0) for t in tensors)
+
+
+_STORAGE_GEN = {}
+
+
+def _storage_key(t):
+    try:
+        return (t.device.type, t.device.index, t.untyped_storage().data_ptr())
+    except Exception:   # noqa: BLE001 - tensors without storage (meta, fake): object identity only
+        return None
 
 
 def _bump_generation(tensors):
+    seen = set()
     for t in tensors:
         t._dfx_gen = getattr(t, "_dfx_gen", 0) + 1
+        k = _storage_key(t)
+        if k is not None and k not in seen:
+            seen.add(k)
+            _STORAGE_GEN[k] = _STORAGE_GEN.get(k, 0) + 1
 
 
 class Adam:

@@ -33,7 +33,11 @@ int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
 void dfx_debug_force_direct(int on);
 /* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
- * 32-point tile per workgroup, eight wavefronts on it); 0 = chosen from the batch size.  All variants are bit-identical. */
+ * 32-point tile per workgroup, eight wavefronts on it; for an fp32 denoiser: the direct kernel), or 64 = k_denoise_pipe2 (bf16 only:
+ * four wavefronts of two 32-point tiles each; when its 256-point workgroup tiles would pad a shape by more than 3x —
+ * ceil(N / 256) * 256 > 3 N — the request falls back SILENTLY to the 8-wavefront kernel, and an fp32 denoiser ignores it);
+ * 0 = chosen from the batch size; any other value is treated as 0.  All variants of one precision are bit-identical.
+ * dfx_last_kernel_variant() (dfx.h) names the kernel a launch actually took. */
 void dfx_debug_pipe_waves(int nw);
 /* Slot-boundary clock stamps of two wavefronts of workgroup 0 (device buffer of 2*capacity uint64; NULL = off).
  * Only effective in a library built with -DDFX_TRACE (tools/trace_slots.py builds one). */

@@ -183,7 +183,17 @@ def test_pointnet_v2_has_no_second_implementation():
     with torch.enable_grad(), pytest.raises(RuntimeError, match="CPU not supported"):
         enc(x, attn)
     with torch.enable_grad(), pytest.raises(NotImplementedError, match="eval"):
-        enc(x.cuda(), attn.cuda())
+        enc(x.cuda(), attn.cuda())             # parameters require grad: a gradient could be asked for
+    # a FROZEN encoder called outside no_grad runs natively, like the reference's nn.Module
+    with torch.no_grad():
+        m0, v0 = enc(x.cuda(), attn.cuda())
+    enc.requires_grad_(False)
+    with torch.enable_grad():
+        m1, v1 = enc(x.cuda(), attn.cuda())
+        assert torch.equal(m0, m1) and torch.equal(v0, v1) and not m1.requires_grad
+        with pytest.raises(NotImplementedError, match="eval"):
+            enc(x.cuda().requires_grad_(True), attn.cuda())
+    enc.requires_grad_(True)
     enc.train()
     with pytest.raises(RuntimeError, match="CPU not supported"):
         enc(x, attn)

@@ -163,7 +163,27 @@ def test_parameter_generation_is_per_parameter_set():
     import torch
     from difffacto_amd import training
     a, b = [torch.zeros(3), torch.zeros(2, 2)], [torch.zeros(5)]
-    assert training.generation_of(a) == 0 and training.generation_of(b) == 0
+    ga, gb, ga0 = training.generation_of(a), training.generation_of(b), training.generation_of(a[:1])
     training._bump_generation(a)
+    g1 = training.generation_of(a)
     training._bump_generation(a)
-    assert training.generation_of(a) == 4 and training.generation_of(b) == 0 and training.generation_of(a[:1]) == 2
+    # every step of a's optimiser moves a's generation (and that of each of its tensors), never b's
+    assert training.generation_of(a) > g1 > ga and training.generation_of(b) == gb and training.generation_of(a[:1]) > ga0
+
+
+def test_generation_counter_follows_storage_aliases():
+    """packed-weight caches key on training.generation_of(their parameters); an update through an ALIAS of a parameter
+    (second Parameter / view on the same storage) must move it too, an update of unrelated tensors must not."""
+    import torch
+    from difffacto_amd import training
+    p, q = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
+    alias = torch.nn.Parameter(p.data)          # same storage, different tensor object
+    view = p.data[2:6]
+    g0p, g0q = training.generation_of([p]), training.generation_of([q])
+    training._bump_generation([alias])
+    assert training.generation_of([p]) > g0p and training.generation_of([q]) == g0q
+    g1p = training.generation_of([p])
+    training._bump_generation([view])
+    assert training.generation_of([p]) > g1p and training.generation_of([q]) == g0q
+    training._bump_generation([q])
+    assert training.generation_of([q]) > g0q
