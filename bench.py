@@ -327,35 +327,28 @@ def chain_line(params, names, B, N, T, precision, dev, noise_scale=100.0, launch
         eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=precision, device=dev)
         sampler = LatentSampler({k[len("encoder."):]: v for k, v in params.items() if k.startswith("encoder.")},
                                 noise_scale=noise_scale, device=dev)
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(seed)
+        torch.cuda.manual_seed(seed)
         valid = torch.from_numpy(synth.make_latents(B, seed=1000 + seed)[3].copy()).to(dev)
 
-        def one(s):
-            lat = sampler.sample_latents(torch.randn(B, 256, 4, device=dev, generator=gen), torch.randn(B, 32, device=dev, generator=gen),
-                                         valid, K=1, npoints=N)
-            ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            pred, _ = eng.sample_chain(ctx, lat["seg_mask"], seed=s)
-            b.record()
-            return a, b, pred
-        # warm-up (code load, LDS attribute, allocator): a whole pass when that is cheap, otherwise the latents + one evaluation
-        # through the same kernel instantiation
+        # the pass as a service runs it (difffacto_amd/pipeline.py): front end = draws + latent sampler + context preparation as ONE
+        # hipGraph, replayed on a side stream beside the previous batch's chain; the chain launch waits on an event, not on the host
+        from difffacto_amd.pipeline import SamplingPipeline
+        pipe = SamplingPipeline(eng, sampler, B, N, valid)
+        # warm-up (code load, LDS attribute, allocator): a whole pass when that is cheap, otherwise one evaluation through the same
+        # kernel instantiation
         if T <= 100:
-            one(1)
+            for _ in pipe.run(1, seed0=1):
+                pass
         else:
-            lat = sampler.sample_latents(torch.randn(B, 256, 4, device=dev, generator=gen), torch.randn(B, 32, device=dev, generator=gen),
-                                         valid, K=1, npoints=N)
-            ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
-            eng.eps(ctx, torch.zeros(B, 3, N, device=dev), lat["seg_mask"], T - 1)
+            lat = pipe.latents(0)
+            eng.eps(pipe.inst[0].ctx, torch.zeros(B, 3, N, device=dev), lat["seg_mask"], T - 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        evs = [one(2 + i) for i in range(launches)]
+        preds = list(pipe.run(launches, seed0=2, time_chain=True))
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) / launches * 1e3
-        ok = all(bool(torch.isfinite(e[2]).all()) for e in evs)
-        ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        ok = all(bool(torch.isfinite(p).all()) for p in preds[-1:])
+        ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.last_chain_events]))
         eng.close()
         ach = flops_per_step(N) * T * B / (ms * 1e-3) / 1e12
         return {"batch": B, "npoints": N, "num_timesteps": T, "dtype": precision, "noise_scale": noise_scale, "kernel_ms": ms,
@@ -396,21 +389,26 @@ def small_batch_line(params, names, sampler, N, precision, dev, T):
     try:
         out = {"num_timesteps": T}
         eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=precision, device=dev)
+        from difffacto_amd.pipeline import SamplingPipeline
         for B in (1, 4):
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(98)
-            valid = torch.ones(B, 4, device=dev)
-            lat = sampler.sample_latents(torch.randn(B, 256, 4, device=dev, generator=gen), torch.randn(B, 32, device=dev, generator=gen),
-                                         valid, K=1, npoints=N)
-            ctx = eng.prepare_shapes(lat["part_code"], lat["params"][:, :3], lat["params"][:, 3:], lat["valid_id"])
-            eng.sample_chain(ctx, lat["seg_mask"], seed=1)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            eng.sample_chain(ctx, lat["seg_mask"], seed=2)
-            b.record()
+            torch.cuda.manual_seed(98)
+            pipe = SamplingPipeline(eng, sampler, B, N, torch.ones(B, 4, device=dev))
+            for _ in pipe.run(1, seed0=1):     # warm-up pass
+                pass
             torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in pipe.run(1, seed0=2, time_chain=True):   # ONE request: front end (one graph launch) -> chain, nothing to overlap with
+                pass
+            torch.cuda.synchronize()
+            wall_one = (time.perf_counter() - t0) * 1e3
+            a, b = pipe.last_chain_events[0]
             ms = a.elapsed_time(b)
-            out[f"B{B}"] = {"ms_per_chain": ms, "shapes_per_s": B / ms * 1e3}
+            t0 = time.perf_counter()
+            for _ in pipe.run(3, seed0=3):     # a stream of requests: the next front end rides beside the running chain
+                pass
+            torch.cuda.synchronize()
+            wall_stream = (time.perf_counter() - t0) / 3 * 1e3
+            out[f"B{B}"] = {"ms_per_chain": ms, "shapes_per_s": B / ms * 1e3, "wall_ms_one_pass": wall_one, "wall_ms_per_pass_streamed": wall_stream}
         eng.close()
         return out
     except Exception as e:
