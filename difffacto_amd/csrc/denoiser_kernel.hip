@@ -170,6 +170,24 @@ __device__ __forceinline__ void ln_to_act(const v16f (&h)[4], Act<PREC> (&xn)[4]
   }
 }
 
+__device__ __forceinline__ v16f zero16() {
+  v16f z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// bf16 path, GEMM1 of the feed-forward: LayerNorm3's output xhat sums to zero over its 128 channels, so channel 127 is redundant
+// (xhat_127 = - sum of the others).  denoiser_setup.hip packs W1'' = W1'[., k] - W1'[., 127] for k < 127 and puts b1' into column 127;
+// here channel 127's K slot — register 15 of tile 3 in the upper half-wave (rho(15, 1) = 31) — carries the constant 1, so
+// [a | g] = W1'' xhat'' comes out of the MFMAs WITH its bias, started from C = 0: the 8 ds_read_b128 of accumulator initialisers per
+// record are gone (2.1 % of a record's energy, profiles/r02_energy_budget.txt; measured +2.5 %, profiles/r04_headline_experiments.txt).
+// Exact in real arithmetic; in bf16 the weight differences round ~1.4x coarser and the implicit channel carries the rounding noise of
+// the other 127: one evaluation deviates from fp32 by rms 8.1e-4 instead of 6.6e-4 (same file).  fp32 kernels keep the plain form.
+__device__ __forceinline__ void bias_slot_one(Act<DFX_PREC_BF16> (&xn)[4], int hf) {
+  if (hf) xn[3].f[1][7] = (__bf16)1.0f;
+}
+__device__ __forceinline__ void bias_slot_one(Act<DFX_PREC_F32> (&)[4], int) {}
+
 __device__ __forceinline__ float gelu_erf(float x) {  // F.gelu default (attention.py:57)
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -376,8 +394,12 @@ __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4],
                                          const float *b1) {
   constexpr int TSTRIDE = tile_units(PREC) * 64;
   v16f a, g;
-  load16(a, b1);
-  load16(g, b1 + 32);
+  if (PREC == DFX_PREC_BF16) {
+    a = zero16(), g = zero16();   // b1' rides on the constant-one K slot (bias_slot_one)
+  } else {
+    load16(a, b1);
+    load16(g, b1 + 32);
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     mma_tile<PREC>(a, ck + (0 + c) * TSTRIDE, xn[c]);
@@ -496,6 +518,10 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
   auto gemm1 = [&](int e, const uint4 &w) {   // GEMM1 MFMA e = 0..15
     const int i = e & 7, half = e >> 3;
     v16f &acc = (i & 1) ? g : a;
+    if (e < 2) {   // first MFMA of a / g: C = 0 (inline constant) — b1' rides on the constant-one K slot (bias_slot_one), no initialiser reads
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], zero16(), 0, 0, 0);
+      return;
+    }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w), xn[2 * half + (i >> 2)].f[(i >> 1) & 1], acc, 0, 0, 0);
   };
   if (S3 && S1) {
@@ -533,7 +559,7 @@ __device__ __forceinline__ void ff_m(v16f (&h)[4], const Act<DFX_PREC_BF16> (&xn
 }
 
 // V slot of the feed-forward: hid = a * gelu(g) as the fp16 B operand of GEMM2.
-__device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float *b1_next, Tracer &tr) {
+__device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, Tracer &tr) {
   if (VALU_PRIO) __builtin_amdgcn_s_setprio(VALU_PRIO);
   h2 aa[8], gg[8];
   gelu16_f16_cvt(a, g, aa, gg);
@@ -548,16 +574,6 @@ __device__ __forceinline__ void ff_v(v16f &a, v16f &g, HidAct &hid, const float 
     hid.f[q] = __builtin_bit_cast(uint4, w);
   }
   tr.stamp(8);
-  if (b1_next) {  // a, g are dead now: preload the accumulator initialisers (b1) of the next chunk
-    // one opaque base register: the eight reads then use immediate offsets (hipcc otherwise rebuilds every address from
-    // the workgroup's LDS base with its own v_add: eight VALU instructions per slot)
-    typedef __attribute__((address_space(3))) const float lds_cf;
-    unsigned addr = (unsigned)(uintptr_t)(lds_cf *)b1_next;
-    asm volatile("" : "+v"(addr));
-    const float *src = (const float *)(lds_cf *)(uintptr_t)addr;
-    load16(a, src);
-    load16(g, src + 32);
-  }
   if (VALU_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
@@ -795,6 +811,7 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
                       bp.ct + (size_t)t * CT_ROW + hf * 64, vmask);
       Act<PREC> xn[4];
       ln_to_act<PREC>(h, xn);
+      bias_slot_one(xn, hf);
 #pragma unroll 1
       for (int u = 0; u < FF_CHUNKS; ++u)
         ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane,
@@ -1188,8 +1205,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
   bool done = false;
   for (int step = 0; step <= p.nsteps && !done; ++step) {
     for (int b = 0; b < depth; ++b, ++seq) {
-      const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
-      const float *b1 = bc + hf * 16;
       const uint4 *ck;
       Act<PREC> xn[4];
       // ---- V0: finish the previous block / step, start this one ----
@@ -1237,8 +1252,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
       // ---- feed-forward: M(F0) V M(F1) V ... M(F16) ----
       v16f a, g;
       HidAct hid;
-      load16(a, b1);  // accumulator initialisers of chunk 0 (block constants: resident since the attention record)
-      load16(g, b1 + 32);
+      bias_slot_one(xn, hf);   // b1' enters GEMM1 through channel 127's K slot: no accumulator initialisers
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<false, true, NEXT_FULL>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
@@ -1246,20 +1260,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe(const KParams p) {
       for (int j = 1; j < FF_CHUNKS - 1; ++j) {
         DFX_SLOT(!grpA);
         issue_in_m.m_begin();
-        ff_v(a, g, hid, b1 + j * 64, tr);
+        ff_v(a, g, hid, tr);
         DFX_SLOT(grpA);
         DFX_NEXT_RECORD();
         ff_m<true, true, NEXT_FULL>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       }
       DFX_SLOT(!grpA);   // record F15: the next one is the block's last (GEMM2 only): its tail prefetch differs
       issue_in_m.m_begin();
-      ff_v(a, g, hid, b1 + (FF_CHUNKS - 1) * 64, tr);
+      ff_v(a, g, hid, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<true, true, NEXT_LAST>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
       DFX_SLOT(!grpA);
       issue_in_m.m_begin();
-      ff_v(a, g, hid, nullptr, tr);
+      ff_v(a, g, hid, tr);
       DFX_SLOT(grpA);
       DFX_NEXT_RECORD();
       ff_m<true, false, NEXT_AS>(h, xn, a, g, hid, ck, P, DFX_PEEK_RECORD(), tr, issue_in_m);
@@ -1582,8 +1596,6 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
   bool done = false;
   for (int step = 0; step <= p.nsteps && !done; ++step) {
     for (int b = 0; b < depth; ++b, ++seq) {
-      const float *bc = reinterpret_cast<const float *>(pipe_smem + L_BCONST + (seq & 1) * BCONST_BYTES);
-      const float *b1 = bc + hf * 16;
       const uint4 *ck;
       Act<PREC> xn[2][4];
 #pragma unroll
@@ -1648,6 +1660,7 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
       for (int tl = 0; tl < 2; ++tl) {
         add_cvec(h[tl], reinterpret_cast<const float *>(rec - lane + 1088) + hf * 64);
         ln_to_act<PREC>(h[tl], xn[tl]);
+        bias_slot_one(xn[tl], hf);
         // LN3's output is read by GEMM1's MFMAs only: into the accumulator file HERE, once per block (an "a" operand whose value
         // lives in VGPRs is otherwise copied in front of every asm MFMA: 64 v_accvgpr_write per record)
 #pragma unroll
@@ -1659,13 +1672,16 @@ __global__ void __launch_bounds__(P2_NW * 64, 1) k_denoise_pipe2(const KParams p
       // ---- feed-forward ----
       v16f a[2], g[2], b1a, b1g;
       h2 aa[2][8], gg[2][8];
-      load_b1(b1a, b1g, b1);
+      // b1' rides on the constant-one K slot: the first MFMA's C operand is zero for every chunk.  The zeros are made opaque so that they
+      // stay in registers: a rematerialised v_mov right in front of an asm MFMA is a VALU-write -> SrcC hazard the compiler does not see
+      b1a = zero16(), b1g = zero16();
+      asm volatile("" : "+v"(b1a), "+v"(b1g));
       DFX_RECORD2(true);
-      ff2<true, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + 64, isr, tr);
+      ff2<true, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr, isr, tr);
 #pragma unroll 1
       for (int j = 1; j < FF_CHUNKS - 1; ++j) {
         DFX_RECORD2(true);
-        ff2<false, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), b1 + (j + 1) * 64, isr, tr);
+        ff2<false, false, P2_NEXT_W1>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr, isr, tr);
       }
       DFX_RECORD2(true);
       ff2<false, false, P2_NEXT_W2>(h, xn, a, g, aa, gg, b1a, b1g, ck, P, DFX_PEEK2(), nullptr, isr, tr);
@@ -2167,6 +2183,7 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
         attention<PREC>(h, rec, reinterpret_cast<const float *>(s_at + 8 * TSTRIDE) + hf * 16, reinterpret_cast<const float *>(s_at + AREC) + hf * 64, vmask);
         Act<PREC> xo[4];
         ln_to_act<PREC>(h, xo);
+        bias_slot_one(xo, hf);
 #pragma unroll
         for (int c = 0; c < 4; ++c) s_xn[2 * c][lane] = __builtin_bit_cast(uint4, xo[c].f[0]), s_xn[2 * c + 1][lane] = __builtin_bit_cast(uint4, xo[c].f[1]);
 #pragma unroll
@@ -2189,9 +2206,7 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
             R[2 * c] = ck[0], R[2 * c + 1] = ck[64];
           }
         }
-        v16f a, g;
-        load16(a, s_bc + u * 64 + hf * 16);
-        load16(g, s_bc + u * 64 + hf * 16 + 32);
+        v16f a = zero16(), g = zero16();   // b1' rides on the constant-one K slot (bias_slot_one)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), xn_frag(2 * c), a, 0, 0, 0);

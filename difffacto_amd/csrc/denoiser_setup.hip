@@ -80,7 +80,8 @@ __device__ __forceinline__ void tile_store(void *dst, long long gi, float v) {
 
 // W1 (1024 x 128) with norm3.weight folded in -> tiles part*4+c of chunk record u
 template <int PREC>
-__global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict__ g3, void *__restrict__ dst) {
+__global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict__ g3, void *__restrict__ dst, const float *__restrict__ b1,
+                          const float *__restrict__ be3) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
   if (gi >= (long long)FF_CHUNKS * 2 * 4 * 1024) return;
   const int tile = (int)(gi >> 10);
@@ -90,6 +91,22 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   const int row = part * FF_HID + 32 * u + i, col = 32 * c + kk;
   const long long di = ((long long)(u * CHUNK_TILES + part * 4 + c) << 10) + (gi & 1023);
   const float sc = PREC != DFX_PREC_BF16 ? 1.0f : part == 0 ? FF_A_SCALE : FF_G_SCALE;   // (denoiser_internal.h)
+  // bf16 path (denoiser_kernel.hip: bias_slot_one): the normalised row sums to zero, so channel 127 is redundant (xhat_127 = - sum of the
+  // others): its K slot carries the constant 1 and the weight there is b1' = b1 + W1 beta3, every other weight has W1'[.][127] subtracted.
+  // Exact in real arithmetic; GEMM1 then needs no accumulator initialisers.
+  if (PREC == DFX_PREC_BF16) {
+    const float w127 = W1[(size_t)row * INNER + 127] * g3[127];
+    float v;
+    if (col == 127) {
+      float acc = 0.f;
+      for (int k = 0; k < INNER; ++k) acc = fmaf(W1[(size_t)row * INNER + k], be3[k], acc);
+      v = b1[row] + acc;
+    } else {
+      v = W1[(size_t)row * INNER + col] * g3[col] - w127;
+    }
+    tile_store<PREC>(dst, di, v * sc);
+    return;
+  }
   tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col] * sc);
 }
 
@@ -467,10 +484,10 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
                                                         precision == DFX_PREC_BF16 ? FF_G_SCALE : 1.0f);
     TRY_LAUNCH("pack_b1");
     if (precision == DFX_PREC_BF16) {
-      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);
+      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b);
       k_pack_w2<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     } else {
-      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks);
+      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b);
       k_pack_w2<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     }
     TRY_LAUNCH("pack_w1w2");

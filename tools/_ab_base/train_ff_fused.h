@@ -117,6 +117,9 @@ struct FfArgs {
   float *dh_in;
   uint4 *pk2;              // with at_frags: [R / 32][2][4][2][64] the tile's xn2 and dh1 as bf16 fragments for k_attn_bwd_param (which
                            // needs nothing else of them); dh1 itself is then not written
+#ifdef DFX_TRACE_FF
+  unsigned long long *trace;
+#endif
 };
 
 // fragment sets of the folded attention per shape (written by afused::k_attn_fold): tile t (4), unit u (2), lane (64) uint4 each
@@ -129,6 +132,59 @@ constexpr float LN_EPS = 1e-5f;
 __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
 }
+
+// Phase stamps of a few workgroups (tools/trace_train_ff.py builds with -DDFX_TRACE_FF; never in the shipped library): wave 0 of the
+// workgroups whose id is a multiple of FFT_EVERY writes (tag, shader clock) pairs into a host-visible buffer dumped at process exit.
+#ifdef DFX_TRACE_FF
+constexpr int FFT_CAP = 128, FFT_WGS = 64, FFT_EVERY = 29;
+struct FfTrace {
+  unsigned long long *buf;
+  int n;
+  __device__ __forceinline__ void init(unsigned long long *base, int kernel_slot) {
+    const int wg = blockIdx.x;
+    buf = (base && wg % FFT_EVERY == 0 && wg / FFT_EVERY < FFT_WGS && threadIdx.x == 0) ? base + ((size_t)kernel_slot * FFT_WGS + wg / FFT_EVERY) * FFT_CAP : nullptr;
+    n = 0;
+  }
+  __device__ __forceinline__ void stamp(int tag) {
+    if (buf && n < FFT_CAP) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      buf[n++] = ((unsigned long long)tag << 56) | ((unsigned long long)(hw & 0xffff) << 40) | (__builtin_readcyclecounter() & 0xffffffffffull);
+    }
+  }
+};
+inline unsigned long long *ff_trace_buffer() {
+  static unsigned long long *buf = [] {
+    unsigned long long *b = nullptr;
+    const size_t n = (size_t)3 * FFT_WGS * FFT_CAP;
+    if (hipHostMalloc(reinterpret_cast<void **>(&b), n * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return (unsigned long long *)nullptr;
+    for (size_t i = 0; i < n; ++i) b[i] = 0;
+    static unsigned long long *keep = b;
+    atexit([] {
+      (void)hipDeviceSynchronize();
+      const char *path = getenv("DFX_TRACE_FF_OUT");
+      FILE *f = fopen(path ? path : "/tmp/ff_trace.txt", "w");
+      if (!f) return;
+      for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < FFT_WGS; ++w) {
+          const unsigned long long *r = keep + ((size_t)k * FFT_WGS + w) * FFT_CAP;
+          if (!r[0]) continue;
+          fprintf(f, "kernel %d wg %d:", k, w * FFT_EVERY);
+          for (int i = 0; i < FFT_CAP && r[i]; ++i) fprintf(f, " %d@%llx:%llu", (int)(r[i] >> 56), (r[i] >> 40) & 0xffff, r[i] & 0xffffffffffull);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    });
+    return b;
+  }();
+  return buf;
+}
+#define FFT_INIT(args, slot) FfTrace fft; fft.init((args).trace, slot)
+#define FFT(tag) fft.stamp(tag)
+#else
+#define FFT_INIT(args, slot)
+#define FFT(tag)
+#endif
 
 __device__ __forceinline__ v8bf as_bf(const uint4 &u) { return __builtin_bit_cast(v8bf, u); }
 __device__ __forceinline__ v16f mfma(const uint4 &a, const uint4 &b, v16f c) {
@@ -344,6 +400,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   row += pj;
 
   constexpr int PIECES = FWD_TILES * 2 / NW;   // forward: LDS-DMA instructions per wave and chunk
+  FFT_INIT(a, BWD ? 1 : 0);
+  FFT(1);
   if (BWD) {
     stage_item(a.frags, 0, lds0, wave, voff);
     stage_item(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
@@ -448,6 +506,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's loads and stores are done: the loop counts only LDS-DMA pieces (+ the backward's tile stores)
+  FFT(2);
 
 #pragma unroll 1
   for (int j = 0; j < NCHUNK; ++j) {
@@ -522,9 +581,12 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       // ---- item boundary: item 2 j + 1 must have landed (loads complete in order: only the six pieces of item 2 j + 2, requested at the
       // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3.  The boundary sits in FRONT
       // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
+      FFT(10);
       if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FFT(11);
       __syncthreads();
+      FFT(12);
       if (2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
       const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
       // second burst, MFMA m: row tile ct = m & 3, operand q = m >> 2 (W1a^T unit 0, unit 1, W1g^T unit 0, unit 1: the order per accumulator)
@@ -559,6 +621,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
     // chunk j + 1 must have landed: loads complete in order, so "at most PIECES outstanding" leaves only chunk j + 2's pieces
     // (whatever the order between loads and the backward's stores); no new pieces in the last two iterations -> drain
+    FFT(13);
     if (BWD) {   // item 2 j + 2 must have landed; the four pieces of item 2 j + 3 may still be out
       if (2 * j + 3 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -567,8 +630,11 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    FFT(14);
     __syncthreads();
+    FFT(15);
   }
+  FFT(3);
   if (!BWD) {
     if (!live) return;
     float *out = a.h2 + row * C;
@@ -577,6 +643,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<v4f *>(out + 32 * c + 8 * q + 4 * hf) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+    FFT(9);
     return;
   }
   // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
@@ -601,6 +668,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
   s1 += xhalf(s1), s2 += xhalf(s2);
   s1 *= (1.0f / C), s2 *= (1.0f / C);
+  FFT(4);
   constexpr int TROW = 36;   // floats per tile row: 16-byte aligned rows, conflict-free column reads
   float *tt = reinterpret_cast<float *>(ff_smem) + wave * 32 * TROW;
   float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][NQ][128]
@@ -642,6 +710,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     colsum(acc[c], 1, c);
     colsum(dv, 2, c);
   }
+  FFT(5);
   if (a.at_frags) {
     // ---- the attention sub-block's input gradient on the same rows (afused::k_attn_bwd_dx's arithmetic): recompute LN2 / sim / P from hin,
     // dP = M_s^T dh1, softmax backward, dxn2 = A_s^T dsim, LayerNorm2 backward: dh_in = dh1 + ... ; column sums for d gamma2, d beta2, d b_o ----
@@ -673,6 +742,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         for (int u = 0; u < 2; ++u) x[c][u] = (x[c][u] - mu2) * rstd2;
       rows_to_acc(x, xh);   // xhat2 in the accumulator layout (xhat3 is done with)
     }
+    FFT(6);
     softmax_regs(P, vmask);
     {
       v8f x[4][2];
@@ -726,6 +796,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       colsum(d1[c], 5, c);
     }
   }
+  FFT(7);
   __syncthreads();
   for (int i = threadIdx.x; i < NQ * C; i += NW * 64) {
     float t = 0.f;
@@ -733,6 +804,10 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     for (int w = 0; w < NW; ++w) t += cred[(w * NQ + i / C) * C + i % C];
     a.cpart[(size_t)blockIdx.x * NQ * C + i] = t;
   }
+#ifdef DFX_TRACE_FF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FFT(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -754,6 +829,9 @@ struct FwArgs {
   float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
   long long ntiles;      // R / 32
   int nslab;
+#ifdef DFX_TRACE_FF
+  unsigned long long *trace;
+#endif
 };
 constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chunk, on the same SIMD
 // LDS: the tiles ([xn3 | dh] fragments, 16 KiB) travel in a ring of three slots, two tiles ahead of the producers (L2 latency under load
@@ -799,6 +877,8 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // fragments (24 MFMAs + the GEGLU arithmetic, weights in registers), the consumer multiplies tile k - 1's fragments with the
   // transposed tile (24 MFMAs into its 192 accumulator registers) — so the matrix pipe of the SIMD works through the producer's VALU
   // stretch, and neither role needs more than 256 registers.
+  FFT_INIT(a, 2);
+  FFT(1);
   stage(-2), stage(-1);   // tiles 0, 1
   if (!consumer) {
     uint4 w1a[4][2], w1g[4][2], w2t[4][2];
@@ -816,7 +896,9 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
     float sa = 0.f, sg = 0.f;
     for (int k = 0; k <= nt; ++k) {
+      if (k < 24) FFT(10);
       arrive(k);   // tile k has landed; everybody is done with tile k - 1's producer half and tile k - 2's consumer half and fragments
+      if (k < 24) FFT(11);
       stage(k);
       if (k == nt) break;
       const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
@@ -846,6 +928,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       po[0 * 64] = pack8(hv, 0), po[1 * 64] = pack8(hv, 1), po[2 * 64] = pack8(da, 0), po[3 * 64] = pack8(da, 1);
       po[4 * 64] = pack8(dg, 0), po[5 * 64] = pack8(dg, 1);
     }
+    FFT(3);
     sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
     if (lane < 32) {
       float *bo = a.bpart + ((size_t)slab * NCHUNK + j) * 64;
@@ -932,7 +1015,13 @@ inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 6
 inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &f) {
   static PerDeviceOnce attrs;
   if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_wgrad), WG_LDS); }) != hipSuccess) return -1;
+#ifdef DFX_TRACE_FF
+  FwArgs at = a;
+  at.trace = ff_trace_buffer();
+  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(at);
+#else
   k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(a);
+#endif
   const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
   k_ff_wgrad_finish<<<(total + 255) / 256, 256, 0, st>>>(f);
   return 0;
@@ -951,7 +1040,13 @@ inline int launch_ff(hipStream_t st, const FfArgs &a) {
   if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff<BWD>), LDS); }) != hipSuccess) return -1;
   constexpr int NW = nw_of<BWD>();
   const long long groups = (a.R / 32 + NW - 1) / NW;
+#ifdef DFX_TRACE_FF
+  FfArgs at = a;
+  at.trace = ff_trace_buffer();
+  k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(at);
+#else
   k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(a);
+#endif
   return 0;
 }
 
