@@ -24,16 +24,17 @@ from difffacto_amd import synth  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# measured on MI355X (profiles/r02_parity_headline.txt); every gate is <= 3x the measured value:
-#   bf16_f32   max-abs / cloud extent, bf16 pipelined kernel vs exact-fp32 chain            (measured 1.2e-5 | see below)
+# measured on MI355X (profiles/r04_parity_prints.txt; r02 / r03 values in brackets: before b1' moved onto the constant-one K slot of
+# GEMM1); every gate is <= 3x the measured value:
+#   bf16_f32   max-abs / cloud extent, bf16 pipelined kernel vs exact-fp32 chain            (measured 1.4e-5 [1.2e-5] | see below)
 #   f32_oracle exact-fp32 HIP chain vs the PyTorch-CPU oracle on a 256-point subset / extent (measured 4.8e-7)
-#   cd         Chamfer-L2(bf16, fp32) / extent^2                                             (measured 6.0e-11)
-#   emd        auction EMD(bf16, fp32) on the unit-box-normalised clouds                     (measured 5.0e-6)
+#   cd         Chamfer-L2(bf16, fp32) / extent^2                                             (measured 8.5e-11 [6.0e-11])
+#   emd        auction EMD(bf16, fp32) on the unit-box-normalised clouds                     (measured 6.1e-6 [5.0e-6])
 GATES = {"contractive": dict(bf16_f32=3.6e-5, f32_oracle=5e-6,   # f32_oracle: ~10x measured (CPU BLAS summation order varies by host)
                                 cd=1.8e-10, emd=1.5e-5),
          # the random-init set is chaotic over 1000 steps (no oracle leg: fp32 rounding differences between two fp32
          # implementations grow the same way); it is kept as the worst case for the bf16 deviation
-         "random-init": dict(bf16_f32=9e-4, f32_oracle=None, cd=6.5e-8, emd=2.8e-4)}   # measured 3.1e-4, 2.2e-8, 9.3e-5
+         "random-init": dict(bf16_f32=9e-4, f32_oracle=None, cd=6.5e-8, emd=2.8e-4)}   # measured 4.2e-4, 2.9e-8, 1.08e-4 [r03: 3.1e-4, 2.2e-8, 9.3e-5]
 
 
 def contractive_weights():
