@@ -140,9 +140,9 @@ constexpr int FFT_CAP = 128, FFT_WGS = 64, FFT_EVERY = 29;
 struct FfTrace {
   unsigned long long *buf;
   int n;
-  __device__ __forceinline__ void init(unsigned long long *base, int kernel_slot) {
+  __device__ __forceinline__ void init(unsigned long long *base, int kernel_slot, int thread = 0) {
     const int wg = blockIdx.x;
-    buf = (base && wg % FFT_EVERY == 0 && wg / FFT_EVERY < FFT_WGS && threadIdx.x == 0) ? base + ((size_t)kernel_slot * FFT_WGS + wg / FFT_EVERY) * FFT_CAP : nullptr;
+    buf = (base && wg % FFT_EVERY == 0 && wg / FFT_EVERY < FFT_WGS && (int)threadIdx.x == thread) ? base + ((size_t)kernel_slot * FFT_WGS + wg / FFT_EVERY) * FFT_CAP : nullptr;
     n = 0;
   }
   __device__ __forceinline__ void stamp(int tag) {
@@ -156,7 +156,7 @@ struct FfTrace {
 inline unsigned long long *ff_trace_buffer() {
   static unsigned long long *buf = [] {
     unsigned long long *b = nullptr;
-    const size_t n = (size_t)3 * FFT_WGS * FFT_CAP;
+    const size_t n = (size_t)4 * FFT_WGS * FFT_CAP;
     if (hipHostMalloc(reinterpret_cast<void **>(&b), n * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return (unsigned long long *)nullptr;
     for (size_t i = 0; i < n; ++i) b[i] = 0;
     static unsigned long long *keep = b;
@@ -165,7 +165,7 @@ inline unsigned long long *ff_trace_buffer() {
       const char *path = getenv("DFX_TRACE_FF_OUT");
       FILE *f = fopen(path ? path : "/tmp/ff_trace.txt", "w");
       if (!f) return;
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 4; ++k)
         for (int w = 0; w < FFT_WGS; ++w) {
           const unsigned long long *r = keep + ((size_t)k * FFT_WGS + w) * FFT_CAP;
           if (!r[0]) continue;
@@ -180,9 +180,11 @@ inline unsigned long long *ff_trace_buffer() {
   return buf;
 }
 #define FFT_INIT(args, slot) FfTrace fft; fft.init((args).trace, slot)
+#define FFT_INIT2(args, slot, thread) FfTrace fft; fft.init((args).trace, slot, thread)
 #define FFT(tag) fft.stamp(tag)
 #else
 #define FFT_INIT(args, slot)
+#define FFT_INIT2(args, slot, thread)
 #define FFT(tag)
 #endif
 
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // fragments (24 MFMAs + the GEGLU arithmetic, weights in registers), the consumer multiplies tile k - 1's fragments with the
   // transposed tile (24 MFMAs into its 192 accumulator registers) — so the matrix pipe of the SIMD works through the producer's VALU
   // stretch, and neither role needs more than 256 registers.
-  FFT_INIT(a, 2);
+  FFT_INIT2(a, consumer ? 3 : 2, consumer ? WG_CHUNKS * 64 : 0);
   FFT(1);
   stage(-2), stage(-1);   // tiles 0, 1
   if (!consumer) {
@@ -914,6 +916,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           gv = mfma(x, w1g[c][u], gv);
           dv = mfma(tl[(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
         }
+      if (k < 12) FFT(14);
       v16f hv, da, dg;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -924,9 +927,11 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
         dg[r] = dv[r] * av[r] * d;
         sa += da[r], sg += dg[r];
       }
+      if (k < 12) FFT(12);
       uint4 *po = packs + ((k & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
       po[0 * 64] = pack8(hv, 0), po[1 * 64] = pack8(hv, 1), po[2 * 64] = pack8(da, 0), po[3 * 64] = pack8(da, 1);
       po[4 * 64] = pack8(dg, 0), po[5 * 64] = pack8(dg, 1);
+      if (k < 12) FFT(13);
     }
     FFT(3);
     sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
@@ -950,7 +955,9 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     sel[u] = *reinterpret_cast<const uint4 *>(o);
   }
   for (int k = 0; k <= nt; ++k) {
+    if (k < 12) FFT(20);
     arrive(k);
+    if (k < 12) FFT(21);
     stage(k);
     if (k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
       const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
@@ -964,6 +971,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
         to[(kind * 8 + cl * 2 + 0) * 64] = pack8(t, 0), to[(kind * 8 + cl * 2 + 1) * 64] = pack8(t, 1);
       }
     }
+    if (k < 12) FFT(22);
     if (k == 0) continue;
     const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_T + ((k - 1) & 1) * 16384) - 16 * 64 + lane;   // (index the slot by PK_XNT, PK_DHT)
     const uint4 *pi = packs + (((k - 1) & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
@@ -976,6 +984,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       dWa[c] = mfma(a1, x1, mfma(a0, x0, dWa[c]));
       dWg[c] = mfma(g1, x1, mfma(g0, x0, dWg[c]));
     }
+    if (k < 12) FFT(23);
   }
   float *out = a.part + ((size_t)slab * NCHUNK + j) * 12 * 1024 + lane;
 #pragma unroll

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from difffacto_amd import build  # noqa: E402
 
-NAMES = {0: "k_ff<false>", 1: "k_ff<true>", 2: "k_ff_wgrad (producer wave 0)"}
+NAMES = {0: "k_ff<false>", 1: "k_ff<true>", 2: "k_ff_wgrad (producer wave 0)", 3: "k_ff_wgrad (consumer wave 4)"}
 
 
 def analyse(path, out):
@@ -68,8 +68,20 @@ def analyse(path, out):
                     span(7, 8, "epilogue e: workgroup reduction + last stores landed")
                 else:
                     span(3, 9, "epilogue: store h2")
+            elif k == 3:
+                arr = [(tag, c) for tag, hw, c in ev]
+                for a_, b_, name in ((20, 21, "consumer: wait at arrive()"), (21, 22, "consumer: turn tile k around (4 MFMAs, packs, LDS writes)"),
+                                     (22, 23, "consumer: reads + 24 MFMAs of tile k - 1 issued"), (23, 20, "consumer: loop back")):
+                    v = [y[1] - x[1] for x, y in zip(arr, arr[1:]) if x[0] == a_ and y[0] == b_]
+                    if v:
+                        tot[name].append(sum(v) / len(v))
             else:
                 arr = [(tag, c) for tag, hw, c in ev]
+                for a_, b_, name in ((11, 14, "producer: tile reads + 24 MFMAs issued"), (14, 12, "producer: MFMA results + GEGLU arithmetic"),
+                                     (12, 13, "producer: 6 fragment stores to LDS")):
+                    v = [y[1] - x[1] for x, y in zip(arr, arr[1:]) if x[0] == a_ and y[0] == b_]
+                    if v:
+                        tot[name].append(sum(v) / len(v))
                 waits = [b[1] - a[1] for a, b in zip(arr, arr[1:]) if a[0] == 10 and b[0] == 11]
                 work = [b[1] - a[1] for a, b in zip(arr, arr[1:]) if a[0] == 11 and b[0] == 10]
                 if waits:
