@@ -187,3 +187,21 @@ def test_generation_counter_follows_storage_aliases():
     assert training.generation_of([p]) > g1p and training.generation_of([q]) == g0q
     training._bump_generation([q])
     assert training.generation_of([q]) > g0q
+
+
+def test_bench_evidence_helpers_read_the_newest_committed_profiles():
+    """bench.py's roofline.traffic names the profile file and round it came from (newest committed rNN_traffic.json),
+    and the power-limited ceiling is parsed from the newest committed micro-benchmark run instead of a hard-coded constant."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    traffic, src = b.measured_traffic(1000, 128, 2048)
+    assert traffic is not None and 1e9 < traffic < 2e10 and src["file"].startswith("profiles/r") and src["file"].endswith("_traffic.json")
+    assert int(src["round"][1:]) >= 4 and "not measured in this run" in src["note"]
+    assert b.measured_traffic(1000, 7, 2048) == (None, None)          # no profile for that batch: no number
+    c = b.power_limited_ceiling()
+    assert c["source"].startswith("profiles/r") and 1500 < c["bare_mfma_tflops"] < 2500 and 1000 < c["kernel_mix_tflops"] < c["refill_per_mfma_tflops"] < c["bare_mfma_tflops"]
+    assert abs(b.flops_per_step(2048) - 4.733899e9) < 1e4
