@@ -103,7 +103,10 @@ struct FfArgs {
   uint4 *pk;             // backward: [R / 32][2][4][2][64] the tile's xn3 / dh as MFMA fragments, for k_ff_wgrad
   float *dh1;            // backward: (R, 128) gradient at h1 = dh + LN3'(W1^T d[a | g])
   float *cpart;          // backward: [workgroups][3][128] column sums for d gamma3, d beta3, d b2
-  long long R;           // multiple of 32
+  long long R;           // B * N
+  int B, N;              // shapes, points per shape (multiple of 32).  A workgroup's NW tiles belong to ONE shape (grid = B x ceil(N / 32 / NW);
+                         // wavefronts past a shape's last tile recompute it and store nothing), so that the shape's folded attention
+                         // fragments can sit in LDS once per workgroup
   // forward with the attention sub-block in front (train_attn_fused.h; at_frags != nullptr): h1 = hin + M_s softmax(A_s LN2(hin)) + b_o is
   // computed here from hin and written out (the backward reads it), instead of being read back from a kernel of its own
   const uint4 *at_frags;   // [B][4 sets][4][2][64] folded (A_s, M_s) fragments of this block
@@ -111,7 +114,6 @@ struct FfArgs {
   const float *g2, *b2n, *bo;
   const float *hin;        // (R, 128)
   float *h1_out;           // (R, 128)
-  int N;                   // points per shape
   // backward with the attention's input gradient behind it (at_frags != nullptr): dh_in = dh1 + LN2'(A_s^T dsim) leaves through dh_in
   // (may alias dh: a wavefront reads its rows of dh before it writes them) and cpart gets three more rows (d gamma2, d beta2, d b_o)
   float *dh_in;
@@ -387,56 +389,102 @@ __device__ __forceinline__ void stage_item(const uint4 *frags, int item, unsigne
 template <bool BWD>
 __device__ __forceinline__ constexpr int lt(int t) { return !BWD ? t : t >= 16 ? t - 16 : t >= 12 ? t - 4 : t; }
 
+// The same row in the accumulator layout straight from memory: register 4 q + m of tile c = channel 32 c + 8 q + 4 hf + m (= 32 c + rho(4 q + m, hf))
+__device__ __forceinline__ void load_rows_acc(const float *__restrict__ hrow, int hf, v16f (&d)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f t = *reinterpret_cast<const v4f *>(hrow + 32 * c + 8 * q + 4 * hf);
+      d[c][4 * q + 0] = t[0], d[c][4 * q + 1] = t[1], d[c][4 * q + 2] = t[2], d[c][4 * q + 3] = t[3];
+    }
+}
+
+// LDS map of k_ff: [ring: 3 slots x 24 KiB][b1 of all chunks 4 KiB][gamma3 | beta3 1 KiB][gamma2 | beta2 | b_o 1.5 KiB][b2 0.5 KiB] = 79 KiB, two
+// workgroups per CU.  The folded attention fragments of the workgroup's shape borrow ring space while the ring is idle: forward, slot 2
+// during the prologue ([A_s | M_s], 16 KiB; chunk 2 is only requested behind the prologue's last barrier); backward, 24 KiB at AT_OFF_BWD
+// behind the loop ([A_s | M_s^T | A_s^T]; the column-sum tiles of the epilogue use the 30 KiB in front of it).
+constexpr int RING_BYTES = NBUF * FWD_TILES * 2048;
+constexpr int TAB_B1 = RING_BYTES, TAB_GB3 = TAB_B1 + B1P_FLOATS * 4, TAB_GB2 = TAB_GB3 + 2 * C * 4, TAB_B2 = TAB_GB2 + 3 * C * 4, FF_LDS = TAB_B2 + C * 4;
+constexpr int AT_OFF_BWD = 32768;
+
+// Memory phases (round 4): every phase that touches HBM issues ALL of its loads before it consumes any of them.  Left to hipcc, the folded
+// attention's 32 fragment loads sat one s_waitcnt vmcnt(0) apart (each behind a store it could alias), the staging loops of the tables were
+// three dependent round trips, and the rows were requested only behind the weight ring's first wait: 14 serial HBM round trips in the
+// forward's prologue, ~6 in the backward's and ~45 in its epilogue — 58 % of a backward wavefront's life.  Now: rows first, tables and ring
+// behind them, ONE wait; attention fragments through LDS (LDS-DMA, no registers); the epilogue's second reads as two batches.  Vector-memory
+// operations complete in issue order (loads, stores and LDS-DMA alike), so stores may stay in flight across the counted waits of the loop.
 template <bool BWD>
 __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   constexpr int NW = nw_of<BWD>();
+  static_assert(NW == 4 && NW * 64 == 2 * C && FWD_TILES == BWD_TILES && B1P_FLOATS * 4 == NW * 1024, "table staging below assumes 256 threads");
   constexpr int BUF_BYTES = (BWD ? BWD_TILES : FWD_TILES) * 2048;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ff_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ff_smem);
   const unsigned voff = lane * 16;
-  long long row = ((long long)blockIdx.x * NW + wave) * 32;
-  const bool live = row < a.R;
-  if (!live) row = a.R - 32;   // a workgroup's trailing wavefronts past the end recompute the last tile and store nothing
-  row += pj;
+  // one shape per workgroup: tiles (blockIdx.x % gps) * NW .. + NW - 1 of shape blockIdx.x / gps
+  const int tps = a.N / 32, gps = (tps + NW - 1) / NW;
+  const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x / gps);
+  int ti = ((int)blockIdx.x - s * gps) * NW + wave;
+  const bool live = ti < tps;
+  if (!live) ti = tps - 1;   // a workgroup's trailing wavefronts past the shape's end recompute its last tile and store nothing
+  // rows: a wave-uniform base (scalar registers) + ONE lane offset for every row-shaped tensor
+  const long long rowbase = ((long long)s * a.N + ti * 32) * C;
+  const unsigned loff = pj * C;
+  const bool at = a.at_frags != nullptr;
 
   constexpr int PIECES = FWD_TILES * 2 / NW;   // forward: LDS-DMA instructions per wave and chunk
   FFT_INIT(a, BWD ? 1 : 0);
   FFT(1);
+  // ---- prologue, memory side: this lane's rows first (the oldest requests come back first), then the tables, then the ring ----
+  v8f x[4][2], xd[4][2];
+  load_rows((BWD || !at ? a.h1 : a.hin) + rowbase + loff, hf, x);
+  if (BWD) load_rows(a.dh + rowbase + loff, hf, xd);
+  float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
+  float *gbs = reinterpret_cast<float *>(ff_smem + TAB_GB3);
+  float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
+  float *b2s = reinterpret_cast<float *>(ff_smem + TAB_B2);
+  // tables: threads 0 .. 127 (waves 0, 1) fetch gamma3 | beta3 | b_o of their channel, the others gamma2 | beta2 | b2 — unconditional loads
+  // through selected pointers (a branch here costs a wait for the rows: hipcc resolves the write-after-write on the other path with vmcnt(0))
+  const int tx = threadIdx.x, tc = tx & (C - 1);
+  const bool lo_half = wave < NW / 2;
+  const float *tp0 = lo_half ? a.g3 : at ? a.g2 : a.g3, *tp1 = lo_half ? a.b3 : at ? a.b2n : a.b3;
+  const float *tp2 = lo_half ? (at ? a.bo : a.g3) : (!BWD ? a.b2p : a.g3);
+  const float tv0 = tp0[tc], tv1 = tp1[tc], tv2 = tp2[tc];
+  dma1k(reinterpret_cast<const char *>(a.b1p) + wave * 1024, voff, lds0 + TAB_B1 + wave * 1024);
   if (BWD) {
     stage_item(a.frags, 0, lds0, wave, voff);
     stage_item(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
   } else {
+    if (at) {   // [A_s | M_s] of this shape -> slot 2
+      const char *src = reinterpret_cast<const char *>(a.at_frags + (size_t)s * SHAPE_U4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dma1k(src + (k * NW + wave) * 1024, voff, lds0 + 2 * BUF_BYTES + (k * NW + wave) * 1024);
+    }
     stage_chunk<BWD>(a.frags, 0, lds0, wave, voff);
-    if (NBUF > 2) stage_chunk<BWD>(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
+    stage_chunk<BWD>(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
   }
-
-  // b1 of all chunks and LayerNorm3's affine -> LDS: inside the loop every operand must come from LDS — vector-memory loads
-  // complete in order, so a global load issued behind a chunk's LDS-DMA pieces could only be consumed after those pieces had
-  // landed as well, and the stream would never run ahead
-  float *b1s = reinterpret_cast<float *>(ff_smem + NBUF * BUF_BYTES);
-  float *gbs = b1s + B1P_FLOATS;
-  float *gb2 = gbs + 2 * C;   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
-  for (int i = threadIdx.x; i < B1P_FLOATS; i += NW * 64) b1s[i] = a.b1p[i];
-  for (int i = threadIdx.x; i < 2 * C; i += NW * 64) gbs[i] = i < C ? a.g3[i] : a.b3[i - C];
-  if (a.at_frags)
-    for (int i = threadIdx.x; i < 3 * C; i += NW * 64) gb2[i] = i < C ? a.g2[i] : i < 2 * C ? a.b2n[i - C] : a.bo[i - 2 * C];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first NBUF - 1 chunks have landed (one-off)
+  unsigned vmask = 0;
+  if (at) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ONE round trip: rows, tables, attention fragments, the first two chunks / items
+  {
+    float *d0 = lo_half ? gbs : gb2, *d2 = lo_half ? gb2 + 2 * C : b2s;
+    d0[tc] = tv0, d0[C + tc] = tv1, d2[tc] = tv2;
+  }
   __syncthreads();
+  FFT(16);
   // B operand of the products over the channels: xn3 = LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   uint4 xn[4][2];
   float mu, rstd;
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
-  if (!BWD && a.at_frags) {
+  if (!BWD && at) {
     // attention sub-block in registers: h1 = hin + M_s softmax(A_s LN2(hin)) + b_o, then straight on to LayerNorm3
-    v8f x[4][2];
-    load_rows(a.hin + row * C, hf, x);
-    const int s = (int)((row - pj) / a.N);
-    const uint4 *fr = a.at_frags + (size_t)s * SHAPE_U4 + lane;
-    unsigned vmask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+    const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + 2 * BUF_BYTES) + lane;
     v16f sim = zero16();
     {
       uint4 xn2[4][2];
@@ -445,7 +493,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sim = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], sim);
+        for (int u = 0; u < 2; ++u) sim = mfma(fl[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], sim);
     }
     softmax_regs(sim, vmask);
     const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
@@ -458,19 +506,18 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[ct][4 * q + m] += b[m];
       }
-      acc[ct] = mfma(fr[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
-      acc[ct] = mfma(fr[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
+      acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
+      acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<v4f *>(a.h1_out + row * C + 32 * ct + 8 * q + 4 * hf) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+          *reinterpret_cast<v4f *>(a.h1_out + rowbase + (loff + 32 * ct + 8 * q + 4 * hf)) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
       }
     }
     acc_to_rows(acc, x);   // h1 in the B-operand layout for LayerNorm3
     ln_rows(x, hf, gbs, xn, mu, rstd);
+    __syncthreads();       // everybody is done with the attention fragments: slot 2 takes chunk 2 at the top of the loop
   } else {
-    v8f x[4][2];
-    load_rows(a.h1 + row * C, hf, x);
     ln_rows(x, hf, gbs, xn, mu, rstd);
     if (!BWD) rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
   }
@@ -479,19 +526,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float *p = a.dh + row * C + 32 * c + k_nat(u, hf, 0);
-        const v4f lo = *reinterpret_cast<const v4f *>(p), hi = *reinterpret_cast<const v4f *>(p + 4);
-        const v8f t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        dhb[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(t, v8bf));
-      }
+      for (int u = 0; u < 2; ++u) dhb[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(xd[c][u], v8bf));
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    // the tile for k_ff_wgrad: xn3 and dh as bf16 B-operand fragments (points on the lanes), 16 KiB of whole 1 KiB stores
+    // the tile for k_ff_wgrad: xn3 and dh as bf16 B-operand fragments (points on the lanes), 16 KiB of whole 1 KiB stores (left in flight)
     if (live) {
-      uint4 *pk = a.pk + (size_t)((row - pj) / 32) * PK_TILE_U4 + lane;
+      uint4 *pk = a.pk + (size_t)(rowbase / (32 * C)) * PK_TILE_U4 + lane;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
@@ -502,12 +544,11 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       v16f b2;
-      load16(b2, a.b2p + hf * 64 + c * 16);
+      load16(b2, b2s + hf * 64 + c * 16);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] += b2[r];
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's loads and stores are done: the loop counts only LDS-DMA pieces (+ the backward's tile stores)
   FFT(2);
 
 #pragma unroll 1
@@ -639,30 +680,41 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   FFT(3);
   if (!BWD) {
     if (!live) return;
-    float *out = a.h2 + row * C;
+    float *out = a.h2 + rowbase;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v4f *>(out + 32 * c + 8 * q + 4 * hf) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+        *reinterpret_cast<v4f *>(out + (loff + 32 * c + 8 * q + 4 * hf)) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
     FFT(9);
     return;
   }
+  // ---- backward epilogue.  The ring is idle (every wave is behind the loop's last barrier): the shape's [A_s | M_s^T | A_s^T] fragments are
+  // requested into it first, then the second reads of h1 and dh (accumulator layout) as one batch ----
+  if (at) {
+    const char *src = reinterpret_cast<const char *>(a.at_frags + (size_t)s * SHAPE_U4);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int p = k * NW + wave;   // destination KiB; the source skips the M_s set (KiB 8 .. 15)
+      dma1k(src + (p < 8 ? p : p + 8) * 1024, voff, lds0 + AT_OFF_BWD + p * 1024);
+    }
+  }
+  v16f xh[4], dv[4];
+  load_rows_acc(a.h1 + rowbase + loff, hf, xh);
+  load_rows_acc(a.dh + rowbase + loff, hf, dv);
   // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
   // - xhat mean(dy g xhat)), and the column sums of dy xhat / dy over the workgroup's points for d gamma3 / d beta3 ----
   // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
   // [channel][point] from the accumulator layout, read back 16 points of one channel per lane.
-  v16f xh[4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int ch = 32 * c + 8 * q + 4 * hf;
-      const v4f x = *reinterpret_cast<const v4f *>(a.h1 + row * C + ch), g = *reinterpret_cast<const v4f *>(gbs + ch);
+      const v4f g = *reinterpret_cast<const v4f *>(gbs + 32 * c + 8 * q + 4 * hf);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        xh[c][4 * q + m] = (x[m] - mu) * rstd;
+        xh[c][4 * q + m] = (xh[c][4 * q + m] - mu) * rstd;
         const float dg = acc[c][4 * q + m] * g[m];
         s1 += dg;
         s2 = fmaf(dg, xh[c][4 * q + m], s2);
@@ -674,96 +726,101 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   constexpr int TROW = 36;   // floats per tile row: 16-byte aligned rows, conflict-free column reads
   float *tt = reinterpret_cast<float *>(ff_smem) + wave * 32 * TROW;
   float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][NQ][128]
-  const int NQ = a.at_frags ? 6 : 3;
+  static_assert((NW * 32 * TROW + NW * 6 * C) * 4 <= AT_OFF_BWD, "column-sum tiles overlap the attention fragments");
+  const int NQ = at ? 6 : 3;
   const float keep = live ? 1.f : 0.f;
-  // (gb2 sits behind the chunk buffers: untouched by the tiles)
   auto colsum = [&](const v16f &v, int which, int c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) tt[rho(r, hf) * TROW + pj] = v[r];
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const v4f x = *reinterpret_cast<const v4f *>(tt + pj * TROW + 16 * hf + 4 * k);
-      t += (x[0] + x[1]) + (x[2] + x[3]);
+      const v4f x4 = *reinterpret_cast<const v4f *>(tt + pj * TROW + 16 * hf + 4 * k);
+      t += (x4[0] + x4[1]) + (x4[2] + x4[3]);
     }
     t += xhalf(t);
     if (hf == 0) cred[(wave * NQ + which) * C + 32 * c + pj] = t * keep;
   };
-  v16f d1[4];   // dh1 in the accumulator layout
+  // dh1 replaces dh in dv, tile by tile
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    v16f dv, gx;
+    v16f gx, d1c;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = 32 * c + 8 * q + 4 * hf;
-      const v4f d = *reinterpret_cast<const v4f *>(a.dh + row * C + ch), g = *reinterpret_cast<const v4f *>(gbs + ch);
+      const v4f g = *reinterpret_cast<const v4f *>(gbs + ch);
       v4f o;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = 4 * q + m;
-        dv[r] = d[m];
         gx[r] = acc[c][r] * xh[c][r];
-        o[m] = d[m] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
-        d1[c][r] = o[m];
+        o[m] = dv[c][r] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
+        d1c[r] = o[m];
       }
-      if (live && !a.at_frags) *reinterpret_cast<v4f *>(a.dh1 + row * C + ch) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
+      if (live && !at) *reinterpret_cast<v4f *>(a.dh1 + rowbase + (loff + ch)) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
     }
     colsum(gx, 0, c);
     colsum(acc[c], 1, c);
-    colsum(dv, 2, c);
+    colsum(dv[c], 2, c);
+    dv[c] = d1c;
   }
   FFT(5);
-  if (a.at_frags) {
+  if (at) {
     // ---- the attention sub-block's input gradient on the same rows (afused::k_attn_bwd_dx's arithmetic): recompute LN2 / sim / P from hin,
     // dP = M_s^T dh1, softmax backward, dxn2 = A_s^T dsim, LayerNorm2 backward: dh_in = dh1 + ... ; column sums for d gamma2, d beta2, d b_o ----
-    const int s = (int)((row - pj) / a.N);
-    const uint4 *fr = a.at_frags + (size_t)s * SHAPE_U4 + lane;
-    unsigned vmask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the attention fragments (requested a phase ago)
+    __syncthreads();
+    const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + AT_OFF_BWD) + lane;
+    constexpr int L_AS = 0, L_MST = SET_U4, L_AST = 2 * SET_U4;
+    load_rows(a.hin + rowbase + loff, hf, x);   // travels while dP is computed
     float mu2, rstd2;
     v16f P = zero16(), ds = zero16();
     // this tile's xn2 | dh1 fragments for k_attn_bwd_param: a wave-uniform base (scalar registers) + the lane
-    uint4 *pk2p = a.pk2 + (size_t)__builtin_amdgcn_readfirstlane((int)((row - pj) / 32)) * (2 * 8 * 64);
+    uint4 *pk2p = a.pk2 + (size_t)(rowbase / (32 * C)) * (2 * 8 * 64);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // dh1 as the B operand, a channel tile at a time
+      v8f t8[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float lo = dv[c][8 * u + m], hi = dv[c][8 * u + 4 + m];
+          const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi), false, false);
+          const unsigned r0 = r[0], r1 = r[1];
+          t8[u][m] = __builtin_bit_cast(float, r0);
+          t8[u][4 + m] = __builtin_bit_cast(float, r1);
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 db = __builtin_bit_cast(uint4, __builtin_convertvector(t8[u], v8bf));
+        ds = mfma(fl[L_MST + (c * 2 + u) * 64], db, ds);
+        if (live) pk2p[(8 + c * 2 + u) * 64 + lane] = db;
+      }
+    }
+    FFT(6);
     {
-      v8f x[4][2];
       uint4 xn2[4][2];
-      load_rows(a.hin + row * C, hf, x);
       ln_rows(x, hf, gb2, xn2, mu2, rstd2);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (live) pk2p[(c * 2 + u) * 64 + lane] = xn2[c][u];
-          P = mfma(fr[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], P);
+          P = mfma(fl[L_AS + (c * 2 + u) * 64], xn2[c][u], P);
         }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) x[c][u] = (x[c][u] - mu2) * rstd2;
       rows_to_acc(x, xh);   // xhat2 in the accumulator layout (xhat3 is done with)
     }
-    FFT(6);
     softmax_regs(P, vmask);
-    {
-      v8f x[4][2];
-      acc_to_rows(d1, x);   // dh1 as the B operand
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint4 db = __builtin_bit_cast(uint4, __builtin_convertvector(x[c][u], v8bf));
-          ds = mfma(fr[F_MST * SET_U4 + (c * 2 + u) * 64], db, ds);
-          if (live) pk2p[(8 + c * 2 + u) * 64 + lane] = db;
-        }
-    }
     softmax_bwd_regs(P, ds);
     const uint4 q0 = pack8(ds, 0), q1 = pack8(ds, 1);
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      acc[c] = mfma(fr[F_AST * SET_U4 + (c * 2 + 1) * 64], q1, mfma(fr[F_AST * SET_U4 + (c * 2 + 0) * 64], q0, zero16()));   // dxn2
+      acc[c] = mfma(fl[L_AST + (c * 2 + 1) * 64], q1, mfma(fl[L_AST + (c * 2 + 0) * 64], q0, zero16()));   // dxn2
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4f g = *reinterpret_cast<const v4f *>(gb2 + 32 * c + 8 * q + 4 * hf);
@@ -789,13 +846,13 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         for (int m = 0; m < 4; ++m) {
           const int r = 4 * q + m;
           gx[r] = acc[c][r] * xh[c][r];
-          o[m] = d1[c][r] + rstd2 * (acc[c][r] * g[m] - t1 - xh[c][r] * t2);
+          o[m] = dv[c][r] + rstd2 * (acc[c][r] * g[m] - t1 - xh[c][r] * t2);
         }
-        if (live) *reinterpret_cast<v4f *>(a.dh_in + row * C + ch) = o;
+        if (live) *reinterpret_cast<v4f *>(a.dh_in + rowbase + (loff + ch)) = o;
       }
       colsum(gx, 3, c);
       colsum(acc[c], 4, c);
-      colsum(d1[c], 5, c);
+      colsum(dv[c], 5, c);
     }
   }
   FFT(7);
@@ -1042,13 +1099,15 @@ inline void launch_pack(hipStream_t st, const PackArgs &a) {
   const int total = NCHUNK * TILES * 128;
   k_ff_pack<<<(total + 255) / 256, 256, 0, st>>>(a);
 }
+// workgroups of k_ff<*> (= rows of the backward's column-sum partials): one shape per workgroup
+inline long long ff_groups(int B, int N) { return (long long)B * ((N / 32 + NW_BWD - 1) / NW_BWD); }
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) {
-  constexpr int LDS = NBUF * (BWD ? BWD_TILES : FWD_TILES) * 2048 + (B1P_FLOATS + 2 * C + 3 * C) * 4;
+  constexpr int LDS = FF_LDS;
   static PerDeviceOnce attrs;
   if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff<BWD>), LDS); }) != hipSuccess) return -1;
   constexpr int NW = nw_of<BWD>();
-  const long long groups = (a.R / 32 + NW - 1) / NW;
+  const long long groups = ff_groups(a.B, a.N);
 #ifdef DFX_TRACE_FF
   FfArgs at = a;
   at.trace = ff_trace_buffer();

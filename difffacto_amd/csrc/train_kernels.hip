@@ -1427,7 +1427,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.at_part = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
   w.at_sum = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
   {
-    const size_t groups = (R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD, a = groups * 6 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
+    const size_t groups = (size_t)dfx::ffused::ff_groups(B, N), a = groups * 6 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
     w.cpart = c.take<float>(a > b ? a : b);
   }
   w.ffw_slabs = dfx::ffused::wgrad_slabs((long long)(R / 32));
@@ -1826,10 +1826,10 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
-      fa.h1 = a.h1, fa.h2 = hout, fa.R = R;
+      fa.h1 = a.h1, fa.h2 = hout, fa.R = R, fa.B = B, fa.N = N;
       if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
-        fa.hin = a.hin, fa.h1_out = a.h1, fa.N = N;
+        fa.hin = a.hin, fa.h1_out = a.h1;
       } else {
         dfx::afused::AttnArgs aa{};
         aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
@@ -1922,15 +1922,15 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // backward -> dh1; hid, d[a | g] and xn3 leave the kernel once, as bf16, for the two weight-gradient products
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
-      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R;
+      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R, fa.B = B, fa.N = N;
       const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
-        fa.hin = a.hin, fa.dh_in = w.dh, fa.N = N;
+        fa.hin = a.hin, fa.dh_in = w.dh;
         fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
-      const int groups = (int)((R / 32 + dfx::ffused::NW_BWD - 1) / dfx::ffused::NW_BWD);
+      const int groups = (int)dfx::ffused::ff_groups(B, N);
       const int nq = dx_in_ff ? 6 : 3;
       k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, nq * C);
       if (dx_in_ff)
