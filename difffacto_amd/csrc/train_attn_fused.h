@@ -444,8 +444,14 @@ struct UnfoldArgs {
   float *sum;               // scratch [B][2][32][128]: partials of a shape summed (written by the shape blocks of launch 1)
   int B, split, ldkv;
 };
-// grid (J, B): one block per key / value token of a shape; 256 threads = 128 channels d x 2 halves of the sum over c
-__global__ __launch_bounds__(256) void k_attn_unfold_kv(UnfoldArgs a) {
+// The unfold kernels run ONCE per backward, for all transformer blocks (blockIdx.z): the parameter kernel of block i leaves its partials in
+// block i's own buffer, nothing on the gradient chain dh waits for them (round 4: ten launches of 128 - 512 workgroups -> two)
+struct UnfoldBatch {
+  UnfoldArgs blk[DFX_MAX_DEPTH];
+};
+// grid (J, B, depth): one block per key / value token of a shape; 256 threads = 128 channels d x 2 halves of the sum over c
+__global__ __launch_bounds__(256) void k_attn_unfold_kv(UnfoldBatch batch) {
+  const UnfoldArgs &a = batch.blk[blockIdx.z];
   __shared__ float dA[HEADS][C], dM[HEADS][C];   // rows (h, j) of this token: summed over the partials
   __shared__ float half_k[C], half_v[C];
   const int j = blockIdx.x, s = blockIdx.y, t = threadIdx.x;
@@ -479,7 +485,8 @@ __global__ __launch_bounds__(256) void k_attn_unfold_kv(UnfoldArgs a) {
   }
 }
 // one block per weight row d (of Wq) / column d (of Wo); 128 channels c x 8 groups of shapes (summed in group order)
-__global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldArgs a) {
+__global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldBatch batch) {   // grid (128, 1, depth)
+  const UnfoldArgs &a = batch.blk[blockIdx.z];
   __shared__ float rq[8][C], ro[8][C];
   const int d = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7, hd = d >> 4;
   float aq = 0.f, ao = 0.f;

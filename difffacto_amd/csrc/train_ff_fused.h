@@ -1060,7 +1060,11 @@ struct FwFinishArgs {
   float *dw1, *db1, *dw2;   // (1024, 128), (1024), (128, 512)
   int nslab;
 };
-__global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishArgs a) {
+struct FwFinishBatch {   // one launch for all transformer blocks (blockIdx.y): block i's partials wait in block i's own buffers
+  FwFinishArgs blk[DFX_MAX_DEPTH];
+};
+__global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
+  const FwFinishArgs &a = batch.blk[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;   // over NCHUNK * 12 * 1024 tile elements, then NCHUNK * 64 bias sums
   constexpr int NT = NCHUNK * 12 * 1024;
   if (idx < NT) {
@@ -1078,7 +1082,11 @@ __global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishArgs a) {
   }
 }
 inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
-inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &f) {
+inline void launch_ff_wgrad_finish(hipStream_t st, const FwFinishBatch &f, int depth) {
+  const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
+  k_ff_wgrad_finish<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(f);
+}
+inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) {
   static PerDeviceOnce attrs;
   if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_wgrad), WG_LDS); }) != hipSuccess) return -1;
 #ifdef DFX_TRACE_FF
@@ -1088,8 +1096,6 @@ inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a, const FwFinishArgs &
 #else
   k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(a);
 #endif
-  const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
-  k_ff_wgrad_finish<<<(total + 255) / 256, 256, 0, st>>>(f);
   return 0;
 }
 

@@ -216,6 +216,32 @@ __global__ __launch_bounds__(1024) void k_sum_parts_multi(const float *__restric
   }
 }
 
+// Up to DFX_MAX_DEPTH x 6 outputs of `cols` columns in ONE launch: job (block b, which q) sums rows of part[b] (row length ld_part, the
+// six vectors side by side).  grid = njobs x cols / 32.
+struct SumJobs {
+  const float *part[DFX_MAX_DEPTH];
+  float *o[DFX_MAX_DEPTH][6];
+};
+__global__ __launch_bounds__(1024) void k_sum_parts_jobs(SumJobs jobs, int nparts, int cols, int ld_part) {
+  __shared__ float red[32][32];
+  const int per = cols / 32, job = blockIdx.x / per, b = job / 6, which = job % 6, c = (blockIdx.x % per) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  const float *src = jobs.part[b] + which * cols + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = q;
+  for (; p + 96 < nparts; p += 128) {
+    a0 += src[(size_t)p * ld_part], a1 += src[(size_t)(p + 32) * ld_part];
+    a2 += src[(size_t)(p + 64) * ld_part], a3 += src[(size_t)(p + 96) * ld_part];
+  }
+  for (; p < nparts; p += 32) a0 += src[(size_t)p * ld_part];
+  red[q][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0) {
+    float t = red[0][threadIdx.x];
+    for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
+    jobs.o[b][which][c] = t;
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752440f)); }
 
 // [a | g] itself is stored as bf16 in bf16 mode (-DDFX_TRAIN_AG_F32 keeps it fp32): written once and read twice per block, it
@@ -1343,10 +1369,10 @@ struct TrainWs {
   float *ff_b1p[DFX_MAX_DEPTH], *ff_b2p[DFX_MAX_DEPTH];
   // fused attention (train_attn_fused.h): per shape the folded (A_s, M_s) fragments of each block; gradient partials
   uint4 *at_frags[DFX_MAX_DEPTH];
-  float *at_part, *at_sum, *cpart;
+  float *at_part[DFX_MAX_DEPTH], *at_sum[DFX_MAX_DEPTH], *cpart[DFX_MAX_DEPTH];   // per block: summed / unfolded behind the block loop, one launch each
   int at_split;
   // weight-stationary feed-forward gradients (k_ff_wgrad): per-slab partial tiles
-  float *ffw_part, *ffw_bpart;
+  float *ffw_part[DFX_MAX_DEPTH], *ffw_bpart[DFX_MAX_DEPTH];
   int ffw_slabs;
   // keys / values of all blocks in one product: packed weights (and transposed), k | v of every block side by side, their gradients
   float *wkv, *wkvT, *kv, *dkv, *dwkv;
@@ -1424,15 +1450,15 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   }
   for (int i = 0; i < depth; ++i) w.at_frags[i] = c.take<uint4>((size_t)B * dfx::afused::SHAPE_U4);
   w.at_split = dfx::afused::param_split(B, N);
-  w.at_part = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
-  w.at_sum = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
-  {
-    const size_t groups = (size_t)dfx::ffused::ff_groups(B, N), a = groups * 6 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
-    w.cpart = c.take<float>(a > b ? a : b);
-  }
   w.ffw_slabs = dfx::ffused::wgrad_slabs((long long)(R / 32));
-  w.ffw_part = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
-  w.ffw_bpart = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
+  for (int i = 0; i < depth; ++i) {
+    w.at_part[i] = c.take<float>((size_t)B * w.at_split * 2 * dfx::afused::HJ * C);
+    w.at_sum[i] = c.take<float>((size_t)B * 2 * dfx::afused::HJ * C);
+    const size_t groups = (size_t)dfx::ffused::ff_groups(B, N), a = groups * 6 * C, b = (size_t)dfx::afused::dx_groups((long long)R) * 3 * C;
+    w.cpart[i] = c.take<float>(a > b ? a : b);
+    w.ffw_part[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
+    w.ffw_bpart[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
+  }
   w.wkv = c.take<float>((size_t)2 * depth * C * CTXP);
   w.wkvT = c.take<float>((size_t)2 * depth * C * CTXP);
   w.dwkv = c.take<float>((size_t)2 * depth * C * CTXP);
@@ -1922,7 +1948,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // backward -> dh1; hid, d[a | g] and xn3 leave the kernel once, as bf16, for the two weight-gradient products
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
-      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart, fa.R = R, fa.B = B, fa.N = N;
+      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart[i], fa.R = R, fa.B = B, fa.N = N;
       const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
@@ -1931,31 +1957,27 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
       const int groups = (int)dfx::ffused::ff_groups(B, N);
-      const int nq = dx_in_ff ? 6 : 3;
-      k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, nq * C);
-      if (dx_in_ff)
-        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart + 3 * C, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, groups, C, nq * C);
-      // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide
+      // (with the attention's input gradient in the same kernel, the six column sums of every block are one launch behind the loop)
+      if (!dx_in_ff)
+        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart[i], SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
+      // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide; the slab partials of every
+      // block are summed in one launch behind the loop
       {
-        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part, w.ffw_bpart, R / 32, w.ffw_slabs};
-        dfx::ffused::FwFinishArgs wf{w.ffw_part, w.ffw_bpart, mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs};
-        if (dfx::ffused::launch_ff_wgrad(st, wa, wf)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
+        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i], R / 32, w.ffw_slabs};
+        if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
       dfx::afused::AttnArgs aa{};
       aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
-      aa.h = a.hin, aa.dh1 = w.dh2, aa.dh = w.dh, aa.part = w.at_part, aa.cpart = w.cpart, aa.N = N, aa.split = w.at_split, aa.R = R;
+      aa.h = a.hin, aa.dh1 = w.dh2, aa.dh = w.dh, aa.part = w.at_part[i], aa.cpart = w.cpart[i], aa.N = N, aa.split = w.at_split, aa.R = R;
       aa.pk2 = dx_in_ff ? reinterpret_cast<const uint4 *>(w.dq) : nullptr;
       if (dx_in_ff) dfx::afused::k_attn_bwd_param<true><<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
       else dfx::afused::k_attn_bwd_param<false><<<B * w.at_split, dfx::afused::NW * 64, 0, st>>>(aa);
       const int np = dfx::afused::dx_groups(R);
-      if (!dx_in_ff) dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
-      const int LDKV = 2 * wt->depth * C;
-      dfx::afused::UnfoldArgs ua{w.at_part, w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
-                                 mut(gw.to_q), mut(gw.to_out_w), w.at_sum, B, w.at_split, LDKV};
-      dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B), 256, 0, st>>>(ua);
-      dfx::afused::k_attn_unfold_w<<<C, 1024, 0, st>>>(ua);
-      if (!dx_in_ff) k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart, SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
+      if (!dx_in_ff) {
+        dfx::afused::k_attn_bwd_dx<<<np, dfx::afused::NW * 64, 0, st>>>(aa);
+        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart[i], SumOuts{{mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b), nullptr}}, np, C, 3 * C);
+      }
     } else {
     if ((rc = wgrad(st, w, w.dh, C, a.hid, FH, mut(gw.ff2_w), mut(gw.ff2_b), C, FH, FH, R, false, bf))) return rc;
     transpose(st, bw.ff2_w, w.wT, C, FH);                                    // (512, 128)
@@ -1995,7 +2017,26 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     transpose(st, bw.to_v, w.wT, C, CTX);
     if ((rc = lin(st, w.dv, C, w.wT, nullptr, w.dctx, CTXP, BJ, CTXP, C, w.dctx, CTXP))) return rc;
   }
-  if (ff_fused(bf, dropout_p, R, N)) {   // d Wk, d Wv of every block and d ctx from the side-by-side key / value gradients
+  if (ff_fused(bf, dropout_p, R, N)) {
+    // parameter gradients of ALL blocks from the partials the block loop left behind: one launch per kind
+    const int LDKV0 = 2 * wt->depth * C;
+    dfx::ffused::FwFinishBatch fb{};
+    dfx::afused::UnfoldBatch ub{};
+    SumJobs sj{};
+    for (int i = 0; i < wt->depth; ++i) {
+      const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
+      fb.blk[i] = dfx::ffused::FwFinishArgs{w.ffw_part[i], w.ffw_bpart[i], mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs};
+      ub.blk[i] = dfx::afused::UnfoldArgs{w.at_part[i], w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
+                                          mut(gw.to_q), mut(gw.to_out_w), w.at_sum[i], B, w.at_split, LDKV0};
+      sj.part[i] = w.cpart[i];
+      float *o6[6] = {mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b)};
+      for (int q = 0; q < 6; ++q) sj.o[i][q] = o6[q];
+    }
+    dfx::ffused::launch_ff_wgrad_finish(st, fb, wt->depth);
+    dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B, wt->depth), 256, 0, st>>>(ub);
+    dfx::afused::k_attn_unfold_w<<<dim3(C, 1, wt->depth), 1024, 0, st>>>(ub);
+    if (t_attn_in_ff) k_sum_parts_jobs<<<wt->depth * 6 * (C / 32), 1024, 0, st>>>(sj, (int)dfx::ffused::ff_groups(B, N), C, 6 * C);
+    // d Wk, d Wv of every block and d ctx from the side-by-side key / value gradients
     const int n2 = 2 * wt->depth, LDKV = n2 * C;
     if ((rc = wgrad(st, w, w.dkv, LDKV, w.ctx, CTXP, w.dwkv, nullptr, LDKV, CTXP, CTXP, BJ))) return rc;
     KvMutPtrs gp{};
