@@ -324,6 +324,43 @@ __device__ __forceinline__ void ln_rows(const float *__restrict__ hrow, int hf, 
   ln_rows(x, hf, gb, xn, mu, rstd);
 }
 
+// ln_rows in two pieces — the statistics, and ONE affine bf16 fragment — for callers that consume the fragments as they are made
+__device__ __forceinline__ void ln_stats(const v8f (&x)[4][2], float &mu, float &rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[c][u][e];
+  s += xhalf(s);
+  mu = s * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = x[c][u][e] - mu;
+        q = fmaf(d, d, q);
+      }
+  q += xhalf(q);
+  rstd = 1.0f / sqrtf(q * (1.0f / C) + LN_EPS);
+}
+__device__ __forceinline__ uint4 ln_frag(const v8f &xcu, int c, int u, int hf, const float *gb, float mu, float rstd) {
+  const int ch = 32 * c + k_nat(u, hf, 0);
+  const v4f g0 = *reinterpret_cast<const v4f *>(gb + ch), g1 = *reinterpret_cast<const v4f *>(gb + ch + 4);
+  const v4f b0 = *reinterpret_cast<const v4f *>(gb + C + ch), b1 = *reinterpret_cast<const v4f *>(gb + C + ch + 4);
+  v8f y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y[e] = fmaf((xcu[e] - mu) * rstd, g0[e], b0[e]);
+    y[4 + e] = fmaf((xcu[4 + e] - mu) * rstd, g1[e], b1[e]);
+  }
+  return __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
+}
+
 // x * sigmoid(k(x)), k(x) = x (c1 + c3 x^2); returns gelu and d gelu / dx
 __device__ __forceinline__ void gelu_fd(float x, float &f, float &d) {
   const float x2 = x * x;
@@ -487,13 +524,12 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + 2 * BUF_BYTES) + lane;
     v16f sim = zero16();
     {
-      uint4 xn2[4][2];
       float mu2, rstd2;
-      ln_rows(x, hf, gb2, xn2, mu2, rstd2);
+      ln_stats(x, mu2, rstd2);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sim = mfma(fl[F_AS * SET_U4 + (c * 2 + u) * 64], xn2[c][u], sim);
+        for (int u = 0; u < 2; ++u) sim = mfma(fl[F_AS * SET_U4 + (c * 2 + u) * 64], ln_frag(x[c][u], c, u, hf, gb2, mu2, rstd2), sim);
     }
     softmax_regs(sim, vmask);
     const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
@@ -515,12 +551,17 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       }
     }
     acc_to_rows(acc, x);   // h1 in the B-operand layout for LayerNorm3
-    ln_rows(x, hf, gbs, xn, mu, rstd);
     __syncthreads();       // everybody is done with the attention fragments: slot 2 takes chunk 2 at the top of the loop
-  } else {
-    ln_rows(x, hf, gbs, xn, mu, rstd);
-    if (!BWD) rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
+  } else if (!BWD) {
+    rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
   }
+  // LayerNorm3 on this lane's row of h1 (one copy of the code for all paths: in both branches hipcc hoisted the gamma / beta reads above the
+  // branch — and spilled them)
+  ln_stats(x, mu, rstd);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xn[c][u] = ln_frag(x[c][u], c, u, hf, gbs, mu, rstd);
   uint4 dhb[4][2];
   if (BWD) {
 #pragma unroll
@@ -799,34 +840,66 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
     FFT(6);
     {
-      uint4 xn2[4][2];
-      ln_rows(x, hf, gb2, xn2, mu2, rstd2);
+      // LayerNorm2 of hin (ln_rows' arithmetic), a fragment at a time: xhat2 replaces the row in place, the affine bf16 fragment goes to
+      // k_attn_bwd_param and into sim = A_s xn2 straight away (no 32-register array of fragments beside the rows)
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sm += x[c][u][e];
+      sm += xhalf(sm);
+      mu2 = sm * (1.0f / C);
+      float qs = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = x[c][u][e] - mu2;
+            qs = fmaf(d, d, qs);
+          }
+      qs += xhalf(qs);
+      rstd2 = 1.0f / sqrtf(qs * (1.0f / C) + LN_EPS);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          if (live) pk2p[(c * 2 + u) * 64 + lane] = xn2[c][u];
-          P = mfma(fl[L_AS + (c * 2 + u) * 64], xn2[c][u], P);
+          const int ch = 32 * c + k_nat(u, hf, 0);
+          const v4f g0 = *reinterpret_cast<const v4f *>(gb2 + ch), g1 = *reinterpret_cast<const v4f *>(gb2 + ch + 4);
+          const v4f b0 = *reinterpret_cast<const v4f *>(gb2 + C + ch), b1 = *reinterpret_cast<const v4f *>(gb2 + C + ch + 4);
+          v8f y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[c][u][e] = (x[c][u][e] - mu2) * rstd2, x[c][u][4 + e] = (x[c][u][4 + e] - mu2) * rstd2;
+            y[e] = fmaf(x[c][u][e], g0[e], b0[e]);
+            y[4 + e] = fmaf(x[c][u][4 + e], g1[e], b1[e]);
+          }
+          const uint4 xn2 = __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
+          if (live) pk2p[(c * 2 + u) * 64 + lane] = xn2;
+          P = mfma(fl[L_AS + (c * 2 + u) * 64], xn2, P);
         }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) x[c][u] = (x[c][u] - mu2) * rstd2;
       rows_to_acc(x, xh);   // xhat2 in the accumulator layout (xhat3 is done with)
     }
     softmax_regs(P, vmask);
     softmax_bwd_regs(P, ds);
-    const uint4 q0 = pack8(ds, 0), q1 = pack8(ds, 1);
+    uint4 q0 = pack8(ds, 0), q1 = pack8(ds, 1);
+    // dxn2 = A_s^T dsim, a channel tile at a time and TWICE (2 MFMAs per tile): once for the row sums of LayerNorm2's backward, once for the
+    // outputs — holding the four tiles across both passes is what used to push d1 / xhat2 into scratch memory, and every reload sat behind the
+    // acknowledgement of the dh_in stores in flight (vector-memory operations complete in order)
+    auto dxn2 = [&](int c) { return mfma(fl[L_AST + (c * 2 + 1) * 64], q1, mfma(fl[L_AST + (c * 2 + 0) * 64], q0, zero16())); };
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      acc[c] = mfma(fl[L_AST + (c * 2 + 1) * 64], q1, mfma(fl[L_AST + (c * 2 + 0) * 64], q0, zero16()));   // dxn2
+      const v16f dx = dxn2(c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4f g = *reinterpret_cast<const v4f *>(gb2 + 32 * c + 8 * q + 4 * hf);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const float dg = acc[c][4 * q + m] * g[m];
+          const float dg = dx[4 * q + m] * g[m];
           t1 += dg;
           t2 = fmaf(dg, xh[c][4 * q + m], t2);
         }
@@ -834,8 +907,11 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
     t1 += xhalf(t1), t2 += xhalf(t2);
     t1 *= (1.0f / C), t2 *= (1.0f / C);
+    // (opaque to the optimiser: the second pass must not be merged with the first)
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      const v16f dx = dxn2(c);
       v16f gx;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -845,13 +921,13 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int r = 4 * q + m;
-          gx[r] = acc[c][r] * xh[c][r];
-          o[m] = dv[c][r] + rstd2 * (acc[c][r] * g[m] - t1 - xh[c][r] * t2);
+          gx[r] = dx[r] * xh[c][r];
+          o[m] = dv[c][r] + rstd2 * (dx[r] * g[m] - t1 - xh[c][r] * t2);
         }
         if (live) *reinterpret_cast<v4f *>(a.dh_in + rowbase + (loff + ch)) = o;
       }
       colsum(gx, 3, c);
-      colsum(acc[c], 4, c);
+      colsum(dx, 4, c);
       colsum(dv[c], 5, c);
     }
   }
