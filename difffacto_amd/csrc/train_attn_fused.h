@@ -312,12 +312,37 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_dx(AttnArgs a) {
   }
 }
 
+// a uint4 pointer that stays in the LDS address space through an opaque asm (a generic pointer would become flat loads)
+typedef const __attribute__((address_space(3))) uint4 *LdsU4;
+__device__ __forceinline__ uint4 lds_u4(LdsU4 p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  (void)p;
+  return uint4{};
+#endif
+}
+
 // ---- backward, parameter side: dA_s, dM_s per shape ----
 // grid = B * split workgroups; workgroup (s, k) walks the row tiles k * per .. (k + 1) * per of shape s, NW at a time
 template <bool PACKED>
 __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float gb[2 * C];
   __shared__ __attribute__((aligned(16))) float red[2 * HJ * C];   // cross-wave sum of dA_s | dM_s^T (32 KiB)
+  // the shape's [A_s | M_s^T] fragments (the B operands of sim^T and dP^T, the same for every tile): once into LDS — read from memory
+  // they were 16 dependent L2 round trips per tile
+  __shared__ __attribute__((aligned(16))) uint4 frs[2 * SET_U4];
+  {
+    const uint4 *src = a.frags + (size_t)(blockIdx.x / a.split) * SHAPE_U4;
+    uint4 t[2 * SET_U4 / (NW * 64)];
+#pragma unroll
+    for (int k = 0; k < 2 * SET_U4 / (NW * 64); ++k) {
+      const int i = k * NW * 64 + threadIdx.x;
+      t[k] = src[(i < SET_U4 ? F_AS * SET_U4 : (F_MST - 1) * SET_U4) + i];
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * SET_U4 / (NW * 64); ++k) frs[k * NW * 64 + threadIdx.x] = t[k];
+  }
   for (int i = threadIdx.x; i < 2 * C; i += NW * 64) gb[i] = i < C ? a.g2[i] : a.b2[i - C];
   for (int i = threadIdx.x; i < 2 * HJ * C; i += NW * 64) red[i] = 0.f;
   __syncthreads();
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
   const int s = blockIdx.x / a.split, part_k = blockIdx.x % a.split;
   const int tiles = a.N / 32, per = (tiles + a.split - 1) / a.split;
   const int t_begin = part_k * per, t_end = t_begin + per < tiles ? t_begin + per : tiles;
-  const uint4 *fr0 = a.frags + (size_t)s * SHAPE_U4 + lane;
+  const LdsU4 fr0 = (LdsU4)frs + lane;   // [0, SET_U4): A_s, [SET_U4, 2 SET_U4): M_s^T
   unsigned vmask = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j) vmask |= (a.valid[s * J + j] != 0.f ? 1u : 0u) << j;
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
   for (int ct = 0; ct < 4; ++ct) dAs[ct] = zero16(), dMs[ct] = zero16();
   for (int t = t_begin + wave; t < t_end; t += NW) {
     const long long row = (long long)s * a.N + (long long)t * 32 + pj;
-    const uint4 *fr = fr0;
+    LdsU4 fr = fr0;
     asm volatile("" : "+v"(fr));   // the fragments are the same for every tile of the shape: hoisted out of the loop they would cost 64 registers (spilled)
     v16f PT = zero16(), dsT = zero16();
     uint4 xn[4][2];
@@ -367,16 +392,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) PT = mfma(xn[c][u], fr[F_AS * SET_U4 + (c * 2 + u) * 64], PT);   // [point][(h, j)]: lane = (h, j), registers = points
+      for (int u = 0; u < 2; ++u) PT = mfma(xn[c][u], lds_u4(fr + (c * 2 + u) * 64), PT);   // [point][(h, j)]: lane = (h, j), registers = points
 #pragma unroll
     for (int r = 0; r < 16; ++r) {   // softmax over j = over the quad
       const float x = keep_lane ? PT[r] : -3.402823466e38f;
       float m = fmaxf(x, quad_xor1(x));
       m = fmaxf(m, quad_xor2(m));
-      const float e = expf(x - m);
+      const float e = __builtin_amdgcn_exp2f((x - m) * 1.44269504088896341f);   // the same hardware exp2 / rcp as ffused::softmax_regs
       float den = e + quad_xor1(e);
       den += quad_xor2(den);
-      PT[r] = e / den;
+      PT[r] = e * __builtin_amdgcn_rcpf(den);
     }
     {
       const uint4 pt0 = pack8(PT, 0), pt1 = pack8(PT, 1);        // A of dM_s^T: [(h, j)][points in register order]
@@ -392,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_attn_bwd_param(AttnArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dsT = mfma(db[c][u], fr[F_MST * SET_U4 + (c * 2 + u) * 64], dsT);
+        for (int u = 0; u < 2; ++u) dsT = mfma(db[c][u], lds_u4(fr + SET_U4 + (c * 2 + u) * 64), dsT);
         uint4 t0, t1;
         transposed(db[c][0], db[c][1], t0, t1);
         dMs[c] = mfma(pt0, t0, dMs[c]);

@@ -264,9 +264,10 @@ __device__ __forceinline__ void softmax_regs(v16f &sim, unsigned vmask) {
     const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
     float den = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = expf(sj[j] - m), den += sj[j];
+    for (int j = 0; j < 4; ++j) sj[j] = __builtin_amdgcn_exp2f((sj[j] - m) * 1.44269504088896341f), den += sj[j];   // hardware exp2 / rcp (these kernels
+    const float inv = __builtin_amdgcn_rcpf(den);                                                                    // run with bf16 products only: P is rounded to bf16 next)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sim[4 * g + j] = sj[j] / den;
+    for (int j = 0; j < 4; ++j) sim[4 * g + j] = sj[j] * inv;
   }
 }
 // softmax backward in the same layout: dsim = P (dP - sum_j P dP)
