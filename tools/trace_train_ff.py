@@ -96,6 +96,14 @@ def analyse(path, out):
         print(f"   distinct (SE, CU, SIMD... HW_ID>>4) values among the traced workgroups: {len(cus)}", file=out)
         if first:
             print(f"   workgroup {first[0]} raw (tag, delta): {first[1][:70]}", file=out)
+        if k < 2:   # first wait of the prologue (tag 1 -> 16, when stamped) and lifetime by workgroup id: later rounds of workgroups start out of step
+            rowsw = []
+            for wg, ev in rows[k]:
+                ft = {tag: c for tag, hw, c in reversed(ev)}
+                if 16 in ft and 1 in ft:
+                    rowsw.append(f"{wg}:{(ft[16] - ft[1]) & 0xffffffffff}/{(ev[-1][2] - ev[0][2]) & 0xffffffffff}")
+            if rowsw:
+                print("   workgroup id : first wait / lifetime   " + "  ".join(rowsw), file=out)
 
 
 def main():
