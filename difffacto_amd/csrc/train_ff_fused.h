@@ -117,6 +117,9 @@ struct FfArgs {
   // backward with the attention's input gradient behind it (at_frags != nullptr): dh_in = dh1 + LN2'(A_s^T dsim) leaves through dh_in
   // (may alias dh: a wavefront reads its rows of dh before it writes them) and cpart gets three more rows (d gamma2, d beta2, d b_o)
   float *dh_in;
+  // Layout of the row-shaped tensors only these kernels touch (bit 1 = tile-major, see tile_b_off): the residual stream between two blocks and the
+  // gradient between two blocks' backward kernels; the ends (written by the stem, read by the head, and back) stay row-major
+  unsigned tiled;          // TL_* bits
   uint4 *pk2;              // with at_frags: [R / 32][2][4][2][64] the tile's xn2 and dh1 as bf16 fragments for k_attn_bwd_param (which
                            // needs nothing else of them); dh1 itself is then not written
 #ifdef DFX_TRACE_FF
@@ -438,6 +441,40 @@ __device__ __forceinline__ void load_rows_acc(const float *__restrict__ hrow, in
     }
 }
 
+// ---- Tile-major rows (round 4).  With row-major (R, 128) fp32 tensors every row access of a wavefront — lane = point — touches 32 cache lines for 1 KiB
+// (16 bytes per row), and each line is requested by four different instructions: the memory phases ran at the rate of their L1 transactions.  Between two
+// of these kernels the layout is free: a 32-point tile (16 KiB, the same bytes as its 32 rows) is stored as 16 blocks (c, u, half) of 1 KiB = 64 lanes x 4
+// floats, the B-operand layout itself; a load or store instruction then covers whole lines — in BOTH register layouts the kernels use:
+//   B-operand layout, block (c, u), element e of lane (pj, hf) = channel 32 c + 16 u + 8 hf + e     -> ((c 2 + u) 2 + e / 4) 256 + lane 4 + e % 4
+//   accumulator layout, register 4 q + m of tile c, lane (pj, hf) = channel 32 c + 8 q + 4 hf + m  -> ((c 2 + q / 2) 2 + hf) 256 + (pj + 32 (q & 1)) 4 + m
+// (the same element either way).  Measured: k_ff<true> 356 -> 334 us, k_ff<false> 180 -> 165 us per block.
+enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16 };
+struct RowMap {   // per tensor: one lane offset for each register layout (floats), tiled or not
+  bool tiled;
+  unsigned lb, la;
+  __device__ __forceinline__ RowMap(bool t, int lane, int pj, int hf) : tiled(t), lb(t ? lane * 4 : pj * C + 8 * hf), la(t ? hf * 256 + pj * 4 : pj * C + 4 * hf) {}
+  __device__ __forceinline__ unsigned b(int c, int u, int half) const { return lb + (tiled ? ((c * 2 + u) * 2 + half) * 256 : 32 * c + 16 * u + 4 * half); }
+  __device__ __forceinline__ unsigned a(int c, int q) const { return la + (tiled ? (c * 2 + (q >> 1)) * 512 + 128 * (q & 1) : 32 * c + 8 * q); }
+};
+__device__ __forceinline__ void load_rows(const float *__restrict__ tile, const RowMap &m, v8f (&x)[4][2]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const v4f lo = *reinterpret_cast<const v4f *>(tile + m.b(c, u, 0)), hi = *reinterpret_cast<const v4f *>(tile + m.b(c, u, 1));
+      x[c][u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+__device__ __forceinline__ void load_rows_acc(const float *__restrict__ tile, const RowMap &m, v16f (&d)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f t = *reinterpret_cast<const v4f *>(tile + m.a(c, q));
+      d[c][4 * q + 0] = t[0], d[c][4 * q + 1] = t[1], d[c][4 * q + 2] = t[2], d[c][4 * q + 3] = t[3];
+    }
+}
+
 // LDS map of k_ff: [ring: 3 slots x 24 KiB][b1 of all chunks 4 KiB][gamma3 | beta3 1 KiB][gamma2 | beta2 | b_o 1.5 KiB][b2 0.5 KiB] = 79 KiB, two
 // workgroups per CU.  The folded attention fragments of the workgroup's shape borrow ring space while the ring is idle: forward, slot 2
 // during the prologue ([A_s | M_s], 16 KiB; chunk 2 is only requested behind the prologue's last barrier); backward, 24 KiB at AT_OFF_BWD
@@ -470,7 +507,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   if (!live) ti = tps - 1;   // a workgroup's trailing wavefronts past the shape's end recompute its last tile and store nothing
   // rows: a wave-uniform base (scalar registers) + ONE lane offset for every row-shaped tensor
   const long long rowbase = ((long long)s * a.N + ti * 32) * C;
-  const unsigned loff = pj * C;
+  const RowMap m_hin(a.tiled & TL_HIN, lane, pj, hf), m_h1(a.tiled & TL_H1, lane, pj, hf), m_h2(a.tiled & TL_H2, lane, pj, hf);
+  const RowMap m_dh(a.tiled & TL_DH, lane, pj, hf), m_dhin(a.tiled & TL_DHIN, lane, pj, hf);
   const bool at = a.at_frags != nullptr;
 
   constexpr int PIECES = FWD_TILES * 2 / NW;   // forward: LDS-DMA instructions per wave and chunk
@@ -478,8 +516,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   FFT(1);
   // ---- prologue, memory side: this lane's rows first (the oldest requests come back first), then the tables, then the ring ----
   v8f x[4][2], xd[4][2];
-  load_rows((BWD || !at ? a.h1 : a.hin) + rowbase + loff, hf, x);
-  if (BWD) load_rows(a.dh + rowbase + loff, hf, xd);
+  load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
+  if (BWD) load_rows(a.dh + rowbase, m_dh, xd);
   float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
   float *gbs = reinterpret_cast<float *>(ff_smem + TAB_GB3);
   float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
@@ -548,7 +586,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<v4f *>(a.h1_out + rowbase + (loff + 32 * ct + 8 * q + 4 * hf)) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+          *reinterpret_cast<v4f *>(a.h1_out + rowbase + m_h1.a(ct, q)) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
       }
     }
     acc_to_rows(acc, x);   // h1 in the B-operand layout for LayerNorm3
@@ -727,7 +765,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v4f *>(out + (loff + 32 * c + 8 * q + 4 * hf)) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+        *reinterpret_cast<v4f *>(out + m_h2.a(c, q)) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
     FFT(9);
     return;
   }
@@ -742,8 +780,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
   }
   v16f xh[4], dv[4];
-  load_rows_acc(a.h1 + rowbase + loff, hf, xh);
-  load_rows_acc(a.dh + rowbase + loff, hf, dv);
+  load_rows_acc(a.h1 + rowbase, m_h1, xh);
+  load_rows_acc(a.dh + rowbase, m_dh, dv);
   // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
   // - xhat mean(dy g xhat)), and the column sums of dy xhat / dy over the workgroup's points for d gamma3 / d beta3 ----
   // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
@@ -799,7 +837,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         o[m] = dv[c][r] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
         d1c[r] = o[m];
       }
-      if (live && !at) *reinterpret_cast<v4f *>(a.dh1 + rowbase + (loff + ch)) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
+      if (live && !at) *reinterpret_cast<v4f *>(a.dh1 + rowbase + (pj * C + ch)) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
     }
     colsum(gx, 0, c);
     colsum(acc[c], 1, c);
@@ -814,7 +852,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     __syncthreads();
     const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + AT_OFF_BWD) + lane;
     constexpr int L_AS = 0, L_MST = SET_U4, L_AST = 2 * SET_U4;
-    load_rows(a.hin + rowbase + loff, hf, x);   // travels while dP is computed
+    load_rows(a.hin + rowbase, m_hin, x);   // travels while dP is computed
     float mu2, rstd2;
     v16f P = zero16(), ds = zero16();
     // this tile's xn2 | dh1 fragments for k_attn_bwd_param: a wave-uniform base (scalar registers) + the lane
@@ -925,7 +963,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
           gx[r] = dx[r] * xh[c][r];
           o[m] = dv[c][r] + rstd2 * (dx[r] * g[m] - t1 - xh[c][r] * t2);
         }
-        if (live) *reinterpret_cast<v4f *>(a.dh_in + rowbase + (loff + ch)) = o;
+        if (live) *reinterpret_cast<v4f *>(a.dh_in + rowbase + m_dhin.a(c, q)) = o;
       }
       colsum(gx, 3, c);
       colsum(dx, 4, c);

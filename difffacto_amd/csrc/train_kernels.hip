@@ -1853,6 +1853,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R, fa.B = B, fa.N = N;
+      // tile-major rows between the fused kernels (train_ff_fused.h): everything but the stem's output and the head's input
+      if (t_attn_in_ff) fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_H2 : 0);
       if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.h1_out = a.h1;
@@ -1949,6 +1951,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart[i], fa.R = R, fa.B = B, fa.N = N;
+      if (t_attn_in_ff)   // the layouts the forward left behind; the gradient is row-major where the head wrote it and where the stem reads it
+        fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN | dfx::ffused::TL_DHIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_DH : 0);
       const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
