@@ -13,6 +13,8 @@ bad = 0
 for case in range(ncases):
     B = int(rng.integers(1, 7))
     N = 32 * int(rng.integers(8, 70)) if case % 4 else 32 * int(rng.integers(8, 12))   # R = B N >= 256 for the bf16 kernels
+    if case % 7 == 3:   # few tiles per shape: workgroups with wavefronts past the shape's end (one shape per workgroup), tile-major rows of one or two tiles
+        B, N = int(rng.integers(8, 13)), 32 * int(rng.integers(1, 4))
     all_valid = bool(rng.integers(0, 2))
     W = synth.make_denoiser_weights(int(rng.integers(0, 1000)))
     pc, mean, logvar, valid = synth.make_latents(B, seed=int(rng.integers(0, 1000)), all_valid=all_valid)
