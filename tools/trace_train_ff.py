@@ -101,7 +101,8 @@ def analyse(path, out):
             for wg, ev in rows[k]:
                 ft = {tag: c for tag, hw, c in reversed(ev)}
                 if 16 in ft and 1 in ft:
-                    rowsw.append(f"{wg}:{(ft[16] - ft[1]) & 0xffffffffff}/{(ev[-1][2] - ev[0][2]) & 0xffffffffff}")
+                    rows_only = f"({(ft[17] - ft[1]) & 0xffffffffff} rows)" if 17 in ft else ""
+                    rowsw.append(f"{wg}:{(ft[16] - ft[1]) & 0xffffffffff}{rows_only}/{(ev[-1][2] - ev[0][2]) & 0xffffffffff}")
             if rowsw:
                 print("   workgroup id : first wait / lifetime   " + "  ".join(rowsw), file=out)
 
