@@ -21,6 +21,11 @@
 // under the other's chunk loop) streams the chunks L2 -> LDS with LDS-DMA through three buffers — forward: whole chunks (24 KiB), two
 // ahead of the compute, one barrier per chunk; backward: two items per chunk (stage_item), two barriers — with counted s_waitcnt vmcnt.
 //
+// A workgroup's four tiles belong to ONE shape (its folded attention fragments sit in LDS once); every memory phase issues all of its loads
+// before it consumes any; both kernels are spill-free (a scratch reload behind output stores waits for their acknowledgements); and between two
+// of these kernels the row-shaped tensors are TILE-MAJOR (RowMap below) so that a wavefront's row accesses cover whole cache lines — see the
+// notes at RowMap and in front of k_ff, and DESIGN.md 5.6.
+//
 // GELU: g * sigmoid(g (c1 + c3 g^2)) in fp32 with the hardware exp2 / rcp (max abs error 2.7e-4 against the erf form, the same
 // form as the direct sampling kernel) and its exact derivative  s + g s (1 - s) (c1 + 3 c3 g^2).
 #pragma once
