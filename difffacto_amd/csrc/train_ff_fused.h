@@ -457,9 +457,9 @@ enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16 };
 struct RowMap {   // per tensor: one lane offset for each register layout (floats), tiled or not
   bool tiled;
   unsigned lb, la;
-  __device__ __forceinline__ RowMap(bool t, int lane, int pj, int hf) : tiled(t), lb(t ? lane * 4 : pj * C + 8 * hf), la(t ? hf * 256 + pj * 4 : pj * C + 4 * hf) {}
-  __device__ __forceinline__ unsigned b(int c, int u, int half) const { return lb + (tiled ? ((c * 2 + u) * 2 + half) * 256 : 32 * c + 16 * u + 4 * half); }
-  __device__ __forceinline__ unsigned a(int c, int q) const { return la + (tiled ? (c * 2 + (q >> 1)) * 512 + 128 * (q & 1) : 32 * c + 8 * q); }
+  __host__ __device__ __forceinline__ RowMap(bool t, int lane, int pj, int hf) : tiled(t), lb(t ? lane * 4 : pj * C + 8 * hf), la(t ? hf * 256 + pj * 4 : pj * C + 4 * hf) {}
+  __host__ __device__ __forceinline__ unsigned b(int c, int u, int half) const { return lb + (tiled ? ((c * 2 + u) * 2 + half) * 256 : 32 * c + 16 * u + 4 * half); }
+  __host__ __device__ __forceinline__ unsigned a(int c, int q) const { return la + (tiled ? (c * 2 + (q >> 1)) * 512 + 128 * (q & 1) : 32 * c + 8 * q); }
 };
 __device__ __forceinline__ void load_rows(const float *__restrict__ tile, const RowMap &m, v8f (&x)[4][2]) {
 #pragma unroll

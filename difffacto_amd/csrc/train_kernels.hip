@@ -2282,6 +2282,20 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
 void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
+// Host-side evaluation of the fused training kernels' row addressing (ffused::RowMap, the code the kernels compile): for a 32-point tile, the float
+// offset of every (point, channel) as the B-operand-layout accessors and as the accumulator-layout accessors see it.  out_b, out_a: [32][128] int32.
+void dfx_debug_rowmap(int tiled, int *out_b, int *out_a) {
+  for (int lane = 0; lane < 64; ++lane) {
+    const int pj = lane & 31, hf = lane >> 5;
+    const dfx::ffused::RowMap m(tiled != 0, lane, pj, hf);
+    for (int c = 0; c < 4; ++c) {
+      for (int u = 0; u < 2; ++u)
+        for (int e = 0; e < 8; ++e) out_b[pj * 128 + 32 * c + dfx::ffused::k_nat(u, hf, e)] = (int)m.b(c, u, e >> 2) + (e & 3);
+      for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 4; ++k) out_a[pj * 128 + 32 * c + dfx::ffused::rho(4 * q + k, hf)] = (int)m.a(c, q) + k;
+    }
+  }
+}
 
 int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long long n, dfx_stream_t stream) {
   DFX_REQUIRE(out && n >= 4 && n % 4 == 0 && p > 0.f && p < 1.f, "debug_dropout_factors: bad argument");

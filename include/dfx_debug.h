@@ -19,6 +19,9 @@ int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long
  * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
  * kernels of their own instead of inside the feed-forward kernels. */
 void dfx_debug_train_fused(int on);
+/* Host-side table of the fused training kernels' row addressing inside a 32-point tile (tiled = 1: the tile-major layout between the fused
+ * kernels; 0: row-major): float offset of (point, channel) through the B-operand-layout and the accumulator-layout accessors; [32][128] int32 each. */
+void dfx_debug_rowmap(int tiled, int *out_b, int *out_a);
 /* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
 void dfx_debug_emd_state_global(int on);
 /* Debug / sweep: workgroup shape of the register-resident FPS kernel (threads in {256, 512, 1024} x points per thread in {2..32},

@@ -89,3 +89,29 @@ def test_cpu_tensors_rejected_like_reference():
         pu.gather_operation(torch.zeros(1, 3, 4), torch.zeros(1, 2, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="CPU not supported"):
         pu.furthest_point_sample(torch.zeros(1, 8, 3), 4)
+
+
+def test_tile_major_row_addressing_is_a_permutation_and_layout_independent(built_lib):
+    """train_ff_fused.h's RowMap (host-compiled from the kernels' own code): inside a 32-point tile the B-operand-layout accessors and the
+    accumulator-layout accessors must address the SAME float for every (point, channel); the tile-major layout must be a permutation of the
+    tile's 4096 floats made of whole 16-byte chunks, and the row-major one the identity."""
+    import numpy as np
+    lib = ctypes.CDLL(built_lib)
+    lib.dfx_debug_rowmap.restype = None
+    lib.dfx_debug_rowmap.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for tiled in (0, 1):
+        b = np.full((32, 128), -1, dtype=np.int32)
+        a = np.full((32, 128), -1, dtype=np.int32)
+        lib.dfx_debug_rowmap(tiled, b.ctypes.data_as(ctypes.c_void_p), a.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(a, b)
+        assert sorted(b.ravel().tolist()) == list(range(4096))
+        if not tiled:
+            assert np.array_equal(b, np.arange(4096, dtype=np.int32).reshape(32, 128))
+        else:
+            # a wavefront's load instruction = one (c, u, half) block: 64 lanes x 16 bytes contiguous (whole cache lines)
+            chunks = b.reshape(32, 32, 4)
+            assert np.all(chunks[:, :, 1:] - chunks[:, :, :1] == np.arange(1, 4)) and np.all(chunks[:, :, 0] % 4 == 0)
+            blocks = (b // 256).reshape(32, 128)
+            for blk in range(16):
+                pts, chs = np.nonzero(blocks == blk)
+                assert len(pts) == 256 and len(set(pts.tolist())) == 32   # every block holds 8 channels of all 32 points
