@@ -2293,6 +2293,246 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   }
 }
 
+// ---- k_denoise_coop2: the co-operative kernel with TWO 32-point tiles per workgroup (round 4; batches of 5 .. 8 shapes at N = 2048, i.e. one to two
+// tiles per CU, where k_denoise_coop needs two rounds of workgroups and k_denoise_pipe<2> leaves half of every CU idle).  Same phases, same device
+// functions, same MFMA order per accumulator as k_denoise_coop — bit-identical results — with the work of a block cut this way:
+//   phase A   waves 0 and 1 (different SIMDs): attention + LayerNorms on tile 0 / tile 1, side by side
+//   phase H   all 8 waves, chunks w and w + 8: every GEMM1 fragment (registers) feeds BOTH tiles' MFMAs; two GELUs per chunk
+//   phase G   waves 0..3 own the four output tiles of tile 0, waves 4..7 those of tile 1 — the eight waves carry all of W2 for their output tile in
+//             the 32 fragment registers phase H has freed (chunks 0..7 requested behind round 0, chunks 8..15 behind round 1's MFMAs: the second
+//             tile's GELU covers their latency), so k_denoise_coop's 64 KiB LDS copy of W2 is gone and the second tile's h home, xn3 and GELU
+//             outputs take its place (153 KiB)
+// The next block's attention record, c_t row and block constants are requested behind barrier 2 (the record is only read in phase A) by all waves.
+constexpr int C2_XN = 0;                                           // 2 tiles x 8 x 64 uint4
+constexpr int C2_HID = C2_XN + 2 * 8 * 1024;                       // 2 tiles x [16][2][64] uint4
+constexpr int C2_BC = C2_HID + 2 * FF_CHUNKS * 2048;               // 2 x block constants, by block parity
+constexpr int C2_AT = C2_BC + 2 * BCONST_BYTES;                    // attention record + c_t row (one shape per workgroup)
+constexpr int C2_HS = C2_AT + asms_bytes(DFX_PREC_BF16) + 1024;    // 2 tiles x 16 KiB: h's home
+constexpr int C2_CONST = C2_HS + 2 * 16 * 1024;                    // chain-invariant operands (as k_denoise_coop)
+constexpr int C2_Z = C2_CONST + 7 * 1024;                          // 2 tiles x (noise z[3][32] | posterior table row at +512)
+constexpr int C2_PS = C2_Z + 2 * 1024;                             // 2 tiles x per-point chain state
+constexpr int C2_TOTAL = C2_PS + 2 * 2048;
+static_assert(C2_TOTAL <= 160 * 1024, "LDS budget of the two-tile co-operative kernel");
+
+__global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop2(const KParams p) {
+  constexpr int PREC = DFX_PREC_BF16;
+  constexpr int TSTRIDE = tile_units(PREC) * 64, AREC = asms_bytes(PREC) / 16;
+  uint4 *s_at = reinterpret_cast<uint4 *>(pipe_smem + C2_AT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const long long g0 = (long long)blockIdx.x * 64;
+  const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));        // both tiles belong to shape s (N % 64 == 0: launch())
+  const int nbase = (int)(g0 - (long long)s * p.N);
+  const int depth = p.d.depth;
+  const bool arole = wave < 2;                 // phase A / step boundary: wave w works on tile w
+  const int gt = wave >> 2, ct = wave & 3;     // phase G: output tile ct of tile gt
+  auto xn_base = [&](int t) { return reinterpret_cast<uint4 (*)[64]>(pipe_smem + C2_XN + t * 8 * 1024); };
+  auto hid_base = [&](int t) { return reinterpret_cast<uint4 (*)[2][64]>(pipe_smem + C2_HID + t * FF_CHUNKS * 2048); };
+  auto hs_ptr = [&](int t, int c, int q) -> v4f * { return reinterpret_cast<v4f *>(pipe_smem + C2_HS + t * 16 * 1024) + (c * 4 + q) * 64 + lane; };
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + C2_PS + (wave & 1) * 2048);   // (waves 0, 1)
+  unsigned vmask = 0;
+  if (arole) {
+    PointState ps0;
+    const int n = nbase + wave * 32 + pj;
+    point_init(p, ps0, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
+    pstate_store(ps_lds, pj, 32, ps0, true);
+  }
+  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC;
+  {   // chain-invariant small operands -> LDS
+    float4 *c_winx = reinterpret_cast<float4 *>(pipe_smem + C2_CONST);
+    float2 *c_pregb = reinterpret_cast<float2 *>(pipe_smem + C2_CONST + 2048);
+    float4 *c_wout = reinterpret_cast<float4 *>(pipe_smem + C2_CONST + 3072);
+    float *c_cp = reinterpret_cast<float *>(pipe_smem + C2_CONST + 5120);
+    const int tid = threadIdx.x;
+    if (tid < 128) c_winx[tid] = p.d.win_x[tid], c_pregb[tid] = p.d.pre_gb[tid], c_wout[tid] = p.d.wout[tid];
+    c_cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+    __syncthreads();
+  }
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + C2_CONST) + hf * 64;
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + C2_CONST + 2048) + hf * 64;
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + C2_CONST + 3072) + hf * 64;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
+
+  uint4 R[32];   // phase H: GEMM1 fragments of round 0 (R[0..15]) / round 1 (R[16..31]); phase G: W2 fragments of the own output tile, chunk u in R[2 u], R[2 u + 1]
+  auto load_w1 = [&](int base, const uint4 *chunks, int u) {
+    const uint4 *ck = reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)u * CHUNK_TILES * TSTRIDE))) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      R[base + 4 * c + 0] = ck[(0 + c) * TSTRIDE], R[base + 4 * c + 1] = ck[(0 + c) * TSTRIDE + 64];
+      R[base + 4 * c + 2] = ck[(4 + c) * TSTRIDE], R[base + 4 * c + 3] = ck[(4 + c) * TSTRIDE + 64];
+    }
+  };
+  auto load_w2 = [&](int first, const uint4 *chunks) {   // W2 of chunks first .. first + 7, output tile ct (W2 of chunk c sits in FF record c + FF_SKEW, tiles 8..11)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint4 *ck = reinterpret_cast<const uint4 *>(pin_ptr(reinterpret_cast<const char *>(chunks + (size_t)(first + c + FF_SKEW) * CHUNK_TILES * TSTRIDE + (8 + ct) * TSTRIDE))) + lane;
+      R[2 * (first + c)] = ck[0], R[2 * (first + c) + 1] = ck[64];
+    }
+  };
+  // attention record, c_t row and block constants of block b at time t -> LDS: 23 pieces over the 8 waves
+  auto stage_block = [&](int b, int t, int parity) {
+    const BlockPack bq = block_pack(p, b);
+    constexpr int NA = asms_bytes(PREC) / 1024, NB = BCONST_BYTES / 1024;
+#pragma unroll
+    for (int i = 0; i < (NA + 1 + NB + COOP_NW - 1) / COOP_NW; ++i) {
+      const int k = i * COOP_NW + wave;
+      if (k < NA) dma1k_pinned(reinterpret_cast<const char *>(asms_s + (size_t)b * AREC) + k * 1024, voff, lds0 + C2_AT + k * 1024);
+      else if (k == NA) dma1k_pinned(reinterpret_cast<const char *>(bq.ct + (size_t)t * CT_ROW), voff, lds0 + C2_AT + NA * 1024);
+      else if (k < NA + 1 + NB) dma1k_pinned(reinterpret_cast<const char *>(bq.bconst) + (k - NA - 1) * 1024, voff, lds0 + C2_BC + parity * BCONST_BYTES + (k - NA - 1) * 1024);
+    }
+  };
+  auto enter_step = [&](const PointState &ps) {   // proj_in + pre_norm of the chain state -> h's home (waves 0, 1)
+    v16f h[4];
+    proj_in_prenorm_tiles(h, ps.x, reinterpret_cast<const float *>(pipe_smem + C2_CONST + 5120) + ps.sg * INNER + hf * 64, winx, pregb);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *hs_ptr(wave, c, q) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
+  };
+  if (arole) {
+    PointState ps;
+    pstate_load(ps_lds, pj, 32, ps, false);
+    enter_step(ps);
+  }
+  int seq = 0;
+  if (p.nsteps > 0) stage_block(0, step_t(p, 0, s), 0);
+  for (int step = 0; step < p.nsteps; ++step) {
+    const int t = step_t(p, step, s);
+    for (int b = 0; b < depth; ++b, ++seq) {
+      const BlockPack bp = block_pack(p, b);
+      float *s_bc = reinterpret_cast<float *>(pipe_smem + C2_BC + (seq & 1) * BCONST_BYTES);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the block's operands (requested a phase G ago)
+      load_w1(0, bp.chunks, wave);   // round 0: in flight through phase A
+      __syncthreads();   // 0: attention record, c_t, block constants of this block are in LDS; h's homes hold the previous block's result
+      if (arole) {       // ---- phase A: wave w on tile w
+        v16f h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f x = *hs_ptr(wave, c, q);
+            h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
+          }
+        const uint4 *rec = s_at + lane;
+        attention<PREC>(h, rec, reinterpret_cast<const float *>(s_at + 8 * TSTRIDE) + hf * 16, reinterpret_cast<const float *>(s_at + AREC) + hf * 64, vmask);
+        Act<PREC> xo[4];
+        ln_to_act<PREC>(h, xo);
+        bias_slot_one(xo, hf);
+        uint4 (*s_xn)[64] = xn_base(wave);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_xn[2 * c][lane] = __builtin_bit_cast(uint4, xo[c].f[0]), s_xn[2 * c + 1][lane] = __builtin_bit_cast(uint4, xo[c].f[1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *hs_ptr(wave, c, q) = v4f{h[c][4 * q], h[c][4 * q + 1], h[c][4 * q + 2], h[c][4 * q + 3]};
+      } else if (wave >= COOP_NW - 2 && b == depth - 1 && p.mode != MODE_EPS) {   // the step's noise and posterior coefficients: wave 6 for tile 0, wave 7 for tile 1
+        const int tz = wave - (COOP_NW - 2), n = nbase + tz * 32 + pj;
+        float z[3];
+        if (p.noise) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
+        } else {
+          philox_normal3(p.seed, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, (unsigned)t, 0u, z);
+        }
+        float *s_z = reinterpret_cast<float *>(pipe_smem + C2_Z + tz * 1024);
+        if (hf == 0) s_z[pj] = z[0], s_z[32 + pj] = z[1], s_z[64 + pj] = z[2];
+        if (lane < 8) s_z[128 + lane] = p.d.tab[(size_t)t * 8 + lane];
+      }
+      __syncthreads();   // 1: xn3 of both tiles and h are in LDS
+      // ---- phase H: every wave, chunks `wave` and `wave + 8`, both tiles per fragment set
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int u = r * COOP_NW + wave, cur = r * 16;
+        if (r == 0) load_w1(16, bp.chunks, u + COOP_NW);
+        else load_w2(0, bp.chunks);   // round 0's registers are free: W2 of chunks 0..7
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          uint4 (*s_xn)[64] = xn_base(tl);
+          v16f a = zero16(), g = zero16();   // b1' rides on the constant-one K slot (bias_slot_one)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const v8bf x0 = __builtin_bit_cast(v8bf, s_xn[2 * c][lane]), x1 = __builtin_bit_cast(v8bf, s_xn[2 * c + 1][lane]);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 0]), x0, a, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 2]), x0, g, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 1]), x1, a, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(R[cur + 4 * c + 3]), x1, g, 0, 0, 0);
+          }
+          if (r == 1 && tl == 1) {   // round 1's fragments are done with: W2 of chunks 8..15 travels under the last GELU
+            __builtin_amdgcn_sched_barrier(0);
+            load_w2(8, bp.chunks);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          h2 aa[8], gg[8];
+          HidAct hid;
+          gelu16_f16_cvt(a, g, aa, gg);
+          gelu16_f16_math(aa, gg, hid);
+          uint4 (*s_hid)[2][64] = hid_base(tl);
+          s_hid[u][0][lane] = hid.f[0], s_hid[u][1][lane] = hid.f[1];
+        }
+      }
+      __syncthreads();   // 2: hid of all chunks of both tiles is in LDS; nobody reads the attention record any more
+      {                  // the next block's operands (next step's c_t row behind the last block)
+        const int nb = b + 1 < depth ? b + 1 : 0;
+        if (b + 1 < depth) stage_block(nb, t, (seq + 1) & 1);
+        else if (step + 1 < p.nsteps) stage_block(0, step_t(p, step + 1, s), (seq + 1) & 1);
+      }
+      // ---- phase G: wave (gt, ct) accumulates output tile ct of tile gt, chunk after chunk (the accumulation order of the pipelined kernel), + b2
+      {
+        v16f ht;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f x = *hs_ptr(gt, ct, q);
+          ht[4 * q] = x[0], ht[4 * q + 1] = x[1], ht[4 * q + 2] = x[2], ht[4 * q + 3] = x[3];
+        }
+        uint4 hq[4][2];   // hid fragments: a ring three chunks deep, fenced per chunk (see k_denoise_coop)
+        unsigned hoff = C2_HID + gt * FF_CHUNKS * 2048 + lane * 16;
+        asm volatile("" : "+v"(hoff));
+        const uint4 *hidb = reinterpret_cast<const uint4 *>(pipe_smem + hoff);
+        auto fetch = [&](int u) { hq[u & 3][0] = hidb[u * 128], hq[u & 3][1] = hidb[u * 128 + 64]; };
+        fetch(0), fetch(1), fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < FF_CHUNKS; ++u) {
+          if (u + 3 < FF_CHUNKS) fetch(u + 3);
+          ht = mma_hid(R[2 * u], hq[u & 3][0], ht);
+          ht = mma_hid(R[2 * u + 1], hq[u & 3][1], ht);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float *b2 = s_bc + BCONST_B2_OFF + hf * 64 + ct * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f bb = *reinterpret_cast<const v4f *>(b2 + 4 * q);
+          *hs_ptr(gt, ct, q) = v4f{ht[4 * q] + bb[0], ht[4 * q + 1] + bb[1], ht[4 * q + 2] + bb[2], ht[4 * q + 3] + bb[3]};
+        }
+      }
+    }
+    __syncthreads();   // the last block's tiles are in h's homes
+    if (arole) {
+      v16f h[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f x = *hs_ptr(wave, c, q);
+          h[c][4 * q] = x[0], h[c][4 * q + 1] = x[1], h[c][4 * q + 2] = x[2], h[c][4 * q + 3] = x[3];
+        }
+      float eps[3];
+      post_eps_tiles(h, wout, p.d.bout, eps);
+      PointState ps;
+      ps.s = s, ps.n = nbase + wave * 32 + pj, ps.gid = 0;   // (gid: the noise was drawn by waves 6, 7)
+      pstate_load(ps_lds, pj, 32, ps, true);
+      const float *s_z = reinterpret_cast<const float *>(pipe_smem + C2_Z + wave * 1024);
+      const float zr[3] = {s_z[pj], s_z[32 + pj], s_z[64 + pj]};
+      const bool zok = p.mode != MODE_EPS;
+      if (step_epilogue(p, ps, eps, step, t, zok ? zr : nullptr, zok ? s_z + 128 : nullptr)) break;   // (the other waves leave through the loop bound: nsteps = 1 in these modes)
+      pstate_store(ps_lds, pj, 32, ps, false);
+      if (step + 1 < p.nsteps) enter_step(ps);
+    }
+  }
+}
+
 // q_sample (anchored_diffusion.py:148-173): x_t = sqrt_acp[t] (x0 - a) + a + sqrt_1m_acp[t] L noise, per-shape t,
 // anchors / variances of the point's part from the shape context (learn_anchor, learn_variance)
 __global__ void k_q_sample(const float *__restrict__ part, const float *__restrict__ qtab, const int32_t *__restrict__ seg,
@@ -2374,21 +2614,26 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     if (cost < best) best = cost, nw = c;
   }
   const bool pipe2 = bf16 && g_force_nw == 64 && tiles(8) * 256 <= 3LL * p.N;   // two tiles per wavefront (k_denoise_pipe2): 256-point workgroup tiles
-  if (g_force_nw > 1 && g_force_nw != 64) nw = g_force_nw;
+  if (g_force_nw > 1 && g_force_nw != 64 && g_force_nw != 16) nw = g_force_nw;
   if (pipe2) nw = 8;
   const long long wpg = tiles(nw);
   // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
   const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
   // the exact-fp32 chain: same tiling; ~3x the direct kernel's rate per point, so a padded small shape may still take it
   const bool pipe_f32 = f32 && g_force_nw != 1 && wpg * nw * 32 <= 3LL * p.N;
-  const bool coop = bf16 && !pipe2 && (g_force_nw == 1 || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));
-  if (pipe || coop || pipe_f32) {
+  const bool coop = bf16 && !pipe2 && (g_force_nw == 1 || (g_force_nw == 16 && p.N % 64 != 0) || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));   // (16 = two tiles per workgroup: needs N % 64 == 0, else this one)
+  // two tiles per co-operative workgroup (k_denoise_coop2; dfx_debug_pipe_waves(16) forces it): 48.2 ms per round of g_num_cus workgroups at N = 2048,
+  // T = 1000 — between one and two rounds of k_denoise_coop (B = 5 .. 8 shapes of 2048 points) the cheapest
+  const double coop_cost = rounds_cost(waves, 32.7, 0.0), coop2_cost = rounds_cost((waves + 1) / 2, 48.2, 0.0);
+  const bool coop2 = bf16 && !pipe2 && p.N % 64 == 0 && (g_force_nw == 16 || (g_force_nw == 0 && coop2_cost < coop_cost && (!pipe || coop2_cost < best)));
+  if (pipe || coop || coop2 || pipe_f32) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {
       hipError_t e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<8>), PipeCfg<8>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<4>), PipeCfg<4>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<2>), PipeCfg<2>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop), CL_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop2), C2_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe2), P2_LDS);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<8>), PipeCfg<8>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<4>), PipeCfg<4>::L_TOTAL);
@@ -2400,6 +2645,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   tm.begin(st);
   const char *variant;
   if (pipe2) variant = "k_denoise_pipe2", k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
+  else if (coop2 && !(g_force_nw == 1)) variant = "k_denoise_coop2", k_denoise_coop2<<<(int)(waves / 2), COOP_NW * 64, C2_TOTAL, st>>>(p);
   else if (coop) variant = "k_denoise_coop", k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
   else if (pipe && nw == 8) variant = "k_denoise_pipe<8>", k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) variant = "k_denoise_pipe<4>", k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
@@ -2536,7 +2782,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1 || nw == 64) ? nw : 0; }
+void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1 || nw == 64 || nw == 16) ? nw : 0; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);
   g_trace_cap = capacity;

@@ -38,7 +38,8 @@ void dfx_debug_force_direct(int on);
 /* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
  * 32-point tile per workgroup, eight wavefronts on it; for an fp32 denoiser: the direct kernel), or 64 = k_denoise_pipe2 (bf16 only:
  * four wavefronts of two 32-point tiles each; when its 256-point workgroup tiles would pad a shape by more than 3x —
- * ceil(N / 256) * 256 > 3 N — the request falls back SILENTLY to the 8-wavefront kernel, and an fp32 denoiser ignores it);
+ * ceil(N / 256) * 256 > 3 N — the request falls back SILENTLY to the 8-wavefront kernel, and an fp32 denoiser ignores it), or 16 =
+ * k_denoise_coop2 (bf16 only: the co-operative kernel with two 32-point tiles per workgroup; N % 64 != 0 falls back to the one-tile kernel);
  * 0 = chosen from the batch size; any other value is treated as 0.  All variants of one precision are bit-identical.
  * dfx_last_kernel_variant() (dfx.h) names the kernel a launch actually took. */
 void dfx_debug_pipe_waves(int nw);

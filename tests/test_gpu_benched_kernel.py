@@ -46,7 +46,7 @@ def test_T1000_chain_benched_kernel_is_bit_identical_to_every_other_variant(prec
     W = synth.make_denoiser_weights(seed=0)
     eng = _engine(W, T, prec)
     g = torch.Generator(device="cuda").manual_seed(17)
-    others = (4, 2, 1, 64) if prec == "bf16" else (4, 2, 1)     # 1 = co-operative kernel (bf16) / direct kernel (fp32); 64 = pipe2
+    others = (4, 2, 1, 64, 16) if prec == "bf16" else (4, 2, 1)     # 1 = co-operative kernel (bf16) / direct kernel (fp32); 64 = pipe2; 16 = co-operative, two tiles per workgroup
     # ---- B = 3: every variant on the whole launch ----
     B = 3
     pc, mean, logvar, valid = synth.make_latents(B, seed=7)

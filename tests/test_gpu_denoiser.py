@@ -412,14 +412,14 @@ def test_small_batch_workgroup_sizes_are_bit_identical(W, N):
     xT, sn = torch.randn(B, 3, N, generator=g), torch.randn(T, B, 3, N, generator=g)
     out = {}
     try:
-        for nw in (8, 4, 2, 1, 64):   # 64 = k_denoise_pipe2: two point tiles per wavefront, four wavefronts per workgroup
+        for nw in (8, 4, 2, 1, 64, 16):   # 64 = k_denoise_pipe2: two point tiles per wavefront, four wavefronts per workgroup; 16 = k_denoise_coop2: two tiles per co-operative workgroup
             _ffi.lib().dfx_debug_pipe_waves(nw)
             out[nw] = (e.sample_chain(cx, sg, x_T_noise=xT, step_noise=sn, ret_interval=2), e.sample_chain(cx, sg, seed=9)[0],
                        e.eps(cx, xT, sg, 2), e.p_sample(cx, xT, sg, 1, noise=sn[0], want_xstart=True))
     finally:
         _ffi.lib().dfx_debug_pipe_waves(0)
     auto = e.sample_chain(cx, sg, seed=9)[0]     # B = 3 is a small batch: the automatic choice is one of the three
-    for nw in (4, 2, 1, 64):
+    for nw in (4, 2, 1, 64, 16):
         assert torch.equal(out[nw][0][0], out[8][0][0]) and torch.equal(out[nw][0][1], out[8][0][1]), nw
         assert torch.equal(out[nw][1], out[8][1]), nw
         assert torch.equal(out[nw][2], out[8][2]), nw
