@@ -91,10 +91,10 @@ def power_limited_ceiling():
             "kernel_mix_tflops": pick("C/D AGPR, refill per MFMA, 5 v_pk per MFMA")}
 
 
-def train_iteration(Wnp, B, N, iters=4):
+def train_iteration(Wnp, B, N, iters=10):
     """Secondary figure (BASELINE configs[4]), outside the timed region of the headline metric: one training
     iteration of the denoiser (forward with saved activations + backward + clip + Adam, bf16 matrix products) on the
-    same batch shape, wall-clock over `iters` iterations after two warm-ups."""
+    same batch shape, wall-clock over `iters` iterations after three warm-ups."""
     import numpy as np
     import torch
     from difffacto_amd import synth, training
@@ -119,7 +119,7 @@ def train_iteration(Wnp, B, N, iters=4):
             training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16"), None).backward()
             opt.step()
 
-        for _ in range(2):
+        for _ in range(3):   # (the block runs behind the chain sweeps: three warm-ups and ten timed iterations keep a 20 ms sample's noise out of the line)
             it()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -141,7 +141,7 @@ def train_iteration(Wnp, B, N, iters=4):
         return {"error": repr(e)[:200]}
 
 
-def stage1_iteration(B, N, iters=4, encoder_precision="f32"):
+def stage1_iteration(B, N, iters=8, encoder_precision="f32"):
     """The whole stage-1 training iteration of configs/train_chair_stage1.py (PointNetV2 part encoder in train mode + prior loss
     through the latent flows + denoiser + clip + Adam) through the drop-in modules (examples/train_stage1.py)."""
     import numpy as np
