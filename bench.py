@@ -383,14 +383,16 @@ def sweep_block(params, names, precision, dev, T):
 
 
 def small_batch_line(params, names, sampler, N, precision, dev, T):
-    """Latency side of the same kernel family (SURVEY.md §8(d) config 2, B = 1): one T-step chain for ONE shape and for four, HIP-event
-    time of the chain launch; the co-operative kernel takes these sizes, bit-identical to the pipelined one (tested)."""
+    """Latency side of the same kernel family (SURVEY.md §8(d) config 2, B = 1): one T-step chain for ONE shape, for four and for eight, HIP-event
+    time of the chain launch; the co-operative kernels (one tile per workgroup up to B = 4, two tiles for B = 5 .. 8) take these sizes,
+    bit-identical to the pipelined one (tested); `kernel_variant` = what the launcher chose."""
     from difffacto_amd.engine import DenoiserEngine
     try:
         out = {"num_timesteps": T}
         eng = DenoiserEngine({k: params[k] for k in names}, num_timesteps=T, precision=precision, device=dev)
         from difffacto_amd.pipeline import SamplingPipeline
-        for B in (1, 4):
+        from difffacto_amd.engine import last_kernel_variant
+        for B in (1, 4, 8):
             torch.cuda.manual_seed(98)
             pipe = SamplingPipeline(eng, sampler, B, N, torch.ones(B, 4, device=dev))
             for _ in pipe.run(1, seed0=1):     # warm-up pass
@@ -408,7 +410,8 @@ def small_batch_line(params, names, sampler, N, precision, dev, T):
                 pass
             torch.cuda.synchronize()
             wall_stream = (time.perf_counter() - t0) / 3 * 1e3
-            out[f"B{B}"] = {"ms_per_chain": ms, "shapes_per_s": B / ms * 1e3, "wall_ms_one_pass": wall_one, "wall_ms_per_pass_streamed": wall_stream}
+            out[f"B{B}"] = {"ms_per_chain": ms, "shapes_per_s": B / ms * 1e3, "wall_ms_one_pass": wall_one, "wall_ms_per_pass_streamed": wall_stream,
+                            "kernel_variant": last_kernel_variant()}
         eng.close()
         return out
     except Exception as e:
