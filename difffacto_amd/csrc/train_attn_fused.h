@@ -510,24 +510,31 @@ __global__ __launch_bounds__(256) void k_attn_unfold_kv(UnfoldBatch batch) {
   }
 }
 // one block per weight row d (of Wq) / column d (of Wo); 128 channels c x 8 groups of shapes (summed in group order)
-__global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldBatch batch) {   // grid (128, 1, depth)
+constexpr int UW_D = 4;   // weight rows per block of k_attn_unfold_w: the 16 rows of a head read the same partial sums (one row per block: 330 MB of L2 traffic per backward)
+__global__ __launch_bounds__(1024) void k_attn_unfold_w(UnfoldBatch batch) {   // grid (128 / UW_D, 1, depth)
   const UnfoldArgs &a = batch.blk[blockIdx.z];
-  __shared__ float rq[8][C], ro[8][C];
-  const int d = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7, hd = d >> 4;
-  float aq = 0.f, ao = 0.f;
+  __shared__ float rq[8][UW_D][C], ro[8][UW_D][C];
+  const int d0 = blockIdx.x * UW_D, c = threadIdx.x & 127, grp = threadIdx.x >> 7, hd = d0 >> 4;
+  float aq[UW_D], ao[UW_D];
+#pragma unroll
+  for (int i = 0; i < UW_D; ++i) aq[i] = ao[i] = 0.f;
   for (int s = grp; s < a.B; s += 8)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const float *sm = a.sum + (size_t)s * 2 * HJ * C + (size_t)(hd * J + j) * C + c;
-      aq = fmaf(a.k[((size_t)s * J + j) * a.ldkv + d], sm[0], aq);
-      ao = fmaf(a.v[((size_t)s * J + j) * a.ldkv + d], sm[HJ * C], ao);
+      const float sq = sm[0], so = sm[HJ * C];
+      const float *kr = a.k + ((size_t)s * J + j) * a.ldkv + d0, *vr = a.v + ((size_t)s * J + j) * a.ldkv + d0;
+#pragma unroll
+      for (int i = 0; i < UW_D; ++i) aq[i] = fmaf(kr[i], sq, aq[i]), ao[i] = fmaf(vr[i], so, ao[i]);   // (per output the same order as with one row per block)
     }
-  rq[grp][c] = aq, ro[grp][c] = ao;
+#pragma unroll
+  for (int i = 0; i < UW_D; ++i) rq[grp][i][c] = aq[i], ro[grp][i][c] = ao[i];
   __syncthreads();
-  if (grp == 0) {
+  if (grp < UW_D) {
+    const int i = grp, d = d0 + i;
     float tq = 0.f, to = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) tq += rq[g][c], to += ro[g][c];
+    for (int g = 0; g < 8; ++g) tq += rq[g][i][c], to += ro[g][i][c];
     a.dwq[(size_t)d * C + c] = 0.25f * tq;
     a.dwo[(size_t)c * C + d] = to;
   }

@@ -2038,7 +2038,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     }
     dfx::ffused::launch_ff_wgrad_finish(st, fb, wt->depth);
     dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B, wt->depth), 256, 0, st>>>(ub);
-    dfx::afused::k_attn_unfold_w<<<dim3(C, 1, wt->depth), 1024, 0, st>>>(ub);
+    dfx::afused::k_attn_unfold_w<<<dim3(C / dfx::afused::UW_D, 1, wt->depth), 1024, 0, st>>>(ub);
     if (t_attn_in_ff) k_sum_parts_jobs<<<wt->depth * 6 * (C / 32), 1024, 0, st>>>(sj, (int)dfx::ffused::ff_groups(B, N), C, 6 * C);
     // d Wk, d Wv of every block and d ctx from the side-by-side key / value gradients
     const int n2 = 2 * wt->depth, LDKV = n2 * C;
