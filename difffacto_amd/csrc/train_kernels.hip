@@ -578,8 +578,23 @@ __global__ void k_mse_bwd(const float *__restrict__ target, const float *__restr
 //   head   eps = W_out post_norm(hfin) + b_out  -> (B, 3, N)        backward: recomputes the LayerNorm; dh, d W_out, d b_out, d gamma, d beta
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int STEM_ROWS = 512, HEAD_ROWS = 128;   // points per block of the backward kernels (rows of their partial sums; the stem's partial is 8 KiB)
-__device__ __forceinline__ float sum32(float v) {
+// Sum over the 32 lanes of a half-wave, in every lane.  Four steps inside the 16-lane rows are DPP modifiers of the adds (quad_perm [1,0,3,2] and
+// [2,3,0,1], row_half_mirror, row_mirror: no LDS crossbar), one ds_swizzle exchanges the two rows — the five ds_bpermute round trips of a __shfl_xor
+// butterfly were the latency chain of the stem / head kernels (four sums per pair of rows).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum32_xbar(float v) {   // the butterfly through the LDS crossbar: k_stem_bwd, whose VALU is the busier pipe (DPP form: 117 vs 107 us)
   for (int o = 16; o; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+__device__ __forceinline__ float sum32(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
   return v;
 }
 struct StemW {   // this lane's four rows of W_in (13 columns) and bias
@@ -593,6 +608,7 @@ __device__ __forceinline__ void stem_load(StemW &sw, const float *__restrict__ W
     sw.b[e] = b[4 * l + e];
   }
 }
+template <bool XBAR = false>
 __device__ __forceinline__ void stem_row(const StemW &sw, const float *__restrict__ xrow, float (&x)[13], v4f &h0, float &mu, float &rstd) {
   const v4f a = *reinterpret_cast<const v4f *>(xrow), b = *reinterpret_cast<const v4f *>(xrow + 4), c = *reinterpret_cast<const v4f *>(xrow + 8);
 #pragma unroll
@@ -605,9 +621,11 @@ __device__ __forceinline__ void stem_row(const StemW &sw, const float *__restric
     for (int k = 0; k < 13; ++k) t = fmaf(sw.w[e][k], x[k], t);
     h0[e] = t;
   }
-  mu = sum32(h0[0] + h0[1] + h0[2] + h0[3]) * (1.0f / C);
+  const float s0 = h0[0] + h0[1] + h0[2] + h0[3];
+  mu = (XBAR ? sum32_xbar(s0) : sum32(s0)) * (1.0f / C);
   const v4f d = {h0[0] - mu, h0[1] - mu, h0[2] - mu, h0[3] - mu};
-  rstd = 1.0f / sqrtf(sum32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / C) + LN_EPS);
+  const float q0 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  rstd = 1.0f / sqrtf((XBAR ? sum32_xbar(q0) : sum32(q0)) * (1.0f / C) + LN_EPS);
 }
 __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ xin, const float *__restrict__ W, const float *__restrict__ b,
                                                    const float *__restrict__ g, const float *__restrict__ be, float *__restrict__ hin, long long R) {
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ dy, 
     if (r >= R) break;
     float x[13], mu, rstd;
     v4f h0;
-    stem_row(sw, xin + r * XIN, x, h0, mu, rstd);
+    stem_row<true>(sw, xin + r * XIN, x, h0, mu, rstd);
     const v4f dv = reinterpret_cast<const v4f *>(dy + r * C)[l];
     v4f xh, dyg;
     float s1 = 0.f, s2 = 0.f;
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ dy, 
       s1 += dyg[e], s2 += dyg[e] * xh[e];
       dg[e] += dv[e] * xh[e], dbe[e] += dv[e];
     }
-    s1 = sum32(s1) * (1.0f / C), s2 = sum32(s2) * (1.0f / C);
+    s1 = sum32_xbar(s1) * (1.0f / C), s2 = sum32_xbar(s2) * (1.0f / C);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float d0 = rstd * (dyg[e] - s1 - xh[e] * s2);   // gradient at h0
