@@ -59,6 +59,20 @@ inline hipError_t set_max_lds(const void *kernel, int bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// A second HIP stream per device for work that is off the caller's critical path (the training step's context branch and its
+// parameter-gradient reductions: small-grid kernels that leave most of the chip idle when they run one after the other on the caller's
+// stream).  Every entry point that uses it forks from and joins back into the caller's stream before it returns, so the caller sees plain
+// stream-ordered behaviour (and a stream capture of the caller's stream captures the side work with it).  Events come from a per-device
+// ring, one per fork / join, so that concurrent calls on different caller streams never wait on each other's records.
+struct SideStream {
+  hipStream_t main = nullptr, side = nullptr;
+  bool on = false;
+  // `enable` false: every launch "on the side stream" goes to the caller's stream (side == main, fork / join do nothing)
+  int open(hipStream_t caller, bool enable);
+  int fork();                 // the side stream waits for everything enqueued on the caller's stream so far
+  int join();                 // the caller's stream waits for everything enqueued on the side stream so far
+};
+
 // Optional HIP-event timing of the hot-path launches (bench.py's roofline leg).
 struct EventTimer {
   hipEvent_t a = nullptr, b = nullptr;

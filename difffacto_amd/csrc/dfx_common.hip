@@ -2,6 +2,7 @@
 #include "dfx_common.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace dfx {
 
@@ -41,6 +42,58 @@ void EventTimer::end() {
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   active = false;
+}
+
+namespace {
+struct DevSide {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[64] = {};
+  std::atomic<unsigned> next{0};
+};
+std::mutex g_side_mu;
+DevSide *g_side[256] = {};
+
+DevSide *dev_side() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (g_side[dev]) return g_side[dev];
+  DevSide *d = new DevSide;
+  if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) {
+    delete d;
+    return nullptr;
+  }
+  for (hipEvent_t &e : d->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;   // (leaks a few handles on a broken device)
+  g_side[dev] = d;
+  return d;
+}
+hipEvent_t next_event(DevSide *d) { return d->ev[d->next.fetch_add(1, std::memory_order_relaxed) & 63]; }
+}  // namespace
+
+int SideStream::open(hipStream_t caller, bool enable) {
+  main = side = caller;
+  on = false;
+  if (!enable) return DFX_OK;
+  DevSide *d = dev_side();
+  if (!d) return set_error(DFX_ERR_HIP, "side stream: cannot create the per-device stream / events");
+  side = d->st;
+  on = true;
+  return DFX_OK;
+}
+int SideStream::fork() {
+  if (!on) return DFX_OK;
+  hipEvent_t e = next_event(dev_side());
+  DFX_HIP_TRY(hipEventRecord(e, main));
+  DFX_HIP_TRY(hipStreamWaitEvent(side, e, 0));
+  return DFX_OK;
+}
+int SideStream::join() {
+  if (!on) return DFX_OK;
+  hipEvent_t e = next_event(dev_side());
+  DFX_HIP_TRY(hipEventRecord(e, side));
+  DFX_HIP_TRY(hipStreamWaitEvent(main, e, 0));
+  return DFX_OK;
 }
 
 }  // namespace dfx

@@ -62,8 +62,13 @@ struct PackArgs {
   float *b2p;        // [2 hf][4 c][16]
 };
 
+struct PackBatch {
+  PackArgs blk[DFX_MAX_DEPTH];   // blockIdx.y = transformer block: every block's weights in one launch
+};
+
 // one thread per (chunk, tile, unit, lane)
-__global__ void k_ff_pack(PackArgs a) {
+__global__ void k_ff_pack(PackBatch batch) {
+  const PackArgs &a = batch.blk[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < NCHUNK * 2 * 2 * 16) {   // b1p
     const int r = idx & 15, hf = (idx >> 4) & 1, p = (idx >> 5) & 1, j = idx >> 6;
@@ -1221,9 +1226,9 @@ inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) {
 
 inline size_t pack_bytes_frags() { return (size_t)NCHUNK * CHUNK_U4 * sizeof(uint4); }
 
-inline void launch_pack(hipStream_t st, const PackArgs &a) {
+inline void launch_pack(hipStream_t st, const PackBatch &b, int depth) {
   const int total = NCHUNK * TILES * 128;
-  k_ff_pack<<<(total + 255) / 256, 256, 0, st>>>(a);
+  k_ff_pack<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(b);
 }
 // workgroups of k_ff<*> (= rows of the backward's column-sum partials): one shape per workgroup
 inline long long ff_groups(int B, int N) { return (long long)B * ((N / 32 + NW_BWD - 1) / NW_BWD); }

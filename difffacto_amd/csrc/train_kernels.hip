@@ -14,6 +14,7 @@
 //   dW = dY^T X, db    -> k_wgrad: one wavefront owns a 64 x 64 tile of dW and a slab of rows, two rows per
 //                         v_mfma_f32_32x32x2_f32 (lane (j, hf) feeds dY[r + hf][o0 + j] and X[r + hf][i0 + j]: 128-byte
 //                         coalesced row segments), partial tiles per slab, deterministic second pass (no atomics)
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 
@@ -1489,6 +1490,12 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
 // layer-by-layer path (A/B timing, and the reference for the fused path's own test).
 bool g_ff_fused = true;
 bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the attention forward as a kernel of its own)
+// Fused path: the context branch of the forward (time-embedding MLP, keys / values, attention folds) and the parameter-gradient
+// reductions of the backward run on the device's side stream (dfx::SideStream) beside the kernels over the points: they are chains of
+// small-grid launches that leave most of the chip idle.  Same kernels, same operands, same results; dfx_debug_train_streams(0) = one stream.
+int g_train_streams = 1;   // 0 = off, 1 = the default set, other values = explicit set of SS_* bits (A/B)
+enum { SS_FWD_CTX = 2, SS_HEAD_EARLY = 4, SS_STEM_EARLY = 8, SS_LEAVES = 16, SS_STEM_END = 32, SS_DEFAULT = SS_HEAD_EARLY | SS_STEM_EARLY | SS_LEAVES };
+inline int ss_mask() { return g_train_streams == 1 ? SS_DEFAULT : g_train_streams; }
 // The switches are sampled ONCE per step, by the forward, and recorded per workspace on the host: the backward follows the record,
 // not the switches, so toggling dfx_debug_train_fused between a forward and its backward (the A/B tests do) cannot pair a fused
 // backward with the activations of a layer-by-layer forward.
@@ -1830,35 +1837,50 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   carve(w, workspace, B, N, wt->depth);
   const long long R = (long long)B * N;
   const int BJ = B * J;
+  const bool fused_ends = ff_fused(bf, dropout_p, R, N);
+  // Two branches meet in front of the first block: the points (input rows, proj_in + pre_norm, the blocks' weight fragments) on the caller's
+  // stream, the context (time embedding -> context rows -> keys / values of every block -> folded attention operands) on the side stream
+  dfx::SideStream ss;
+  if ((rc = ss.open(st, (ss_mask() & SS_FWD_CTX) && fused_ends))) return rc;
+  hipStream_t sc = ss.side;
+  if ((rc = ss.fork())) return rc;
   // time embedding -> context rows
-  k_timestep_embedding<<<(B * TE + 255) / 256, 256, 0, st>>>(t, w.te_in, B);
-  if ((rc = lin(st, w.te_in, TE, wt->te0_w, wt->te0_b, w.te_ag, 2 * TEH, B, 2 * TEH, TE))) return rc;
-  k_geglu_fwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH, Drop{dropout_p, dropout_seed, SITE_TE});
-  if ((rc = lin(st, w.te_hid, TEH, wt->te2_w, wt->te2_b, w.te_out, TE, B, TE, TEH))) return rc;
-  k_build_ctx<<<(BJ * CTXP + 255) / 256, 256, 0, st>>>(ctx_code, ctx_mv, w.te_out, w.ctx, B);
+  k_timestep_embedding<<<(B * TE + 255) / 256, 256, 0, sc>>>(t, w.te_in, B);
+  if ((rc = lin(sc, w.te_in, TE, wt->te0_w, wt->te0_b, w.te_ag, 2 * TEH, B, 2 * TEH, TE))) return rc;
+  k_geglu_fwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, sc>>>(w.te_ag, w.te_hid, TEH, (long long)B * TEH, Drop{dropout_p, dropout_seed, SITE_TE});
+  if ((rc = lin(sc, w.te_hid, TEH, wt->te2_w, wt->te2_b, w.te_out, TE, B, TE, TEH))) return rc;
+  k_build_ctx<<<(BJ * CTXP + 255) / 256, 256, 0, sc>>>(ctx_code, ctx_mv, w.te_out, w.ctx, B);
+  const int LDKV = 2 * wt->depth * C;
+  if (fused_ends) {   // packed key / value weights of every block (the side stream's product below reads them: second fork)
+    KvPtrs kp{};
+    for (int i = 0; i < wt->depth; ++i) kp.p[2 * i] = wt->blk[i].to_k, kp.p[2 * i + 1] = wt->blk[i].to_v;
+    k_pack_kv<<<(2 * wt->depth * C * CTXP + 255) / 256, 256, 0, st>>>(kp, w.wkv, 2 * wt->depth);
+  }
   if (valid) DFX_HIP_TRY(hipMemcpyAsync(w.valid, valid, sizeof(float) * BJ, hipMemcpyDeviceToDevice, st));
   else DFX_HIP_TRY(hipMemsetAsync(w.valid, 0x3f, sizeof(float) * BJ, st));   // any non-zero value = keep
+  if ((rc = ss.fork())) return rc;
   // proj_in + pre_norm
   k_build_xin<<<(int)((R + 255) / 256), 256, 0, st>>>(x, anchors, variances, assignment, w.xin, N, R);
-  const bool fused_ends = ff_fused(bf, dropout_p, R, N);
   if (fused_ends) {
     k_stem_fwd<<<2048, 256, 0, st>>>(w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, R);
+    // W1 / W2 of every block as bf16 MFMA fragments (train_ff_fused.h), one launch
+    dfx::ffused::PackBatch pb{};
+    for (int i = 0; i < wt->depth; ++i)
+      pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]};
+    dfx::ffused::launch_pack(st, pb, wt->depth);
   } else {
     k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
     if ((rc = lin(st, w.xin, XIN, w.wpad, wt->proj_in_b, w.h0, C, R, C, XIN))) return rc;
     k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.h0, wt->pre_norm_w, wt->pre_norm_b, w.blk[0].hin, w.st_pre, R);
   }
-  const int LDKV = 2 * wt->depth * C;
-  if (ff_fused(bf, dropout_p, R, N)) {   // keys and values of every block: one product over the B x 4 context tokens
-    KvPtrs kp{};
-    for (int i = 0; i < wt->depth; ++i) kp.p[2 * i] = wt->blk[i].to_k, kp.p[2 * i + 1] = wt->blk[i].to_v;
-    k_pack_kv<<<(2 * wt->depth * C * CTXP + 255) / 256, 256, 0, st>>>(kp, w.wkv, 2 * wt->depth);
-    if ((rc = lin(st, w.ctx, CTXP, w.wkv, nullptr, w.kv, LDKV, BJ, LDKV, CTXP))) return rc;
+  if (fused_ends) {   // keys and values of every block: one product over the B x 4 context tokens
+    if ((rc = lin(sc, w.ctx, CTXP, w.wkv, nullptr, w.kv, LDKV, BJ, LDKV, CTXP))) return rc;
     dfx::afused::FoldArgs fo{};
     fo.kv = w.kv, fo.ldkv = LDKV;
     for (int i = 0; i < wt->depth; ++i) fo.wq[i] = wt->blk[i].to_q, fo.wo[i] = wt->blk[i].to_out_w, fo.frags[i] = w.at_frags[i];
-    dfx::afused::k_attn_fold<<<dim3(B, wt->depth), 256, 0, st>>>(fo);
+    dfx::afused::k_attn_fold<<<dim3(B, wt->depth), 256, 0, sc>>>(fo);
   }
+  if ((rc = ss.join())) return rc;
   for (int i = 0; i < wt->depth; ++i) {
     const dfx_block_weights &bw = wt->blk[i];
     BlockAct &a = w.blk[i];
@@ -1867,7 +1889,6 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if (fused) {
       // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
       // q, P, att, xn2, xn3, [a | g], hid never exist in memory
-      dfx::ffused::launch_pack(st, dfx::ffused::PackArgs{bw.ff0_w, bw.ff0_b, bw.ff2_w, bw.ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]});
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R, fa.B = B, fa.N = N;
@@ -1944,12 +1965,29 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   const int BJ = B * J;
   // proj_out, post_norm
   const bool fused_ends = ff_fused(bf, dropout_p, R, N);
+  // Parameter-gradient reductions that nothing on the way back to the input waits for run on the side stream (joined before the return):
+  // the head's and the stem's partial sums — in buffers of their own (w.hn, w.datt: free on the fused path), because the products behind
+  // the block loop use w.part on the caller's stream meanwhile — and the leaves of the finishing kernels behind the block loop.
+  dfx::SideStream ss;
+  const int ssm = ss_mask();
+  if ((rc = ss.open(st, (ssm & ~SS_FWD_CTX) && ssm != 0 && fused_ends))) return rc;
+  hipStream_t sp = ss.side;
+  std::function<void(hipStream_t)> head_sums;
+  bool head_done = false;
   if (fused_ends) {
     const int nb = (int)((R + HEAD_ROWS - 1) / HEAD_ROWS);
-    k_head_bwd<<<nb, 256, 0, st>>>(d_eps, w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, w.dh, w.part, N, R);
-    k_sum_parts<<<3 * C / 32, 1024, 0, st>>>(w.part, mut(grads->proj_out_w), nb, 3 * C, HEAD_PART);
-    k_sum_parts_multi<<<2 * C / 32, 1024, 0, st>>>(w.part + 3 * C, SumOuts{{mut(grads->post_norm_w), mut(grads->post_norm_b), nullptr, nullptr}}, nb, C, HEAD_PART);
-    k_sum_parts<<<1, 1024, 0, st>>>(w.part + 5 * C, mut(grads->proj_out_b), nb, 3, HEAD_PART);
+    float *hp = w.hn;
+    k_head_bwd<<<nb, 256, 0, st>>>(d_eps, w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, w.dh, hp, N, R);
+    head_sums = [&, nb, hp](hipStream_t s) {
+      k_sum_parts<<<3 * C / 32, 1024, 0, s>>>(hp, mut(grads->proj_out_w), nb, 3 * C, HEAD_PART);
+      k_sum_parts_multi<<<2 * C / 32, 1024, 0, s>>>(hp + 3 * C, SumOuts{{mut(grads->post_norm_w), mut(grads->post_norm_b), nullptr, nullptr}}, nb, C, HEAD_PART);
+      k_sum_parts<<<1, 1024, 0, s>>>(hp + 5 * C, mut(grads->proj_out_b), nb, 3, HEAD_PART);
+    };
+    if (!ss.on) head_sums(st), head_done = true;
+    else if (ssm & SS_HEAD_EARLY) {
+      if ((rc = ss.fork())) return rc;
+      head_sums(sp), head_done = true;
+    }
   } else {
     const int nb = (int)((R + EPSB_ROWS - 1) / EPSB_ROWS);
     k_eps_bwd<<<nb, 128, 0, st>>>(d_eps, w.hn, wt->proj_out_w, w.dh2, w.part, N, R);
@@ -1958,6 +1996,14 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   }
   if (!fused_ends && (rc = ln_bwd(st, w, w.dh2, w.hfin, w.st_post, wt->post_norm_w, nullptr, w.dh, mut(grads->post_norm_w), mut(grads->post_norm_b), R))) return rc;
   DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));
+  bool stem_done = false;
+  const bool dx_in_ff_all = t_attn_in_ff;
+  auto stem_backward = [&](hipStream_t s, float *part) {   // pre_norm, proj_in (fused ends): reads w.dh, the input rows and the weights
+    const int nb = (int)((R + STEM_ROWS - 1) / STEM_ROWS);
+    k_stem_bwd<<<nb, 256, 0, s>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, part, R);
+    k_sum_parts<<<C * 13 / 32, 1024, 0, s>>>(part, mut(grads->proj_in_w), nb, C * 13, 2048);
+    k_sum_parts_multi<<<3 * C / 32, 1024, 0, s>>>(part + C * 13, SumOuts{{mut(grads->proj_in_b), mut(grads->pre_norm_w), mut(grads->pre_norm_b), nullptr}}, nb, C, 2048);
+  };
   for (int i = wt->depth - 1; i >= 0; --i) {
     const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
     BlockAct &a = w.blk[i];
@@ -1978,6 +2024,11 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
         fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
+      if (i == 0 && dx_in_ff && ss.on && (ssm & SS_STEM_EARLY)) {   // w.dh is final: pre_norm / proj_in backward beside the rest of the block's parameter kernels
+        if ((rc = ss.fork())) return rc;
+        stem_backward(sp, w.datt);
+        stem_done = true;
+      }
       const int groups = (int)dfx::ffused::ff_groups(B, N);
       // (with the attention's input gradient in the same kernel, the six column sums of every block are one launch behind the loop)
       if (!dx_in_ff)
@@ -2054,10 +2105,17 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       float *o6[6] = {mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b)};
       for (int q = 0; q < 6; ++q) sj.o[i][q] = o6[q];
     }
-    dfx::ffused::launch_ff_wgrad_finish(st, fb, wt->depth);
+    // the chain towards the context gradient (unfold_kv -> d Wk / d Wv / d ctx -> time-embedding MLP) stays on the caller's stream; the
+    // leaves (slab sums of dW1 / dW2, dWq / dWo, the six column sums per block) go beside it
+    if ((rc = ss.fork())) return rc;
+    hipStream_t sl = (ssm & SS_LEAVES) ? sp : st;
     dfx::afused::k_attn_unfold_kv<<<dim3(dfx::afused::J, B, wt->depth), 256, 0, st>>>(ub);
-    dfx::afused::k_attn_unfold_w<<<dim3(C / dfx::afused::UW_D, 1, wt->depth), 1024, 0, st>>>(ub);
-    if (t_attn_in_ff) k_sum_parts_jobs<<<wt->depth * 6 * (C / 32), 1024, 0, st>>>(sj, (int)dfx::ffused::ff_groups(B, N), C, 6 * C);
+    if (ss.on && !stem_done && dx_in_ff_all && (ssm & SS_STEM_END)) stem_backward(sp, w.datt), stem_done = true;
+    dfx::ffused::launch_ff_wgrad_finish(sl, fb, wt->depth);
+    if (t_attn_in_ff) k_sum_parts_jobs<<<wt->depth * 6 * (C / 32), 1024, 0, sl>>>(sj, (int)dfx::ffused::ff_groups(B, N), C, 6 * C);
+    if (!head_done && head_sums) head_sums(sp), head_done = true;
+    if ((rc = ss.fork())) return rc;   // (k_attn_unfold_w reads the per-shape sums k_attn_unfold_kv leaves in at_sum)
+    dfx::afused::k_attn_unfold_w<<<dim3(C / dfx::afused::UW_D, 1, wt->depth), 1024, 0, sl>>>(ub);
     // d Wk, d Wv of every block and d ctx from the side-by-side key / value gradients
     const int n2 = 2 * wt->depth, LDKV = n2 * C;
     if ((rc = wgrad(st, w, w.dkv, LDKV, w.ctx, CTXP, w.dwkv, nullptr, LDKV, CTXP, CTXP, BJ))) return rc;
@@ -2069,10 +2127,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   }
   // pre_norm, proj_in
   if (fused_ends) {
-    const int nb = (int)((R + STEM_ROWS - 1) / STEM_ROWS);
-    k_stem_bwd<<<nb, 256, 0, st>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, w.part, R);
-    k_sum_parts<<<C * 13 / 32, 1024, 0, st>>>(w.part, mut(grads->proj_in_w), nb, C * 13, 2048);
-    k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.part + C * 13, SumOuts{{mut(grads->proj_in_b), mut(grads->pre_norm_w), mut(grads->pre_norm_b), nullptr}}, nb, C, 2048);
+    if (!stem_done) stem_backward(st, w.part);
   } else {
     if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
     if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
@@ -2084,6 +2139,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   if ((rc = lin(st, w.dte_out, TE, w.wT, nullptr, w.dte_hid, TEH, B, TEH, TE))) return rc;
   k_geglu_bwd<false><<<(int)(((long long)B * TEH / 4 + 255) / 256), 256, 0, st>>>(w.te_ag, w.dte_hid, w.dte_ag, TEH, (long long)B * TEH, Drop{dropout_p, dropout_seed, SITE_TE});
   if ((rc = wgrad(st, w, w.dte_ag, 2 * TEH, w.te_in, TE, mut(grads->te0_w), mut(grads->te0_b), 2 * TEH, TE, TE, B))) return rc;
+  if ((rc = ss.join())) return rc;
   return dfx::check_launch("denoiser_train_backward");
 }
 
@@ -2300,6 +2356,7 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
 void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
+void dfx_debug_train_streams(int on) { g_train_streams = on < 0 ? 0 : on; }
 // Host-side evaluation of the fused training kernels' row addressing (ffused::RowMap, the code the kernels compile): for a 32-point tile, the float
 // offset of every (point, channel) as the B-operand-layout accessors and as the accumulator-layout accessors see it.  out_b, out_a: [32][128] int32.
 void dfx_debug_rowmap(int tiled, int *out_b, int *out_a) {

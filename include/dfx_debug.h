@@ -19,6 +19,10 @@ int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long
  * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
  * kernels of their own instead of inside the feed-forward kernels. */
 void dfx_debug_train_fused(int on);
+/* Debug / A-B switch: 0 keeps every launch of the fused training path on the caller's stream (default 1: the context branch of the forward
+ * and the parameter-gradient reductions of the backward run on a per-device side stream, forked from and joined into the caller's stream
+ * inside the call).  Same kernels and operands either way: bit-identical results. */
+void dfx_debug_train_streams(int on);
 /* Host-side table of the fused training kernels' row addressing inside a 32-point tile (tiled = 1: the tile-major layout between the fused
  * kernels; 0: row-major): float offset of (point, channel) through the B-operand-layout and the accumulator-layout accessors; [32][128] int32 each. */
 void dfx_debug_rowmap(int tiled, int *out_b, int *out_a);

@@ -255,6 +255,44 @@ def test_fused_training_step_is_bit_reproducible():
         assert np.array_equal(a["grads"][k], b["grads"][k]), k
 
 
+@pytest.mark.parametrize("B,N", [(4, 1024), (3, 160), (16, 2048)])
+def test_side_stream_training_step_is_bit_identical_to_the_single_stream_one(B, N):
+    """The fused path forks its context branch (forward) and its parameter-gradient reductions (backward: head / stem partial sums in
+    buffers of their own, the finishing kernels' leaves) onto the device's side stream and joins before it returns
+    (dfx_debug_train_streams, default on).  Same kernels, operands and summation orders: eps, loss and every gradient are the same
+    bits as with every launch on the caller's stream — also when the call itself runs on a non-default torch stream, and three times in
+    a row (the event ring, buffers written by one iteration's side work and read by the next)."""
+    import torch
+    from difffacto_amd import _ffi, synth
+    rng = np.random.Generator(np.random.PCG64(77 + B))
+    W = synth.make_denoiser_weights(3)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=31, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    _ffi.lib().dfx_debug_train_streams(0)
+    try:
+        one = _run(c, True, precision="bf16")
+    finally:
+        _ffi.lib().dfx_debug_train_streams(1)
+    runs = [_run(c, True, precision="bf16") for _ in range(3)]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        runs.append(_run(c, True, precision="bf16"))
+    torch.cuda.synchronize()
+    for two in runs:
+        assert two["loss"] == one["loss"]
+        assert np.array_equal(two["eps"], one["eps"])
+        for k in one["grads"]:
+            assert np.array_equal(two["grads"][k], one["grads"][k]), k
+        assert np.array_equal(two["d_ctx_code"], one["d_ctx_code"]) and np.array_equal(two["d_ctx_mv"], one["d_ctx_mv"])
+
+
 def test_dropout_factors_and_replayed_mask_parity():
     """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
     seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the

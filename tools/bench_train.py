@@ -11,9 +11,10 @@ import torch
 
 from difffacto_amd import synth, training
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-PREC = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+_pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--streams"]
+B = int(_pos[0]) if len(_pos) > 0 else 128
+N = int(_pos[1]) if len(_pos) > 1 else 2048
+PREC = _pos[2] if len(_pos) > 2 else "bf16"
 dev = "cuda"
 W = synth.make_denoiser_weights(0)
 P = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in W.items()}
@@ -30,6 +31,9 @@ args = [x_t, t, cu(pc), cu(np.concatenate([mean, var], 1).astype(np.float32)), c
         cu(valid), cu(seg.astype(np.int32))]
 noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
 opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
+if "--streams" in sys.argv:   # dfx_debug_train_streams: 0 = every launch of the fused path on the caller's stream, 1 = default, else a set of SS_* bits
+    from difffacto_amd import _ffi
+    _ffi.lib().dfx_debug_train_streams(int(sys.argv[sys.argv.index("--streams") + 1]))
 if "--layerwise" in sys.argv:   # the layer-by-layer feed-forward kernels (A/B against the fused ones)
     from difffacto_amd import _ffi
     _ffi.lib().dfx_debug_train_fused(0)
@@ -47,14 +51,14 @@ for _ in range(2):
     it()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 5
+K = 20 if "--long" in sys.argv else 5
 for _ in range(K):
     loss = it()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
 flops = 3 * 4.734e9 * B * (N / 2048)
 peak = 157.3 if PREC == "f32" else 2500.0
-print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.1f} ms = {B / ms * 1e3:.0f} shapes/s, "
+print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.2f} ms = {B / ms * 1e3:.0f} shapes/s, "
       f"{flops / ms / 1e9:.1f} TFLOP/s of the {peak} TFLOP/s {PREC} matrix peak ({flops / ms / 1e9 / peak * 100:.1f} %), loss {float(loss.detach()):.4f}, "
       f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak, optimiser in {'one launch' if opt.last_step_was_flat else 'one launch per tensor'}")
 if PREC == "bf16" and "--ab" in sys.argv:   # the same loop through the layer-by-layer feed-forward kernels
