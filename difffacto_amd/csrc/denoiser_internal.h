@@ -123,10 +123,10 @@ struct dfx_denoiser {
   void *pool = nullptr;     // one device allocation holding every packed array
   size_t pool_bytes = 0;
   // raw fp32 copies needed again at shape-prepare time (owned, inside pool)
-  const float *wq[DFX_MAX_DEPTH], *wk[DFX_MAX_DEPTH], *wv[DFX_MAX_DEPTH], *wo[DFX_MAX_DEPTH];
+  const float *wq[DFX_MAX_DEPTH], *wk[DFX_MAX_DEPTH], *wv[DFX_MAX_DEPTH], *wo[DFX_MAX_DEPTH];   // wk / wv: static columns, transposed [266][128]
   const float *g2[DFX_MAX_DEPTH], *be2[DFX_MAX_DEPTH];
   const float *win, *bin;   // proj_in weight (128,13), bias
-  const float *const *wptrs_dev = nullptr;  // device array [depth][6] = {wq, wk, wv, wo, g2, be2}
+  const float *const *wptrs_dev = nullptr;  // device array [depth][7] = {wq, wk^T (static columns), wv^T, wo^T, g2, be2, Wq be2}
   float *host_tables = nullptr;             // [8][T] fp32, order of dfx_denoiser_get_tables
   double *host_ac_pv = nullptr;             // [2][T] float64: alphas_cumprod, posterior_variance (DDIM coefficients per call)
 };

@@ -72,6 +72,14 @@ __device__ __forceinline__ void tile_decode(int idx, int &i, int &kk) {
   }
 }
 
+// inverse of tile_decode: position of element (row i, column kk) inside its 32 x 32 tile
+template <int PREC>
+__device__ __forceinline__ int tile_index(int i, int kk) {
+  const int lane = i + 32 * ((kk >> 2) & 1);
+  if (PREC == DFX_PREC_BF16) return (kk >> 4) * 512 + lane * 8 + (kk & 3) + 4 * ((kk >> 3) & 1);
+  return (kk >> 3) * 256 + lane * 4 + (kk & 3);
+}
+
 template <int PREC>
 __device__ __forceinline__ void tile_store(void *dst, long long gi, float v) {
   if (PREC == DFX_PREC_BF16) reinterpret_cast<__bf16 *>(dst)[gi] = (__bf16)v;
@@ -150,21 +158,43 @@ __global__ void k_pack_misc(const float *__restrict__ win, const float *__restri
                           wout[2 * INNER + ch] * post_g[ch], 0.f);
 }
 
+// to_k / to_v (128, 522) -> the static columns transposed, [266][128] (k_shape_ctx reads them with thread = row)
+__global__ void k_transpose_static(const float *__restrict__ W, float *__restrict__ WT) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= CTX_STATIC * INNER) return;
+  const int k = idx / INNER, row = idx % INNER;
+  WT[idx] = W[(size_t)row * CTX_DIM + k];
+}
+
+// Wq beta2 (the LayerNorm2 shift folded into the similarity bias): one thread per row, summed over k in order
+__global__ void k_wq_beta(const float *__restrict__ Wq, const float *__restrict__ be2, float *__restrict__ out) {
+  const int row = threadIdx.x;
+  float acc = 0.f;
+  for (int k = 0; k < INNER; ++k) acc = fmaf(Wq[(size_t)row * INNER + k], be2[k], acc);
+  out[row] = acc;
+}
+__global__ void k_transpose_sq(const float *__restrict__ W, float *__restrict__ WT) {   // (128, 128)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < INNER * INNER) WT[idx] = W[(size_t)(idx % INNER) * INNER + idx / INNER];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-(shape, block) static attention operands.  One 256-thread workgroup per (s, b).
 template <int PREC>
 __global__ void __launch_bounds__(256) k_shape_ctx(const float *__restrict__ part_code, const float *__restrict__ mean,
                                                    const float *__restrict__ var, const float *__restrict__ valid,
-                                                   const float *const *__restrict__ wptrs /* [depth][6] */,
+                                                   const float *const *__restrict__ wptrs /* [depth][7] */,
                                                    const float *__restrict__ win, const float *__restrict__ bin,
                                                    ShapeCtxView out, int depth) {
-  __shared__ float s_ctx[NCLS][CTX_STATIC + 2];
-  __shared__ float s_k[NCLS][INNER], s_v[NCLS][INNER];
+  // token-minor LDS tables: one ds_read_b128 hands a thread the value of all four tokens (the reads are broadcasts: every lane the same address)
+  __shared__ __attribute__((aligned(16))) float s_ctx[CTX_STATIC + 2][NCLS];
+  __shared__ __attribute__((aligned(16))) float s_k[INNER][NCLS], s_v[INNER][NCLS];
   __shared__ float s_wqb[INNER];
+  __shared__ float s_out[8 * 1024];   // the record's eight tiles in fragment order
   const int s = blockIdx.x / depth, b = blockIdx.x % depth;
   const int tid = threadIdx.x;
-  const float *Wq = wptrs[b * 6 + 0], *Wk = wptrs[b * 6 + 1], *Wv = wptrs[b * 6 + 2], *Wo = wptrs[b * 6 + 3];
-  const float *g2 = wptrs[b * 6 + 4], *be2 = wptrs[b * 6 + 5];
+  const float *Wq = wptrs[b * 7 + 0], *Wk = wptrs[b * 7 + 1], *Wv = wptrs[b * 7 + 2], *Wo = wptrs[b * 7 + 3];
+  const float *g2 = wptrs[b * 7 + 4], *wqb = wptrs[b * 7 + 6];   // (Wk, Wv: static columns transposed; Wo transposed; wqb = Wq beta2, from create)
   // static context rows: [part_code(256) | mean(3) | var(3) | onehot(4)]   (attention.py:386-391)
   for (int i = tid; i < NCLS * CTX_STATIC; i += 256) {
     const int j = i / CTX_STATIC, k = i % CTX_STATIC;
@@ -173,47 +203,81 @@ __global__ void __launch_bounds__(256) k_shape_ctx(const float *__restrict__ par
     else if (k < ZDIM + 3) v = mean[((size_t)s * 3 + (k - ZDIM)) * NCLS + j];
     else if (k < ZDIM + 6) v = var[((size_t)s * 3 + (k - ZDIM - 3)) * NCLS + j];
     else v = (k - ZDIM - 6) == j ? 1.f : 0.f;
-    s_ctx[j][k] = v;
+    s_ctx[k][j] = v;
   }
   __syncthreads();
-  // k_static / v_static = W[:, :266] ctx_j
-  for (int o = tid; o < 2 * NCLS * INNER; o += 256) {
-    const int which = o / (NCLS * INNER), j = (o / INNER) % NCLS, row = o % INNER;
-    const float *w = (which ? Wv : Wk) + (size_t)row * CTX_DIM;
-    float acc = 0.f;
-    for (int k = 0; k < CTX_STATIC; ++k) acc = fmaf(w[k], s_ctx[j][k], acc);
-    (which ? s_v : s_k)[j][row] = acc;
+  // k_static / v_static = W[:, :266] ctx_j.  Wk / Wv arrive TRANSPOSED ([266][128], k_transpose_static at create): thread = output row, so every
+  // load instruction of a wavefront reads 256 contiguous bytes (one thread per output walking its own row of the (128, 522) matrix touched 64 cache
+  // lines per instruction: 86 us per batch of 128 shapes; a wavefront per row with a lane reduction was a serial chain of round trips: 127 us);
+  // the sum runs over k in order, as before: the same bits
+  static_assert(NCLS == 4 && INNER == 128, "256 threads = 2 matrices x 128 rows, four context tokens per shape");
+  {
+    const int which = tid >> 7, row = tid & (INNER - 1);
+    const float *wT = (which ? Wv : Wk) + row;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // 38 loads in flight per thread: seven round trips to the L2 instead of one per unrolled group of eight (the kernel is a chain of round trips)
+    constexpr int KB = 38;
+    static_assert(CTX_STATIC % KB == 0, "266 = 7 x 38");
+#pragma unroll 1
+    for (int kb = 0; kb < CTX_STATIC; kb += KB) {
+      float wv[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) wv[u] = wT[(size_t)(kb + u) * INNER];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const float4 cx = *reinterpret_cast<const float4 *>(s_ctx[kb + u]);
+        a0 = fmaf(wv[u], cx.x, a0), a1 = fmaf(wv[u], cx.y, a1), a2 = fmaf(wv[u], cx.z, a2), a3 = fmaf(wv[u], cx.w, a3);
+      }
+    }
+    *reinterpret_cast<float4 *>((which ? s_v : s_k)[row]) = make_float4(a0, a1, a2, a3);
   }
-  if (tid < INNER) {
-    float acc = 0.f;
-    for (int k = 0; k < INNER; ++k) acc = fmaf(Wq[(size_t)tid * INNER + k], be2[k], acc);
-    s_wqb[tid] = acc;
-  }
+  if (tid < INNER) s_wqb[tid] = wqb[tid];
   __syncthreads();
   const float scale = 0.25f;  // dim_head ** -0.5 (attention.py:167)
   const size_t sb = (size_t)s * depth + b;
   char *rec = reinterpret_cast<char *>(out.as_ms) + sb * asms_bytes(PREC);
   void *tiles = rec;
   float *sbias = reinterpret_cast<float *>(rec + 8 * tile_bytes(PREC));
-  for (int gi = tid; gi < 8 * 1024; gi += 256) {
-    const int tile = gi >> 10;
-    int i, kk;
-    tile_decode<PREC>(gi & 1023, i, kk);
-    float acc = 0.f;
-    if (tile < 4) {  // A_s: row R = 4*head + j, column channel
-      const int head = i >> 2, j = i & 3, ch = 32 * tile + kk;
-      for (int d = 0; d < DHEAD; ++d) acc = fmaf(Wq[(size_t)(head * DHEAD + d) * INNER + ch], s_k[j][head * DHEAD + d], acc);
-      acc *= scale * g2[ch];
-    } else {  // M_s: row = out channel, k = R
-      const int row = 32 * (tile - 4) + i, head = kk >> 2, j = kk & 3;
-      for (int d = 0; d < DHEAD; ++d) acc = fmaf(Wo[(size_t)row * INNER + head * DHEAD + d], s_v[j][head * DHEAD + d], acc);
+  // A_s (threads 0..127: channel = thread) and M_s (threads 128..255: output row = thread, Wo arrives TRANSPOSED): every weight load of a
+  // wavefront is 256 contiguous bytes and serves the four tokens; the sums run over d in order (the same bits as one thread per output, which
+  // read Wq / Wo with a 512-byte stride between lanes).  The 8 tiles are put together in LDS in fragment order and leave as whole lines.
+  {
+    const int c = tid & (INNER - 1);
+    const bool ms = tid >= INNER;
+    const float *wsrc = (ms ? Wo : Wq) + c;
+    const float(*kv)[NCLS] = ms ? s_v : s_k;
+    const float post = ms ? 1.f : scale * g2[c];
+#pragma unroll 1
+    for (int h0 = 0; h0 < INNER / DHEAD; h0 += 4) {   // four heads' weights (64 loads) in flight
+      float wv[4 * DHEAD];
+#pragma unroll
+      for (int u = 0; u < 4 * DHEAD; ++u) wv[u] = wsrc[(size_t)(h0 * DHEAD + u) * INNER];
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+      const int head = h0 + hh;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DHEAD; ++d) {
+        const float w1 = wv[hh * DHEAD + d];
+        const float4 t4 = *reinterpret_cast<const float4 *>(kv[head * DHEAD + d]);
+        a0 = fmaf(w1, t4.x, a0), a1 = fmaf(w1, t4.y, a1), a2 = fmaf(w1, t4.z, a2), a3 = fmaf(w1, t4.w, a3);
+      }
+      const float av[4] = {a0, a1, a2, a3};
+#pragma unroll
+      for (int j = 0; j < NCLS; ++j) {
+        // A_s: tile c / 32, row i = 4 head + j, column kk = c % 32;  M_s: tile 4 + c / 32, row i = c % 32, column kk = 4 head + j
+        const int tile = (ms ? 4 : 0) + (c >> 5), i = ms ? (c & 31) : 4 * head + j, kk = ms ? 4 * head + j : (c & 31);
+        s_out[tile * 1024 + tile_index<PREC>(i, kk)] = av[j] * post;
+      }
+      }
     }
-    tile_store<PREC>(tiles, gi, acc);
   }
+  __syncthreads();
+  for (int gi = tid; gi < 8 * 1024; gi += 256) tile_store<PREC>(tiles, gi, s_out[gi]);
   if (tid < 32) {  // sbias in C-layout [hf][16]
     const int hf = tid >> 4, r = tid & 15, R = rho(r, hf), head = R >> 2, j = R & 3;
     float acc = 0.f;
-    for (int d = 0; d < DHEAD; ++d) acc = fmaf(s_wqb[head * DHEAD + d], s_k[j][head * DHEAD + d], acc);
+    for (int d = 0; d < DHEAD; ++d) acc = fmaf(s_wqb[head * DHEAD + d], s_k[head * DHEAD + d][j], acc);
     sbias[tid] = acc * scale;
   } else if (tid < 256) {
     sbias[tid] = 0.f;  // pad of the 1 KiB piece
@@ -231,8 +295,8 @@ __global__ void __launch_bounds__(256) k_shape_ctx(const float *__restrict__ par
       const int j = o / INNER, ch = o % INNER;
       const float *w = win + (size_t)ch * IN_CH;
       float acc = bin[ch];
-      for (int i = 0; i < 3; ++i) acc = fmaf(w[3 + i], s_ctx[j][ZDIM + i], acc);
-      for (int i = 0; i < 3; ++i) acc = fmaf(w[6 + i], s_ctx[j][ZDIM + 3 + i], acc);
+      for (int i = 0; i < 3; ++i) acc = fmaf(w[3 + i], s_ctx[ZDIM + i][j], acc);
+      for (int i = 0; i < 3; ++i) acc = fmaf(w[6 + i], s_ctx[ZDIM + 3 + i][j], acc);
       acc += w[9 + j];
       out.cpart[((size_t)s * NCLS + j) * INNER + cvec_index(ch)] = acc;
     }
@@ -332,7 +396,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     const float **wptrs;
     struct {
       uint4 *chunks;
-      float *bconst, *ct, *wq, *wk, *wv, *wo, *g2, *be2;
+      float *bconst, *ct, *wq, *wk, *wv, *wo, *g2, *be2, *wqb;
     } blk[DFX_MAX_DEPTH];
   } cv;
   auto carve = [&](char *base) {
@@ -350,17 +414,18 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     cv.pre_gb = bp.take<float2>(INNER);
     cv.win = bp.take<float>(INNER * IN_CH);
     cv.bin = bp.take<float>(INNER);
-    cv.wptrs = bp.take<const float *>(DFX_MAX_DEPTH * 6);
+    cv.wptrs = bp.take<const float *>(DFX_MAX_DEPTH * 7);
     for (int b = 0; b < depth; ++b) {
       cv.blk[b].chunks = reinterpret_cast<uint4 *>(bp.take<char>((size_t)FF_STAGES * chunk_bytes(precision)));
       cv.blk[b].bconst = bp.take<float>(BCONST_BYTES / 4);
       cv.blk[b].ct = bp.take<float>((size_t)(T + 1) * CT_ROW);
       cv.blk[b].wq = bp.take<float>(INNER * INNER);
-      cv.blk[b].wk = bp.take<float>(INNER * CTX_DIM);
-      cv.blk[b].wv = bp.take<float>(INNER * CTX_DIM);
+      cv.blk[b].wk = bp.take<float>(CTX_STATIC * INNER);   // static columns of to_k / to_v, transposed
+      cv.blk[b].wv = bp.take<float>(CTX_STATIC * INNER);
       cv.blk[b].wo = bp.take<float>(INNER * INNER);
       cv.blk[b].g2 = bp.take<float>(INNER);
       cv.blk[b].be2 = bp.take<float>(INNER);
+      cv.blk[b].wqb = bp.take<float>(INNER);
     }
     return bp.off;
   };
@@ -455,14 +520,16 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   }
 
   // ---- per block ----
-  std::vector<const float *> wptrs((size_t)DFX_MAX_DEPTH * 6, nullptr);
+  std::vector<const float *> wptrs((size_t)DFX_MAX_DEPTH * 7, nullptr);
   for (int b = 0; b < depth; ++b) {
     const dfx_block_weights &k = w->blk[b];
     auto &c = cv.blk[b];
     TRY_HIP(hipMemcpyAsync(c.wq, k.to_q, sizeof(float) * INNER * INNER, hipMemcpyDeviceToDevice, st));
-    TRY_HIP(hipMemcpyAsync(c.wk, k.to_k, sizeof(float) * INNER * CTX_DIM, hipMemcpyDeviceToDevice, st));
-    TRY_HIP(hipMemcpyAsync(c.wv, k.to_v, sizeof(float) * INNER * CTX_DIM, hipMemcpyDeviceToDevice, st));
-    TRY_HIP(hipMemcpyAsync(c.wo, k.to_out_w, sizeof(float) * INNER * INNER, hipMemcpyDeviceToDevice, st));
+    k_transpose_static<<<nblk((long long)CTX_STATIC * INNER), 256, 0, st>>>(k.to_k, c.wk);
+    k_transpose_static<<<nblk((long long)CTX_STATIC * INNER), 256, 0, st>>>(k.to_v, c.wv);
+    TRY_LAUNCH("transpose_static");
+    k_transpose_sq<<<nblk((long long)INNER * INNER), 256, 0, st>>>(k.to_out_w, c.wo);   // Wo^T: k_shape_ctx reads it with thread = output row
+    TRY_LAUNCH("transpose_wo");
     TRY_HIP(hipMemcpyAsync(c.g2, k.norm2_w, sizeof(float) * INNER, hipMemcpyDeviceToDevice, st));
     TRY_HIP(hipMemcpyAsync(c.be2, k.norm2_b, sizeof(float) * INNER, hipMemcpyDeviceToDevice, st));
     // c_t = Wo (Wv[:,266:] t_emb(t)) + b_o, cvec order
@@ -493,10 +560,12 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     TRY_LAUNCH("pack_w1w2");
     d->dev.blk[b] = BlockPack{c.chunks, c.bconst, c.ct};
     d->wq[b] = c.wq; d->wk[b] = c.wk; d->wv[b] = c.wv; d->wo[b] = c.wo; d->g2[b] = c.g2; d->be2[b] = c.be2;
-    wptrs[(size_t)b * 6 + 0] = c.wq; wptrs[(size_t)b * 6 + 1] = c.wk; wptrs[(size_t)b * 6 + 2] = c.wv;
-    wptrs[(size_t)b * 6 + 3] = c.wo; wptrs[(size_t)b * 6 + 4] = c.g2; wptrs[(size_t)b * 6 + 5] = c.be2;
+    k_wq_beta<<<1, INNER, 0, st>>>(k.to_q, k.norm2_b, c.wqb);
+    TRY_LAUNCH("wq_beta");
+    wptrs[(size_t)b * 7 + 0] = c.wq; wptrs[(size_t)b * 7 + 1] = c.wk; wptrs[(size_t)b * 7 + 2] = c.wv;
+    wptrs[(size_t)b * 7 + 3] = c.wo; wptrs[(size_t)b * 7 + 4] = c.g2; wptrs[(size_t)b * 7 + 5] = c.be2; wptrs[(size_t)b * 7 + 6] = c.wqb;
   }
-  TRY_HIP(hipMemcpyAsync(cv.wptrs, wptrs.data(), sizeof(const float *) * DFX_MAX_DEPTH * 6, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipMemcpyAsync(cv.wptrs, wptrs.data(), sizeof(const float *) * DFX_MAX_DEPTH * 7, hipMemcpyHostToDevice, st));
   TRY_HIP(hipStreamSynchronize(st));  // host staging vectors die here; user parameters no longer needed
 #undef TRY_HIP
 #undef TRY_LAUNCH
