@@ -29,10 +29,14 @@ struct LinArgs {
   int M, N, K;                               // N = output columns (dual epilogues read 2N weight rows)
 };
 
-template <int EPI>
-static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
+// SPLIT > 1: split-K.  A call with few rows (the flows' and the aligner's 128-512 rows, the time-embedding MLP) is 100-odd single-wavefront
+// workgroups, each ONE dependent chain of K / 32 trips (~1 us of L2 latency per trip): SPLIT wavefronts per tile take every SPLIT-th trip, wavefronts
+// 1 .. SPLIT - 1 hand their accumulators over through LDS and wavefront 0 adds them in wave order and runs the epilogue (fixed order: deterministic;
+// the sum over K is grouped differently from SPLIT = 1, i.e. equal up to fp32 rounding).
+template <int EPI, int SPLIT = 1>
+static __global__ __launch_bounds__(64 * SPLIT) void k_lin(LinArgs a) {
   constexpr bool DUAL = (EPI == EPI_COUPLING || EPI == EPI_GEGLU);
-  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = SPLIT > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, j = lane & 31, hf = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, g = blockIdx.z;
   const int mrow = min(m0 + j, a.M - 1), nrow = min(n0 + j, a.N - 1);   // clamped rows are never stored
   const float *xp = a.X + g * a.x_gs + (size_t)mrow * a.ldx + 4 * hf;
@@ -67,23 +71,45 @@ static __global__ __launch_bounds__(64) void k_lin(LinArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) block(t.xv[u], t.wv[u], t.uv[u]);
   };
-  const int ntrip = a.K / 32;
-  int k = 32 * ntrip;
+  const int ntrip_all = a.K / 32;
+  // this wavefront's trips: wave, wave + SPLIT, ... (SPLIT = 1: all of them, in order)
+  const int ntrip = ntrip_all > wave ? (ntrip_all - wave + SPLIT - 1) / SPLIT : 0;
+  auto kof = [&](int t) { return 32 * (wave + t * SPLIT); };
   if (ntrip > 0) {
     Trip ta, tb;
-    load_trip(0, ta);
+    load_trip(kof(0), ta);
     int t = 0;
     for (; t + 1 < ntrip; t += 2) {
-      load_trip(32 * (t + 1), tb);
+      load_trip(kof(t + 1), tb);
       __builtin_amdgcn_sched_barrier(0);
       run_trip(ta);
-      load_trip(32 * min(t + 2, ntrip - 1), ta);
+      load_trip(kof(min(t + 2, ntrip - 1)), ta);
       __builtin_amdgcn_sched_barrier(0);
       run_trip(tb);
     }
     if (t < ntrip) run_trip(ta);
   }
-  for (; k < a.K; k += 8) block(ld(xp + k), ld(wp + k), DUAL ? ld(wq + k) : v4f{0.f, 0.f, 0.f, 0.f});
+  if (wave == 0)
+    for (int k = 32 * ntrip_all; k < a.K; k += 8) block(ld(xp + k), ld(wp + k), DUAL ? ld(wq + k) : v4f{0.f, 0.f, 0.f, 0.f});
+  if constexpr (SPLIT > 1) {
+    __shared__ float red[SPLIT - 1][DUAL ? 2 : 1][16][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[wave - 1][0][r][lane] = acc0[r];
+        if (DUAL) red[wave - 1][DUAL ? 1 : 0][r][lane] = acc1[r];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < SPLIT - 1; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] += red[w][0][r][lane];
+        if (DUAL) acc1[r] += red[w][DUAL ? 1 : 0][r][lane];
+      }
+  }
   const int m = m0 + j;
   if (m >= a.M) return;
   const float *bp = a.Wtab[0] ? a.btab[g] : (a.b ? a.b + g * a.b_gs : nullptr);
@@ -301,7 +327,11 @@ inline void launch(hipStream_t st, int groups, const LinArgs &a) {
     }
   }
   dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, groups);
-  k_lin<EPI><<<grid, 64, 0, st>>>(a);
+  // at most one tile per CU and a long K: four wavefronts per tile (split-K) — the call is a chain of round trips, not of MFMAs (measured per call of
+  // the latent sampler at B = 128: flows 7.1 / 8.8 / 13.7 -> 6.4 / 7.9 / 11.1 us, the aligner's K = 1024 projection 20.3 -> 14.1; with 384-512 tiles
+  // the split costs 1-2 us instead)
+  if ((long long)grid.x * grid.y * groups <= 256 && a.K >= 128) k_lin<EPI, 4><<<grid, 256, 0, st>>>(a);
+  else k_lin<EPI><<<grid, 64, 0, st>>>(a);
 }
 
 }  // namespace lin
