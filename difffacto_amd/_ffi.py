@@ -118,6 +118,7 @@ SIGNATURES = {
     "dfx_debug_dropout_factors": (_I, [_U64, _I, _F, _P, ctypes.c_longlong, _P]),
     "dfx_debug_train_fused": (None, [_I]),
     "dfx_debug_train_streams": (None, [_I]),
+    "dfx_debug_bn_fused_stats": (None, [_I]),
     "dfx_debug_rowmap": (None, [_I, _P, _P]),
     "dfx_debug_emd_state_global": (None, [_I]),
     "dfx_debug_fps_shape": (None, [_I, _I]),

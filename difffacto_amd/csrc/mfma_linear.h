@@ -27,7 +27,23 @@ struct LinArgs {
   const float *R; int ldr; int r_mod;        // RESID: Y = acc + b + R[(r_mod ? m % r_mod : m)][n]
   long long r_gs;                            // k_lin only: group stride of R
   int M, N, K;                               // N = output columns (dual epilogues read 2N weight rows)
+  float *stats;                              // k_lin_wide_lds<.., STATS = true> only: [gridDim.y][N][3] per-workgroup (count, mean, M2) of every
+                                             // output column over the workgroup's rows (BatchNorm batch statistics without a pass over Y)
 };
+
+// (count, mean, sum of squared deviations) of two disjoint sets of values -> of their union (Chan et al.); exact in real arithmetic and as
+// accurate as a two-pass computation; either side may be empty
+__host__ __device__ inline void stats_merge(float &n, float &mean, float &m2, float nb, float mb, float qb) {
+  if (nb == 0.f) return;
+  if (n == 0.f) {
+    n = nb, mean = mb, m2 = qb;
+    return;
+  }
+  const float nn = n + nb, d = mb - mean;
+  mean += d * (nb / nn);
+  m2 += qb + d * d * (n * nb / nn);
+  n = nn;
+}
 
 // SPLIT > 1: split-K.  A call with few rows (the flows' and the aligner's 128-512 rows, the time-embedding MLP) is 100-odd single-wavefront
 // workgroups, each ONE dependent chain of K / 32 trips (~1 us of L2 latency per trip): SPLIT wavefronts per tile take every SPLIT-th trip, wavefronts
@@ -208,9 +224,12 @@ static __global__ __launch_bounds__(256) void k_lin_wide(LinArgs a) {
 // kernel sits on the texture-address path at ~43 % of the matrix peak whatever the prefetch distance.  Here a workgroup of eight
 // wavefronts stages its 128-channel weight block ONCE, fragment-ready ([tile][K step][lane] float4: K / 2 KiB for 128 channels, K <= 272; 64-channel blocks up to K = 544), and walks over
 // row tiles of 256 with it: per K step one global load (the activations, one step ahead) and four conflict-free ds_read_b128.
-template <int EPI, int NT>   // NT = 4: 128 channels per block, K <= 272; NT = 2: 64 channels, K <= 544 (the block fits LDS either way)
+// STATS: the workgroup also leaves (count, mean, M2) of every output column over ITS rows in a.stats — a lane holds 16 rows of one channel, so a
+// tile's share is 16 in-lane adds per pass; tiles, lane halves, wavefronts are merged with stats_merge in a fixed order (deterministic).
+template <int EPI, int NT, bool STATS = false>   // NT = 4: 128 channels per block, K <= 272; NT = 2: 64 channels, K <= 544 (the block fits LDS either way)
 static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
   static_assert(EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_RESID, "plain epilogues only");
+  static_assert(!STATS || EPI == EPI_NONE, "statistics of the plain output");
   extern __shared__ __align__(16) float lin_smem[];
   v4f *wl = reinterpret_cast<v4f *>(lin_smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
@@ -236,6 +255,9 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
   __syncthreads();
   const float *bp = a.b ? a.b + g * a.b_gs : nullptr;
   const v4f *wlane = wl + lane;
+  float sn = 0.f, smean[NT], sm2[NT];   // STATS: running (count, mean, M2) of this lane's 16-row column pieces
+#pragma unroll
+  for (int t = 0; t < NT; ++t) smean[t] = 0.f, sm2[t] = 0.f;
   for (long long rt = blockIdx.y; rt * 256 < a.M; rt += gridDim.y) {   // (no barrier inside: wavefronts past the end just skip)
     const int m0 = (int)(rt * 256) + wave * 32;
     if (m0 >= a.M) continue;
@@ -277,10 +299,16 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
     // tools/ubench/mfma_f32_feed.hip.)
     float *ybase = a.Y + g * a.y_gs;
     auto epilogue = [&](auto full) {   // full: all 32 rows of the tile exist (every tile but the last one of a ragged M): no per-store mask
+      float cnt = 0.f;
+      if (STATS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt += (decltype(full)::value || m0 + (r & 3) + 8 * (r >> 2) + 4 * hf < a.M) ? 1.f : 0.f;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int n = n0 + 32 * t + j;
         const float bias = bp ? bp[n] : 0.f;
+        float ssum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
@@ -289,13 +317,63 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
             if (EPI == EPI_RELU) y = fmaxf(y, 0.f);
             if (EPI == EPI_RESID) y += a.R[(size_t)(a.r_mod ? m % a.r_mod : m) * a.ldr + n];
             ybase[(size_t)m * a.ldy + n] = y;
+            if (STATS) ssum += y;
           }
         }
+        if (STATS && cnt > 0.f) {
+          const float mt = ssum / cnt;
+          float q = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (decltype(full)::value || m < a.M) {
+              const float d = (acc[t][r] + bias) - mt;
+              q = fmaf(d, d, q);
+            }
+          }
+          float nn = sn;
+          stats_merge(nn, smean[t], sm2[t], cnt, mt, q);
+        }
       }
+      if (STATS) sn += cnt;
     };
     if (m0 + 32 <= a.M) epilogue(std::true_type{});
     else epilogue(std::false_type{});
   }
+  if constexpr (STATS) {
+    // lane halves (rows 4 hf + ... of the same channel), then the eight wavefronts in order, through LDS
+    __shared__ float sred[8][NT * 32][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float on = __shfl_xor(sn, 32), om = __shfl_xor(smean[t], 32), oq = __shfl_xor(sm2[t], 32);
+      float n2 = sn, mean = smean[t], m2 = sm2[t];
+      if (hf == 0) {   // (half 0 = the first operand for both lanes' results: one order)
+        stats_merge(n2, mean, m2, on, om, oq);
+        sred[wave][t * 32 + j][0] = n2, sred[wave][t * 32 + j][1] = mean, sred[wave][t * 32 + j][2] = m2;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < NT * 32) {
+      float n2 = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) stats_merge(n2, mean, m2, sred[w][threadIdx.x][0], sred[w][threadIdx.x][1], sred[w][threadIdx.x][2]);
+      float *o = a.stats + ((size_t)blockIdx.y * a.N + n0 + threadIdx.x) * 3;
+      o[0] = n2, o[1] = mean, o[2] = m2;
+    }
+  }
+}
+
+// The wide LDS-resident kernel with the statistics epilogue, when its conditions hold (returns the number of partial rows = gridDim.y, or 0:
+// the caller then takes the plain launch and a separate statistics pass).  stats: room for (M + 255) / 256 x N x 3 floats at most.
+inline int launch_wide_lds_stats(hipStream_t st, const LinArgs &a) {
+  if (!(a.N % 128 == 0 && a.M >= 8192 && a.K % 8 == 0 && a.K <= 272 && a.ldx % 4 == 0 && a.stats)) return 0;
+  const size_t lds = (size_t)a.K / 8 * 4096;
+  static PerDeviceOnce attrs;
+  (void)attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_lin_wide_lds<EPI_NONE, 4, true>), 34 * 4096); });
+  const int cols = a.N / 128, per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 16 * 1024) / lds));
+  const int rows = (int)std::min<long long>((a.M + 255) / 256, std::max(1, 256 * per_cu / cols));
+  k_lin_wide_lds<EPI_NONE, 4, true><<<dim3(cols, rows, 1), 512, lds, st>>>(a);
+  return rows;
 }
 
 template <int EPI>

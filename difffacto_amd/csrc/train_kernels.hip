@@ -1046,6 +1046,36 @@ __global__ void k_bn_rstd(const float *__restrict__ ssq, const float *__restrict
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
   }
 }
+// Batch statistics from the per-workgroup (count, mean, M2) partials the producing product left behind (k_lin_wide_lds<.., STATS>): merged per
+// column in partial order (fixed: deterministic), then what k_bn_mean / k_bn_rstd do.  32 lanes share a column's partials and meet in a tree of
+// stats_merge steps (one thread per column walking up to 512 partials was a 10 us chain of dependent loads).
+__global__ __launch_bounds__(256) void k_bn_merge(const float *__restrict__ stats, int P, float *__restrict__ mean, float *__restrict__ rstd,
+                                                  float *run_mean, float *run_var, float unbias, float eps, float momentum, int Cc) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (c >= Cc) return;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int p = l; p < P; p += 32) {
+    const float *q = stats + ((size_t)p * Cc + c) * 3;
+    dfx::lin::stats_merge(n, mu, m2, q[0], q[1], q[2]);
+  }
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const float on = __shfl_xor(n, o), om = __shfl_xor(mu, o), oq = __shfl_xor(m2, o);
+    // both partners must form the SAME merged triple: the lane with the lower index is the first operand for both
+    float a_n = (l & o) ? on : n, a_m = (l & o) ? om : mu, a_q = (l & o) ? oq : m2;
+    const float b_n = (l & o) ? n : on, b_m = (l & o) ? mu : om, b_q = (l & o) ? m2 : oq;
+    dfx::lin::stats_merge(a_n, a_m, a_q, b_n, b_m, b_q);
+    n = a_n, mu = a_m, m2 = a_q;
+  }
+  if (l != 0) return;
+  const float var = m2 / n;
+  mean[c] = mu;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (momentum >= 0.f && run_mean && run_var) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
+  }
+}
 // BatchNorm affine y = (z - mu) rs g + b: ONE definition with the contraction pinned off, shared by the forward (k_bn_apply), the
 // pooling (k_pool_fwd) and the two backward passes that re-derive the ReLU mask from z instead of reading a stored y — the sign of a
 // value within an ulp of 0 must not depend on how a particular kernel's multiply-adds were fused.
@@ -1493,6 +1523,7 @@ bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the atte
 // Fused path: the context branch of the forward (time-embedding MLP, keys / values, attention folds) and the parameter-gradient
 // reductions of the backward run on the device's side stream (dfx::SideStream) beside the kernels over the points: they are chains of
 // small-grid launches that leave most of the chip idle.  Same kernels, same operands, same results; dfx_debug_train_streams(0) = one stream.
+bool g_bn_fused_stats = true;   // PointNetV2 training forward: batch statistics from the products' epilogues (dfx_debug_bn_fused_stats(0): separate passes)
 int g_train_streams = 1;   // 0 = off, 1 = the default set, other values = explicit set of SS_* bits (A/B)
 enum { SS_FWD_CTX = 2, SS_HEAD_EARLY = 4, SS_STEM_EARLY = 8, SS_LEAVES = 16, SS_STEM_END = 32, SS_DEFAULT = SS_HEAD_EARLY | SS_STEM_EARLY | SS_LEAVES };
 inline int ss_mask() { return g_train_streams == 1 ? SS_DEFAULT : g_train_streams; }
@@ -1682,10 +1713,14 @@ size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int /*zdim: the heads 
 }
 
 // y = [relu] BN_train(z) over R rows; leaves mean / rstd behind and updates the running statistics when momentum >= 0
+// stat_parts > 0: the product that wrote z left that many rows of per-workgroup (count, mean, M2) partials in w.pb.part (lin_stats below): no pass over z
 int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, const float *g, const float *b, float *run_mean,
-           float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu, bool apply = true) {
+           float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu, bool apply = true, int stat_parts = 0) {
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
+  if (stat_parts > 0) {
+    k_bn_merge<<<(Cc + 7) / 8, 256, 0, st>>>(w.pb.part, stat_parts, mean, rstd, run_mean, run_var, R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
+  } else {
   k_col_stats<0><<<grid, 256, 0, st>>>(z, nullptr, w.pb.part, R, Cc);
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
   k_bn_mean<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, 1.0f / (float)R, Cc);
@@ -1693,6 +1728,7 @@ int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, c
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, w.sums, ns, Cc, Cc);
   k_bn_rstd<<<(Cc + 255) / 256, 256, 0, st>>>(w.sums, mean, rstd, run_mean, run_var, 1.0f / (float)R,
                                               R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
+  }
   const long long total = R * Cc;
   if (!apply) return dfx::check_launch("train: bn_fwd");   // (the consumer forms y itself: k_pool_fwd)
   if (relu) k_bn_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(z, mean, rstd, g, b, y, total, Cc);
@@ -2177,9 +2213,18 @@ int dfx_pointnet_v2_train_forward(const dfx_pointnet_v2_weights *wt, void *works
   for (int l = 0; l < 4; ++l) {
     const float *in = l == 0 ? w.X8 : w.y[l - 1];
     const int K = PN_C[l], Co = PN_C[l + 1];
-    if ((rc = lin(st, in, K, l == 0 ? w.wpad : wt->conv_w[l], wt->conv_b[l], w.z[l], Co, R, Co, K))) return rc;
+    // fp32 trunk: the product's epilogue leaves the BatchNorm batch statistics of its output (per-workgroup (count, mean, M2) partials): the two
+    // statistics passes over z (0.64 ms of the 2.1 ms forward at 128 x 2048 points) are gone
+    int parts = 0;
+    if (g_prec == DFX_PREC_F32 && g_bn_fused_stats) {
+      LinArgs la{};
+      la.X = in, la.ldx = K, la.W = l == 0 ? w.wpad : wt->conv_w[l], la.b = wt->conv_b[l], la.Y = w.z[l], la.ldy = Co, la.M = (int)R, la.N = Co, la.K = K;
+      la.stats = w.pb.part;
+      if ((size_t)std::min<long long>((R + 255) / 256, 512) * Co * 3 <= w.pb.part_floats) parts = dfx::lin::launch_wide_lds_stats(st, la);
+    }
+    if (!parts && (rc = lin(st, in, K, l == 0 ? w.wpad : wt->conv_w[l], wt->conv_b[l], w.z[l], Co, R, Co, K))) return rc;
     if ((rc = bn_fwd(st, w, w.z[l], R, Co, wt->bn_w[l], wt->bn_b[l], mut(wt->bn_mean[l]), mut(wt->bn_var[l]), momentum, wt->bn_eps,
-                     w.mean[l], w.rstd[l], w.y[l], l < 3, l < 3))) return rc;
+                     w.mean[l], w.rstd[l], w.y[l], l < 3, l < 3, parts))) return rc;
   }
   const float scale = wt->reweight_by_anchor ? (float)A : 1.0f;
   k_pool_fwd<4, 16><<<dim3(512 / 64, B), 1024, 0, st>>>(w.z[3], w.mean[3], w.rstd[3], wt->bn_w[3], wt->bn_b[3], attn, w.pooled, w.arg, N, 512, scale);
@@ -2356,6 +2401,7 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
 void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
+void dfx_debug_bn_fused_stats(int on) { g_bn_fused_stats = on != 0; }
 void dfx_debug_train_streams(int on) { g_train_streams = on < 0 ? 0 : on; }
 // Host-side evaluation of the fused training kernels' row addressing (ffused::RowMap, the code the kernels compile): for a 32-point tile, the float
 // offset of every (point, channel) as the B-operand-layout accessors and as the accumulator-layout accessors see it.  out_b, out_a: [32][128] int32.

@@ -32,8 +32,12 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.0)
     ap.add_argument("--encoder-precision", default="f32", choices=["bf16", "f32"], help="matrix products of the PointNetV2 trunk")
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--two-pass-bn", action="store_true", help="A/B: BatchNorm batch statistics with two passes over each layer's output")
     a = ap.parse_args()
     torch.cuda.set_device(0)
+    if a.two_pass_bn:
+        from difffacto_amd import _ffi
+        _ffi.lib().dfx_debug_bn_fused_stats(0)
     enc = PartEncoderForTransformerDecoder(encoder=dict(type="PointNetV2", zdim=256, per_part_mlp=True), n_class=4, part_aligner=None,
                                            include_z=False, include_part_code=True, include_params=True, use_gt_params=True, kl_weight=5e-4,
                                            use_flow=True, latent_flow_depth=14, latent_flow_hidden_dim=256, gen=True, prior_var=1.0)

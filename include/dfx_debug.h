@@ -23,6 +23,10 @@ void dfx_debug_train_fused(int on);
  * and the parameter-gradient reductions of the backward run on a per-device side stream, forked from and joined into the caller's stream
  * inside the call).  Same kernels and operands either way: bit-identical results. */
 void dfx_debug_train_streams(int on);
+/* Debug / A-B switch: 0 = the PointNetV2 training forward computes its BatchNorm batch statistics with two passes over each layer's output
+ * (mean, then centred sum of squares); default 1 = from (count, mean, M2) partials the fp32 product kernels leave in their epilogues
+ * (>= 8192 rows).  Equal up to fp32 rounding of the statistics. */
+void dfx_debug_bn_fused_stats(int on);
 /* Host-side table of the fused training kernels' row addressing inside a 32-point tile (tiled = 1: the tile-major layout between the fused
  * kernels; 0: row-major): float offset of (point, channel) through the B-operand-layout and the accumulator-layout accessors; [32][128] int32 each. */
 void dfx_debug_rowmap(int tiled, int *out_b, int *out_a);
