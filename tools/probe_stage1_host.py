@@ -13,9 +13,9 @@ from difffacto_amd.encoders import PartEncoderForTransformerDecoder
 from difffacto_amd.modules import AnchoredDiffusion
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 10
-if "--two-pass-bn" in sys.argv:   # A/B: BatchNorm batch statistics with two passes over each layer's output
+if "--bn" in sys.argv:   # A/B: dfx_debug_bn_fused_stats (0 = separate BatchNorm statistics passes, 1 = default: from the product epilogues)
     from difffacto_amd import _ffi
-    _ffi.lib().dfx_debug_bn_fused_stats(0)
+    _ffi.lib().dfx_debug_bn_fused_stats(int(sys.argv[sys.argv.index("--bn") + 1]))
 QUIET = "--quiet" in sys.argv
 B, N = 128, 2048
 torch.cuda.set_device(0)
