@@ -119,6 +119,7 @@ SIGNATURES = {
     "dfx_debug_train_fused": (None, [_I]),
     "dfx_debug_train_streams": (None, [_I]),
     "dfx_debug_bn_fused_stats": (None, [_I]),
+    "dfx_debug_stats_merge": (None, [_P, _I, _I, _P]),
     "dfx_debug_rowmap": (None, [_I, _P, _P]),
     "dfx_debug_emd_state_global": (None, [_I]),
     "dfx_debug_fps_shape": (None, [_I, _I]),

@@ -1150,6 +1150,80 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ dy, const float *__rest
   }
   *reinterpret_cast<v4f *>(dz + i) = o;
 }
+// BatchNorm over FEW rows (R <= BN_SLAB: the per-part heads normalise over the B shapes) in ONE launch per direction instead of seven / four:
+// a workgroup owns 64 channels and all R rows.  The sums run in the order of the multi-launch path (k_col_stats' four row groups of one slab,
+// k_sum_parts over that single partial): the same bits.
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_small_fwd(const float *__restrict__ z, const float *__restrict__ g, const float *__restrict__ b,
+                                                       float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var,
+                                                       float *__restrict__ y, int R, int Cc, float invR, float unbias, float eps, float momentum) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const bool ok = c < Cc;
+  float a = 0.f;
+  if (ok)
+    for (int r = rgp; r < R; r += 4) a += z[(size_t)r * Cc + c];
+  red[rgp][cl] = a;
+  __syncthreads();
+  const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * invR;
+  __syncthreads();
+  a = 0.f;
+  if (ok)
+    for (int r = rgp; r < R; r += 4) {
+      const float v = z[(size_t)r * Cc + c] - mu;
+      a += v * v;
+    }
+  red[rgp][cl] = a;
+  __syncthreads();
+  const float var = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * invR;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (!ok) return;
+  if (rgp == 0) {
+    mean[c] = mu, rstd[c] = rs;
+    if (momentum >= 0.f && run_mean && run_var) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
+    }
+  }
+  const float gv = g[c], bv = b[c];
+  for (int r = rgp; r < R; r += 4) {
+    float o = bn_affine(z[(size_t)r * Cc + c], mu, rs, gv, bv);
+    if (RELU) o = fmaxf(o, 0.f);
+    y[(size_t)r * Cc + c] = o;
+  }
+}
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_small_bwd(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ mean,
+                                                       const float *__restrict__ rstd, const float *__restrict__ g, const float *__restrict__ be,
+                                                       float *__restrict__ dbeta, float *__restrict__ dgamma, float *__restrict__ dz, int R, int Cc,
+                                                       float invR) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const bool ok = c < Cc;
+  float sb = 0.f, sg = 0.f, mu = 0.f, rs = 0.f, gv = 0.f, bv = 0.f;
+  if (ok) {
+    mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
+    for (int r = rgp; r < R; r += 4) {
+      float gm = dy[(size_t)r * Cc + c];
+      const float zv = z[(size_t)r * Cc + c];
+      if (RELU && !(bn_affine(zv, mu, rs, gv, bv) > 0.f)) gm = 0.f;
+      sb += gm;
+      sg += gm * (zv - mu) * rs;
+    }
+  }
+  red[0][rgp][cl] = sb, red[1][rgp][cl] = sg;
+  __syncthreads();
+  if (!ok) return;
+  const float db = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  const float dg = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  if (rgp == 0) dbeta[c] = db, dgamma[c] = dg;
+  for (int r = rgp; r < R; r += 4) {
+    const float zv = z[(size_t)r * Cc + c];
+    const float gm = (RELU && !(bn_affine(zv, mu, rs, gv, bv) > 0.f)) ? 0.f : dy[(size_t)r * Cc + c];
+    const float xh = (zv - mu) * rs;
+    dz[(size_t)r * Cc + c] = gv * rs * (gm - db * invR - xh * dg * invR);
+  }
+}
 // x (B,N,3) -> rows of 8 (zero padded)
 __global__ void k_pn_rows(const float *__restrict__ x, float *__restrict__ X8, long long R) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1523,7 +1597,6 @@ bool g_attn_in_ff = true;   // (debug: 2 in dfx_debug_train_fused keeps the atte
 // Fused path: the context branch of the forward (time-embedding MLP, keys / values, attention folds) and the parameter-gradient
 // reductions of the backward run on the device's side stream (dfx::SideStream) beside the kernels over the points: they are chains of
 // small-grid launches that leave most of the chip idle.  Same kernels, same operands, same results; dfx_debug_train_streams(0) = one stream.
-bool g_bn_fused_stats = true;   // PointNetV2 training forward: batch statistics from the products' epilogues (dfx_debug_bn_fused_stats(0): separate passes)
 int g_train_streams = 1;   // 0 = off, 1 = the default set, other values = explicit set of SS_* bits (A/B)
 enum { SS_FWD_CTX = 2, SS_HEAD_EARLY = 4, SS_STEM_EARLY = 8, SS_LEAVES = 16, SS_STEM_END = 32, SS_DEFAULT = SS_HEAD_EARLY | SS_STEM_EARLY | SS_LEAVES };
 inline int ss_mask() { return g_train_streams == 1 ? SS_DEFAULT : g_train_streams; }
@@ -1699,7 +1772,7 @@ size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int /*zdim: the heads 
   w.dh[0] = c.take<float>((size_t)B * A * 256);
   w.dh[1] = c.take<float>((size_t)B * A * 256);
   w.wpad = c.take<float>(128 * 8);
-  w.wT = c.take<float>((size_t)512 * 512);
+  w.wT = c.take<float>((size_t)4 * 512 * 256);   // a transposed trunk weight (<= 512 x 256), or the four parts' transposed head weights side by side
   w.sums = c.take<float>(4 * 1024);
   const size_t nslab = (R + BN_SLAB - 1) / BN_SLAB;
   size_t pf = nslab * 2 * 1024;                            // BatchNorm column-sum partials (up to A * 256 channels)
@@ -1712,12 +1785,21 @@ size_t carve_pn(PnWs &w, void *base, int B, int N, int A, int /*zdim: the heads 
   return c.off;
 }
 
+// PointNetV2 training: batch statistics from the products' epilogues and one-launch BatchNorm for few rows (dfx_debug_bn_fused_stats(0): the
+// multi-launch passes)
+bool g_bn_fused_stats = true;
 // y = [relu] BN_train(z) over R rows; leaves mean / rstd behind and updates the running statistics when momentum >= 0
 // stat_parts > 0: the product that wrote z left that many rows of per-workgroup (count, mean, M2) partials in w.pb.part (lin_stats below): no pass over z
 int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, const float *g, const float *b, float *run_mean,
            float *run_var, float momentum, float eps, float *mean, float *rstd, float *y, bool relu, bool apply = true, int stat_parts = 0) {
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
+  if (stat_parts == 0 && apply && R <= BN_SLAB && g_bn_fused_stats) {   // few rows (the heads: R = B): statistics + apply in one launch, the same bits
+    const float unbias = R > 1 ? (float)R / (float)(R - 1) : 1.0f;
+    if (relu) k_bn_small_fwd<true><<<(Cc + 63) / 64, 256, 0, st>>>(z, g, b, mean, rstd, run_mean, run_var, y, (int)R, Cc, 1.0f / (float)R, unbias, eps, momentum);
+    else k_bn_small_fwd<false><<<(Cc + 63) / 64, 256, 0, st>>>(z, g, b, mean, rstd, run_mean, run_var, y, (int)R, Cc, 1.0f / (float)R, unbias, eps, momentum);
+    return dfx::check_launch("train: bn_fwd");
+  }
   if (stat_parts > 0) {
     k_bn_merge<<<(Cc + 7) / 8, 256, 0, st>>>(w.pb.part, stat_parts, mean, rstd, run_mean, run_var, R > 1 ? (float)R / (float)(R - 1) : 1.0f, eps, momentum, Cc);
   } else {
@@ -1740,6 +1822,11 @@ int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *be, cons
            const float *mean, const float *rstd, float *dz, float *dgamma, float *dbeta, bool relu) {
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
+  if (R <= BN_SLAB && dz != dy && g_bn_fused_stats) {   // few rows: column sums + apply in one launch, the same bits (dz must not alias dy: the sums read all of dy first)
+    if (relu) k_bn_small_bwd<true><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, 1.0f / (float)R);
+    else k_bn_small_bwd<false><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, 1.0f / (float)R);
+    return dfx::check_launch("train: bn_bwd");
+  }
   if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, z, mean, rstd, g, be, w.pb.part, R, Cc);
   else k_bn_bwd_part<false><<<grid, 256, 0, st>>>(dy, z, mean, rstd, g, be, w.pb.part, R, Cc);
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
@@ -2268,6 +2355,19 @@ int dfx_pointnet_v2_train_backward(const dfx_pointnet_v2_weights *wt, void *work
                          mut(grads->head_bn_w[k][l]), mut(grads->head_bn_b[k][l]), true))) return rc;
         dz = w.dh[1];
       }
+      if (A == NPART) {   // the four parts' weight gradient, transpose and input gradient as ONE launch each (the flows' grouped kernels): 9 launches
+                          // per head layer instead of ~14 x 4 — the heads' backward was ~100 launches of ~5 us
+        Ptr4 gw{}, gb{};
+        CPtr4 wp{};
+        for (int a = 0; a < A; ++a)
+          gw.p[a] = mut(grads->head_w[k][l]) + (size_t)a * cout * cin, gb.p[a] = mut(grads->head_b[k][l]) + a * cout, wp.p[a] = wt->head_w[k][l] + (size_t)a * cout * cin;
+        const long long wt_gs = (long long)cout * cin;
+        k_wgrad_g4<<<dim3((cin + 63) / 64, (cout + 63) / 64, NPART), 256, 0, st>>>(dz, A * cout, cout, in, A * cin, cin, gw, gb, cout, cin, B);
+        k_transpose_g4<<<dim3((cin + 31) / 32, (cout + 31) / 32, NPART), 256, 0, st>>>(wp, w.wT, wt_gs, cout, cin);   // (cin, cout) per part
+        if (l == 0) {   // d pooled accumulates over the two heads
+          if ((rc = lin_g4<dfx::lin::EPI_RESID>(st, dz, A * cout, cout, nullptr, nullptr, w.wT, wt_gs, w.dpooled, A * cin, cin, B, cin, cout, w.dpooled, A * cin, cin))) return rc;
+        } else if ((rc = lin_g4<dfx::lin::EPI_NONE>(st, dz, A * cout, cout, nullptr, nullptr, w.wT, wt_gs, w.dh[0], A * cin, cin, B, cin, cout))) return rc;
+      } else
       for (int a = 0; a < A; ++a) {   // per-part weights: group a of the grouped 1x1 convolution
         if ((rc = wgrad(st, w.pb, dz + a * cout, A * cout, in + a * cin, A * cin, mut(grads->head_w[k][l]) + (size_t)a * cout * cin,
                         mut(grads->head_b[k][l]) + a * cout, cout, cin, cin, B))) return rc;
@@ -2402,6 +2502,24 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
 void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
 void dfx_debug_bn_fused_stats(int on) { g_bn_fused_stats = on != 0; }
+// Host-side run of the statistics arithmetic of k_lin_wide_lds<.., LM_STATS> / k_bn_merge (the same stats_merge, compiled for the host): `n` values cut
+// into pieces of `chunk` (a lane's 16 rows of a tile), each piece as (count, mean, sum of squared deviations from its own mean), merged left to right.
+void dfx_debug_stats_merge(const float *values, int n, int chunk, float *out3) {
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int i0 = 0; i0 < n; i0 += chunk) {
+    const int i1 = i0 + chunk < n ? i0 + chunk : n;
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += values[i];
+    const float c = (float)(i1 - i0), mt = s / c;
+    float q = 0.f;
+    for (int i = i0; i < i1; ++i) {
+      const float d = values[i] - mt;
+      q = fmaf(d, d, q);
+    }
+    dfx::lin::stats_merge(cnt, mean, m2, c, mt, q);
+  }
+  out3[0] = cnt, out3[1] = mean, out3[2] = m2;
+}
 void dfx_debug_train_streams(int on) { g_train_streams = on < 0 ? 0 : on; }
 // Host-side evaluation of the fused training kernels' row addressing (ffused::RowMap, the code the kernels compile): for a 32-point tile, the float
 // offset of every (point, channel) as the B-operand-layout accessors and as the accumulator-layout accessors see it.  out_b, out_a: [32][128] int32.

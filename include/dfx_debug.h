@@ -25,8 +25,12 @@ void dfx_debug_train_fused(int on);
 void dfx_debug_train_streams(int on);
 /* Debug / A-B switch: 0 = the PointNetV2 training forward computes its BatchNorm batch statistics with two passes over each layer's output
  * (mean, then centred sum of squares); default 1 = from (count, mean, M2) partials the fp32 product kernels leave in their epilogues
- * (>= 8192 rows).  Equal up to fp32 rounding of the statistics. */
+ * (>= 8192 rows), equal up to fp32 rounding of the statistics; and BatchNorm over at most 512 rows (the per-part heads: over the B shapes) as one
+ * launch per direction instead of seven / four, bit-identical to the multi-launch passes. */
 void dfx_debug_bn_fused_stats(int on);
+/* Host-side run (no GPU) of that statistics arithmetic: n values in pieces of `chunk`, each piece as (count, mean, M2), merged left to right with
+ * the kernels' own merge function; out3 = (count, mean, sum of squared deviations). */
+void dfx_debug_stats_merge(const float *values, int n, int chunk, float *out3);
 /* Host-side table of the fused training kernels' row addressing inside a 32-point tile (tiled = 1: the tile-major layout between the fused
  * kernels; 0: row-major): float offset of (point, channel) through the B-operand-layout and the accumulator-layout accessors; [32][128] int32 each. */
 void dfx_debug_rowmap(int tiled, int *out_b, int *out_a);

@@ -115,3 +115,23 @@ def test_tile_major_row_addressing_is_a_permutation_and_layout_independent(built
             for blk in range(16):
                 pts, chs = np.nonzero(blocks == blk)
                 assert len(pts) == 256 and len(set(pts.tolist())) == 32   # every block holds 8 channels of all 32 points
+
+
+def test_epilogue_batch_statistics_merge_is_as_good_as_two_passes(built_lib):
+    """The (count, mean, M2) arithmetic of k_lin_wide_lds<.., LM_STATS> / k_bn_merge, host-compiled from the kernels' own stats_merge
+    (dfx_debug_stats_merge): pieces of 16 values, merged left to right, against float64 mean / variance — also for a column whose mean is
+    300 standard deviations away from zero (where E[x^2] - E[x]^2 in fp32 would keep two digits) — and with a ragged last piece."""
+    import numpy as np
+    lib = ctypes.CDLL(built_lib)
+    lib.dfx_debug_stats_merge.restype = None
+    lib.dfx_debug_stats_merge.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n, chunk, mean, std in ((262144, 16, 0.3, 1.0), (8192, 16, 300.0, 1.0), (9000, 16, -2.0, 0.01), (1000, 7, 5.0, 2.0), (5, 16, 1.0, 1.0)):
+        v = (mean + std * rng.standard_normal(n)).astype(np.float32)
+        out = np.zeros(3, dtype=np.float32)
+        lib.dfx_debug_stats_merge(v.ctypes.data_as(ctypes.c_void_p), n, chunk, out.ctypes.data_as(ctypes.c_void_p))
+        v64 = v.astype(np.float64)
+        assert out[0] == n
+        assert abs(out[1] - v64.mean()) <= 1e-6 * max(1.0, abs(v64.mean())), (n, out[1], v64.mean())
+        var = ((v64 - v64.mean()) ** 2).sum() / n
+        assert abs(out[2] / n - var) <= 2e-5 * var, (n, mean, out[2] / n, var)

@@ -132,6 +132,29 @@ def test_batch_statistics_from_the_product_epilogue_match_the_two_pass_ones(B, N
     print(f"B={B} N={N}: epilogue vs two-pass batch statistics: m max-abs {np.abs(fused['m'] - two['m']).max():.1e}, worst gradient error / max-abs {worst:.1e}")
 
 
+def test_one_launch_batchnorm_of_the_heads_is_bit_identical_to_the_multi_launch_passes():
+    """BatchNorm over few rows (the heads normalise over the B shapes) runs as one kernel per direction with the sums in the multi-launch path's
+    order.  Below 8192 points the trunk takes the same kernels under both settings of dfx_debug_bn_fused_stats, so everything must be the same bits."""
+    from difffacto_amd import _ffi, synth
+    rng = np.random.Generator(np.random.PCG64(91))
+    B, N = 7, 333
+    W = synth.make_pointnet_v2_weights(6)
+    x = rng.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    attn = np.eye(4, dtype=np.float32)[rng.integers(0, 4, size=(B, N))]
+    dm, dv = rng.standard_normal((B, 4, 256)).astype(np.float32), rng.standard_normal((B, 4, 256)).astype(np.float32)
+    one = _run(W, x, attn, dm, dv)
+    _ffi.lib().dfx_debug_bn_fused_stats(0)
+    try:
+        multi = _run(W, x, attn, dm, dv)
+    finally:
+        _ffi.lib().dfx_debug_bn_fused_stats(1)
+    assert np.array_equal(one["m"], multi["m"]) and np.array_equal(one["v"], multi["v"])
+    for k in multi["running"]:
+        assert np.array_equal(one["running"][k], multi["running"][k]), k
+    for k in multi["grads"]:
+        assert np.array_equal(one["grads"][k], multi["grads"][k]), k
+
+
 def test_bf16_products_run_and_stay_close():
     """precision="bf16" rounds the trunk's matrix-product operands to bf16.  Through four BatchNorm layers, a max-pool whose
     arg-max can flip under that noise, and BatchNorm over only B samples in the heads, outputs move by a few percent and
