@@ -1160,19 +1160,44 @@ __global__ __launch_bounds__(256) void k_bn_small_fwd(const float *__restrict__ 
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   const bool ok = c < Cc;
+  // up to 128 rows: this thread's <= 32 values stay in registers for the three passes (ONE batch of loads instead of three chains of them)
+  constexpr int KEEP = 32;
+  const bool keep = R <= 4 * KEEP;
+  float zk[KEEP];
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) zk[q] = (ok && rgp + 4 * q < R) ? z[(size_t)(rgp + 4 * q) * Cc + c] : 0.f;
+  }
   float a = 0.f;
-  if (ok)
-    for (int r = rgp; r < R; r += 4) a += z[(size_t)r * Cc + c];
+  if (ok) {
+    if (keep) {
+#pragma unroll
+      for (int q = 0; q < KEEP; ++q)
+        if (rgp + 4 * q < R) a += zk[q];
+    } else {
+      for (int r = rgp; r < R; r += 4) a += z[(size_t)r * Cc + c];
+    }
+  }
   red[rgp][cl] = a;
   __syncthreads();
   const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * invR;
   __syncthreads();
   a = 0.f;
-  if (ok)
-    for (int r = rgp; r < R; r += 4) {
-      const float v = z[(size_t)r * Cc + c] - mu;
-      a += v * v;
+  if (ok) {
+    if (keep) {
+#pragma unroll
+      for (int q = 0; q < KEEP; ++q)
+        if (rgp + 4 * q < R) {
+          const float v = zk[q] - mu;
+          a += v * v;
+        }
+    } else {
+      for (int r = rgp; r < R; r += 4) {
+        const float v = z[(size_t)r * Cc + c] - mu;
+        a += v * v;
+      }
     }
+  }
   red[rgp][cl] = a;
   __syncthreads();
   const float var = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * invR;
@@ -1186,6 +1211,16 @@ __global__ __launch_bounds__(256) void k_bn_small_fwd(const float *__restrict__ 
     }
   }
   const float gv = g[c], bv = b[c];
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q)
+      if (rgp + 4 * q < R) {
+        float o = bn_affine(zk[q], mu, rs, gv, bv);
+        if (RELU) o = fmaxf(o, 0.f);
+        y[(size_t)(rgp + 4 * q) * Cc + c] = o;
+      }
+    return;
+  }
   for (int r = rgp; r < R; r += 4) {
     float o = bn_affine(z[(size_t)r * Cc + c], mu, rs, gv, bv);
     if (RELU) o = fmaxf(o, 0.f);
@@ -1201,14 +1236,33 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(const float *__restrict__ 
   const int cl = threadIdx.x & 63, rgp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   const bool ok = c < Cc;
   float sb = 0.f, sg = 0.f, mu = 0.f, rs = 0.f, gv = 0.f, bv = 0.f;
+  constexpr int KEEP = 32;   // (as in the forward: up to 128 rows stay in registers, dy already masked)
+  const bool keep = R <= 4 * KEEP;
+  float zk[KEEP], gk[KEEP];
   if (ok) {
     mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
+    if (keep) {
+#pragma unroll
+      for (int q = 0; q < KEEP; ++q) {
+        const bool in = rgp + 4 * q < R;
+        zk[q] = in ? z[(size_t)(rgp + 4 * q) * Cc + c] : 0.f;
+        gk[q] = in ? dy[(size_t)(rgp + 4 * q) * Cc + c] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < KEEP; ++q)
+        if (rgp + 4 * q < R) {
+          if (RELU && !(bn_affine(zk[q], mu, rs, gv, bv) > 0.f)) gk[q] = 0.f;
+          sb += gk[q];
+          sg += gk[q] * (zk[q] - mu) * rs;
+        }
+    } else {
     for (int r = rgp; r < R; r += 4) {
       float gm = dy[(size_t)r * Cc + c];
       const float zv = z[(size_t)r * Cc + c];
       if (RELU && !(bn_affine(zv, mu, rs, gv, bv) > 0.f)) gm = 0.f;
       sb += gm;
       sg += gm * (zv - mu) * rs;
+    }
     }
   }
   red[0][rgp][cl] = sb, red[1][rgp][cl] = sg;
@@ -1217,6 +1271,15 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(const float *__restrict__ 
   const float db = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
   const float dg = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   if (rgp == 0) dbeta[c] = db, dgamma[c] = dg;
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q)
+      if (rgp + 4 * q < R) {
+        const float xh = (zk[q] - mu) * rs;
+        dz[(size_t)(rgp + 4 * q) * Cc + c] = gv * rs * (gk[q] - db * invR - xh * dg * invR);
+      }
+    return;
+  }
   for (int r = rgp; r < R; r += 4) {
     const float zv = z[(size_t)r * Cc + c];
     const float gm = (RELU && !(bn_affine(zv, mu, rs, gv, bv) > 0.f)) ? 0.f : dy[(size_t)r * Cc + c];
