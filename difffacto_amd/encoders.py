@@ -141,10 +141,10 @@ class PointNetV2(nn.Module):
             m, v = _training.pointnet_v2_train_forward(sd_p, sd_b, x, attn_weight, num_anchors=A, zdim=self.zdim,
                                                        reweight_by_anchor=self.reweight_by_anchor, eps=self.bn1.eps, momentum=momentum,
                                                        precision=getattr(self, "train_precision", "f32"))
-            with torch.no_grad():
-                for mod in self.modules():
-                    if isinstance(mod, nn.BatchNorm1d) and mod.num_batches_tracked is not None:
-                        mod.num_batches_tracked += 1
+            with torch.no_grad():   # (one launch for the eight counters instead of eight)
+                nbt = [mod.num_batches_tracked for mod in self.modules() if isinstance(mod, nn.BatchNorm1d) and mod.num_batches_tracked is not None]
+                if nbt:
+                    torch._foreach_add_(nbt, 1)
             self.__dict__["_ver"] = None      # the running statistics changed under the eval handle's feet
             return m, v
         # No second implementation behind the native one: what libdfx does not run raises, like every other
