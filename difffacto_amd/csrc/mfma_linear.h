@@ -268,11 +268,6 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    auto operands = [&](int u, v4f &xv, v4f (&wv)[NT]) {
-      xv = ld(xp + 8 * u);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) wv[t] = wlane[(t * U + u) * 64];
-    };
     auto step = [&](const v4f &xv, const v4f (&wv)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -280,19 +275,50 @@ static __global__ __launch_bounds__(512) void k_lin_wide_lds(LinArgs a) {
         for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], wv[t][s], acc[t], 0, 0, 0);   // rows on the M axis
     };
     {
-      v4f xa, xb, wa[NT], wb[NT];
-      operands(0, xa, wa);
+      // The activations come from HBM, the weights from LDS: the activation fragments are requested XD K steps ahead (a step is 16 MFMAs = 0.43 us
+      // of matrix pipe, an HBM round trip under load is longer), the weight fragments one step ahead.  Requests past the end re-read the last
+      // step: the same number of loads in flight on every path.  Same MFMA order as before: the same bits.
+      constexpr int XD = 4;   // (same box, PointNetV2 training forward + backward: one step ahead 4.565 ms, 4: 4.51, 8: 4.55)
+      v4f xr[XD], wa[NT], wb[NT];
+#pragma unroll
+      for (int q = 0; q < XD; ++q) xr[q] = ld(xp + 8 * min(q, U - 1));
+      auto weights = [&](int u, v4f (&wv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wv[t] = wlane[(t * U + u) * 64];
+      };
+      weights(0, wa);
       int u = 0;
-      for (; u + 1 < U; u += 2) {
-        operands(u + 1, xb, wb);
-        __builtin_amdgcn_sched_barrier(0);
-        step(xa, wa);
-        operands(min(u + 2, U - 1), xa, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        step(xb, wb);
+      for (; u + XD <= U; u += XD) {
+#pragma unroll
+        for (int q = 0; q < XD; ++q) {
+          const v4f xv = xr[q];
+          xr[q] = ld(xp + 8 * min(u + q + XD, U - 1));
+          if (q & 1) {
+            weights(min(u + q + 1, U - 1), wa);
+            __builtin_amdgcn_sched_barrier(0);
+            step(xv, wb);
+          } else {
+            weights(min(u + q + 1, U - 1), wb);
+            __builtin_amdgcn_sched_barrier(0);
+            step(xv, wa);
+          }
+        }
       }
-      if (u < U) step(xa, wa);
+      // tail (U % XD steps): the fragments are already in xr[0 ..]; (XD is even, so the weight buffers alternate from wa again)
+#pragma unroll
+      for (int q = 0; q < XD - 1; ++q) {
+        if (u + q < U) {
+          if (q & 1) {
+            weights(min(u + q + 1, U - 1), wa);
+            step(xr[q], wb);
+          } else {
+            weights(min(u + q + 1, U - 1), wb);
+            step(xr[q], wa);
+          }
+        }
+      }
     }
+
     // Rows on the MFMA's M axis (accumulator registers), channels on the lanes: a store instruction writes 32 consecutive channels
     // = one full 128-byte line of two rows.  (With the channels in the registers — the orientation of k_lin_wide — a store was 16 bytes
     // per lane at the row stride: 32 lines touched per instruction, each a quarter written: 10 % of the kernel in
