@@ -800,8 +800,8 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
-  // eight rows (16 loads, 16 MFMAs) per block; the loads of block q + 1 are issued before the MFMAs of block q (two register sets
-  // used alternately; the request behind the last block re-reads it, so that every path has the same number of loads in flight)
+  // eight rows (16 loads, 16 MFMAs) per block; the loads of block q + 2 are issued before the MFMAs of block q (a ring of three register
+  // sets; requests behind the last block re-read it, so that every path has the same number of loads in flight)
   struct Rows {
     float ya[4], yb[4], xa[4], xb[4];
   };
@@ -831,18 +831,25 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
   const long long nfull = (r1 - r0) / 8;
   long long r = r0 + 8 * nfull;
   if (nfull > 0) {
-    Rows wa, wb;
-    load8(r0, wa);
+    // the row blocks come from HBM / the L2: requested RD - 1 blocks (of 16 MFMAs) ahead through a ring of RD register sets
+    constexpr int RD = 3;   // (same box, PointNetV2 training forward + backward: two sets 4.51 ms, three 4.48, four 4.48; the same sums in the same order)
+    Rows ring[RD];
+#pragma unroll
+    for (int k = 0; k < RD - 1; ++k) load8(r0 + 8 * (k < nfull ? k : nfull - 1), ring[k]);
     long long q = 0;
-    for (; q + 1 < nfull; q += 2) {
-      load8(r0 + 8 * (q + 1), wb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm8(wa);
-      load8(r0 + 8 * (q + 2 < nfull ? q + 2 : nfull - 1), wa);
-      __builtin_amdgcn_sched_barrier(0);
-      mm8(wb);
+    for (; q + RD <= nfull; q += RD) {
+#pragma unroll
+      for (int k = 0; k < RD; ++k) {
+        const long long nx = q + k + RD - 1;
+        load8(r0 + 8 * (nx < nfull ? nx : nfull - 1), ring[(k + RD - 1) % RD]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm8(ring[k]);
+      }
     }
-    if (q < nfull) mm8(wa);
+#pragma unroll
+    for (int k = 0; k < RD - 1; ++k) {
+      if (q + k < nfull) mm8(ring[k]);   // (the tail's blocks are in the ring already)
+    }
   }
   for (; r < r1; r += 2) {
     const long long rr = r + hf;
