@@ -1319,11 +1319,22 @@ __global__ __launch_bounds__(64 * PH) void k_pool_fwd(const float *__restrict__ 
   for (int a = 0; a < A; ++a) best[a] = -3.402823466e38f, bi[a] = 0;
   if (c < Cc) {
     const float mu = mean[c], rs = rstd[c], gv = g[c], bv = be[c];
+    // (eight points' loads in flight per thread; the A weights of a point as one wave-uniform 16-byte load when A = 4)
+#pragma unroll 8
     for (int n = ph; n < N; n += PH) {
       const float v = bn_affine(z[((size_t)b * N + n) * Cc + c], mu, rs, gv, bv);
+      float aw[A];
+      if (A == 4) {
+        const v4f t = *reinterpret_cast<const v4f *>(attn + ((size_t)b * N + n) * A);
+#pragma unroll
+        for (int a = 0; a < A; ++a) aw[a] = t[a];
+      } else {
+#pragma unroll
+        for (int a = 0; a < A; ++a) aw[a] = attn[((size_t)b * N + n) * A + a];
+      }
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        const float w = v * attn[((size_t)b * N + n) * A + a] * scale;
+        const float w = v * aw[a] * scale;
         if (w > best[a]) best[a] = w, bi[a] = n;
       }
     }
