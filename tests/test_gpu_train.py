@@ -293,6 +293,52 @@ def test_side_stream_training_step_is_bit_identical_to_the_single_stream_one(B, 
         assert np.array_equal(two["d_ctx_code"], one["d_ctx_code"]) and np.array_equal(two["d_ctx_mv"], one["d_ctx_mv"])
 
 
+def test_training_step_with_its_side_stream_is_capturable_as_one_hip_graph():
+    """The fork / join onto libdfx's side stream inside dfx_denoiser_train_backward uses plain event record / wait pairs, so a stream capture of
+    the caller's stream (torch.cuda.graph) takes the side work into the same graph: forward + loss + backward captured once, replayed twice,
+    gives the eager call's bits."""
+    import torch
+    from difffacto_amd import synth, training
+    B, N = 4, 1024
+    rng = np.random.Generator(np.random.PCG64(123))
+    W = synth.make_denoiser_weights(3)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=41, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    P = {k: cu(v).requires_grad_(True) for k, v in W.items()}
+    args = [cu((anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32)), cu(rng.integers(0, 1000, size=(B,)).astype(np.int32)), cu(pc),
+            cu(np.concatenate([mean, var], 1).astype(np.float32)), cu(anc.transpose(0, 2, 1)), cu(vr.transpose(0, 2, 1)), cu(valid), cu(seg.astype(np.int32))]
+    noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args, precision="bf16"), None)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):   # warm-up: lazy initialisation (LDS attributes, the side stream and its events) must not happen under capture
+            eager_loss = step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    eager = {k: p.grad.clone() for k, p in P.items()}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        cap_loss = step()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(cap_loss.detach()) == float(eager_loss.detach())
+    for k, p in P.items():
+        assert torch.equal(p.grad, eager[k]), k
+
+
 def test_dropout_factors_and_replayed_mask_parity():
     """Dropout of train() mode: (i) the Philox factors are 0 or 1/(1-p) with the right frequency and differ between sites and
     seeds; (ii) forward + backward with dropout agree with torch autograd when the SAME factors are replayed into the
