@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps
 // over all 262 144 points had 2 wavefronts per SIMD, each waiting ~2 us for operands that come from HBM (40 % of the matrix peak);
 // four times the wavefronts for the same number of partial tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int NI = 2>   // NI = 32-column blocks of the tile along I: 2 (64 x 64) or 4 (64 x 128: every dY fragment feeds four MFMAs instead of two)
 __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                            float *__restrict__ pp, float *__restrict__ bp, int O, int I, long long r0, long long r1,
                                            int bx, int by) {
@@ -789,49 +789,53 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
     r0 = r0 + wave * q < r1 ? r0 + wave * q : r1;
     r1 = r0 + q < r1 ? r0 + q : r1;
   }
-  const int i0 = bx * 64, o0 = by * 64;
-  const bool oa = o0 + j < O, ob = o0 + 32 + j < O, ia = i0 + j < I, ib = i0 + 32 + j < I;
+  const int i0 = bx * 32 * NI, o0 = by * 64;
+  const bool oa = o0 + j < O, ob = o0 + 32 + j < O;
   const float *py = dY + o0 + j, *px = X + i0 + j;
-  v16f acc[2][2];
+  v16f acc[2][NI];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NI; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
-  // eight rows (16 loads, 16 MFMAs) per block; the loads of block q + 2 are issued before the MFMAs of block q (a ring of three register
+  // eight rows (4 + 2 NI loads per lane, 8 NI MFMAs) per block; the loads of block q + 2 are issued before the MFMAs of block q (a ring of three register
   // sets; requests behind the last block re-read it, so that every path has the same number of loads in flight)
   struct Rows {
-    float ya[4], yb[4], xa[4], xb[4];
+    float ya[4], yb[4], x[NI][4];
   };
   // (row base in scalar registers + a per-lane 32-bit offset that never changes: with the row index per lane the address arithmetic
   // was most of the 9 VALU instructions per MFMA of this kernel)
   // Columns past the edge are not predicated either: they are read from the last valid column instead, and what they contribute
   // lands only in rows / columns of the tile (and bias sums) that are never stored.
   const unsigned offy = (unsigned)(hf * ldy + min(o0 + j, O - 1)), offy2 = (unsigned)(hf * ldy + min(o0 + 32 + j, O - 1));
-  const unsigned offx = (unsigned)(hf * ldx + min(i0 + j, I - 1)), offx2 = (unsigned)(hf * ldx + min(i0 + 32 + j, I - 1));
+  unsigned offx[NI];
+#pragma unroll
+  for (int b = 0; b < NI; ++b) offx[b] = (unsigned)(hf * ldx + min(i0 + 32 * b + j, I - 1));
   auto load8 = [&](long long r, Rows &w) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float *ry = dY + (r + 2 * u) * ldy, *rx = X + (r + 2 * u) * ldx;
-      w.ya[u] = ry[offy], w.yb[u] = ry[offy2], w.xa[u] = rx[offx], w.xb[u] = rx[offx2];
+      w.ya[u] = ry[offy], w.yb[u] = ry[offy2];
+#pragma unroll
+      for (int b = 0; b < NI; ++b) w.x[b][u] = rx[offx[b]];
     }
   };
   auto mm8 = [&](const Rows &w) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.ya[u], w.xa[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.ya[u], w.xb[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.yb[u], w.xa[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.yb[u], w.xb[u], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NI; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.ya[u], w.x[b][u], acc[0][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NI; ++b) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.yb[u], w.x[b][u], acc[1][b], 0, 0, 0);
       bs0 += w.ya[u], bs1 += w.yb[u];
     }
   };
   const long long nfull = (r1 - r0) / 8;
   long long r = r0 + 8 * nfull;
   if (nfull > 0) {
-    // the row blocks come from HBM / the L2: requested RD - 1 blocks (of 16 MFMAs) ahead through a ring of RD register sets
+    // the row blocks come from HBM / the L2: requested RD - 1 blocks ahead through a ring of RD register sets
     constexpr int RD = 3;   // (same box, PointNetV2 training forward + backward: two sets 4.51 ms, three 4.48, four 4.48; the same sums in the same order)
     Rows ring[RD];
 #pragma unroll
@@ -855,46 +859,51 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
     const long long rr = r + hf;
     const bool in = rr < r1;
     const float ya = (in && oa) ? py[rr * ldy] : 0.f, yb = (in && ob) ? py[rr * ldy + 32] : 0.f;
-    const float xa = (in && ia) ? px[rr * ldx] : 0.f, xb = (in && ib) ? px[rr * ldx + 32] : 0.f;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xa, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xb, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xa, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < NI; ++b) {
+      const float xb = (in && i0 + 32 * b + j < I) ? px[rr * ldx + 32 * b] : 0.f;
+      acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xb, acc[0][b], 0, 0, 0);
+      acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][b], 0, 0, 0);
+    }
     bs0 += ya, bs1 += yb;
   }
-  if (NW > 1) {   // wavefronts 2, 3 -> 0, 1, then 1 -> 0 (two 17 KiB slots)
+  if (NW > 1) {   // wavefronts 2, 3 -> 0, 1, then 1 -> 0 (two 17 KiB slots), two column blocks of the tile per pass
     __shared__ float red[2][4096 + 128];
-    auto put = [&](float *d) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int b0 = 0; b0 < NI; b0 += 2) {
+      auto put = [&](float *d) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int rg = 0; rg < 16; ++rg) d[((a * 2 + b) * 16 + rg) * 64 + lane] = acc[a][b][rg];
-      d[4096 + lane] = bs0, d[4096 + 64 + lane] = bs1;
-    };
-    auto add = [&](const float *d) {
+          for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+            for (int rg = 0; rg < 16; ++rg) d[((a * 2 + b) * 16 + rg) * 64 + lane] = acc[a][b0 + b][rg];
+        if (b0 == 0) d[4096 + lane] = bs0, d[4096 + 64 + lane] = bs1;
+      };
+      auto add = [&](const float *d) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int rg = 0; rg < 16; ++rg) acc[a][b][rg] += d[((a * 2 + b) * 16 + rg) * 64 + lane];
-      bs0 += d[4096 + lane], bs1 += d[4096 + 64 + lane];
-    };
-    if (wave >= 2) put(red[wave - 2]);
-    __syncthreads();
-    if (wave < 2) add(red[wave]);
-    __syncthreads();
-    if (wave == 1) put(red[0]);
-    __syncthreads();
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[a][b0 + b][rg] += d[((a * 2 + b) * 16 + rg) * 64 + lane];
+        if (b0 == 0) bs0 += d[4096 + lane], bs1 += d[4096 + 64 + lane];
+      };
+      if (b0 > 0) __syncthreads();   // wavefront 0 is done with red[0] of the previous pass
+      if (wave >= 2) put(red[wave - 2]);
+      __syncthreads();
+      if (wave < 2) add(red[wave]);
+      __syncthreads();
+      if (wave == 1) put(red[0]);
+      __syncthreads();
+      if (wave == 0) add(red[0]);
+    }
     if (wave != 0) return;
-    add(red[0]);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NI; ++b) {
       const int i = i0 + 32 * b + j;   // C/D layout: column = lane % 32 (the B operand's index), row = (r&3) + 8(r>>2) + 4 hf
       if (i >= I) continue;
 #pragma unroll
@@ -911,6 +920,7 @@ __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dY, int ldy
     }
   }
 }
+template <int NI>
 __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                                float *__restrict__ part, float *__restrict__ bpart, int O, int I,
                                                long long R, int rows_per_slab) {
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dY, int
   }
   const long long r0 = (long long)slab * rows_per_slab;
   const long long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
-  wgrad_tile<4>(dY, ldy, X, ldx, part + (size_t)slab * O * I, bpart ? bpart + (size_t)slab * O : nullptr, O, I, r0, r1, t % gridDim.x, t / gridDim.x);
+  wgrad_tile<4, NI>(dY, ldy, X, ldx, part + (size_t)slab * O * I, bpart ? bpart + (size_t)slab * O : nullptr, O, I, r0, r1, t % gridDim.x, t / gridDim.x);
 }
 // Up to four independent few-row products in one launch (blockIdx.z = group): operands at uniform group strides, results
 // through pointer tables (the per-part flows' parameters are separate tensors); all R rows in one slab, written directly
@@ -1777,10 +1787,14 @@ int wgrad(hipStream_t st, const PartBufs &w, const float *dY, int ldy, const flo
       ns = (int)((R + slab - 1) / slab);
     }
     if (ns == 1 && I_valid == I) {   // one slab: the "partial" tile is the result (few-row products: heads, flows, time embedding)
-      k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, 1), 256, 0, st>>>(dY, ldy, X, ldx, dW, db, O, I, R, slab);
+      k_wgrad<2><<<dim3((I + 63) / 64, (O + 63) / 64, 1), 256, 0, st>>>(dY, ldy, X, ldx, dW, db, O, I, R, slab);
       return dfx::check_launch("train: wgrad");
     }
-    k_wgrad<<<dim3((I + 63) / 64, (O + 63) / 64, ns), 256, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
+    // many rows and I a multiple of 128: 64 x 128 tiles — a dY fragment feeds four MFMAs instead of two (6 loads per 8 MFMAs instead of 4 per 4) and the
+    // slab's dY strip is read I / 128 times instead of I / 64; every output still sums its rows in the same order: the same bits.  Same box, PointNetV2
+    // training forward + backward: 4.615 / 4.620 -> 4.342 / 4.337 ms
+    if (I % 128 == 0 && R >= 8192) k_wgrad<4><<<dim3(I / 128, (O + 63) / 64, ns), 256, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
+    else k_wgrad<2><<<dim3((I + 63) / 64, (O + 63) / 64, ns), 256, 0, st>>>(dY, ldy, X, ldx, w.part, db ? w.bpart : nullptr, O, I, R, slab);
   }
   if (I_valid == I) k_sum_parts<<<(O * I + 31) / 32, 1024, 0, st>>>(w.part, dW, ns, O * I, O * I);   // parallel over slabs too
   else k_wgrad_finish<<<(O * I_valid + 31) / 32, 256, 0, st>>>(w.part, dW, ns, O, I, I_valid);
