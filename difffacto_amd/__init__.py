@@ -8,7 +8,7 @@ import sys
 __version__ = "0.1.0"
 
 
-def install(register_in_reference=True):
+def install(register_in_reference=True, full=False):
     """Make this package the provider of the reference's names.
 
     * ``sys.modules['pointnet2_ops']`` (+ ``.pointnet2_utils`` / ``.pointnet2_modules``) -> ``difffacto_amd.pointnet2_ops``
@@ -16,9 +16,12 @@ def install(register_in_reference=True):
       utils/misc.py:7, shapenet_seg.py:13) resolves to the HIP kernels;
     * if the reference package ``difffacto`` is importable and ``register_in_reference``: replace
       ``NETS['TransformerNet']`` and ``DIFFUSIONS['AnchoredDiffusion']`` (utils/registry.py:49-63) by the libdfx-backed
-      classes, so ``configs/gen_*.py`` build them through ``build_from_cfg`` unchanged.  The encoder registry entry
-      is left alone (its encode side serves training / reconstruction); accelerate the generation entry point of a
-      built model with ``difffacto_amd.encoders.attach(model.encoder)``.
+      classes, so ``configs/gen_*.py`` build them through ``build_from_cfg`` unchanged.  By default the encoder registry
+      entries are left alone (the reference's own encoder then serves every option it has); accelerate the generation entry point
+      of a built model with ``difffacto_amd.encoders.attach(model.encoder)``;
+    * ``full=True``: also ``MODELS['AnchorDiffAE']``, ``ENCODERS['PartEncoderForTransformerDecoder' / 'PointNetV2' /
+      'PartAlignerTransformer']`` and ``SAMPLERS['Uniform']`` -> the mirrors of ``networks.py`` / ``encoders.py`` (the shipped
+      gen_* / train_*_stage1 configurations run end to end on libdfx; any other option raises NotImplementedError).
     """
     from . import pointnet2_ops
     sys.modules["pointnet2_ops"] = pointnet2_ops
@@ -32,5 +35,12 @@ def install(register_in_reference=True):
         from .modules import TransformerNet, AnchoredDiffusion
         NETS._modules["TransformerNet"] = TransformerNet
         DIFFUSIONS._modules["AnchoredDiffusion"] = AnchoredDiffusion
+        if full:
+            from difffacto.utils.registry import MODELS, ENCODERS, SAMPLERS
+            from . import encoders, networks
+            MODELS._modules["AnchorDiffAE"] = networks.AnchorDiffAE
+            SAMPLERS._modules["Uniform"] = networks.Uniform
+            for name in ("PartEncoderForTransformerDecoder", "PointNetV2", "PartAlignerTransformer"):
+                ENCODERS._modules[name] = getattr(encoders, name)
         return True
     return False

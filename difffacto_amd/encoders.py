@@ -267,6 +267,7 @@ class PartEncoderForTransformerDecoder(nn.Module):
                 _unsupported(flag)
         # training-side settings (part_encoders.py:320-390)
         self.use_gt_params, self.origin_scale, self.kl_weight = use_gt_params, origin_scale, kl_weight
+        self.fit_loss_type, self.fit_loss_weight = fit_loss_type, fit_loss_weight
         self.kl_weight_annealing = kwargs.get("kl_weight_annealing", False)
         self.min_kl_weight = kwargs.get("min_kl_weight", 1e-7)
         self.kl_weight_annealing_end_epoch = kwargs.get("kl_weight_annealing_end_epoch", 3000)
@@ -360,36 +361,91 @@ class PartEncoderForTransformerDecoder(nn.Module):
             d[f"part_{i}_mean"], d[f"part_{i}_logvar"] = mmean[i], mlv[i]
         return d
 
-    def forward(self, pcds, device, noise=None, epoch=-1):
-        """Training forward of the encoder (part_encoders.py:1185-1260) for the stage-1 configuration (gen, use_flow,
-        use_gt_params, no part_aligner): part codes from PointNetV2 (train-mode kernels), reparameterisation, prior loss,
-        ground-truth anchors / variances gathered per point, ctx for the denoiser.
-        Returns (ctx, mean_per_point, logvar_per_point, flag_per_point, loss_dict, [part_code, mean, logvar, noise])."""
-        if not self.use_gt_params:
-            _unsupported("encoder training forward with a part_aligner (stage 2)")
+    def get_fit_loss(self, mean, logvar, valid_id, gt_shift, gt_var):
+        """part_encoders.py:489-521 for the shipped ``fit_loss_type`` 4 (:514-519; 1 = the same on exp(logvar) / gt_var, :495-500):
+        per-shape MSE between the aligner's (mean, logvar) and the ground-truth part parameters over the present parts.  (B,)
+        — 96 numbers per shape: host-side elementwise glue like ``gather_all``, nothing for a kernel to win.  Without a
+        part_aligner the reference returns zeros(1) (:520-521)."""
+        if self.part_aligner is None:
+            return torch.zeros(1, device=valid_id.device)
+        if self.fit_loss_type not in (1, 4):
+            _unsupported(f"fit_loss_type={self.fit_loss_type} (configs/gen_*.py and train_*_stage2.py use 4)")
+        if self.fit_loss_type == 4:
+            pred, target = torch.cat([mean, logvar], dim=1), torch.cat([gt_shift, torch.log(gt_var)], dim=1)
+        else:
+            pred, target = torch.cat([mean, torch.exp(logvar)], dim=1), torch.cat([gt_shift, gt_var], dim=1)
+        d = (pred - target) ** 2 * valid_id.unsqueeze(1)
+        return d.sum(dim=(-1, -2)) / valid_id.sum(dim=-1)
+
+    def _batch(self, pcds, device, attn_key):
         inp = pcds["input"].to(device)
         valid_id = pcds["present"].to(device).to(torch.float32)
         ref = pcds["ref"].to(device).transpose(1, 2)
         seg_mask = pcds["ref_seg_mask"].to(device).to(torch.int32)
-        seg_flag = pcds["ref_attn_map"].to(device)
+        seg_flag = pcds[attn_key].to(device)
         B = ref.shape[0]
         gt_shift = pcds.get("part_shift", torch.zeros(B, 3, self.n_class)).to(device)
         gt_var = pcds.get("part_scale", torch.ones(B, 3, self.n_class)).to(device)
-        if noise is None:
-            noise = pcds["noise"].to(device).unsqueeze(1)
-        if noise.shape[1] != 1:
-            _unsupported("more than one noise sample per shape in the encoder's training forward")
         if not self.origin_scale:
             gt_var = gt_var ** 2
+        return inp, valid_id, ref, seg_mask, seg_flag, gt_shift, gt_var
+
+    def _reparameterize(self, m, lv):
+        # reparameterize_gaussian (utils/misc.py:282-285): the reference draws eps on the HOST (torch.randn(size).to(mean)) — kept in
+        # eval(), so that one torch.manual_seed gives both implementations the same part codes.  train(): drawn on the device (a
+        # pageable host->device copy in the middle of the step drains the stream; dropout makes training draws unmatchable anyway)
+        eps = torch.randn(lv.size(), device=lv.device) if self.training else torch.randn(lv.size()).to(m)
+        return (m + torch.exp(0.5 * lv) * eps).transpose(1, 2)                             # (B, zdim, n_class)
+
+    def forward(self, pcds, device, noise=None, epoch=-1):
+        """The encoder's forward (part_encoders.py:1185-1260): part codes from PointNetV2, reparameterisation, prior loss, part
+        parameters, per-point gathers, fit loss, ctx for the denoiser.  Two shipped configurations:
+
+        * stage 1 (``use_gt_params``, no part_aligner; train_chair_stage1.py): ground-truth anchors / variances; train() runs the
+          PointNetV2 / prior-loss training kernels;
+        * gen / stage 2 (a ``part_aligner``, ``fit_loss_type`` 4; configs/gen_*.py, train_*_stage2.py): (mean, logvar) from the
+          native aligner on the sampled part codes, ``noise`` (B, num, noise_dim) rows = B * num like the reference's
+          ``repeat_interleave`` (:1215-1218).  Inference only: the aligner has no native backward, so a gradient through it raises.
+
+        Returns (ctx, mean_per_point, logvar_per_point, flag_per_point, loss_dict, [part_code, mean, logvar, noise])."""
+        inp, valid_id, ref, seg_mask, seg_flag, gt_shift, gt_var = self._batch(pcds, device, "ref_attn_map")
+        B = ref.shape[0]
+        if noise is None:
+            noise = pcds["noise"].to(device).unsqueeze(1)
+        if self.use_gt_params and noise.shape[1] != 1:
+            _unsupported("more than one noise sample per shape in the stage-1 training forward")
+        if not self.use_gt_params and torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.part_aligner.parameters())):
+            _unsupported("a gradient through the part aligner (stage-2 training): the native aligner is inference-only; call under "
+                         "torch.no_grad() in eval()")
         m, lv = self.get_part_code(inp, seg_flag)
-        eps = torch.randn(lv.size(), device=lv.device)                                     # reparameterize_gaussian, misc.py:282-285
-        part_code = (m + torch.exp(0.5 * lv) * eps).transpose(1, 2)                         # (B, zdim, n_class)
+        part_code = self._reparameterize(m, lv)
         loss_dict = dict(self.get_prior_loss(part_code, m, lv, valid_id, epoch=epoch))
-        mean, logvar = self.get_params_from_part_code(part_code, valid_id, gt_mean=gt_shift, gt_var=gt_var, ref=ref, noise=noise.reshape(B, -1))
+        num = noise.shape[1]
+        noise = noise.reshape(B * num, -1)
+        if num > 1:                                                                        # :1215-1218
+            part_code, valid_id, seg_mask, ref, gt_shift, gt_var = (t.repeat_interleave(num, dim=0) for t in
+                                                                    (part_code, valid_id, seg_mask, ref, gt_shift, gt_var))
+        mean, logvar = self.get_params_from_part_code(part_code, valid_id, gt_mean=gt_shift, gt_var=gt_var, ref=ref, noise=noise)
         mean_pp, logvar_pp, flag_pp = self.gather_all(seg_mask, anchors=mean, variances=logvar, valid_id=valid_id)
-        loss_dict["fit_loss"] = torch.zeros(1, device=ref.device)                          # no part_aligner: part_encoders.py:489,521
+        loss_dict["fit_loss"] = self.get_fit_loss(mean, logvar, valid_id, gt_shift, gt_var)
         ctx = self.prepare_ctx(part_code, mean, logvar, anchor_assignments=seg_mask)
-        return ctx, mean_pp, logvar_pp + self.log_scale_var, flag_pp, loss_dict, [part_code, mean, logvar, noise.reshape(B, -1)]
+        return ctx, mean_pp, logvar_pp + self.log_scale_var, flag_pp, loss_dict, [part_code, mean, logvar, noise]
+
+    @torch.no_grad()
+    def sample_noise(self, pcds, device, num):
+        """part_encoders.py:388-414 (cIMLE noise selection): ``num`` aligner-noise candidates per shape, the fit loss of each, and
+        the arg-min.  Returns (noise (B, num, noise_dim), id (B,))."""
+        if self.part_aligner is None:
+            _unsupported("sample_noise without a part_aligner")
+        inp, valid_id, ref, seg_mask, seg_flag, gt_shift, gt_var = self._batch(pcds, device, "attn_map")
+        B = inp.shape[0]
+        m, lv = self.get_part_code(inp, seg_flag)
+        part_code = self._reparameterize(m, lv) if self.gen else m.transpose(1, 2)
+        noise = torch.randn(B * num, self.part_aligner.noise_dim).to(device)               # :406 (host draw, like the reference)
+        part_code, valid_id, gt_shift, gt_var = (t.repeat_interleave(num, dim=0) for t in (part_code, valid_id, gt_shift, gt_var))
+        mean, logvar = self.get_params_from_part_code(part_code, valid_id, noise=noise, gt_mean=gt_shift, gt_var=gt_var)
+        fit = self.get_fit_loss(mean, logvar, valid_id, gt_shift, gt_var)
+        return noise.reshape(B, num, -1), fit.reshape(B, num).min(1)[1]
 
     @torch.no_grad()
     def sample_latents(self, sample_num, sample_points, device, fixed_id=None, valid_id=None, epoch=0, K=None,
@@ -399,10 +455,11 @@ class PartEncoderForTransformerDecoder(nn.Module):
         al = self.part_aligner
         w = None
         if part_code is None:
-            w = torch.randn(sample_num, self.zdim, self.n_class, device=device)           # :1054 (scaled in-kernel)
+            w = torch.randn(sample_num, self.zdim, self.n_class).to(device)               # :1054 — drawn on the HOST like the reference
+            #                                                                               (one torch.manual_seed -> the same latents in both); scaled in-kernel
         if al.cimle:
             K = 10 if K is None else K                                                    # :1062
-            noise = torch.randn(sample_num * K, al.noise_dim, device=device)              # :1065
+            noise = torch.randn(sample_num * K, al.noise_dim).to(device)                  # :1065 (host draw as well)
             if al.cimle_start_epoch > epoch:
                 noise = torch.zeros_like(noise)
         else:
@@ -417,14 +474,15 @@ class PartEncoderForTransformerDecoder(nn.Module):
 
 
 @torch.no_grad()
-def generate(encoder, diffusion, sample_num, npoints, valid_id=None, fixed_id=None, K=10, epoch=0, seed=0,
-             ret_traj=False, ret_interval=20):
-    """anchor_gen.py:1034-1084 (gen branch): latents once per batch, then the fused reverse chain.
-    Returns decode's dict + 'pred_seg_mask', 'anchors' (rows, npoints, 3), 'present'."""
+def generate(encoder, diffusion, sample_num, npoints, valid_id=None, fixed_id=None, K=10, epoch=0, seed=None,
+             ret_traj=False, ret_interval=20, generator=None):
+    """anchor_gen.py:1034-1084 (gen branch) without the batch bookkeeping: latents once per batch, then the fused reverse chain.
+    Returns decode's dict + 'pred_seg_mask', 'anchors' (rows, npoints, 3), 'present'.  ``seed=None``: fresh noise per call
+    (engine.resolve_seed).  The reference's full output dict is ``networks.AnchorDiffAE.forward``."""
     device = next(encoder.parameters()).device
     ctx, mean_pp, logvar_pp, seg, valid, latents = encoder.sample_latents(sample_num, npoints, device, fixed_id=fixed_id,
                                                                           valid_id=valid_id, epoch=epoch, K=K)
-    pred = decode(diffusion, ctx, seg, valid_id=valid, ret_traj=ret_traj, ret_interval=ret_interval, seed=seed)
+    pred = decode(diffusion, ctx, seg, valid_id=valid, ret_traj=ret_traj, ret_interval=ret_interval, seed=seed, generator=generator)
     pred["pred_seg_mask"] = seg
     pred["anchors"] = mean_pp.transpose(1, 2)
     pred["present"] = valid
@@ -449,6 +507,7 @@ def attach(ref_encoder):
         include_z=ref_encoder.include_z, include_part_code=ref_encoder.include_part_code,
         include_params=ref_encoder.include_params, use_gt_params=ref_encoder.use_gt_params,
         encode_ref=ref_encoder.encode_ref, scale_var=math.exp(ref_encoder.log_scale_var), gen=ref_encoder.gen,
+        fit_loss_type=ref_encoder.fit_loss_type, fit_loss_weight=ref_encoder.fit_loss_weight,
         use_flow=getattr(ref_encoder, "use_flow", False),
         latent_flow_depth=len(ref_encoder.flow[0].chain) if getattr(ref_encoder, "use_flow", False) else 0,
         latent_flow_hidden_dim=ref_encoder.flow[0].chain[0].net_s_t[0].out_features if getattr(ref_encoder, "use_flow", False) else 0,

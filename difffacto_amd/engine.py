@@ -53,6 +53,19 @@ def _dev_f32(t, name, device):
     return t
 
 
+def resolve_seed(seed=None, generator=None):
+    """The 64-bit Philox key of one sampling call.  ``seed=None`` (the default everywhere above the C-ABI) draws it from
+    ``generator`` or, without one, from torch's global CPU generator — so noise is FRESH per call, and governed by
+    ``torch.manual_seed`` / the reference's ``set_random_seed`` (runner.py:39), like the ``torch.randn`` /
+    ``randn_like`` draws it replaces (anchored_diffusion.py:476,564).  A device generator is honoured as well (one
+    host sync).  An explicit integer is used as it is: the reproducible / sharded calls (parallel.py) pass one."""
+    if seed is not None:
+        return int(seed)
+    if generator is not None and generator.device.type != "cpu":
+        return int(torch.randint(0, 2 ** 62, (), device=generator.device, generator=generator).item())
+    return int(torch.randint(0, 2 ** 62, (), generator=generator).item())
+
+
 def last_kernel_variant():
     """Name of the denoiser kernel the most recent launch took (``dfx_last_kernel_variant``), e.g. ``"k_denoise_pipe<8>"``."""
     return _ffi.lib().dfx_last_kernel_variant().decode()
@@ -170,7 +183,8 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_denoise_eps")
         return out
 
-    def p_sample(self, ctx, x, seg, t, noise=None, seed=0, want_xstart=False, shape_offset=0):
+    def p_sample(self, ctx, x, seg, t, noise=None, seed=None, want_xstart=False, shape_offset=0, generator=None):
+        seed = 0 if noise is not None and seed is None else resolve_seed(seed, generator)   # explicit noise: no draw
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
         B, _, N = x.shape
@@ -190,11 +204,13 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_p_sample")
         return (out, xs) if want_xstart else out
 
-    def sample_chain(self, ctx, seg, x_T_noise=None, step_noise=None, seed=0, ret_interval=None, shape_offset=0):
+    def sample_chain(self, ctx, seg, x_T_noise=None, step_noise=None, seed=None, ret_interval=None, shape_offset=0, generator=None):
         """Whole reverse chain in one launch.  Returns (pred (B,N,3), traj or None) where traj is
         (n_keep,B,N,3) with snapshot k <-> t = (T // ret_interval - k) * ret_interval.  `shape_offset` = global index of
         shape 0 of this call: the in-kernel Philox noise is keyed by the global point id, so a batch split over calls / ranks
-        gives the clouds of the unsplit call."""
+        gives the clouds of the unsplit call.  ``seed=None``: a fresh key from ``generator`` / torch's global generator
+        (``resolve_seed``); nothing is drawn when both noise tensors are given."""
+        seed = 0 if (x_T_noise is not None and step_noise is not None and seed is None) else resolve_seed(seed, generator)
         seg = self._seg(seg, self.device)
         B, N = seg.shape
         T = self.num_timesteps
@@ -272,8 +288,9 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_masked_mse_f32")
         return loss[0]
 
-    def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=0, want_xstart=False, shape_offset=0):
+    def p_sample_ddim(self, ctx, x, seg, t, eta, noise=None, seed=None, want_xstart=False, shape_offset=0, generator=None):
         """One DDIM update (anchored_diffusion.py:368-377, :480-481)."""
+        seed = 0 if noise is not None and seed is None else resolve_seed(seed, generator)
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         seg = self._seg(seg, self.device)
         B, _, N = x.shape
@@ -293,9 +310,11 @@ class DenoiserEngine:
         _ffi.check(rc, "dfx_p_sample_ddim")
         return (out, xs) if want_xstart else out
 
-    def sample_chain_ddim(self, ctx, seg, steps, eta, x_T_noise=None, step_noise=None, seed=0, ret_interval=None, shape_offset=0):
+    def sample_chain_ddim(self, ctx, seg, steps, eta, x_T_noise=None, step_noise=None, seed=None, ret_interval=None, shape_offset=0,
+                          generator=None):
         """DDIM chain in one launch over the ascending step list ``steps`` (executed in reverse).  Returns
         (pred, traj or None); traj slots follow ``snapshot_times``; only timesteps in ``steps`` are written."""
+        seed = 0 if (x_T_noise is not None and step_noise is not None and seed is None) else resolve_seed(seed, generator)
         seg = self._seg(seg, self.device)
         B, N = seg.shape
         steps = [int(v) for v in steps]

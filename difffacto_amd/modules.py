@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import training as _training
-from .engine import DenoiserEngine
+from .engine import DenoiserEngine, resolve_seed
 
 
 # ---- parameter containers with the reference's attribute names (no torch math in them) -----------------------
@@ -236,29 +236,34 @@ class AnchoredDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_sample(self, x, t, anchors, ctx=None, variance=None, anchor_assignment=None, valid_id=None, noise=None,
-                 seed=0):
-        """anchored_diffusion.py:450-484.  Returns {'sample', 'pred_xstart'} like the reference."""
+                 seed=None, generator=None):
+        """anchored_diffusion.py:450-484.  Returns {'sample', 'pred_xstart'} like the reference.  The step's noise z is the
+        in-kernel Philox stream keyed by (seed, point, t); ``seed=None`` draws a fresh key per call from ``generator`` / torch's
+        global generator (``engine.resolve_seed``), as the reference draws a fresh ``randn_like`` (:476)."""
         tt = t if isinstance(t, int) else int(t.reshape(-1)[0].item())
         if self.ddim_sampling:
             sample, xs = self.model.engine().p_sample_ddim(self._sc(ctx, valid_id), x, anchor_assignment, tt, self.ddim_eta,
-                                                           noise=noise, seed=seed, want_xstart=True)
+                                                           noise=noise, seed=seed, want_xstart=True, generator=generator)
             return {"sample": sample, "pred_xstart": xs}
         sample, xs = self.model.engine().p_sample(self._sc(ctx, valid_id), x, anchor_assignment, tt, noise=noise,
-                                                  seed=seed, want_xstart=True)
+                                                  seed=seed, want_xstart=True, generator=generator)
         return {"sample": sample, "pred_xstart": xs}
 
     @torch.no_grad()
     def p_sample_loop_progressive(self, shape, anchors, ctx=None, variance=None, anchor_assignment=None,
-                                  valid_id=None, noise=None, device=None, progress=False, seed=0):
+                                  valid_id=None, noise=None, device=None, progress=False, seed=None, generator=None):
         """Generator of (t, {'sample': ...}) with the reference's protocol (:528-588): first (T, x_T), then one
-        p_sample per step.  One kernel launch per step; use ``sample_chain`` for the single-launch path."""
+        p_sample per step.  One kernel launch per step; use ``sample_chain`` for the single-launch path.
+        ``seed=None`` (what the reference's ``decode`` passes, anchor_gen.py:149-158): ONE fresh key for this loop, drawn from
+        ``generator`` / torch's global generator — every call sees new noise, ``torch.manual_seed`` replays it."""
         B, _, N = shape
+        seed = resolve_seed(seed, generator)
         if noise is not None:
             pcd = noise
         else:
             L = torch.sqrt(variance)
             g = torch.Generator(device=variance.device)
-            g.manual_seed(int(seed))
+            g.manual_seed(seed)
             pcd = L * torch.randn(*shape, device=variance.device, generator=g) + anchors
         yield self.num_timesteps, dict(sample=pcd)
         for i in self.steps[::-1]:
@@ -269,8 +274,9 @@ class AnchoredDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_sample_loop(self, shape, anchors, ctx=None, noise=None, variance=None, anchor_assignment=None,
-                      valid_id=None, device=None, progress=False, seed=0):
+                      valid_id=None, device=None, progress=False, seed=None, generator=None):
         """:486-526 — final sample only; runs the fused chain when no explicit x_T is given."""
+        seed = resolve_seed(seed, generator)
         if noise is None:
             pred, _ = self.sample_chain(ctx, anchor_assignment, valid_id, seed=seed)
             return pred.transpose(1, 2).contiguous()
@@ -281,17 +287,18 @@ class AnchoredDiffusion(nn.Module):
         return final["sample"]
 
     @torch.no_grad()
-    def sample_chain(self, ctx, anchor_assignment, valid_id=None, x_T_noise=None, step_noise=None, seed=0,
-                     ret_interval=None, shape_offset=0):
+    def sample_chain(self, ctx, anchor_assignment, valid_id=None, x_T_noise=None, step_noise=None, seed=None,
+                     ret_interval=None, shape_offset=0, generator=None):
         """Whole reverse chain in ONE persistent launch: (pred (B,N,3), traj (n_keep,B,N,3) | None).  `shape_offset`: global
-        index of shape 0 (a rank of a sharded run passes its first shape's index: same clouds for any GPU count)."""
+        index of shape 0 (a rank of a sharded run passes its first shape's index: same clouds for any GPU count).
+        ``seed=None``: a fresh Philox key per call (``engine.resolve_seed``); sharded runs pass ONE explicit seed to all ranks."""
         if self.ddim_sampling:
             return self.model.engine().sample_chain_ddim(self._sc(ctx, valid_id), anchor_assignment, self.steps, self.ddim_eta,
                                                          x_T_noise=x_T_noise, step_noise=step_noise, seed=seed,
-                                                         ret_interval=ret_interval, shape_offset=shape_offset)
+                                                         ret_interval=ret_interval, shape_offset=shape_offset, generator=generator)
         return self.model.engine().sample_chain(self._sc(ctx, valid_id), anchor_assignment, x_T_noise=x_T_noise,
                                                 step_noise=step_noise, seed=seed, ret_interval=ret_interval,
-                                                shape_offset=shape_offset)
+                                                shape_offset=shape_offset, generator=generator)
 
     def training_losses(self, x_start, t, anchors=None, variance=None, ctx=None, reduce=True, anchor_assignment=None,
                         valid_id=None, flags=None, noise=None):
@@ -330,15 +337,66 @@ class AnchoredDiffusion(nn.Module):
 
 
 @torch.no_grad()
-def decode(diffusion, ctx, anchor_assignments, valid_id=None, ret_traj=False, ret_interval=20, seed=0,
-           x_T_noise=None, step_noise=None, shape_offset=0):
-    """``AnchorDiffAE.decode`` (anchor_gen.py:145-169): {'pred': (B,N,3), t: (B,N,3) for t % ret_interval == 0}."""
+def decode(diffusion, ctx, anchor_assignments, valid_id=None, ret_traj=False, ret_interval=20, seed=None,
+           x_T_noise=None, step_noise=None, shape_offset=0, generator=None, save_pred_xstart=False, x_T=None):
+    """``AnchorDiffAE.decode`` (anchor_gen.py:145-169): {'pred': (B,N,3), t: (B,N,3) for t % ret_interval == 0}.
+    ``seed=None`` (the default, and what the reference's call amounts to): fresh noise per call, replayable with
+    ``torch.manual_seed``.  ``save_pred_xstart`` (:160-167) adds 'pred_xstart' / 'pred_xstart_{t}': those are outputs of every
+    step, so that mode walks the chain one ``dfx_p_sample`` launch per step (the reference's own loop) instead of the
+    single persistent launch.  ``x_T`` (B,3,N): an explicit starting CLOUD (the reference's ``noise`` argument of
+    p_sample_loop_progressive, anchored_diffusion.py:560-561) instead of the draw ``x_T_noise``: stepwise as well."""
+    if save_pred_xstart or x_T is not None:
+        return _decode_stepwise(diffusion, ctx, anchor_assignments, valid_id, ret_traj, ret_interval, seed, x_T_noise, step_noise,
+                                shape_offset, generator, save_pred_xstart, x_T)
     pred, traj = diffusion.sample_chain(ctx, anchor_assignments, valid_id, x_T_noise=x_T_noise, step_noise=step_noise,
-                                        seed=seed, ret_interval=ret_interval if ret_traj else None, shape_offset=shape_offset)
+                                        seed=seed, ret_interval=ret_interval if ret_traj else None, shape_offset=shape_offset,
+                                        generator=generator)
     final = {"pred": pred}
     if ret_traj:
         visited = set(diffusion.steps) | {diffusion.num_timesteps}   # the prior sample t = T is always yielded (:565)
         for k, t in enumerate(diffusion.model.engine().snapshot_times(ret_interval)):
             if t in visited:
                 final[t] = traj[k]
+    return final
+
+
+@torch.no_grad()
+def _decode_stepwise(diffusion, ctx, seg, valid_id, ret_traj, ret_interval, seed, x_T_noise, step_noise, shape_offset, generator,
+                     save_pred_xstart=True, x_T=None):
+    """decode() with pred_xstart outputs: the reference's loop (anchor_gen.py:149-167) over ``dfx_p_sample`` launches.  x_T and every
+    z_t are the explicit tensors when given, else the Philox streams of ONE key (x_T from a torch device generator seeded with it)."""
+    seed = resolve_seed(seed, generator)
+    eng = diffusion.model.engine()
+    sc = diffusion._sc(ctx, valid_id)
+    seg = seg.to(device=eng.device, dtype=torch.int32)
+    B, N = seg.shape
+    params = ctx[1].to(eng.device, torch.float32)
+    idx = seg.long()[:, None, :].expand(-1, 3, -1)
+    anchors, variance = torch.gather(params[:, :3], 2, idx), torch.gather(params[:, 3:], 2, idx)   # gather_all, part_encoders.py:417-428
+    if x_T is not None:
+        x = x_T.to(eng.device, torch.float32)                                                        # anchored_diffusion.py:560-561
+    else:
+        if x_T_noise is None:
+            g = torch.Generator(device=eng.device)
+            g.manual_seed(seed)
+            x_T_noise = torch.randn(B, 3, N, device=eng.device, generator=g)
+        x = torch.sqrt(variance) * x_T_noise.to(eng.device, torch.float32) + anchors                 # :563-564
+    final = {}
+    T = diffusion.num_timesteps
+    if ret_traj and T % ret_interval == 0:
+        final[T] = x.transpose(1, 2).contiguous()
+    for k, t in enumerate(diffusion.steps[::-1]):
+        z = None if step_noise is None else step_noise[k]
+        if diffusion.ddim_sampling:
+            x, xs = eng.p_sample_ddim(sc, x, seg, t, diffusion.ddim_eta, noise=z, seed=seed, want_xstart=True, shape_offset=shape_offset)
+        else:
+            x, xs = eng.p_sample(sc, x, seg, t, noise=z, seed=seed, want_xstart=True, shape_offset=shape_offset)
+        if t == 0:
+            final["pred"] = x.transpose(1, 2).contiguous()
+            if save_pred_xstart:
+                final["pred_xstart"] = xs.transpose(1, 2).contiguous()
+        elif ret_traj and t % ret_interval == 0:
+            final[t] = x.transpose(1, 2).contiguous()
+            if save_pred_xstart:
+                final[f"pred_xstart_{t}"] = xs.transpose(1, 2).contiguous()
     return final

@@ -12,7 +12,8 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from _train_case import check_against_golden, load_case  # noqa: E402
+from _train_case import GOLD, check_against_golden, load_case  # noqa: E402
+from difffacto_amd import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -544,3 +545,64 @@ def test_inference_engine_follows_the_weights_across_adam_steps():
         assert torch.equal(cur, ref), it
         assert (cur - prev).abs().max().item() > 1e-4, it
         prev = cur
+
+
+def test_training_loop_over_iterations_matches_the_reference_loop():
+    """tests/golden/train_loop_B3_N64_T10.npz: three iterations of the reference's loop (runner/runner.py:299-316: zero_grad ->
+    training_losses -> backward -> clip_grad_norm_(10) -> Adam.step -> LinearLR.step, optimizers/schedulers.py:8-19) on the reference's
+    denoiser (dropout 0, fp32).  The same loop through the drop-in modules + training.Adam + training.linear_lr in DFX_PREC_F32:
+    per-iteration loss, gradient norm and learning rate at 1e-5 relative, the parameter vector's L2 norm / sum and 256 sampled elements
+    of every parameter after every step.  (Adam's first steps move every element by ~lr * sign(g): elements whose gradient is within
+    rounding of zero may differ by up to 2 lr, so sampled elements are gated at 1e-5 x max|p| for all but 0.5 % of them.)"""
+    from difffacto_amd import training
+    from difffacto_amd.modules import AnchoredDiffusion
+    from test_modules_cpu import DIFF_CFG
+    g = np.load(os.path.join(GOLD, "train_loop_B3_N64_T10.npz"))
+    W = synth.make_denoiser_weights(int(g["weight_seed"]))
+    d = AnchoredDiffusion(num_timesteps=10, precision="f32", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)})
+    d.model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    d = d.cuda().train()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    seg = g["seg"].astype(np.int64)
+    mean, var = g["mean"], np.exp(g["logvar"]).astype(np.float32)
+    idx = np.broadcast_to(seg[:, None, :], (seg.shape[0], 3, seg.shape[1]))
+    anchors, variance = cu(np.take_along_axis(mean, idx, 2)), cu(np.take_along_axis(var, idx, 2))
+    ctx = [cu(g["part_code"]), cu(np.concatenate([mean, var], 1).astype(np.float32))]
+    s0, s1, lr0, lr1 = (float(v) for v in g["sched"])
+    opt = training.Adam(list(d.model.parameters()), lr=lr0, max_norm=float(g["max_norm"]))
+    named = list(d.model.named_parameters())
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
+    worst = {"loss": 0.0, "grad_norm": 0.0, "l2": 0.0, "elem": 0.0}
+    for it in range(int(g["iters"])):
+        opt.lr = training.linear_lr(it, s0, s1, lr0, lr1)
+        assert rel(opt.lr, float(g["lr"][it])) < 1e-12
+        opt.zero_grad()
+        loss = d.training_losses(cu(g["x_start"][it]), cu(g["t"][it]), anchors=anchors, variance=variance, ctx=ctx,
+                                 anchor_assignment=cu(g["seg"].astype(np.int32)), valid_id=cu(g["valid"]), flags=None, noise=cu(g["noise"][it]))["mse_loss"]
+        loss.backward()
+        norm = opt.step()
+        worst["loss"] = max(worst["loss"], rel(float(loss.detach()), float(g["loss"][it])))
+        worst["grad_norm"] = max(worst["grad_norm"], rel(float(norm), float(g["grad_norm"][it])))
+        flat = torch.cat([p.detach().reshape(-1).double() for _, p in named])
+        worst["l2"] = max(worst["l2"], rel(float(flat.norm()), float(g["param_l2"][it])))
+        assert abs(float(flat.sum()) - float(g["param_sum"][it])) <= 1e-5 * float(flat.abs().sum())
+        bad = tot = 0
+        for name, p in named:
+            ref = g["ps/" + name][it].astype(np.float64)
+            got = p.detach().reshape(-1)[torch.from_numpy(g["pi/" + name]).cuda()].cpu().numpy().astype(np.float64)
+            err = np.abs(got - ref)
+            scale = max(float(np.abs(ref).max()), 1e-3)
+            bad += int((err > 1e-5 * scale).sum())
+            tot += err.size
+            assert err.max() <= 2.5 * lr0 * (it + 1), (name, it, err.max())
+            worst["elem"] = max(worst["elem"], float(np.median(err) / scale))
+        assert bad <= 0.005 * tot, (it, bad, tot)
+    print("training loop vs reference:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert worst["loss"] < 1e-5 and worst["grad_norm"] < 1e-5 and worst["l2"] < 1e-5, worst
+
+
+def test_linear_lr_schedule_values():
+    """optimizers/schedulers.py:8-19 at the shipped settings (configs/gen_chair.py: 2e-3 -> 1e-4 over epochs 4000..8000)."""
+    from difffacto_amd.training import linear_lr
+    f = lambda e: linear_lr(e, 4000, 8000, 2e-3, 1e-4)
+    assert f(0) == f(4000) == 2e-3 and abs(f(6000) - 1.05e-3) < 1e-15 and abs(f(8000) - 1e-4) < 1e-15 and abs(f(9000) - 1e-4) < 1e-15

@@ -205,3 +205,153 @@ def test_bench_evidence_helpers_read_the_newest_committed_profiles():
     c = b.power_limited_ceiling()
     assert c["source"].startswith("profiles/r") and 1500 < c["bare_mfma_tflops"] < 2500 and 1000 < c["kernel_mix_tflops"] < c["refill_per_mfma_tflops"] < c["bare_mfma_tflops"]
     assert abs(b.flops_per_step(2048) - 4.733899e9) < 1e4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python/difffacto"), reason="dev container only")
+def test_reference_forward_through_install_and_attach_dry_run(monkeypatch):
+    """The drop-in protocol end to end WITHOUT a GPU: the reference's OWN AnchorDiffAE (built by its registry after
+    difffacto_amd.install(), encoder accelerated with encoders.attach()) runs its gen branch (anchor_gen.py:1034-1084); the two libdfx
+    handles are replaced by numpy-oracle stand-ins (tests/_oracle_backend.py, test-only).  Checks:
+      * the kwargs the reference passes (decode -> p_sample_loop_progressive(shape, anchors=, variance=, ctx=, noise=None,
+        anchor_assignment=, valid_id=, device=, progress=) -> p_sample) are accepted, and the dict it builds equals the golden the
+        unmodified reference produced (forward_gen_B2_K2_T10.npz) when the recorded draws are replayed at the same sites;
+      * seed-less sampling is FRESH per decode() call — ONE key per loop, a new one per call — and replays under torch.manual_seed."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import ref_import
+    from _oracle_backend import OracleEngine, OracleLatentSampler
+    from _replay import load_forward_fixture, replay_draws
+    import difffacto_amd
+    from difffacto_amd import encoders, modules
+    ref_import.import_reference()
+    from difffacto.config.config import init_cfg, get_cfg
+    from difffacto.utils.registry import NETS, DIFFUSIONS, MODELS, build_from_cfg
+
+    batch, draws, expect, meta = load_forward_fixture(os.path.join(ROOT, "tests", "golden", "forward_gen_B2_K2_T10.npz"))
+    T, K, N = int(meta["T"]), int(meta["K"]), batch["ref"].shape[1]
+    saved = (NETS._modules["TransformerNet"], DIFFUSIONS._modules["AnchoredDiffusion"], dict(sys.modules))
+    try:
+        assert difffacto_amd.install() is True
+        init_cfg(os.path.join(ref_import.REF_ROOT, "configs", "gen_chair.py"))
+        cfg = get_cfg()
+        cfg.model["num_timesteps"] = T
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = build_from_cfg(cfg.model, MODELS).eval()
+        assert type(model).__module__.startswith("difffacto.") and isinstance(model.diffusion, modules.AnchoredDiffusion)
+        model.npoints, model.cimle_sample_num, model.ret_traj, model.ret_interval = N, K, True, int(meta["ret_interval"])
+        model.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_denoiser_weights(0).items()})
+        sd = model.encoder.state_dict()
+        for k, v in synth.make_latent_weights(0).items():
+            sd[k] = torch.from_numpy(v.copy())
+        for k, v in synth.make_pointnet_v2_weights(0).items():
+            sd["encoder." + k] = torch.from_numpy(v.copy())
+        model.encoder.load_state_dict(sd)
+        encoders.attach(model.encoder)
+
+        engines = {}
+
+        def fake_engine(net):
+            key = id(net)
+            if key not in engines:
+                engines[key] = OracleEngine({k: v.detach() for k, v in net.named_parameters()}, net._dfx_T, *net._dfx_betas)
+            return engines[key]
+
+        monkeypatch.setattr(modules.TransformerNet, "engine", fake_engine)
+        monkeypatch.setattr(encoders, "LatentSampler", OracleLatentSampler)
+        monkeypatch.setattr(torch.Tensor, "cuda", lambda t, *a, **k: t, raising=False)    # hard-coded .cuda() in the reference's prior loss
+
+        chain_at = 3
+        OracleEngine.replay_steps = list(draws[chain_at + 1:chain_at + T + 1])
+        with replay_draws(draws[:chain_at + 1] + draws[chain_at + T + 1:]) as queue, torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out = model(batch, device="cpu", epoch=0)
+        assert not queue and not OracleEngine.replay_steps
+        OracleEngine.replay_steps = None
+        pred, name = out[0]
+        assert name == str(meta["name"]) and set(map(str, pred)) == set(expect)
+        for k, v in pred.items():
+            ref, got = expect[str(k)], v.numpy()
+            assert got.shape == ref.shape, k
+            if ref.dtype.kind in "iub":
+                assert np.array_equal(got, ref), k
+            else:
+                assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), k
+
+        # ---- fresh noise per decode() call of the REFERENCE (it passes no seed: anchor_gen.py:149-158) ----
+        pc, mean, logvar, valid = synth.make_latents(2, seed=5)
+        t_ = torch.from_numpy
+        ctx = [t_(pc), torch.cat([t_(mean), torch.exp(t_(logvar))], 1)]
+        seg = t_(synth.make_seg_mask(valid, 32))
+        idx = seg.long()[:, None, :].expand(-1, 3, -1)
+        anchors, variance = torch.gather(ctx[1][:, :3], 2, idx), torch.gather(ctx[1][:, 3:], 2, idx)
+        kw = dict(ctx=ctx, variance=variance, anchor_assignments=seg.to(torch.int32), valid_id=t_(valid), device="cpu")
+        OracleEngine.seeds_seen = []
+        torch.manual_seed(11)
+        with torch.no_grad():
+            a, b = model.decode(anchors, **kw)["pred"], model.decode(anchors, **kw)["pred"]
+        seeds = list(OracleEngine.seeds_seen)
+        assert len(seeds) == 2 * T and len(set(seeds[:T])) == 1 and len(set(seeds[T:])) == 1 and seeds[0] != seeds[T]   # one key per loop
+        assert not torch.equal(a, b)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            a2 = model.decode(anchors, **kw)["pred"]
+        assert torch.equal(a, a2)
+    finally:
+        OracleEngine.replay_steps = None
+        NETS._modules["TransformerNet"], DIFFUSIONS._modules["AnchoredDiffusion"] = saved[0], saved[1]
+        for k in ("pointnet2_ops", "pointnet2_ops.pointnet2_utils", "pointnet2_ops.pointnet2_modules"):
+            sys.modules[k] = saved[2][k]
+
+
+@pytest.mark.parametrize("tag,chain_at", [("gen_B2_K2_T10", 3), ("sample_B2_K2_T10", 4)])
+def test_anchor_diff_ae_mirror_bookkeeping_on_oracle_backends(tag, chain_at, monkeypatch):
+    """networks.AnchorDiffAE.forward (the mirror's dict bookkeeping, draw order, K-fold regrouping) with every libdfx handle replaced by
+    the numpy oracle (test-only stand-ins): equals the golden of the reference's AnchorDiffAE.forward.  The GPU twin of this test
+    (tests/test_gpu_forward.py) runs the same comparison through the real kernels."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from _oracle_backend import OracleEngine, OracleLatentSampler
+    from _replay import load_forward_fixture, replay_draws
+    from difffacto_amd import encoders, modules, training
+    from difffacto_amd.networks import AnchorDiffAE
+    from oracle import pointnet_v2 as opv
+    from oracle import prior_loss as opl
+    batch, draws, expect, meta = load_forward_fixture(os.path.join(ROOT, "tests", "golden", f"forward_{tag}.npz"))
+    T, K, N = int(meta["T"]), int(meta["K"]), batch["ref"].shape[1]
+    m = AnchorDiffAE(encoder=dict(type="PartEncoderForTransformerDecoder", **ENC_CFG), diffusion=dict(type="AnchoredDiffusion", **DIFF_CFG),
+                     sampler=dict(type="Uniform"), num_anchors=4, num_timesteps=T, npoints=N, gen=tag.startswith("gen"), cimle=True,
+                     cimle_sample_num=K, ret_traj=True, ret_interval=int(meta["ret_interval"]))
+    W = {"diffusion.model." + k: v for k, v in synth.make_denoiser_weights(0).items()}
+    W.update({"encoder." + k: v for k, v in synth.make_latent_weights(0).items()})
+    W.update({"encoder.encoder." + k: v for k, v in synth.make_pointnet_v2_weights(0).items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    m.eval()
+    engines = {}
+    monkeypatch.setattr(modules.TransformerNet, "engine", lambda net: engines.setdefault(id(net), OracleEngine(
+        {k: v.detach() for k, v in net.named_parameters()}, net._dfx_T, *net._dfx_betas)))
+    monkeypatch.setattr(encoders, "LatentSampler", OracleLatentSampler)
+    Wpn = synth.make_pointnet_v2_weights(0)
+    monkeypatch.setattr(encoders.PointNetV2, "forward", lambda self, x, a: tuple(map(torch.from_numpy, opv.forward(Wpn, x.numpy(), a.numpy()))))
+
+    def prior(params, part_code, logvar, valid, depth=14, hidden=256, prior_var=1.0, kl_weight=5e-4, stream=None):
+        return opl.prior_loss({k: v.detach() for k, v in params.items()}, part_code, logvar, valid, depth=depth, prior_var=prior_var, kl_weight=kl_weight)
+    monkeypatch.setattr(training, "prior_loss", prior)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: __import__("contextlib").nullcontext())
+    chain = draws[chain_at:chain_at + T + 1]
+    orig = m.decode
+    m.decode = lambda *a, **k: orig(*a, x_T_noise=torch.from_numpy(chain[0]), step_noise=torch.from_numpy(np.stack(chain[1:])), **k)
+    with replay_draws(draws[:chain_at] + draws[chain_at + T + 1:]) as queue:
+        out = m(batch, device="cpu", epoch=0)
+    assert not queue
+    pred, name = out[0]
+    assert name == str(meta["name"]) and set(map(str, pred)) == set(expect), (sorted(map(str, pred)), sorted(expect))
+    for k, v in pred.items():
+        ref, got = expect[str(k)], v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if ref.dtype.kind in "iub":
+            assert np.array_equal(got, ref), k
+        else:
+            assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), k

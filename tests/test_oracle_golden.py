@@ -239,3 +239,61 @@ def test_golden_manifest():
     missing, extra, changed = m.diff()
     assert not missing and not extra and not changed, (missing, extra, changed)
     assert len(m.read()) >= 34
+
+
+# ---------------------------------------------------------------------------------- top-level compositions (oracle/forward.py)
+def _forward_weights():
+    W_enc = dict(synth.make_latent_weights(0))
+    W_enc.update({"encoder." + k: v for k, v in synth.make_pointnet_v2_weights(0).items()})
+    return W_enc, synth.make_denoiser_weights(0)
+
+
+def _cmp_dict(pred, expect, tol):
+    assert set(map(str, pred)) == set(expect), (sorted(map(str, pred)), sorted(expect))
+    worst = 0.0
+    for k, v in pred.items():
+        ref, got = expect[str(k)], np.asarray(v)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if ref.dtype.kind in "iub":
+            assert np.array_equal(got, ref), k
+        else:
+            err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
+            assert err <= tol, (k, err)
+            worst = max(worst, err)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["gen_B2_K2_T10", "sample_B2_K2_T10"])
+def test_oracle_anchor_forward_matches_reference_golden(tag):
+    """oracle/forward.anchor_forward vs AnchorDiffAE.forward of the reference (every key of the dict Runner.val saves)."""
+    from _replay import load_forward_fixture
+    from oracle import forward as ofw
+    batch, draws, expect, meta = load_forward_fixture(os.path.join(GOLDEN, f"forward_{tag}.npz"))
+    W_enc, W_den = _forward_weights()
+    nb = {k: v.numpy() for k, v in batch.items()}
+    pred, name = ofw.anchor_forward(W_enc, W_den, nb, draws, int(meta["T"]), nb["ref"].shape[1], int(meta["K"]), gen=tag.startswith("gen"),
+                                    ret_interval=int(meta["ret_interval"]))
+    assert name == str(meta["name"])
+    worst = _cmp_dict(pred, expect, 2e-5)
+    print(f"oracle forward[{tag}]: worst rel err {worst:.2e}")
+
+
+def test_oracle_encoder_forward_matches_reference_golden():
+    from _replay import load_forward_fixture
+    from oracle import forward as ofw
+    batch, draws, expect, meta = load_forward_fixture(os.path.join(GOLDEN, "encoder_fwd_B3_N96.npz"))
+    W_enc, _ = _forward_weights()
+    nb = {k: v.numpy() for k, v in batch.items()}
+    draws = list(draws)
+    kw = dict(kl_weight=float(meta["kl_weight"]), epoch=int(meta["epoch"]))
+    e1 = ofw.encoder_forward(W_enc, nb, draws, **kw)
+    noise, idx = ofw.sample_noise(W_enc, nb, draws, int(meta["num"]))
+    e2 = ofw.encoder_forward(W_enc, nb, draws, noise=noise, **kw)
+    assert not draws
+    got = {"ctx0": e1["ctx"][0], "ctx1": e1["ctx"][1], "mean_pp": e1["mean_pp"], "logvar_pp": e1["logvar_pp"], "flag_pp": e1["flag_pp"],
+           "part_code": e1["part_code"], "mean": e1["mean"], "logvar": e1["logvar"], "noise": e1["noise"], "sn_noise": noise, "sn_id": idx,
+           "k_ctx0": e2["ctx"][0], "k_ctx1": e2["ctx"][1], "k_mean_pp": e2["mean_pp"], "k_logvar_pp": e2["logvar_pp"],
+           "k_flag_pp": e2["flag_pp"], "k_fit_loss": e2["losses"]["fit_loss"]}
+    got.update({"loss/" + k: np.asarray(v).reshape(expect["loss/" + k].shape) for k, v in e1["losses"].items()})
+    worst = _cmp_dict(got, expect, 2e-5)
+    print(f"oracle encoder forward: worst rel err {worst:.2e}")
