@@ -85,6 +85,8 @@ SIGNATURES = {
     "dfx_denoiser_destroy": (None, [_P]),
     "dfx_denoiser_num_timesteps": (_I, [_P]),
     "dfx_denoiser_precision": (_I, [_P]),
+    "dfx_denoiser_w1_fold": (_I, [_P, ctypes.POINTER(ctypes.c_float)]),
+    "dfx_debug_w1_fold": (None, [_I]),
     "dfx_denoiser_get_tables": (_I, [_P, _P]),
     "dfx_shape_ctx_bytes": (_SZ, [_P, _I]),
     "dfx_shape_ctx_prepare": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
@@ -136,6 +138,7 @@ SIGNATURES = {
     "dfx_p_sample_ddim": (_I, [_P, _P, _P, _P, _I, _F, _P, _U64, _U64, _P, _P, _I, _I, _P]),
     "dfx_sample_chain_ddim": (_I, [_P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _F, _P, _P, _U64, _U64, _I, _P, _P, _I, _I, _P]),
     "dfx_debug_force_direct": (None, [_I]),
+    "dfx_debug_bare_mfma": (_I, [_I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), _P]),
     "dfx_debug_pipe_waves": (None, [_I]),
     "dfx_debug_trace": (None, [_P, _I]),
     "dfx_set_event_timing": (None, [_I]),

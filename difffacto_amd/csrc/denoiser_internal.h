@@ -84,6 +84,7 @@ constexpr float FF_A_SCALE = 0.0625f, FF_G_SCALE = 0.5f;
 
 struct DenoiserDev {
   int depth, T, prec;
+  int w1_fold;           // bf16: b1' rides in channel 127's K slot of W1 (denoiser_setup.hip: k_pack_w1); 0 = plain W1' + accumulator initialisers
   BlockPack blk[DFX_MAX_DEPTH];
   long long blk_stride;  // bytes from block b's chunks / bconst / ct to block b+1's (one carve per block: uniform)
   const float4 *win_x;   // cvec order, {W_in[ch][0], W_in[ch][1], W_in[ch][2], 0}
@@ -129,4 +130,5 @@ struct dfx_denoiser {
   const float *const *wptrs_dev = nullptr;  // device array [depth][7] = {wq, wk^T (static columns), wv^T, wo^T, g2, be2, Wq be2}
   float *host_tables = nullptr;             // [8][T] fp32, order of dfx_denoiser_get_tables
   double *host_ac_pv = nullptr;             // [2][T] float64: alphas_cumprod, posterior_variance (DDIM coefficients per call)
+  float w1_fold_ratio = 0.f;                // bf16: max_r |W1'[r][127]| / mean_c |W1'[r][c]| over the blocks (what decided dev.w1_fold)
 };

@@ -392,12 +392,12 @@ __device__ __forceinline__ v16f mma_hid(const uint4 &w, const uint4 &hid, v16f a
 //   a = W1a xn + b1a; g = W1g xn + b1g; hid = a * gelu(g); h += W2[:, chunk] hid.  Hidden stays in registers.
 template <int PREC>
 __device__ __forceinline__ void ff_chunk(v16f (&h)[4], const Act<PREC> (&xn)[4], const uint4 *ck, const uint4 *ck2,
-                                         const float *b1) {
+                                         const float *b1, bool fold) {
   constexpr int TSTRIDE = tile_units(PREC) * 64;
   v16f a, g;
-  if (PREC == DFX_PREC_BF16) {
+  if (PREC == DFX_PREC_BF16 && fold) {
     a = zero16(), g = zero16();   // b1' rides on the constant-one K slot (bias_slot_one)
-  } else {
+  } else {                        // fp32, and bf16 engines whose weights ruled the fold out (DenoiserDev::w1_fold = 0): plain W1', b1' initialisers
     load16(a, b1);
     load16(g, b1 + 32);
   }
@@ -812,11 +812,12 @@ __global__ void __launch_bounds__(NW * 64) k_denoise(const KParams p) {
                       bp.ct + (size_t)t * CT_ROW + hf * 64, vmask);
       Act<PREC> xn[4];
       ln_to_act<PREC>(h, xn);
-      bias_slot_one(xn, hf);
+      const bool fold = p.d.w1_fold != 0;   // (wave-uniform)
+      if (fold) bias_slot_one(xn, hf);
 #pragma unroll 1
       for (int u = 0; u < FF_CHUNKS; ++u)
         ff_chunk<PREC>(h, xn, bp.chunks + (size_t)u * CHUNK_TILES * TSTRIDE + lane,
-                       bp.chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16);
+                       bp.chunks + (size_t)(u + FF_SKEW) * CHUNK_TILES * TSTRIDE + lane, bp.bconst + u * 64 + hf * 16, fold);
       add_cvec(h, bp.bconst + BCONST_B2_OFF + hf * 64);
     }
     float eps[3];
@@ -2604,7 +2605,9 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     auto f = [](double L) { return 1.0 + 0.36 * L * L * L * L; };
     return base * (full * f(g_num_cus * fill_per_wg) + (rest ? f(rest * fill_per_wg) : 0.0));
   };
-  const bool bf16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct;
+  // (a bf16 engine without the W1 bias fold — DenoiserDev::w1_fold = 0, decided at create from its weights — has the plain pack, which only
+  // the direct kernel reads: the pipelined / co-operative kernels take b1' from channel 127's K slot)
+  const bool bf16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && d->dev.w1_fold;
   const bool f32 = d->dev.prec == DFX_PREC_F32 && !g_force_direct;
   int nw = PIPE_NW;
   double best = 1e300;

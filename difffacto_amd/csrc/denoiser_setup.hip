@@ -24,6 +24,9 @@ using namespace dfx;
 
 namespace {
 
+int g_w1_fold_mode = -1;                       // dfx_debug_w1_fold: -1 = decide per engine from its weights, 0 = never, 1 = always
+constexpr float W1_FOLD_MAX_RATIO = 8.0f;      // (random-init and unit-gamma weights: ~1-3; the fold's extra rounding scales with the ratio)
+
 // ---------------------------------------------------------------------------------------------
 // small fp32 helper kernels (setup only: one thread per output, no tuning)
 
@@ -89,7 +92,7 @@ __device__ __forceinline__ void tile_store(void *dst, long long gi, float v) {
 // W1 (1024 x 128) with norm3.weight folded in -> tiles part*4+c of chunk record u
 template <int PREC>
 __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict__ g3, void *__restrict__ dst, const float *__restrict__ b1,
-                          const float *__restrict__ be3) {
+                          const float *__restrict__ be3, int fold) {
   const long long gi = blockIdx.x * 256LL + threadIdx.x;
   if (gi >= (long long)FF_CHUNKS * 2 * 4 * 1024) return;
   const int tile = (int)(gi >> 10);
@@ -102,7 +105,7 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   // bf16 path (denoiser_kernel.hip: bias_slot_one): the normalised row sums to zero, so channel 127 is redundant (xhat_127 = - sum of the
   // others): its K slot carries the constant 1 and the weight there is b1' = b1 + W1 beta3, every other weight has W1'[.][127] subtracted.
   // Exact in real arithmetic; GEMM1 then needs no accumulator initialisers.
-  if (PREC == DFX_PREC_BF16) {
+  if (PREC == DFX_PREC_BF16 && fold) {
     const float w127 = W1[(size_t)row * INNER + 127] * g3[127];
     float v;
     if (col == 127) {
@@ -116,6 +119,24 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
     return;
   }
   tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col] * sc);
+}
+
+// How much coarser the fold makes a row of W1' = W1 diag(gamma3): every weight of row r becomes W1'[r][c] - W1'[r][127], so its bf16 rounding
+// step follows |W1'[r][127]| instead of |W1'[r][c]|.  out[0] = max over the rows of |W1'[r][127]| / mean_c |W1'[r][c]| (1 for weights of one
+// scale; a LayerNorm outlier gamma3[127] shows up as itself).  One workgroup of 1024 threads = one row each.
+__global__ void __launch_bounds__(1024) k_w1_fold_ratio(const float *__restrict__ W1, const float *__restrict__ g3, float *__restrict__ out) {
+  __shared__ float red[1024];
+  const int row = threadIdx.x;
+  float s = 0.f;
+  for (int c = 0; c < INNER - 1; ++c) s += fabsf(W1[(size_t)row * INNER + c] * g3[c]);
+  const float w127 = fabsf(W1[(size_t)row * INNER + 127] * g3[127]);
+  red[row] = w127 / fmaxf(s / (INNER - 1), 1e-30f);
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if (row < k) red[row] = fmaxf(red[row], red[row + k]);
+    __syncthreads();
+  }
+  if (row == 0) out[0] = red[0];
 }
 
 // b1' = b1 + W1 beta3, stored [u][part][hf][16]
@@ -519,6 +540,25 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     d->dev.bout[3] = 0.f;
   }
 
+  // ---- bf16: may b1' ride in channel 127's K slot of W1 (k_pack_w1)?  The fold costs precision in proportion to |W1'[., 127]|:
+  // taken unless a block's column 127 is an outlier of its row (threshold W1_FOLD_MAX_RATIO) or dfx_debug_w1_fold() says otherwise; without
+  // it the engine runs the direct kernel with the plain pack and fp32 accumulator initialisers (slower, same arithmetic as the fp32 form) ----
+  int w1_fold = 0;
+  d->w1_fold_ratio = 0.f;
+  if (precision == DFX_PREC_BF16) {
+    static_assert(FF_HID * 2 == 1024, "k_w1_fold_ratio: one thread per row of W1");
+    std::vector<float> ratio(depth, 0.f);
+    for (int b = 0; b < depth; ++b) {
+      k_w1_fold_ratio<<<1, 1024, 0, st>>>(w->blk[b].ff0_w, w->blk[b].norm3_w, cv.y + b);
+      TRY_LAUNCH("w1_fold_ratio");
+    }
+    TRY_HIP(hipMemcpyAsync(ratio.data(), cv.y, sizeof(float) * depth, hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < depth; ++b) d->w1_fold_ratio = std::max(d->w1_fold_ratio, ratio[b]);
+    w1_fold = g_w1_fold_mode < 0 ? (d->w1_fold_ratio <= W1_FOLD_MAX_RATIO) : g_w1_fold_mode;
+  }
+  d->dev.w1_fold = w1_fold;
+
   // ---- per block ----
   std::vector<const float *> wptrs((size_t)DFX_MAX_DEPTH * 7, nullptr);
   for (int b = 0; b < depth; ++b) {
@@ -551,10 +591,10 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
                                                         precision == DFX_PREC_BF16 ? FF_G_SCALE : 1.0f);
     TRY_LAUNCH("pack_b1");
     if (precision == DFX_PREC_BF16) {
-      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b);
+      k_pack_w1<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b, w1_fold);
       k_pack_w2<DFX_PREC_BF16><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     } else {
-      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b);
+      k_pack_w1<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 8 * 1024), 256, 0, st>>>(k.ff0_w, k.norm3_w, c.chunks, k.ff0_b, k.norm3_b, 0);
       k_pack_w2<DFX_PREC_F32><<<nblk((long long)FF_CHUNKS * 4 * 1024), 256, 0, st>>>(k.ff2_w, c.chunks);
     }
     TRY_LAUNCH("pack_w1w2");
@@ -604,6 +644,11 @@ void dfx_denoiser_destroy(dfx_denoiser *d) {
 
 int dfx_denoiser_num_timesteps(const dfx_denoiser *d) { return d ? d->dev.T : 0; }
 int dfx_denoiser_precision(const dfx_denoiser *d) { return d ? d->dev.prec : -1; }
+int dfx_denoiser_w1_fold(const dfx_denoiser *d, float *ratio) {
+  if (d && ratio) *ratio = d->w1_fold_ratio;
+  return d ? d->dev.w1_fold : -1;
+}
+void dfx_debug_w1_fold(int mode) { g_w1_fold_mode = mode < 0 ? -1 : mode != 0; }
 
 int dfx_denoiser_get_tables(const dfx_denoiser *d, float *host_out) {
   DFX_REQUIRE(d && host_out, "get_tables: null argument");

@@ -67,6 +67,9 @@ inline hipError_t set_max_lds(const void *kernel, int bytes) {
 struct SideStream {
   hipStream_t main = nullptr, side = nullptr;
   bool on = false;
+  bool pending = false;       // forked and not joined since: the destructor joins (an entry point's early error return must not leave side work
+                              // running against a workspace the caller may free, nor a stream capture with an unjoined fork — ADVICE r4)
+  ~SideStream() { if (on && pending) (void)join(); }
   // `enable` false: every launch "on the side stream" goes to the caller's stream (side == main, fork / join do nothing)
   int open(hipStream_t caller, bool enable);
   int fork();                 // the side stream waits for everything enqueued on the caller's stream so far

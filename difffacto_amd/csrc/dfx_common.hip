@@ -86,11 +86,13 @@ int SideStream::fork() {
   hipEvent_t e = next_event(dev_side());
   DFX_HIP_TRY(hipEventRecord(e, main));
   DFX_HIP_TRY(hipStreamWaitEvent(side, e, 0));
+  pending = true;
   return DFX_OK;
 }
 int SideStream::join() {
   if (!on) return DFX_OK;
   hipEvent_t e = next_event(dev_side());
+  pending = false;
   DFX_HIP_TRY(hipEventRecord(e, side));
   DFX_HIP_TRY(hipStreamWaitEvent(main, e, 0));
   return DFX_OK;
@@ -98,7 +100,79 @@ int SideStream::join() {
 
 }  // namespace dfx
 
+// ---- box calibration (bench.py's `roofline.box_bare_mfma_tflops`): a bare stream of v_mfma_f32_32x32x16_bf16 with pseudo-random operands, one
+// wavefront per SIMD on every CU, four independent accumulators (back-to-back issue), nothing else — what THIS chip sustains on the matrix pipe at
+// its power cap and clocks right now (tools/ubench/pair_issue.hip's first row, inside the library so that the driver's bench line can normalise
+// itself: boxes of this pool differ by several percent) ----
+namespace dfx {
+typedef float cal_v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 cal_v8bf __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256, 1) k_bare_mfma(float *out, int iters) {
+  auto frag = [](unsigned seed) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h = (seed + 0x9E3779B9u * (i + 1)) * 2654435761u;
+      h ^= h >> 15;
+      w[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 9) & 0x00800080u);   // two bf16 of magnitude 0.5 .. 2, random sign and mantissa
+    }
+    return __builtin_bit_cast(cal_v8bf, w);
+  };
+  const unsigned tid = threadIdx.x + 256u * blockIdx.x;
+  const cal_v8bf a0 = frag(tid * 8 + 0), a1 = frag(tid * 8 + 1), a2 = frag(tid * 8 + 2), a3 = frag(tid * 8 + 3);
+  const cal_v8bf b0 = frag(tid * 8 + 4), b1 = frag(tid * 8 + 5);
+  cal_v16f c0, c1, c2, c3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c3, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+  if (s == 12345.678f) out[0] = s;   // (keeps the accumulators alive)
+}
+}  // namespace dfx
+
 extern "C" {
+
+int dfx_debug_bare_mfma(int iters, float *ms_out, double *tflops_out, dfx_stream_t stream) {
+  DFX_REQUIRE(iters > 0 && ms_out && tflops_out, "debug_bare_mfma: bad argument");
+  hipStream_t st = dfx::as_stream(stream);
+  int dev = 0, cus = 0;
+  DFX_HIP_TRY(hipGetDevice(&dev));
+  DFX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  float *scratch = nullptr;
+  DFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), 256));
+  hipEvent_t a, b;
+  DFX_HIP_TRY(hipEventCreate(&a));
+  DFX_HIP_TRY(hipEventCreate(&b));
+  dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, 16);   // code load
+  (void)hipEventRecord(a, st);
+  dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, iters);
+  (void)hipEventRecord(b, st);
+  const hipError_t e = hipEventSynchronize(b);
+  float ms = -1.f;
+  if (e == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(scratch);
+  if (e != hipSuccess || ms <= 0.f) return dfx::set_error(DFX_ERR_HIP, "debug_bare_mfma: %s", hipGetErrorString(e));
+  *ms_out = ms;
+  *tflops_out = (double)cus * 4.0 * iters * 16.0 * 32768.0 / (ms * 1e-3) / 1e12;   // executed MFMA flops: 2 x 32 x 32 x 16 each
+  return DFX_OK;
+}
 
 int dfx_version(void) { return 100; }
 int dfx_abi_version(void) { return DFX_ABI_VERSION; }

@@ -125,6 +125,12 @@ class DenoiserEngine:
         except Exception:
             pass
 
+    def w1_fold(self):
+        """(folded, ratio): whether this bf16 engine carries b1' in channel 127's K slot of the packed W1 (``dfx_denoiser_w1_fold``) and the
+        outlier ratio max_r |W1[r,127] gamma3[127]| / mean_c |W1[r,c] gamma3[c]| that decided it (> 8: plain pack, direct kernel)."""
+        r = ctypes.c_float(0.0)
+        return bool(_ffi.lib().dfx_denoiser_w1_fold(self._h, ctypes.byref(r))), float(r.value)
+
     # ------------------------------------------------------------------------------------------
     def tables(self):
         """The fp32 schedule tables the kernels use, dict name -> (T,) numpy."""

@@ -143,6 +143,11 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int n
 void dfx_denoiser_destroy(dfx_denoiser *d);
 int dfx_denoiser_num_timesteps(const dfx_denoiser *d);
 int dfx_denoiser_precision(const dfx_denoiser *d);
+/* DFX_PREC_BF16 engines: 1 if b1' = b1 + W1 beta3 rides in channel 127's K slot of the packed W1 (no accumulator initialisers in the chain
+ * kernels; exact in real arithmetic, and it rounds every weight of a row with a step that follows |W1[r][127] gamma3[127]|), 0 if the engine
+ * was created with the plain pack because that column is an outlier (ratio > 8 of the row's mean magnitude) — it then runs the direct kernel
+ * (same results as before the fold existed, ~3x slower).  *ratio (may be NULL) receives the measured ratio.  fp32 engines: 0. */
+int dfx_denoiser_w1_fold(const dfx_denoiser *d, float *ratio);
 
 /* Copies the 8 fp32 schedule tables the kernels use to HOST memory, each `num_timesteps` long, in the
  * order: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, _coef2, _coef3,

@@ -46,7 +46,14 @@ int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *
                         const float *resid, float *C, float *db, float *workspace, size_t workspace_floats, int M, int N, int K,
                         dfx_stream_t stream);
 /* Debug/A-B switch: force the direct (non LDS-pipelined) kernel for every launch. */
+/* Box calibration for bench.py: a bare v_mfma_f32_32x32x16_bf16 stream (one wavefront per SIMD on every CU, pseudo-random operands, nothing
+ * else) of `iters` x 16 MFMAs per wavefront; *ms_out = HIP-event duration, *tflops_out = executed MFMA TFLOP/s — what this chip sustains on the
+ * matrix pipe at its power cap and clocks (iters = 150000 runs ~50 ms).  Synchronises `stream`. */
+int dfx_debug_bare_mfma(int iters, float *ms_out, double *tflops_out, dfx_stream_t stream);
 void dfx_debug_force_direct(int on);
+/* dfx_denoiser_create's decision about the W1 bias fold of bf16 engines (dfx_denoiser_w1_fold): -1 = from the weights (default),
+ * 0 = never, 1 = always.  Applies to engines created afterwards. */
+void dfx_debug_w1_fold(int mode);
 /* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
  * 32-point tile per workgroup, eight wavefronts on it; for an fp32 denoiser: the direct kernel), or 64 = k_denoise_pipe2 (bf16 only:
  * four wavefronts of two 32-point tiles each; when its 256-point workgroup tiles would pad a shape by more than 3x —

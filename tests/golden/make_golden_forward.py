@@ -12,7 +12,8 @@ encoder_fwd_B3_N96.npz        PartEncoder.forward with the part aligner (part_en
                               that the prior loss is exercised) and sample_noise (:388-414)
 train_loop_B3_N64_T10.npz     three iterations of the reference's training loop on the denoiser (runner/runner.py:299-316: zero_grad,
                               training_losses, backward, clip_grad_norm_(10), Adam.step, LinearLR.step), dropout 0, fp32: per-iteration
-                              loss, gradient norm, learning rate and parameter checksums / samples
+                              loss, gradient norm, learning rate, parameter checksums and 256 sampled elements per parameter
+                              (values after the step + the clipped gradient the step consumed)
 
 Every torch.randn / torch.randn_like the reference executes is served from a numpy PCG64 stream and RECORDED in call order
 ("draw_{i}"); the tests replay the draws at the same sites of the mirror (the T + 1 chain draws are handed to decode as explicit
@@ -184,6 +185,7 @@ def gen_train_loop(tag, B=3, N=64, T=10, seed=121, iters=3):
     sample_idx = {n: np.sort(srng.choice(p.numel(), size=min(256, p.numel()), replace=False)).astype(np.int64) for n, p in net.named_parameters()}
     out = {"x_start": [], "noise": [], "t": [], "loss": [], "grad_norm": [], "lr": [], "param_sum": [], "param_l2": []}
     samples = {n: [] for n in names}
+    gsamples = {n: [] for n in names}
     for it in range(iters):
         x0 = (np.sqrt(variance.numpy()) * rng.standard_normal((B, 3, N)).astype(F32) * 0.5 + anchors.numpy()).astype(F32)
         noise = rng.standard_normal((B, 3, N)).astype(F32)
@@ -194,6 +196,8 @@ def gen_train_loop(tag, B=3, N=64, T=10, seed=121, iters=3):
         loss = r["mse_loss"]
         loss.backward()
         gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 10)
+        for n, p in net.named_parameters():     # the (clipped) gradient Adam consumes, at the sampled positions
+            gsamples[n].append(p.grad.reshape(-1)[torch.from_numpy(sample_idx[n])].numpy().astype(F32))
         out["lr"].append(opt.param_groups[0]["lr"])
         opt.step()
         sched.step()
@@ -208,15 +212,17 @@ def gen_train_loop(tag, B=3, N=64, T=10, seed=121, iters=3):
     arrays = {k: np.stack(v) if k in ("x_start", "noise", "t") else np.array(v, np.float64) for k, v in out.items()}
     np.savez_compressed(os.path.join(HERE, f"train_loop_{tag}.npz"), part_code=case[0], mean=case[1], logvar=case[2], valid=case[3], seg=case[4],
                         weight_seed=np.array(0), iters=np.array(iters), max_norm=np.array(10.0), sched=np.array([0, 2, 2e-3, 1e-4], np.float64),
-                        **arrays, **{"pi/" + n: sample_idx[n] for n in names}, **{"ps/" + n: np.stack(samples[n]) for n in names})
+                        **arrays, **{"pi/" + n: sample_idx[n] for n in names}, **{"ps/" + n: np.stack(samples[n]) for n in names},
+                        **{"pg/" + n: np.stack(gsamples[n]) for n in names})
     print(f"wrote train_loop_{tag}: loss", out["loss"], "grad_norm", out["grad_norm"], "lr", out["lr"])
 
 
 def main():
     torch.manual_seed(0)
-    gen_forward("gen_B2_K2_T10", gen=True)
-    gen_forward("sample_B2_K2_T10", gen=False, seed=131)
-    gen_encoder_forward("B3_N96")
+    if "--only-train-loop" not in sys.argv:
+        gen_forward("gen_B2_K2_T10", gen=True)
+        gen_forward("sample_B2_K2_T10", gen=False, seed=131)
+        gen_encoder_forward("B3_N96")
     gen_train_loop("B3_N64_T10")
 
 

@@ -466,3 +466,44 @@ def test_f32_pipelined_chain_is_bit_identical_to_the_direct_kernel(W, N):
     for k in (8, 4, 2, "auto"):
         for i, (x, y) in enumerate(zip(flat(out[k]), ref)):
             assert torch.equal(x, y), (k, i, (x - y).abs().max().item())
+
+
+def test_w1_bias_fold_backs_off_on_an_outlier_channel_and_is_selectable(W):
+    """the bf16 pack carries b1' in channel 127's K slot of W1 and subtracts W1[., 127] gamma3[127] from every other column — exact in
+    real arithmetic, but every weight of a row then rounds with a step that follows that column.  dfx_denoiser_create measures the column
+    (dfx_denoiser_w1_fold) and keeps the plain pack + fp32 accumulator initialisers (direct kernel) when it is an outlier; dfx_debug_w1_fold
+    forces either form.  Checked against the exact fp32 engine on the N = 2048 golden inputs:
+      * synthetic weights: folded by default (ratio ~1-3), forced-plain agrees with fp32 within the bf16 gate as well;
+      * gamma3[127] of block 2 times 64: NOT folded, error within the same gate; forcing the fold on those weights is measurably worse."""
+    from difffacto_amd import _ffi
+    from difffacto_amd.engine import last_kernel_variant
+    g = np.load(os.path.join(GOLDEN, "denoiser_eps_B1_N2048.npz"))
+    x, seg, t = torch.from_numpy(g["x"]), torch.from_numpy(g["seg"]), int(g["ts"][0])
+
+    def err(Wx, mode):
+        _ffi.lib().dfx_debug_w1_fold(mode)
+        try:
+            eb = _engine(Wx, 10, "bf16")
+        finally:
+            _ffi.lib().dfx_debug_w1_fold(-1)
+        ef = _engine(Wx, 10, "f32")
+        out = eb.eps(_prep(eb, g), x, seg, t).cpu().numpy()
+        variant = last_kernel_variant()
+        ref = ef.eps(_prep(ef, g), x, seg, t).cpu().numpy()
+        return float(np.abs(out - ref).max()), eb.w1_fold(), variant, float(np.abs(ref).max())
+
+    e_def, (folded, ratio), variant, scale = err(W, -1)
+    assert folded and ratio < 8 and "pipe" in variant, (folded, ratio, variant)
+    e_plain, (folded_p, _), variant_p, _ = err(W, 0)
+    assert not folded_p and variant_p == "k_denoise<bf16>"
+    assert e_def <= TOL_BF16_EPS and e_plain <= TOL_BF16_EPS, (e_def, e_plain)
+    Wo = {k: v.copy() for k, v in W.items()}
+    Wo["transformer_blocks.2.norm3.weight"][127] *= 64.0
+    e_auto, (folded_o, ratio_o), variant_o, scale_o = err(Wo, -1)
+    assert not folded_o and ratio_o > 8 and variant_o == "k_denoise<bf16>", (folded_o, ratio_o, variant_o)
+    e_forced, (folded_f, _), _, _ = err(Wo, 1)
+    assert folded_f
+    print(f"W1 bias fold: synthetic weights ratio {ratio:.2f}: folded {e_def:.2e} / plain {e_plain:.2e} (|eps| {scale:.2f}); "
+          f"gamma3[127] x 64 (ratio {ratio_o:.1f}): auto = plain {e_auto:.2e}, forced fold {e_forced:.2e} (|eps| {scale_o:.2f})")
+    assert e_auto <= TOL_BF16_EPS * max(1.0, scale_o / scale), e_auto
+    assert e_forced > e_auto
