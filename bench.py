@@ -101,11 +101,18 @@ class BoxSampler:
         import threading
         self.period, self.samples, self._stop = period_s, [], threading.Event()
         self.files = {}
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = []
+        try:   # the hwmon directory of THIS HIP device (a box exposes all eight cards in sysfs, one of them to the process): by PCI address
+            pr = torch.cuda.get_device_properties(device_index)
+            cards = glob.glob("/sys/bus/pci/devices/%04x:%02x:%02x.0/hwmon/hwmon*" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        except Exception:   # noqa: BLE001
+            pass
+        if not cards:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
         cards = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
         if cards:
-            h = cards[min(device_index, len(cards) - 1)]
-            for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)), ("temp_mc", ("temp1_input",))):
+            h = cards[0] if len(cards) == 1 else cards[min(device_index, len(cards) - 1)]
+            for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)), ("temp_mc", ("temp2_input", "temp1_input"))):
                 for n in names:
                     if os.path.exists(os.path.join(h, n)):
                         self.files[key] = os.path.join(h, n)
@@ -239,21 +246,31 @@ def train_iteration(Wnp, B, N, iters=10):
         noise = cu(rng.standard_normal((B, 3, N)).astype(np.float32))
         opt = training.Adam(list(P.values()), lr=1e-4, max_norm=10.0)
 
-        def it():
+        step = [0]
+
+        def it(p=0.0):
             opt.zero_grad()
-            training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16"), None).backward()
+            step[0] += 1
+            drop = (p, 7000 + step[0]) if p > 0 else None     # a fresh Philox key per step, like the module API draws one (modules.TransformerNet._forward_train)
+            training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16", dropout=drop), None).backward()
             opt.step()
 
-        for _ in range(3):   # (the block runs behind the chain sweeps: three warm-ups and ten timed iterations keep a 20 ms sample's noise out of the line)
-            it()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            it()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / iters * 1e3
+        def timed(p):
+            for _ in range(3):   # (the block runs behind the chain sweeps: three warm-ups and ten timed iterations keep a 20 ms sample's noise out of the line)
+                it(p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                it(p)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters * 1e3
+
+        ms = timed(0.0)
+        ms_p02 = timed(0.2)    # configs/train_chair_stage1.py:38 as shipped: nn.Dropout(0.2) behind every to_out and GEGLU, in the fused kernels (k_ff<*, true>)
         out = {"what": "denoiser forward + backward + clip + Adam, bf16 matrix products, fp32 master weights (tools/bench_train.py)",
-               "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters}
+               "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters, "dropout": 0.0,
+               "dropout_0.2": {"ms": ms_p02, "shapes_per_s": B / ms_p02 * 1e3, "vs_dropout_0": ms_p02 / ms,
+                               "what": "the same iteration with the shipped dropout = 0.2 (Philox factors drawn in the fused forward kernel, one bit per element kept for the backward kernels)"}}
         del P, a, noise, opt
         torch.cuda.empty_cache()
         out["stage1"] = stage1_iteration(B, N, iters)
@@ -261,12 +278,13 @@ def train_iteration(Wnp, B, N, iters=10):
         # BASELINE configs[4] is a bf16 configuration: the same step with bf16 operands for the PointNetV2 trunk's products as well
         # (module.train_precision = "bf16"; the default keeps the encoder in exact fp32)
         out["stage1"]["encoder_bf16_ms"] = stage1_iteration(B, N, iters, encoder_precision="bf16")["ms"]
+        out["stage1"]["dropout_0.2_ms"] = stage1_iteration(B, N, iters, dropout=0.2)["ms"]   # the configuration as shipped
         return out
     except Exception as e:   # secondary line: never fail the headline measurement
         return {"error": repr(e)[:200]}
 
 
-def stage1_iteration(B, N, iters=16, encoder_precision="f32"):
+def stage1_iteration(B, N, iters=16, encoder_precision="f32", dropout=0.0):
     """The whole stage-1 training iteration of configs/train_chair_stage1.py (PointNetV2 part encoder in train mode + prior loss
     through the latent flows + denoiser + clip + Adam) through the drop-in modules (examples/train_stage1.py)."""
     import numpy as np
@@ -277,7 +295,7 @@ def stage1_iteration(B, N, iters=16, encoder_precision="f32"):
     enc = PartEncoderForTransformerDecoder(encoder=dict(type="PointNetV2", zdim=256, per_part_mlp=True), n_class=4, part_aligner=None,
                                            include_z=False, include_part_code=True, include_params=True, use_gt_params=True, kl_weight=5e-4,
                                            use_flow=True, latent_flow_depth=14, latent_flow_hidden_dim=256, gen=True, prior_var=1.0)
-    net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=0.0, context_dim=256 + 6,
+    net = dict(type='TransformerNet', in_channels=3, out_channels=3, n_heads=8, d_head=16, depth=5, dropout=dropout, context_dim=256 + 6,
                n_class=4, class_cond=True, use_linear=True, cat_params_to_x=True, use_checkpoint=False, single_attn=True, cat_class_to_x=True)
     diff = AnchoredDiffusion(net=net, num_timesteps=1000, beta_1=1e-4, beta_T=.02, k=1.0, res=False, mode='linear', use_beta=False,
                              rescale_timesteps=False, model_mean_type="epsilon", learn_variance=True, loss_type='mse', include_anchors=False,

@@ -30,6 +30,7 @@
 // form as the direct sampling kernel) and its exact derivative  s + g s (1 - s) (c1 + 3 c3 g^2).
 #pragma once
 #include "dfx_common.h"
+#include "dfx_dropout.h"
 
 namespace dfx {
 namespace ffused {
@@ -60,6 +61,8 @@ struct PackArgs {
   uint4 *frags;      // [NCHUNK][TILES][2][64]
   float *b1p;        // [NCHUNK][2 parts][2 hf][16]
   float *b2p;        // [2 hf][4 c][16]
+  float keep_a;      // dropout behind the GEGLU (attention.py:84): its scale 1 / (1 - p) rides on the `a` half of W1 / b1 (hid = a gelu(g) is linear in a),
+                     // i.e. on the tiles W1a, W1a^T and b1a; 1 when dropout is off.  The kernels then only SELECT (k_ff_wgrad_finish scales dW1a, db1a back)
 };
 
 struct PackBatch {
@@ -72,7 +75,7 @@ __global__ void k_ff_pack(PackBatch batch) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < NCHUNK * 2 * 2 * 16) {   // b1p
     const int r = idx & 15, hf = (idx >> 4) & 1, p = (idx >> 5) & 1, j = idx >> 6;
-    a.b1p[idx] = a.b1[p * FH + 32 * j + rho(r, hf)];
+    a.b1p[idx] = a.b1[p * FH + 32 * j + rho(r, hf)] * (p == 0 ? a.keep_a : 1.0f);
   }
   if (idx < 2 * 4 * 16) {
     const int r = idx & 15, c = (idx >> 4) & 3, hf = idx >> 6;
@@ -87,7 +90,7 @@ __global__ void k_ff_pack(PackBatch batch) {
     float x;
     if (t < T_W2) {                      // W1a / W1g, k-tile c, natural K
       const int p = t >> 2, c = t & 3;
-      x = a.w1[(size_t)(p * FH + 32 * j + i) * C + 32 * c + k_nat(u, hf, e)];
+      x = a.w1[(size_t)(p * FH + 32 * j + i) * C + 32 * c + k_nat(u, hf, e)] * (p == 0 ? a.keep_a : 1.0f);
     } else if (t < T_W2T) {              // W2 row tile ct, K = hidden units in register order
       const int ct = t - T_W2;
       x = a.w2[(size_t)(32 * ct + i) * FH + 32 * j + k_reg(u, hf, e)];
@@ -96,7 +99,7 @@ __global__ void k_ff_pack(PackBatch batch) {
       x = a.w2[(size_t)(32 * c + k_nat(u, hf, e)) * FH + 32 * j + i];
     } else {                             // W1a^T / W1g^T: rows = channels 32 ct + i, K = hidden units in register order
       const int p = (t - T_W1AT) >> 2, ct = (t - T_W1AT) & 3;
-      x = a.w1[(size_t)(p * FH + 32 * j + k_reg(u, hf, e)) * C + 32 * ct + i];
+      x = a.w1[(size_t)(p * FH + 32 * j + k_reg(u, hf, e)) * C + 32 * ct + i] * (p == 0 ? a.keep_a : 1.0f);
     }
     v[e] = (__bf16)x;
   }
@@ -132,10 +135,52 @@ struct FfArgs {
   unsigned tiled;          // TL_* bits
   uint4 *pk2;              // with at_frags: [R / 32][2][4][2][64] the tile's xn2 and dh1 as bf16 fragments for k_attn_bwd_param (which
                            // needs nothing else of them); dh1 itself is then not written
+  // dropout (k_ff<*, true>; dfx_dropout.h): the step's key, this block's two sites and ONE BIT per element of the two dropped tensors.
+  // The forward draws the factors and leaves the bits; the backward kernels read them (k_ff_wgrad needs them in the transposed orientation,
+  // where a regeneration would cost four Philox calls per group).  dmask [R / 32][DM_WORDS][64 lanes]: word w < 8, half h = hidden chunk 2 w + h,
+  // bit r of the half = register r of the chunk's accumulator (unit 32 j + rho(r, hf) of point pj); words 8, 9 = the to_out site, half h =
+  // channel tile 2 (w - 8) + h.  The GEGLU site's scale rides on W1a (PackArgs::keep_a); the to_out site's is applied here (dk.keep).
+  DropKey dk;
+  unsigned site_att, site_ff;
+  unsigned *dmask;
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
 };
+constexpr int DM_WORDS = 10, DM_TILE = DM_WORDS * 64;   // dwords per 32-point tile (2.5 KiB)
+
+// The factors of 4 x 8 consecutive elements of one row — groups g8 .. g8 + 3 — for the two half-waves of a point together: lane (pj, hf) holds elements
+// 4 hf .. 4 hf + 3 of every group (accumulator layout: register 4 q + m = element 8 q + 4 hf + m), so the pair computes each group ONCE (half hf
+// takes groups hf and hf + 2) and trades the halves with four v_permlane32_swap.  w[q] = the two words (4 draws) of this lane's elements of group q.
+__device__ __forceinline__ void drop_words(const DropKey &k, unsigned site, unsigned long long g8, int hf, unsigned (&w)[4][2]) {
+  uint4 A = drop_group(k, site, g8 + hf), B = drop_group(k, site, g8 + hf + 2);
+  auto swap = [](unsigned &lo, unsigned &hi) {   // -> lo = [lo of the low half-wave | hi of the low half-wave], hi = [lo of the high | hi of the high]
+    const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+    lo = r[0], hi = r[1];
+  };
+  swap(A.x, A.z), swap(A.y, A.w), swap(B.x, B.z), swap(B.y, B.w);
+  w[0][0] = A.x, w[0][1] = A.y, w[1][0] = A.z, w[1][1] = A.w;
+  w[2][0] = B.x, w[2][1] = B.y, w[3][0] = B.z, w[3][1] = B.w;
+}
+// select in place + the 16 keep bits (bit r = register r)
+__device__ __forceinline__ unsigned drop_apply(v16f &v, const unsigned (&w)[4][2], unsigned thr) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const unsigned word = w[q][m >> 1];
+      const bool keep = (m & 1) ? drop_keep_hi(word, thr) : drop_keep_lo(word, thr);
+      v[4 * q + m] = keep ? v[4 * q + m] : 0.f;
+      bits |= keep ? 1u << (4 * q + m) : 0u;
+    }
+  return bits;
+}
+// the same selection from stored bits (bit r of `bits`)
+__device__ __forceinline__ void drop_select(v16f &v, unsigned bits) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = (bits >> r) & 1u ? v[r] : 0.f;
+}
 
 // fragment sets of the folded attention per shape (written by afused::k_attn_fold): tile t (4), unit u (2), lane (64) uint4 each
 enum { F_AS = 0, F_MS = 1, F_MST = 2, F_AST = 3, NSETS = 4 };
@@ -146,6 +191,11 @@ constexpr float LN_EPS = 1e-5f;
 
 __device__ __forceinline__ void dma1k(const void *gbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
+}
+
+// 256 B per wavefront (one dword per lane) through the same path
+__device__ __forceinline__ void dma256(const void *gbase, unsigned voff4, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff4), "s"(gbase), "s"(lds_addr) : "memory");
 }
 
 // Phase stamps of a few workgroups (tools/trace_train_ff.py builds with -DDFX_TRACE_FF; never in the shipped library): wave 0 of the
@@ -499,7 +549,7 @@ constexpr int AT_OFF_BWD = 32768;
 // forward's prologue, ~6 in the backward's and ~45 in its epilogue — 58 % of a backward wavefront's life.  Now: rows first, tables and ring
 // behind them, ONE wait; attention fragments through LDS (LDS-DMA, no registers); the epilogue's second reads as two batches.  Vector-memory
 // operations complete in issue order (loads, stores and LDS-DMA alike), so stores may stay in flight across the counted waits of the loop.
-template <bool BWD>
+template <bool BWD, bool DROP>
 __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   constexpr int NW = nw_of<BWD>();
   static_assert(NW == 4 && NW * 64 == 2 * C && FWD_TILES == BWD_TILES && B1P_FLOATS * 4 == NW * 1024, "table staging below assumes 256 threads");
@@ -528,6 +578,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   v8f x[4][2], xd[4][2];
   load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
   if (BWD) load_rows(a.dh + rowbase, m_dh, xd);
+  // dropout: this tile's bit words (one lane = one point half, the forward's mapping); the backward holds the eight feed-forward words across the loop
+  unsigned *dmk = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE + lane : nullptr;
+  const unsigned long long prow = (unsigned long long)(rowbase / C) + pj;   // this lane's row of the (R, .) tensors
+  unsigned dmw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (BWD && DROP) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dmw[w] = dmk[w * 64];
+  }
   float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
   float *gbs = reinterpret_cast<float *>(ff_smem + TAB_GB3);
   float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
@@ -583,8 +641,32 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     softmax_regs(sim, vmask);
     const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
     rows_to_acc(x, acc);
+    unsigned attw = 0;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
+      if (DROP) {
+        // h1 = hin + dropout(M_s P + b_o)  (attention.py:177: to_out = Sequential(Linear, Dropout)): the sub-block's output in a fresh accumulator,
+        // selected and scaled, then added to the residual; element (row, channel 32 ct + 8 q + 4 hf + m) = group row * 16 + 4 ct + q of the site
+        v16f t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f b = *reinterpret_cast<const v4f *>(gb2 + 2 * C + 32 * ct + 8 * q + 4 * hf);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) t[4 * q + m] = b[m];
+        }
+        t = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, t);
+        t = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, t);
+        unsigned w[4][2];
+        drop_words(a.dk, a.site_att, prow * (C / 8) + 4 * ct, hf, w);
+        const unsigned bits = drop_apply(t, w, a.dk.thr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = fmaf(a.dk.keep, t[r], acc[ct][r]);
+        attw |= bits << (16 * (ct & 1));
+        if (ct & 1) {
+          if (live) dmk[(8 + (ct >> 1)) * 64] = attw;
+          attw = 0;
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4f b = *reinterpret_cast<const v4f *>(gb2 + 2 * C + 32 * ct + 8 * q + 4 * hf);
@@ -593,6 +675,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       }
       acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
       acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
+      }
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -682,6 +765,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       v16f hv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) hv[r] = av[r] * gelu_f(gv[r]);
+      if (DROP) {
+        // dropout behind the GEGLU (attention.py:84): element (row, unit 32 j + 8 q + 4 hf + m) = group row * 64 + 4 j + q of the site; the scale rides on `a`
+        unsigned w[4][2];
+        drop_words(a.dk, a.site_ff, prow * (FH / 8) + 4 * j, hf, w);
+        const unsigned bits = drop_apply(hv, w, a.dk.thr);
+        dmw[0] = (j & 1) ? dmw[0] | (bits << 16) : bits;
+        if ((j & 1) && live) dmk[(j >> 1) * 64] = dmw[0];   // (a store in flight only tightens the counted waits below: operations complete in order)
+      }
       const uint4 h0 = pack8(hv, 0), h1 = pack8(hv, 1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i & 3] = mfma(P[i], (i >> 2) ? h1 : h0, acc[i & 3]);
@@ -727,6 +818,10 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) P[i] = f2(i);
       __builtin_amdgcn_sched_barrier(0);
+      if (DROP) {   // d hid in front of the dropout = selected d hid behind it (the scale rides on `a` and on W1a^T)
+        const unsigned sel = j < 8 ? (j < 4 ? (j < 2 ? dmw[0] : dmw[1]) : (j < 6 ? dmw[2] : dmw[3])) : (j < 12 ? (j < 10 ? dmw[4] : dmw[5]) : (j < 14 ? dmw[6] : dmw[7]));
+        drop_select(dhid, (j & 1) ? sel >> 16 : sel);
+      }
       // ---- GEGLU backward on the registers ----
       v16f da, dg;
 #pragma unroll
@@ -792,6 +887,17 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   v16f xh[4], dv[4];
   load_rows_acc(a.h1 + rowbase, m_h1, xh);
   load_rows_acc(a.dh + rowbase, m_dh, dv);
+  unsigned attw[2] = {0, 0};
+  if (DROP && at) attw[0] = dmk[8 * 64], attw[1] = dmk[9 * 64];   // the to_out site's bits of this tile (same batch of loads)
+  // gradient in front of the to_out dropout = selected, scaled gradient at h1 (channel tile c)
+  auto att_drop = [&](v16f v, int c) {
+    if (DROP) {
+      drop_select(v, attw[c >> 1] >> (16 * (c & 1)));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] *= a.dk.keep;
+    }
+    return v;
+  };
   // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
   // - xhat mean(dy g xhat)), and the column sums of dy xhat / dy over the workgroup's points for d gamma3 / d beta3 ----
   // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
@@ -868,13 +974,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     // this tile's xn2 | dh1 fragments for k_attn_bwd_param: a wave-uniform base (scalar registers) + the lane
     uint4 *pk2p = a.pk2 + (size_t)(rowbase / (32 * C)) * (2 * 8 * 64);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {   // dh1 as the B operand, a channel tile at a time
+    for (int c = 0; c < 4; ++c) {   // dh1 (behind the to_out dropout: what reaches M_s P + b_o) as the B operand, a channel tile at a time
       v8f t8[2];
+      const v16f dvc = att_drop(dv[c], c);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const float lo = dv[c][8 * u + m], hi = dv[c][8 * u + 4 + m];
+          const float lo = dvc[8 * u + m], hi = dvc[8 * u + 4 + m];
           const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi), false, false);
           const unsigned r0 = r[0], r1 = r[1];
           t8[u][m] = __builtin_bit_cast(float, r0);
@@ -977,7 +1084,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       }
       colsum(gx, 3, c);
       colsum(dx, 4, c);
-      colsum(dv[c], 5, c);
+      colsum(att_drop(dv[c], c), 5, c);   // d b_o
     }
   }
   FFT(7);
@@ -1013,6 +1120,8 @@ struct FwArgs {
   float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
   long long ntiles;      // R / 32
   int nslab;
+  const unsigned *dmask; // k_ff_wgrad<true>: the forward's dropout bits (FfArgs::dmask); words 0 .. 7 of a tile (2 KiB) travel with the tile
+  float keep_a;          // 1 / (1 - p): b1a here (the W1a fragments carry it already, PackArgs::keep_a)
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
@@ -1022,6 +1131,8 @@ constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chun
 // is longer than one tile's arithmetic); the consumers turn tile k around (two MFMAs with a 0/1 selection matrix per 32 x 32 tile, exact)
 // into one of two 16 KiB slots while they multiply tile k - 1
 constexpr int WG_RING_A = 0, WG_RING_T = 3 * 16384, WG_RING = 5 * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
+constexpr int WG_MASK = WG_LDS, WG_LDS_DROP = WG_LDS + 3 * 2048;   // dropout: the tiles' bit words (2 KiB each) in a ring of their own, same three slots
+template <bool DROP>
 __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 3 tiles x 32 KiB | 2 x 4 chunks x 6 KiB of hid / da / dg fragments
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1047,13 +1158,17 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
 #pragma unroll
       for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
+      if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront
+        dma256(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + 2) * DM_TILE) + wave * 256, lane * 4, lds0 + WG_MASK + ((k + 2) % 3) * 2048 + wave * 256);
     }
   };
   // top of iteration k: everything requested before iteration k - 1 has landed (loads complete in order; the last iterations request
   // nothing: drain)
   auto arrive = [&](int k) {
-    if (k + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (k + 1 < nt) {
+      if (DROP) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
   uint4 *packs = reinterpret_cast<uint4 *>(fw_smem + WG_RING);
@@ -1077,8 +1192,11 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
         }
     }
-    const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
+    const float ba = a.b1[32 * j + pj] * (DROP ? a.keep_a : 1.0f), bg = a.b1[FH + 32 * j + pj];
     float sa = 0.f, sg = 0.f;
+    // dropout bits in this orientation (unit pj of chunk j on the lane, point 8 q + 4 half + m in register 4 q + m): the forward's lane of that point is
+    // (point, (pj >> 2) & 1), its bit 16 (j & 1) + 4 (pj >> 3) + (pj & 3) of word j >> 1 — four consecutive lanes' words per 16-byte LDS read
+    const int dm_off = (j >> 1) * 64 + 32 * ((pj >> 2) & 1) + 4 * (lane >> 5), dm_bit = 16 * (j & 1) + 4 * (pj >> 3) + (pj & 3);
     for (int k = 0; k <= nt; ++k) {
       if (k < 24) FFT(10);
       arrive(k);   // tile k has landed; everybody is done with tile k - 1's producer half and tile k - 2's consumer half and fragments
@@ -1099,12 +1217,28 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           dv = mfma(tl[(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
         }
       if (k < 12) FFT(14);
+      unsigned keepm[16];
+      if (DROP) {
+        const unsigned *mk = reinterpret_cast<const unsigned *>(fw_smem + WG_MASK + (k % 3) * 2048) + dm_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 mq = *reinterpret_cast<const uint4 *>(mk + 8 * q);
+          const unsigned wq[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            keepm[4 * q + m] = 0u - ((wq[m] >> dm_bit) & 1u);   // all ones = kept
+            const float dvr = dv[4 * q + m];   // (copies: a bit_cast applied to a vector-element expression reads element 0)
+            dv[4 * q + m] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, dvr) & keepm[4 * q + m]);
+          }
+        }
+      }
       v16f hv, da, dg;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float f, d;
         gelu_fd(gv[r], f, d);
-        hv[r] = av[r] * f;
+        const float hr = av[r] * f;
+        hv[r] = DROP ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hr) & keepm[r]) : hr;
         da[r] = dv[r] * f;
         dg[r] = dv[r] * av[r] * d;
         sa += da[r], sg += dg[r];
@@ -1184,6 +1318,7 @@ struct FwFinishArgs {
   const float *part, *bpart;
   float *dw1, *db1, *dw2;   // (1024, 128), (1024), (128, 512)
   int nslab;
+  float keep_a;             // dropout: the `a` half's gradients were accumulated against keep_a a (PackArgs::keep_a): d W1a, d b1a get the factor back; 1 otherwise
 };
 struct FwFinishBatch {   // one launch for all transformer blocks (blockIdx.y): block i's partials wait in block i's own buffers
   FwFinishArgs blk[DFX_MAX_DEPTH];
@@ -1198,12 +1333,12 @@ __global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
     const int lane = idx & 63, r = (idx >> 6) & 15, tile = (idx >> 10) % 12, j = idx / (12 * 1024);
     const int unit = 32 * j + rho(r, lane >> 5), ch = 32 * (tile & 3) + (lane & 31);
     if (tile < 4) a.dw2[(size_t)ch * FH + unit] = t;
-    else a.dw1[(size_t)((tile < 8 ? 0 : FH) + unit) * C + ch] = t;
+    else a.dw1[(size_t)((tile < 8 ? 0 : FH) + unit) * C + ch] = tile < 8 ? t * a.keep_a : t;
   } else if (idx < NT + NCHUNK * 64) {
     const int k = idx - NT, j = k >> 6, p = (k >> 5) & 1, i = k & 31;
     float t = 0.f;
     for (int s = 0; s < a.nslab; ++s) t += a.bpart[(size_t)s * NCHUNK * 64 + k];
-    a.db1[p * FH + 32 * j + i] = t;
+    a.db1[p * FH + 32 * j + i] = p == 0 ? t * a.keep_a : t;
   }
 }
 inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
@@ -1211,18 +1346,21 @@ inline void launch_ff_wgrad_finish(hipStream_t st, const FwFinishBatch &f, int d
   const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
   k_ff_wgrad_finish<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(f);
 }
-inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) {
+template <bool DROP>
+inline int launch_ff_wgrad_t(hipStream_t st, const FwArgs &a) {
+  constexpr int LDS = DROP ? WG_LDS_DROP : WG_LDS;
   static PerDeviceOnce attrs;
-  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_wgrad), WG_LDS); }) != hipSuccess) return -1;
+  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_wgrad<DROP>), LDS); }) != hipSuccess) return -1;
 #ifdef DFX_TRACE_FF
   FwArgs at = a;
   at.trace = ff_trace_buffer();
-  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(at);
+  k_ff_wgrad<DROP><<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, LDS, st>>>(at);
 #else
-  k_ff_wgrad<<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, WG_LDS, st>>>(a);
+  k_ff_wgrad<DROP><<<a.nslab * (NCHUNK / WG_CHUNKS), WG_NW * 64, LDS, st>>>(a);
 #endif
   return 0;
 }
+inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) { return a.dmask ? launch_ff_wgrad_t<true>(st, a) : launch_ff_wgrad_t<false>(st, a); }
 
 inline size_t pack_bytes_frags() { return (size_t)NCHUNK * CHUNK_U4 * sizeof(uint4); }
 
@@ -1232,22 +1370,25 @@ inline void launch_pack(hipStream_t st, const PackBatch &b, int depth) {
 }
 // workgroups of k_ff<*> (= rows of the backward's column-sum partials): one shape per workgroup
 inline long long ff_groups(int B, int N) { return (long long)B * ((N / 32 + NW_BWD - 1) / NW_BWD); }
-template <bool BWD>
-inline int launch_ff(hipStream_t st, const FfArgs &a) {
+template <bool BWD, bool DROP>
+inline int launch_ff_t(hipStream_t st, const FfArgs &a) {
   constexpr int LDS = FF_LDS;
   static PerDeviceOnce attrs;
-  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff<BWD>), LDS); }) != hipSuccess) return -1;
+  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff<BWD, DROP>), LDS); }) != hipSuccess) return -1;
   constexpr int NW = nw_of<BWD>();
   const long long groups = ff_groups(a.B, a.N);
 #ifdef DFX_TRACE_FF
   FfArgs at = a;
   at.trace = ff_trace_buffer();
-  k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(at);
+  k_ff<BWD, DROP><<<(int)groups, NW * 64, LDS, st>>>(at);
 #else
-  k_ff<BWD><<<(int)groups, NW * 64, LDS, st>>>(a);
+  k_ff<BWD, DROP><<<(int)groups, NW * 64, LDS, st>>>(a);
 #endif
   return 0;
 }
+// dropout (FfArgs::dmask set) takes the DROP instantiations; the p = 0 kernels are the ones of round 4, untouched
+template <bool BWD>
+inline int launch_ff(hipStream_t st, const FfArgs &a) { return a.dmask ? launch_ff_t<BWD, true>(st, a) : launch_ff_t<BWD, false>(st, a); }
 
 }  // namespace ffused
 }  // namespace dfx

@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "dfx_common.h"
+#include "dfx_dropout.h"
 #include "gemm_bf16.h"
 #include "train_attn_fused.h"
 #include "mfma_linear.h"
@@ -41,24 +42,16 @@ constexpr float LN_EPS = 1e-5f;
 // entering the MFMAs are the same and the HBM traffic of these tensors halves.
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 
-// Dropout (nn.Dropout in train mode: attention.py:84 after the GEGLU, :177 after to_out): Philox4x32-10 keyed by the step's
-// seed, counter = (group of four consecutive elements, site), one 32-bit draw per element; factor = keep ? 1 / (1 - p) : 0.
-// The backward regenerates the factors from the same (seed, site, index): no mask is stored.  torch's own CUDA dropout
-// stream depends on its launch geometry and cannot be reproduced; the contract here is (seed, site, element index).
+// Dropout (nn.Dropout in train mode: attention.py:84 after the GEGLU, :177 after to_out): the contract of dfx_dropout.h — Philox4x32-7 keyed by the
+// step's seed, counter = (group of eight consecutive elements, site), one 16-bit draw per element; factor = keep ? 1 / (1 - p) : 0.  The layer-by-layer
+// kernels below work on four consecutive elements per thread = one half of a group.  The backward regenerates the factors from the same
+// (seed, site, index): no mask is stored here (the fused kernels of train_ff_fused.h store one bit per element instead).
 __device__ __forceinline__ v4f dropout4(unsigned long long seed, unsigned site, unsigned long long idx4, float p) {
-  uint4 c = make_uint4((unsigned)idx4, (unsigned)(idx4 >> 32), site, 0xD20F0u);
-  uint2 k = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u;
-    k.y += 0xBB67AE85u;
-  }
-  const float keep = 1.0f / (1.0f - p);
-  const unsigned thr = (unsigned)((double)p * 4294967296.0);   // drop when the draw is below p * 2^32
-  return v4f{c.x < thr ? 0.f : keep, c.y < thr ? 0.f : keep, c.z < thr ? 0.f : keep, c.w < thr ? 0.f : keep};
+  const dfx::DropKey k = dfx::drop_key(seed, p);
+  const uint4 c = dfx::drop_group(k, site, idx4 >> 1);
+  const unsigned w0 = (idx4 & 1) ? c.z : c.x, w1 = (idx4 & 1) ? c.w : c.y;
+  return v4f{dfx::drop_keep_lo(w0, k.thr) ? k.keep : 0.f, dfx::drop_keep_hi(w0, k.thr) ? k.keep : 0.f,
+             dfx::drop_keep_lo(w1, k.thr) ? k.keep : 0.f, dfx::drop_keep_hi(w1, k.thr) ? k.keep : 0.f};
 }
 struct Drop {
   float p;                  // 0 = off
@@ -1699,7 +1692,8 @@ unsigned long long g_path_seq = 0;   // forward counter: the record with the sma
 std::mutex g_path_mu;
 std::unordered_map<const void *, PathRecord> g_path;   // keyed by workspace pointer (a handful per process)
 thread_local bool t_ff_fused = true, t_attn_in_ff = true;   // what the call in progress on this thread uses
-inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return t_ff_fused && bf && dropout_p == 0.f && R % 32 == 0 && N % 32 == 0; }
+// (dropout > 0 takes the fused kernels when the attention sub-block sits inside them — the default — : k_ff<*, true> / k_ff_wgrad<true>)
+inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return t_ff_fused && bf && (dropout_p == 0.f || t_attn_in_ff) && R % 32 == 0 && N % 32 == 0; }
 
 // bf16 operands (fp32 accumulate, fp32 results) for the large products when the caller asked for DFX_PREC_BF16
 thread_local int g_prec = DFX_PREC_F32;
@@ -2084,7 +2078,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     // W1 / W2 of every block as bf16 MFMA fragments (train_ff_fused.h), one launch
     dfx::ffused::PackBatch pb{};
     for (int i = 0; i < wt->depth; ++i)
-      pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i]};
+      pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i],
+                                        dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f};
     dfx::ffused::launch_pack(st, pb, wt->depth);
   } else {
     k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
@@ -2115,6 +2110,10 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.h1_out = a.h1;
+        if (dropout_p > 0.f) {   // the two sites of block i (the layer-by-layer path's numbering); bits -> a.p (R x 32 floats, unused by the fused path; 80 B per point needed)
+          fa.dk = dfx::drop_key(dropout_seed, dropout_p), fa.site_att = (unsigned)(2 * i), fa.site_ff = (unsigned)(2 * i + 1);
+          fa.dmask = reinterpret_cast<unsigned *>(a.p);
+        }
       } else {
         dfx::afused::AttnArgs aa{};
         aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
@@ -2241,6 +2240,11 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
         fa.hin = a.hin, fa.dh_in = w.dh;
         fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
+      const float keep_a = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+      if (dropout_p > 0.f) {   // the bits the forward left in a.p (ff_fused() admits dropout only with the attention inside these kernels)
+        fa.dk = dfx::drop_key(dropout_seed, dropout_p), fa.site_att = (unsigned)(2 * i), fa.site_ff = (unsigned)(2 * i + 1);
+        fa.dmask = reinterpret_cast<unsigned *>(a.p);
+      }
       if (dfx::ffused::launch_ff<true>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward backward launch");
       if (i == 0 && dx_in_ff && ss.on && (ssm & SS_STEM_EARLY)) {   // w.dh is final: pre_norm / proj_in backward beside the rest of the block's parameter kernels
         if ((rc = ss.fork())) return rc;
@@ -2254,7 +2258,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide; the slab partials of every
       // block are summed in one launch behind the loop
       {
-        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i], R / 32, w.ffw_slabs};
+        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i], R / 32, w.ffw_slabs,
+                               dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr, keep_a};
         if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
@@ -2316,7 +2321,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     SumJobs sj{};
     for (int i = 0; i < wt->depth; ++i) {
       const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
-      fb.blk[i] = dfx::ffused::FwFinishArgs{w.ffw_part[i], w.ffw_bpart[i], mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs};
+      fb.blk[i] = dfx::ffused::FwFinishArgs{w.ffw_part[i], w.ffw_bpart[i], mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs,
+                                            dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f};
       ub.blk[i] = dfx::afused::UnfoldArgs{w.at_part[i], w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
                                           mut(gw.to_q), mut(gw.to_out_w), w.at_sum[i], B, w.at_split, LDKV0};
       sj.part[i] = w.cpart[i];

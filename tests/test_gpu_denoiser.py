@@ -493,7 +493,7 @@ def test_w1_bias_fold_backs_off_on_an_outlier_channel_and_is_selectable(W):
         return float(np.abs(out - ref).max()), eb.w1_fold(), variant, float(np.abs(ref).max())
 
     e_def, (folded, ratio), variant, scale = err(W, -1)
-    assert folded and ratio < 8 and "pipe" in variant, (folded, ratio, variant)
+    assert folded and ratio < 8 and variant != "k_denoise<bf16>", (folded, ratio, variant)   # (B = 1: the co-operative chain kernel)
     e_plain, (folded_p, _), variant_p, _ = err(W, 0)
     assert not folded_p and variant_p == "k_denoise<bf16>"
     assert e_def <= TOL_BF16_EPS and e_plain <= TOL_BF16_EPS, (e_def, e_plain)

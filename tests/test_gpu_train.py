@@ -157,13 +157,17 @@ def test_bf16_matrix_products_within_stated_tolerance():
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
 
 
+@pytest.mark.parametrize("dropout", [None, (0.2, 777)], ids=["p0", "p0.2"])
 @pytest.mark.parametrize("B,N", [(2, 1024), (3, 160), (1, 4096)])
-def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
+def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout):
     """train_ff_fused.h (one kernel per direction for the GEGLU feed-forward: [a | g] and hid stay in registers, recomputed in
     the backward) against the layer-by-layer bf16 kernels it replaces: same bf16 operands; differences = fp32 summation order,
     the fast sigmoid-form GELU (2.7e-4) instead of erf, and [a | g] no longer rounded to bf16 between forward and backward.
     Both must sit inside the stated bf16 tolerance against the fp32 oracle; here they are compared with each other.
-    N = 160: a workgroup's trailing wavefronts fall off the end of the rows (ragged last tile)."""
+    N = 160: a workgroup's trailing wavefronts fall off the end of the rows (ragged last tile).
+    dropout = (0.2, seed) — the shipped train_chair_stage1.py setting: the fused kernels draw the SAME Philox factors (dfx_dropout.h: keyed by
+    (seed, site, element)) as the layer-by-layer kernels — forward in k_ff<false, true>, kept as one bit per element for k_ff<true, true> and
+    k_ff_wgrad<true> — so the two paths must agree within the same gates as without dropout."""
     from difffacto_amd import _ffi, synth
     rng = np.random.Generator(np.random.PCG64(B * 1000 + N))
     W = synth.make_denoiser_weights(5)
@@ -177,13 +181,17 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
              anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
              valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
              flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
-    fused = _run(c, True, precision="bf16")
+    fused = _run(c, True, precision="bf16", dropout=dropout)
     _ffi.lib().dfx_debug_train_fused(0)
     try:
-        layer = _run(c, True, precision="bf16")
+        layer = _run(c, True, precision="bf16", dropout=dropout)
     finally:
         _ffi.lib().dfx_debug_train_fused(1)
     assert any(not np.array_equal(fused["grads"][k], layer["grads"][k]) for k in layer["grads"]), "fused path not taken"
+    if dropout is not None:   # dropout did something, and a different seed gives different factors on the fused path
+        plain = _run(c, True, precision="bf16")
+        other = _run(c, True, precision="bf16", dropout=(dropout[0], dropout[1] + 1))
+        assert abs(plain["loss"] - fused["loss"]) > 1e-4 and abs(other["loss"] - fused["loss"]) > 1e-6
     e_eps = np.abs(fused["eps"] - layer["eps"]).max()
     worst_max = worst_l2 = 0.0
     for k, gr in layer["grads"].items():
@@ -193,7 +201,7 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N):
         worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
         # measured worst over the three shapes (r03 box; `transformer_blocks.1.norm2.weight`): 6.7e-3 of max-abs / 4.4e-3 relative L2 -> gates at 3x
         assert e_max < 2e-2 and e_l2 < 1.3e-2, (k, e_max, e_l2)
-    print(f"fused vs layer-by-layer FF (B={B}, N={N}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
+    print(f"fused vs layer-by-layer FF (B={B}, N={N}, dropout={dropout}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
     # measured over the three shapes here and ~120 random ones (tools/fuzz_parity.py, r03): loss up to 1.9e-4 relative, eps up to 3.3e-3 -> 3x
     e_loss = abs(fused["loss"] - layer["loss"]) / abs(layer["loss"])

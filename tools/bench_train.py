@@ -11,7 +11,8 @@ import torch
 
 from difffacto_amd import synth, training
 
-_pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--streams"]
+_pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in ("--streams", "--dropout")]
+DROPOUT = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.0   # e.g. 0.2 = train_chair_stage1.py as shipped
 B = int(_pos[0]) if len(_pos) > 0 else 128
 N = int(_pos[1]) if len(_pos) > 1 else 2048
 PREC = _pos[2] if len(_pos) > 2 else "bf16"
@@ -39,9 +40,13 @@ if "--layerwise" in sys.argv:   # the layer-by-layer feed-forward kernels (A/B a
     _ffi.lib().dfx_debug_train_fused(0)
 
 
+_step = [0]
+
+
 def it():
     opt.zero_grad()
-    loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args, precision=PREC), None)
+    _step[0] += 1
+    loss = training.masked_mse(noise, training.denoiser_train_forward(P, *args, precision=PREC, dropout=(DROPOUT, 1000 + _step[0]) if DROPOUT > 0 else None), None)
     loss.backward()
     opt.step()
     return loss
@@ -58,7 +63,7 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
 flops = 3 * 4.734e9 * B * (N / 2048)
 peak = 157.3 if PREC == "f32" else 2500.0
-print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, matrix products in {PREC}: {ms:.2f} ms = {B / ms * 1e3:.0f} shapes/s, "
+print(f"training iteration (forward + backward + clip + Adam), B={B} N={N}, dropout {DROPOUT}, matrix products in {PREC}: {ms:.2f} ms = {B / ms * 1e3:.0f} shapes/s, "
       f"{flops / ms / 1e9:.1f} TFLOP/s of the {peak} TFLOP/s {PREC} matrix peak ({flops / ms / 1e9 / peak * 100:.1f} %), loss {float(loss.detach()):.4f}, "
       f"workspace {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak, optimiser in {'one launch' if opt.last_step_was_flat else 'one launch per tensor'}")
 if PREC == "bf16" and "--ab" in sys.argv:   # the same loop through the layer-by-layer feed-forward kernels
