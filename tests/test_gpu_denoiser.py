@@ -505,5 +505,7 @@ def test_w1_bias_fold_backs_off_on_an_outlier_channel_and_is_selectable(W):
     assert folded_f
     print(f"W1 bias fold: synthetic weights ratio {ratio:.2f}: folded {e_def:.2e} / plain {e_plain:.2e} (|eps| {scale:.2f}); "
           f"gamma3[127] x 64 (ratio {ratio_o:.1f}): auto = plain {e_auto:.2e}, forced fold {e_forced:.2e} (|eps| {scale_o:.2f})")
-    assert e_auto <= TOL_BF16_EPS * max(1.0, scale_o / scale), e_auto
-    assert e_forced > e_auto
+    # measured (r05): synthetic weights folded 3.5e-3 / plain 2.0e-3; outlier weights plain 7.7e-3 (the outlier channel's own bf16 rounding, in any
+    # bf16 formulation) / forced fold 1.4e-1 -> the back-off is worth a factor ~19 there
+    assert e_auto <= 2 * TOL_BF16_EPS, e_auto
+    assert e_forced > 5 * e_auto, (e_forced, e_auto)
