@@ -334,16 +334,20 @@ def stage1_iteration(B, N, iters=16, encoder_precision="f32", dropout=0.0):
 
 def measured_traffic(T, B, N):
     """Fabric-side bytes per launch from the newest committed PMC profile (profiles/rNN_traffic.json: separate rocprofv3 --pmc
-    passes of this command, see profiles/README.md — counters cannot be read from inside the run), which scales linearly with the
-    number of diffusion steps.  Returns (bytes or None, provenance or None): the bench line names the file and round it came from."""
+    passes of this command, see profiles/README.md — counters cannot be read from inside the run).  Round 5 measured at TWO chain lengths
+    (T = 20 and 40, tools/prof_write_size.sh): traffic(T) = fixed + per_step * T — the writes and most of the reads are a per-launch constant
+    (WRITE_SIZE does not grow with T at all, profiles/r05_write_size_scaling.txt); older files hold one T = 20 launch divided by 20.
+    Returns (bytes or None, provenance or None): the bench line names the file and round it came from."""
     best = _newest_profile("traffic.json")
     if best is None:
         return None, None
     try:
         d = json.load(open(best[1]))
         if d["B"] == B and d["N"] == N:
-            return d["bytes_per_step"] * T, {"file": os.path.relpath(best[1], ROOT), "round": d.get("round", f"r{best[0]:02d}"),
-                                             "T_profiled": d.get("T_profiled"), "note": "PMC pass of an earlier run of this command, scaled by T; not measured in this run"}
+            fixed = d.get("bytes_per_launch_fixed", 0.0)
+            return fixed + d["bytes_per_step"] * T, {"file": os.path.relpath(best[1], ROOT), "round": d.get("round", f"r{best[0]:02d}"),
+                                                     "T_profiled": d.get("T_profiled"), "bytes_per_launch_fixed": fixed, "bytes_per_step": d["bytes_per_step"],
+                                                     "note": "PMC passes of an earlier run of this command at two chain lengths, fixed + per_step * T; not measured in this run"}
     except Exception:
         pass
     return None, None
