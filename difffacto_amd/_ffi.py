@@ -100,6 +100,9 @@ SIGNATURES = {
     "dfx_part_aligner": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "dfx_sample_latents": (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32), _I, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfx_aligner_train_workspace_bytes": (_SZ, [_I] * 7),
+    "dfx_aligner_train_forward": (_I, [ctypes.POINTER(LatentWeights), _P, _SZ, _P, _P, _P, _P, _P, _I, _P]),
+    "dfx_aligner_train_backward": (_I, [ctypes.POINTER(LatentWeights), _P, _SZ, _P, _P, _P, ctypes.POINTER(LatentWeights), _P, _I, _P]),
     "dfx_shared_mlp_create": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_fp)] * 6 + [_F, ctypes.c_uint32, _P]),
     "dfx_pointnet_v2_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(PointNetV2Weights), _P]),
     "dfx_pointnet_v2_destroy": (None, [_P]),

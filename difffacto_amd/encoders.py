@@ -210,13 +210,27 @@ class PartAlignerTransformer(nn.Module):
         self.proj_out = nn.Linear(inner, out_channels)
 
     def forward(self, x, mask=None, noise=None):
-        """(B,zdim,n_class), (B,n_class), (B,noise_dim) -> mean (B,3,n_class), logvar (B,3,n_class)."""
+        """(B,zdim,n_class), (B,n_class), (B,noise_dim) -> mean (B,3,n_class), logvar (B,3,n_class).  With a gradient required through it (stage 2:
+        train_*_stage2.py / train_aligner) the forward and its backward are libdfx's exact-fp32 training kernels (training.aligner_train_forward);
+        otherwise the inference kernels of the latent sampler."""
+        if self.cimle and (noise is None or noise.shape[1] != self.noise_dim):
+            noise = torch.zeros(x.shape[0], self.noise_dim, device=x.device)             # part_encoders.py:97-98
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if not self.cimle:
+                _unsupported("training the part aligner without cimle (pre_norm path)")
+            if any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()) and self.training:
+                _unsupported("dropout > 0 inside the part aligner (the shipped configurations use 0)")
+            if not x.is_cuda:
+                raise RuntimeError("PartAlignerTransformer: CPU not supported")
+            from . import training as _training
+            if mask is None:
+                mask = torch.ones(x.shape[0], self.n_class, device=x.device)
+            return _training.aligner_train_forward(dict(self.named_parameters()), x, mask, noise, n_class=self.n_class, zdim=self.zdim,
+                                                   n_heads=self.n_heads, d_head=self.d_head, noise_dim=self.noise_dim, noise_scale=self.noise_scale)
         owner = getattr(self, "_owner", None)
         owner = owner() if owner is not None else None
         if owner is None:
             owner = _StandaloneAligner.of(self)
-        if self.cimle and (noise is None or noise.shape[1] != self.noise_dim):
-            noise = torch.zeros(x.shape[0], self.noise_dim, device=x.device)             # part_encoders.py:97-98
         return owner.sampler().part_aligner(x, mask, noise if self.cimle else None)
 
 
@@ -405,7 +419,8 @@ class PartEncoderForTransformerDecoder(nn.Module):
           PointNetV2 / prior-loss training kernels;
         * gen / stage 2 (a ``part_aligner``, ``fit_loss_type`` 4; configs/gen_*.py, train_*_stage2.py): (mean, logvar) from the
           native aligner on the sampled part codes, ``noise`` (B, num, noise_dim) rows = B * num like the reference's
-          ``repeat_interleave`` (:1215-1218).  Inference only: the aligner has no native backward, so a gradient through it raises.
+          ``repeat_interleave`` (:1215-1218).  With gradients enabled (stage-2 training) the aligner runs its exact-fp32 training
+          kernels (training.AlignerTrainFn): fit_loss and the denoiser's d ctx[1] reach the aligner's parameters through torch autograd.
 
         Returns (ctx, mean_per_point, logvar_per_point, flag_per_point, loss_dict, [part_code, mean, logvar, noise])."""
         inp, valid_id, ref, seg_mask, seg_flag, gt_shift, gt_var = self._batch(pcds, device, "ref_attn_map")
@@ -414,9 +429,6 @@ class PartEncoderForTransformerDecoder(nn.Module):
             noise = pcds["noise"].to(device).unsqueeze(1)
         if self.use_gt_params and noise.shape[1] != 1:
             _unsupported("more than one noise sample per shape in the stage-1 training forward")
-        if not self.use_gt_params and torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.part_aligner.parameters())):
-            _unsupported("a gradient through the part aligner (stage-2 training): the native aligner is inference-only; call under "
-                         "torch.no_grad() in eval()")
         m, lv = self.get_part_code(inp, seg_flag)
         part_code = self._reparameterize(m, lv)
         loss_dict = dict(self.get_prior_loss(part_code, m, lv, valid_id, epoch=epoch))

@@ -132,8 +132,6 @@ class AnchorDiffAE(nn.Module):
         if self.npoints < N:
             _unsupported("npoints smaller than the reference cloud (anchor_gen.py:997-1001)")
         if self.training:
-            if not self.encoder.use_gt_params:
-                _unsupported("training with a part_aligner (stage 2: the aligner has no native backward)")
             from . import training as _training
             t, _ = self.sampler.sample(B, device)
             return _training.stage1_losses(self.encoder, self.diffusion, pcds, device=device, epoch=epoch, t=t,

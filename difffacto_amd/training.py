@@ -397,6 +397,93 @@ def prior_loss(flow_params, part_code, logvar, valid, depth=14, hidden=256, prio
     return out
 
 
+ALIGNER_TOP = {"proj_in_w": "proj_in.weight", "proj_in_b": "proj_in.bias", "class_emb": "class_emb.weight", "post_norm_w": "post_norm.weight",
+               "post_norm_b": "post_norm.bias", "proj_out_w": "proj_out.weight", "proj_out_b": "proj_out.bias"}
+ALIGNER_BLOCK = {"norm2_w": "norm2.weight", "norm2_b": "norm2.bias", "to_q": "attn2.to_q.weight", "to_k": "attn2.to_k.weight", "to_v": "attn2.to_v.weight",
+                 "to_out_w": "attn2.to_out.0.weight", "to_out_b": "attn2.to_out.0.bias", "norm3_w": "norm3.weight", "norm3_b": "norm3.bias",
+                 "ff_proj_w": "ff.net.0.proj.weight", "ff_proj_b": "ff.net.0.proj.bias", "ff_out_w": "ff.net.2.weight", "ff_out_b": "ff.net.2.bias"}
+
+
+def aligner_param_names(depth):
+    """state_dict names (relative to the part aligner) of the parameters the training kernels differentiate, in a fixed order.  ``pre_norm.*``
+    exists in the state_dict but is unused with cimle / cond_noise_type 0 (part_encoders.py:119-131): no gradient, like under torch autograd."""
+    return list(ALIGNER_TOP.values()) + [f"transformer_blocks.{i}.{k}" for i in range(depth) for k in ALIGNER_BLOCK.values()]
+
+
+def _aligner_struct(tensors, cfg):
+    n_class, zdim, n_heads, d_head, noise_dim, noise_scale, depth = cfg
+    w = _ffi.LatentWeights()
+    w.n_class, w.zdim, w.flow_depth, w.flow_hidden, w.depth, w.n_heads, w.d_head = n_class, zdim, 0, 0, depth, n_heads, d_head
+    w.cimle, w.noise_dim, w.noise_scale, w.prior_var, w.log_scale_var = 1, noise_dim, float(noise_scale), 1.0, 0.0
+    it = iter(tensors)
+    for field in ALIGNER_TOP:
+        setattr(w, field, next(it).data_ptr())
+    for i in range(depth):
+        for field in ALIGNER_BLOCK:
+            setattr(w.blocks[i], field, next(it).data_ptr())
+    return w
+
+
+class AlignerTrainFn(torch.autograd.Function):
+    """PartAlignerTransformer.forward (part_encoders.py:88-143; the shipped cIMLE configuration) with its backward on libdfx's exact-fp32 training
+    kernels (aligner_train.hip): differentiable in the aligner's parameters and in part_code."""
+
+    @staticmethod
+    def forward(ctx, cfg, part_code, valid, noise, *params):
+        n_class, zdim, n_heads, d_head, noise_dim, noise_scale, depth = cfg
+        ps = [_need(p.detach(), "aligner parameter") for p in params]
+        z = _need(part_code.detach().to(torch.float32).contiguous(), "part_code")
+        B = z.shape[0]
+        if tuple(z.shape) != (B, zdim, n_class):
+            raise ValueError(f"part_code: expected (B, {zdim}, {n_class}), got {tuple(z.shape)}")
+        vd = valid.detach().to(device=z.device, dtype=torch.float32).contiguous()
+        nz = noise.detach().to(device=z.device, dtype=torch.float32).contiguous()
+        if tuple(vd.shape) != (B, n_class) or tuple(nz.shape) != (B, noise_dim):
+            raise ValueError("valid (B, n_class) and noise (B, noise_dim) expected")
+        lib = _ffi.lib()
+        nbytes = lib.dfx_aligner_train_workspace_bytes(B, n_class, zdim, noise_dim, n_heads, d_head, depth)
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=z.device)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        mean = torch.empty(B, 3, n_class, dtype=torch.float32, device=z.device)
+        logvar = torch.empty_like(mean)
+        w = _aligner_struct(ps, cfg)
+        with torch.cuda.device(z.device):
+            _ffi.check(lib.dfx_aligner_train_forward(w, ws_ptr, nbytes, z.data_ptr(), vd.data_ptr(), nz.data_ptr(), mean.data_ptr(), logvar.data_ptr(), B,
+                                                     _ffi.current_stream()), "dfx_aligner_train_forward")
+        ctx.cfg, ctx.ps, ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.vd, ctx.B = cfg, ps, ws, ws_ptr, nbytes, vd, B
+        ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
+        return mean, logvar
+
+    @staticmethod
+    def backward(ctx, d_mean, d_logvar):
+        _check_first_backward(ctx, "AlignerTrainFn")
+        n_class, zdim = ctx.cfg[0], ctx.cfg[1]
+        dev = ctx.vd.device
+        views = _flat_slices([p.shape for p in ctx.ps], dev)
+        dz = torch.empty(ctx.B, zdim, n_class, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dm = None if d_mean is None else _need(d_mean.contiguous(), "d_mean")
+        dl = None if d_logvar is None else _need(d_logvar.contiguous(), "d_logvar")
+        w, g = _aligner_struct(ctx.ps, ctx.cfg), _aligner_struct(views, ctx.cfg)
+        with torch.cuda.device(dev):
+            _ffi.check(_ffi.lib().dfx_aligner_train_backward(w, ctx.ws_ptr, ctx.nbytes, ctx.vd.data_ptr(), _ffi.ptr(dm), _ffi.ptr(dl), g, _ffi.ptr(dz), ctx.B,
+                                                             _ffi.current_stream()), "dfx_aligner_train_backward")
+        ctx.ws = None
+        ctx.ws_ptr = None
+        out = _assign_or_return(ctx.leaves, views)
+        ctx.leaves = None
+        return (None, dz, None, None) + tuple(out)
+
+
+def aligner_train_forward(params, part_code, valid, noise, n_class=4, zdim=256, n_heads=8, d_head=32, noise_dim=32, noise_scale=100.0):
+    """`params`: dict state_dict-key (relative to the part aligner) -> fp32 cuda tensor.  Returns (mean, logvar), each (B, 3, n_class), differentiable in
+    the parameters and in part_code (valid / noise are data)."""
+    depth = 0
+    while f"transformer_blocks.{depth}.norm2.weight" in params:
+        depth += 1
+    cfg = (n_class, zdim, n_heads, d_head, noise_dim, float(noise_scale), depth)
+    return AlignerTrainFn.apply(cfg, part_code, valid, noise, *[params[n] for n in aligner_param_names(depth)])
+
+
 def dropout_factors(seed, site, p, n, device="cuda"):
     """The factors (0 or 1/(1-p)) the training kernels apply to `n` consecutive elements of a dropout site (tests / debugging):
     site 2 i = behind to_out of block i over (B N, 128); 2 i + 1 = behind the GEGLU of block i over (B N, 512); 1000 =

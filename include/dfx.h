@@ -297,6 +297,19 @@ int dfx_sample_latents(dfx_latents *h, const float *w_noise, const float *part_c
                        float *valid_out, float *noise_out, float *mean, float *logvar, float *params, int32_t *seg,
                        float *mean_per_point, float *logvar_per_point, dfx_stream_t stream);
 
+/* Training forward / backward of the part aligner (stage 2: configs/train_*_stage2.py and gen_*.py with train_aligner; replaces torch autograd through
+ * PartAlignerTransformer, part_encoders.py:88-143, for the shipped options: cimle with cond_noise_type 0, class_cond + add_class_cond, single_attn,
+ * mask_out_unreferenced_code, dropout 0).  Exact fp32, no atomics (aligner_train.hip).  `w` holds the parameter pointers (flow fields unused), `grads` the
+ * gradient buffers in the same struct (overwritten; pre_norm_* untouched: unused by this configuration).
+ *   part_code (B,zdim,n_class), valid (B,n_class) 0/1 = the key mask, noise (B,noise_dim) -> mean / logvar (B,3,n_class)
+ *   backward: d_mean / d_logvar (B,3,n_class) (either may be NULL = zero) -> grads, d_part_code (B,zdim,n_class) or NULL
+ *   workspace: dfx_aligner_train_workspace_bytes(...) device bytes, shared by the forward and the backward of a step. */
+size_t dfx_aligner_train_workspace_bytes(int B, int n_class, int zdim, int noise_dim, int n_heads, int d_head, int depth);
+int dfx_aligner_train_forward(const dfx_latent_weights *w, void *workspace, size_t workspace_bytes, const float *part_code, const float *valid,
+                              const float *noise, float *mean, float *logvar, int B, dfx_stream_t stream);
+int dfx_aligner_train_backward(const dfx_latent_weights *w, void *workspace, size_t workspace_bytes, const float *valid, const float *d_mean,
+                               const float *d_logvar, const dfx_latent_weights *grads, float *d_part_code, int B, dfx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * PointNet++ set-abstraction / feature-propagation layers, eval mode — the part of
  * pointnet2_ops the reference leaves to PyTorch: QueryAndGroup / GroupAll

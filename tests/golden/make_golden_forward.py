@@ -15,6 +15,10 @@ train_loop_B3_N64_T10.npz     three iterations of the reference's training loop 
                               loss, gradient norm, learning rate, parameter checksums and 256 sampled elements per parameter
                               (values after the step + the clipped gradient the step consumed)
 
+aligner_grads_B5.npz          torch autograd through the reference's PartAlignerTransformer (outputs, d / d parameters, d / d part_code)
+stage2_step_B4_N64_T10.npz    one stage-2 training forward + backward of the reference's AnchorDiffAE in train() mode (part aligner + fit loss + masked
+                              MSE, Dropout 0): loss dict, total, d total / d (aligner parameters), the BatchNorm running statistics left behind
+
 Every torch.randn / torch.randn_like the reference executes is served from a numpy PCG64 stream and RECORDED in call order
 ("draw_{i}"); the tests replay the draws at the same sites of the mirror (the T + 1 chain draws are handed to decode as explicit
 x_T / step noise).  Weights are not stored (difffacto_amd.synth regenerates them from seeds on both sides).
@@ -217,13 +221,100 @@ def gen_train_loop(tag, B=3, N=64, T=10, seed=121, iters=3):
     print(f"wrote train_loop_{tag}: loss", out["loss"], "grad_norm", out["grad_norm"], "lr", out["lr"])
 
 
+def _store_grads(named_grads, out, prefix, srng):
+    """full tensors up to 4096 elements, else 1024 sampled elements + (sum, L2 norm) — the convention of train_grads_*.npz"""
+    for name, g in named_grads:
+        g = g.numpy().astype(F32).ravel()
+        if g.size <= 4096:
+            out[f"{prefix}g/" + name] = g
+        else:
+            idx = np.sort(srng.choice(g.size, size=1024, replace=False)).astype(np.int64)
+            out[f"{prefix}gi/" + name] = idx
+            out[f"{prefix}gs/" + name] = g[idx]
+            out[f"{prefix}gn/" + name] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+
+
+def gen_aligner_grads(tag, B=5, seed=141):
+    """torch autograd through the reference's PartAlignerTransformer (part_encoders.py:88-143): outputs and d (sum(mean dm) + sum(logvar dl)) / d (every
+    parameter, part_code)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, cfg = ref_import.build_reference_model("gen_chair.py", num_timesteps=10)
+    load_all_weights(model)
+    al = model.encoder.part_aligner
+    al.train()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    code = rng.standard_normal((B, 256, 4)).astype(F32)
+    noise = rng.standard_normal((B, 32)).astype(F32)
+    valid = np.ones((B, 4), F32)
+    valid[1, 2] = 0
+    valid[3, 0] = 0
+    valid[3, 3] = 0
+    dm, dl = rng.standard_normal((B, 3, 4)).astype(F32), rng.standard_normal((B, 3, 4)).astype(F32)
+    for p_ in al.parameters():
+        p_.grad = None
+    z = torch.from_numpy(code).requires_grad_(True)
+    mean, logvar = al(z, torch.from_numpy(valid), noise=torch.from_numpy(noise))
+    ((mean * torch.from_numpy(dm)).sum() + (logvar * torch.from_numpy(dl)).sum()).backward()
+    out = {"part_code": code, "noise": noise, "valid": valid, "d_mean": dm, "d_logvar": dl, "mean": mean.detach().numpy().astype(F32),
+           "logvar": logvar.detach().numpy().astype(F32), "d_part_code": z.grad.numpy().astype(F32), "weight_seed": np.array(0)}
+    _store_grads([(n, p_.grad) for n, p_ in al.named_parameters() if p_.grad is not None], out, "", np.random.Generator(np.random.PCG64(4244)))
+    out["no_grad_params"] = np.array([n for n, p_ in al.named_parameters() if p_.grad is None])
+    al.eval()
+    np.savez_compressed(os.path.join(HERE, f"aligner_grads_{tag}.npz"), **out)
+    print(f"wrote aligner_grads_{tag}:", len(out), "arrays; parameters without gradient:", list(out["no_grad_params"]), "| |mean| max", float(np.abs(out["mean"]).max()))
+
+
+def gen_stage2_step(tag, B=4, N=64, T=10, seed=151):
+    """One stage-2 training forward + backward of the reference's AnchorDiffAE (anchor_gen.py:970-1021 in train() mode, the gen_chair configuration =
+    part aligner + fit_loss_type 4, every Dropout set to 0): the loss dict and d (sum of the 'loss' entries, runner.py:310-312 / parse_losses) / d (the
+    aligner's parameters) — what stage 2 optimises (runner.py:76-90: the optimiser holds encoder.part_aligner.parameters()).  np.random is seeded for the
+    timestep sampler (samplers/sampler.py:33); the torch draws (reparameterisation eps, the diffusion noise) are recorded."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, cfg = ref_import.build_reference_model("gen_chair.py", num_timesteps=T)
+    load_all_weights(model)
+    model.npoints = N
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    for p_ in model.parameters():
+        p_.grad = None
+    batch = make_batch(B, N, seed, absent=((2, 1),))
+    batch["dp_present"] = batch["present"].copy()
+    np.random.seed(seed)
+    with DrawRecorder(seed + 1) as rec, contextlib.redirect_stdout(io.StringIO()):
+        losses = model(to_torch(batch), device="cpu", epoch=3)
+        total = sum(v.mean() for k, v in losses.items() if "loss" in k)
+        total.backward()
+    np.random.seed(seed)
+    t = np.random.choice(T, size=(B,), p=np.ones(T) / T)
+    out = {f"in/{k}": v for k, v in batch.items()}
+    out.update(rec.as_dict())
+    out.update({"loss/" + k: v.detach().numpy().astype(F32) for k, v in losses.items()})
+    out.update({"total": np.array(float(total), F32), "t": t.astype(np.int64), "n_draws": np.array(len(rec.draws)), "np_seed": np.array(seed), "epoch": np.array(3),
+                "weight_seed": np.array(0)})
+    bn = model.encoder.encoder
+    out.update({"bn/" + k: v.numpy().astype(F32) for k, v in bn.state_dict().items() if "running" in k})
+    _store_grads([(n, p_.grad) for n, p_ in model.encoder.part_aligner.named_parameters() if p_.grad is not None], out, "", np.random.Generator(np.random.PCG64(4245)))
+    model.eval()
+    np.savez_compressed(os.path.join(HERE, f"stage2_step_{tag}.npz"), **out)
+    print(f"wrote stage2_step_{tag}: total {float(total):.6f}", {k: float(v.detach().float().mean()) for k, v in losses.items() if 'loss' in k}, "t", t.tolist(), len(rec.draws), "draws",
+          [a.shape for a in rec.draws])
+
+
 def main():
     torch.manual_seed(0)
+    if "--only-stage2" in sys.argv:
+        gen_aligner_grads("B5")
+        gen_stage2_step("B4_N64_T10")
+        return
     if "--only-train-loop" not in sys.argv:
         gen_forward("gen_B2_K2_T10", gen=True)
         gen_forward("sample_B2_K2_T10", gen=False, seed=131)
         gen_encoder_forward("B3_N96")
     gen_train_loop("B3_N64_T10")
+    gen_aligner_grads("B5")
+    gen_stage2_step("B4_N64_T10")
 
 
 if __name__ == "__main__":

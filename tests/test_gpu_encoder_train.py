@@ -419,3 +419,76 @@ def test_stage1_prior_branch_on_a_second_stream_is_bit_identical():
                 assert torch.equal(x, y)
         for x, y in zip(wa, wb):
             assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------- stage 2: the part aligner's training kernels
+def test_part_aligner_training_kernels_vs_reference_autograd_golden():
+    """aligner_train.hip (exact fp32) against torch autograd through the reference's PartAlignerTransformer (tests/golden/aligner_grads_B5.npz, shapes
+    with one and two absent parts): outputs 1e-4, gradients of every parameter and of part_code 5e-4 of the tensor's max-abs; pre_norm.* gets no
+    gradient in either (unused with cimle / cond_noise_type 0, part_encoders.py:119-131)."""
+    from _train_case import check_against_golden
+    from difffacto_amd import synth, training
+    g = dict(np.load(os.path.join(GOLD, "aligner_grads_B5.npz")))
+    W = {k[len("part_aligner."):]: v for k, v in synth.make_latent_weights(int(g["weight_seed"])).items() if k.startswith("part_aligner.")}
+    P = {k: torch.from_numpy(v.copy()).cuda().requires_grad_(True) for k, v in W.items()}
+    z = torch.from_numpy(g["part_code"]).cuda().requires_grad_(True)
+    mean, logvar = training.aligner_train_forward(P, z, torch.from_numpy(g["valid"]).cuda(), torch.from_numpy(g["noise"]).cuda(), noise_scale=100.0)
+    assert np.abs(mean.detach().cpu().numpy() - g["mean"]).max() < 1e-4 and np.abs(logvar.detach().cpu().numpy() - g["logvar"]).max() < 1e-4
+    ((mean * torch.from_numpy(g["d_mean"]).cuda()).sum() + (logvar * torch.from_numpy(g["d_logvar"]).cuda()).sum()).backward()
+    grads = {k: p.grad.cpu().numpy() for k, p in P.items() if p.grad is not None}
+    assert set(P) - set(grads) == set(g["no_grad_params"].tolist()) == {"pre_norm.weight", "pre_norm.bias"}
+    n, worst = check_against_golden(g, grads, rtol=5e-4, atol=1e-7)
+    assert n == len(grads) == 72, (n, len(grads))
+    e = np.abs(z.grad.cpu().numpy() - g["d_part_code"]).max() / np.abs(g["d_part_code"]).max()
+    print(f"part aligner training kernels vs reference autograd: {n} parameter gradients, worst {worst:.1e} of max-abs; d part_code {e:.1e}")
+    assert e < 5e-4
+    # the inference kernels of the latent sampler compute the same forward
+    from difffacto_amd.latents import LatentSampler
+    ls = LatentSampler(synth.make_latent_weights(int(g["weight_seed"])), noise_scale=100.0)
+    m2, lv2 = ls.part_aligner(z.detach(), torch.from_numpy(g["valid"]).cuda(), torch.from_numpy(g["noise"]).cuda())
+    assert float((m2 - mean.detach()).abs().max()) < 1e-4 and float((lv2 - logvar.detach()).abs().max()) < 1e-4
+
+
+def test_stage2_training_step_matches_the_reference():
+    """tests/golden/stage2_step_B4_N64_T10.npz: ONE stage-2 training forward + backward of the reference's AnchorDiffAE (train() mode, gen_chair
+    configuration with the part aligner and fit_loss_type 4, Dropout 0; anchor_gen.py:970-1021, runner.py:310-312).  The mirror (networks.AnchorDiffAE,
+    fp32 kernels) with the same numpy seed for the timestep sampler and the recorded torch draws replayed: every entry of the loss dict, the total,
+    the BatchNorm running statistics PointNetV2 leaves behind, and d total / d (every parameter of the part aligner) — what stage 2 optimises."""
+    from _replay import replay_draws
+    from _train_case import check_against_golden
+    from difffacto_amd import synth
+    from difffacto_amd.networks import AnchorDiffAE
+    from test_modules_cpu import DIFF_CFG, ENC_CFG
+    g = dict(np.load(os.path.join(GOLD, "stage2_step_B4_N64_T10.npz")))
+    batch = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in/")}
+    draws = [g[f"draw_{i}"] for i in range(int(g["n_draws"]))]
+    T, N = 10, batch["ref"].shape[1]
+    m = AnchorDiffAE(encoder=dict(type="PartEncoderForTransformerDecoder", **ENC_CFG), diffusion=dict(type="AnchoredDiffusion", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)}),
+                     sampler=dict(type="Uniform"), num_anchors=4, num_timesteps=T, npoints=N, gen=True, cimle=True, cimle_sample_num=1, precision="f32")
+    W = {"diffusion.model." + k: v for k, v in synth.make_denoiser_weights(0).items()}
+    W.update({"encoder." + k: v for k, v in synth.make_latent_weights(0).items()})
+    W.update({"encoder.encoder." + k: v for k, v in synth.make_pointnet_v2_weights(0).items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    m = m.cuda().train()
+    np.random.seed(int(g["np_seed"]))
+    with replay_draws(draws) as queue:
+        losses = m(batch, device="cuda", epoch=int(g["epoch"]))
+    assert not queue
+    total = sum(v.mean() for k, v in losses.items() if "loss" in k)          # parse_losses (utils/misc.py:120-132)
+    total.backward()
+    for k in [k for k in g if k.startswith("loss/")]:
+        ref, got = g[k], losses[k[5:]].detach().cpu().numpy().reshape(g[k].shape)
+        assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (k, got, ref)
+    assert abs(float(total.detach()) - float(g["total"])) <= 2e-4 * abs(float(g["total"]))
+    bn = m.encoder.encoder.state_dict()
+    for k in [k for k in g if k.startswith("bn/")]:
+        assert np.abs(bn[k[3:]].cpu().numpy() - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+    grads = {k: p.grad.cpu().numpy() for k, p in m.encoder.part_aligner.named_parameters() if p.grad is not None}
+    n, worst = check_against_golden(g, grads, rtol=2e-3, atol=1e-7)
+    assert n == 72
+    print(f"stage-2 step vs reference: total {float(total.detach()):.6f} / {float(g['total']):.6f}, {n} aligner gradients, worst {worst:.1e} of max-abs")
+    # ... and the optimiser of stage 2 (runner.py:88: encoder.part_aligner.parameters()) moves exactly those
+    from difffacto_amd import training
+    before = m.encoder.part_aligner.proj_out.weight.detach().clone()
+    training.Adam(list(m.encoder.part_aligner.parameters()), lr=2e-3, max_norm=10.0).step()
+    assert not torch.equal(before, m.encoder.part_aligner.proj_out.weight.detach())
