@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdfx.so")
 DFX_PREC_F32 = 0
 DFX_PREC_BF16 = 1
 DFX_MAX_DEPTH = 8
-DFX_ABI_VERSION = 3   # include/dfx.h: the argument lists this binding was written against
+DFX_ABI_VERSION = 4   # include/dfx.h: the argument lists this binding was written against
 
 
 class DfxLibraryError(RuntimeError):
@@ -119,7 +119,7 @@ SIGNATURES = {
     "dfx_masked_mse_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "dfx_denoiser_train_workspace_bytes": (_SZ, [_I, _I, _I]),
     "dfx_denoiser_train_forward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P]),
-    "dfx_denoiser_train_backward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, ctypes.POINTER(DenoiserWeights), _P, _P, _I, _I, _I, _F, _U64, _P]),
+    "dfx_denoiser_train_backward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, ctypes.POINTER(DenoiserWeights), _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P]),
     "dfx_debug_dropout_factors": (_I, [_U64, _I, _F, _P, ctypes.c_longlong, _P]),
     "dfx_debug_train_fused": (None, [_I]),
     "dfx_debug_train_streams": (None, [_I]),

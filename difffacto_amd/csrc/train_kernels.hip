@@ -637,6 +637,50 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ xin,
     reinterpret_cast<v4f *>(hin + r * C)[l] = o;
   }
 }
+// Gradient at the denoiser's INPUT rows, for the two columns groups a caller may differentiate (stage 2 of the reference: `variance` reaches
+// training_losses undetached, anchor_gen.py:1002-1020 — it enters through q_sample's sqrt(variance) * noise term of x_t and through the per-point
+// feature columns): d x (B, 3, N) = columns 0..2, d variances (B, N, 3) = columns 6..8 of  d h0 W_in,  d h0 = LayerNorm'(dy) recomputed like k_stem_bwd.
+__global__ __launch_bounds__(256) void k_stem_dx(const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ W,
+                                                  const float *__restrict__ b, const float *__restrict__ g, float *__restrict__ d_x,
+                                                  float *__restrict__ d_var, int N, long long R) {
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  StemW sw;
+  stem_load(sw, W, b, l);
+  const v4f gv = reinterpret_cast<const v4f *>(g)[l];
+  for (long long r = (long long)blockIdx.x * 8 + grp; r < R; r += (long long)gridDim.x * 8) {
+    float x[13], mu, rstd;
+    v4f h0;
+    stem_row(sw, xin + r * XIN, x, h0, mu, rstd);
+    const v4f dv = reinterpret_cast<const v4f *>(dy + r * C)[l];
+    v4f xh, dyg;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = (h0[e] - mu) * rstd;
+      dyg[e] = dv[e] * gv[e];
+      s1 += dyg[e], s2 += dyg[e] * xh[e];
+    }
+    s1 = sum32(s1) * (1.0f / C), s2 = sum32(s2) * (1.0f / C);
+    float px[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = rstd * (dyg[e] - s1 - xh[e] * s2);   // gradient at h0
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] = fmaf(d0, sw.w[e][c], px[c]), pv[c] = fmaf(d0, sw.w[e][6 + c], pv[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[c] = sum32(px[c]), pv[c] = sum32(pv[c]);
+    if (l == 0) {
+      const long long bb = r / N;
+      const int n = (int)(r % N);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (d_x) d_x[(bb * 3 + c) * N + n] = px[c];
+        if (d_var) d_var[r * 3 + c] = pv[c];
+      }
+    }
+  }
+}
 // part[block] = [d W_in (128 x 13) | d b_in (128) | d gamma (128) | d beta (128)] = 2048 floats
 __global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ dy, const float *__restrict__ xin, const float *__restrict__ W,
                                                    const float *__restrict__ b, const float *__restrict__ g, float *__restrict__ part, long long R) {
@@ -2157,7 +2201,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
 
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream) {
+                                float *d_x, float *d_variances, int B, int N, int precision, float dropout_p, uint64_t dropout_seed,
+                                dfx_stream_t stream) {
   int rc = check_args(wt, workspace, workspace_bytes, B, N, "denoiser_train_backward");
   if (rc) return rc;
   DFX_REQUIRE(precision == DFX_PREC_F32 || precision == DFX_PREC_BF16, "denoiser_train_backward: precision %d", precision);
@@ -2356,6 +2401,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = ln_bwd(st, w, w.dh, w.h0, w.st_pre, wt->pre_norm_w, nullptr, w.dh2, mut(grads->pre_norm_w), mut(grads->pre_norm_b), R))) return rc;
     if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
   }
+  // gradient at the input rows (optional; w.dh = the gradient behind pre_norm is final and row-major on either path)
+  if (d_x || d_variances) k_stem_dx<<<2048, 256, 0, st>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, d_x, d_variances, N, R);
   // context -> part codes, (mean, var), time embedding MLP
   k_ctx_bwd<<<(B * CTX + 255) / 256, 256, 0, st>>>(w.dctx, d_ctx_code, d_ctx_mv, w.dte_out, B);
   if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;

@@ -304,9 +304,8 @@ class AnchoredDiffusion(nn.Module):
                         valid_id=None, flags=None, noise=None):
         """anchored_diffusion.py:760-853: {'mse_loss'} of the epsilon objective at per-shape timesteps ``t`` (B,)
         (q_sample -> denoiser -> masked MSE).  Under ``no_grad`` in ``eval()`` the value comes from the inference
-        engine; with gradients enabled it is differentiable in the denoiser's parameters and in ``ctx`` through libdfx's
-        training kernels (Dropout(p) of train() mode included; anchors / variance are data, as the reference detaches them,
-        anchor_gen.py:1011-1014)."""
+        engine; with gradients enabled it is differentiable in the denoiser's parameters, in ``ctx`` and in ``variance`` through libdfx's
+        training kernels (Dropout(p) of train() mode included; anchors are data: the reference's agent detaches them, anchor_gen.py:1011-1012)."""
         if not reduce:
             _unsupported("training_losses(reduce=False)")
         if noise is None:
@@ -314,10 +313,19 @@ class AnchoredDiffusion(nn.Module):
         if self.training or torch.is_grad_enabled():
             if anchors is None or variance is None:
                 _unsupported("anchors / variance (B,3,N) are required on the training path")
-            x_t = self.q_sample(x_start, t, anchors.detach(), noise=noise, variance=variance.detach())
-            eps = self.model(x_t, t, ctx, anchors=anchors.detach().transpose(1, 2).contiguous(),
-                             variances=variance.detach().transpose(1, 2).contiguous(), valid_id=valid_id,
-                             anchor_assignment=anchor_assignment)
+            if anchors.requires_grad:
+                _unsupported("a gradient through the anchors (AnchorDiffAE detaches them: detach_anchor=True, anchor_gen.py:1011-1012)")
+            # Like the reference, nothing is detached HERE (:779-791).  `variance` may carry a gradient: the reference's agent computes it from
+            # logvar_per_point BEFORE its detach_variance line (anchor_gen.py:1002 vs :1013-1014), so in stage 2 the loss reaches the part aligner
+            # through q_sample's sqrt(variance) * noise and through the network's per-point variance columns as well — reproduced.
+            if variance.requires_grad:
+                sa = torch.from_numpy(self.sqrt_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+                s1 = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+                x_t = sa * (x_start - anchors) + anchors + s1 * torch.sqrt(variance) * noise          # q_sample (:148-173), differentiable
+            else:
+                x_t = self.q_sample(x_start, t, anchors, noise=noise, variance=variance)
+            eps = self.model(x_t, t, ctx, anchors=anchors.transpose(1, 2).contiguous(), variances=variance.transpose(1, 2).contiguous(),
+                             valid_id=valid_id, anchor_assignment=anchor_assignment)
             return {"mse_loss": _training.masked_mse(noise, eps, flags)}
         eng = self.model.engine()
         sc = self._sc(ctx, valid_id)

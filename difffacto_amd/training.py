@@ -50,8 +50,9 @@ def _check_first_backward(ctx, who):
 
 class DenoiserTrainFn(torch.autograd.Function):
     """eps = TransformerNet(x, t, [ctx_code, ctx_mv], anchors, variances, valid_id, anchor_assignment), differentiable in
-    the parameters and in the two context tensors (x_t, anchors and variances are data: anchored_diffusion.py detaches
-    them, agent :1011-1014)."""
+    the parameters, in the two context tensors and — when they require it — in x and in the per-point variances (stage 2:
+    the reference's `variance` reaches training_losses UNdetached, anchor_gen.py:1002-1020, and enters through q_sample's
+    x_t and through the feature columns); anchors are data (detach_anchor, :1011-1012)."""
 
     @staticmethod
     def forward(ctx, depth, precision, dropout, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, *params):
@@ -100,6 +101,7 @@ class DenoiserTrainFn(torch.autograd.Function):
         ctx.tensors = tensors
         ctx.leaves = [p if (p.is_leaf and p.requires_grad) else None for p in params]
         ctx.need_ctx = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
+        ctx.need_in = (ctx.needs_input_grad[3], ctx.needs_input_grad[8])   # x, variances
         return eps
 
     @staticmethod
@@ -123,11 +125,13 @@ class DenoiserTrainFn(torch.autograd.Function):
         grads = {n: flat[o:o + k].view(ctx.tensors[n].shape) for n, o, k in zip(names, starts, sizes)}
         d_code = torch.empty(B, 256, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[0] else None
         d_mv = torch.empty(B, 6, 4, dtype=torch.float32, device=dev) if ctx.need_ctx[1] else None
+        d_x = torch.empty(B, 3, N, dtype=torch.float32, device=dev) if ctx.need_in[0] else None
+        d_var = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if ctx.need_in[1] else None
         w, g = _struct(ctx.tensors, depth), _struct(grads, depth)
         with torch.cuda.device(dev):
             _ffi.check(_ffi.lib().dfx_denoiser_train_backward(ctypes.byref(w), ctx.ws_ptr, ctx.nbytes, d_eps.data_ptr(),
                                                               ctypes.byref(g), None if d_code is None else d_code.data_ptr(),
-                                                              None if d_mv is None else d_mv.data_ptr(), B, N,
+                                                              None if d_mv is None else d_mv.data_ptr(), _ffi.ptr(d_x), _ffi.ptr(d_var), B, N,
                                                               ctx.prec, ctx.drop[0], ctx.drop[1], _ffi.current_stream()),
                        "dfx_denoiser_train_backward")
         ctx.ws = None
@@ -146,7 +150,7 @@ class DenoiserTrainFn(torch.autograd.Function):
                     leaf.grad.add_(grads[n])
                 out.append(None)
         ctx.leaves = None
-        return (None, None, None, None, None, d_code, d_mv, None, None, None, None) + tuple(out)
+        return (None, None, None, d_x, None, d_code, d_mv, None, d_var, None, None) + tuple(out)
 
 
 def denoiser_train_forward(params, x, t, ctx_code, ctx_mv, anchors, variances, valid, assignment, precision="f32", dropout=None):
@@ -731,13 +735,15 @@ class _PinnedRing:
 _pinned = _PinnedRing()
 
 
-def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None, overlap_prior=True):
+def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diffusion_loss_weight=1.0, noise=None, overlap_prior=True, detach_anchor=True):
     """The training forward of the reference's agent for stage 1 (AnchorDiffAE.forward, anchor_gen.py:970-1020): the encoder's
     training forward (part codes, prior loss, ground-truth anchors per point, ctx), one timestep per shape, and the denoiser's
     masked MSE.  `encoder` / `diffusion`: difffacto_amd.encoders.PartEncoderForTransformerDecoder / modules.AnchoredDiffusion in
     train() mode; `t`: (B,) timesteps (the reference draws them with its Uniform sampler, samplers/sampler.py:25-40); `noise`: the
     diffusion noise (B,3,N) or None.  Returns the loss dict; sum the entries whose key contains 'loss' and call backward().
-    overlap_prior: the prior loss (flows) runs on a second stream beside the denoiser, forward and backward; results are the same."""
+    overlap_prior: the prior loss (flows) runs on a second stream beside the denoiser, forward and backward; results are the same.
+    The same function serves stage 2 (an encoder with a part aligner: fit_loss in the dict, gradients to the aligner through ctx[1] and through
+    the per-point variance); the name is historical."""
     import numpy as np
     ref = pcds["ref"].to(device)
     seg = pcds["ref_seg_mask"].to(device).to(torch.int32)
@@ -748,7 +754,10 @@ def stage1_losses(encoder, diffusion, pcds, device="cuda", epoch=0, t=None, diff
         ctx, mean_pp, logvar_pp, _flag_pp, losses, _ = encoder(pcds, device, epoch=epoch)
     finally:
         encoder.prior_loss_stream = None
-    variance_pp = torch.exp(logvar_pp)
+    variance_pp = torch.exp(logvar_pp)     # BEFORE the detaches, like anchor_gen.py:1002: with a part aligner (stage 2) it carries the gradient to logvar
+    if not detach_anchor:
+        raise NotImplementedError("detach_anchor=False (a gradient through the per-point anchors) is not implemented natively")
+    mean_pp = mean_pp.detach()                                                                                 # anchor_gen.py:1011-1012
     if t is None:
         t = _pinned.to_device(np.random.choice(diffusion.num_timesteps, size=(B,)), device)   # (host-drawn like the reference's sampler)
     dp = pcds.get("dp_present", None)

@@ -41,7 +41,7 @@ int dfx_version(void);
  * calls: 2; round 4 added dfx_last_kernel_variant: 3 — additive, bumped so that a binding written against 3 does not load a library without it).
  * Bindings compare dfx_abi_version() with the DFX_ABI_VERSION they were written against at load time (_ffi.py does)
  * instead of shifting arguments silently. */
-#define DFX_ABI_VERSION 3
+#define DFX_ABI_VERSION 4
 int dfx_abi_version(void);
 const char *dfx_last_error(void);
 
@@ -429,6 +429,8 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
  *   the forward of the SAME (B, N) call left in it.
  *   grads: a dfx_denoiser_weights whose pointers name WRITABLE device buffers of the parameters' shapes; every one of
  *   them is overwritten (not accumulated).  d_ctx_code / d_ctx_mv: (B,256,4) / (B,6,4) or NULL.
+ *   d_x (B,3,N) / d_variances (B,N,3) or NULL (ABI 4): the gradient at the input x and at the per-point variance feature columns — stage 2 of the
+ *   reference differentiates `variance` (it reaches training_losses undetached, anchor_gen.py:1002-1020), through q_sample and through these columns.
  * ------------------------------------------------------------------------------------------ */
 size_t dfx_denoiser_train_workspace_bytes(int B, int N, int depth);
 int dfx_denoiser_train_forward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes, const float *x,
@@ -437,7 +439,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *w, void *workspace, s
                                int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream);
 int dfx_denoiser_train_backward(const dfx_denoiser_weights *w, void *workspace, size_t workspace_bytes,
                                 const float *d_eps, const dfx_denoiser_weights *grads, float *d_ctx_code, float *d_ctx_mv,
-                                int B, int N, int precision, float dropout_p, uint64_t dropout_seed, dfx_stream_t stream);
+                                float *d_x, float *d_variances, int B, int N, int precision, float dropout_p, uint64_t dropout_seed,
+                                dfx_stream_t stream);
 /* d loss / d pred of dfx_masked_mse_f32, times grad_scale; workspace2 = the two doubles its forward left behind */
 int dfx_masked_mse_backward_f32(const float *target, const float *pred, const float *flags, const double *workspace2,
                                 float grad_scale, float *d_pred, int B, int N, dfx_stream_t stream);

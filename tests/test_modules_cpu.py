@@ -199,8 +199,11 @@ def test_bench_evidence_helpers_read_the_newest_committed_profiles():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     traffic, src = b.measured_traffic(1000, 128, 2048)
-    assert traffic is not None and 1e9 < traffic < 2e10 and src["file"].startswith("profiles/r") and src["file"].endswith("_traffic.json")
-    assert int(src["round"][1:]) >= 4 and "not measured in this run" in src["note"]
+    # round 5: fixed + per_step * T from PMC passes at two chain lengths (profiles/r05_write_size_scaling.txt: the writes do not grow with T at all;
+    # rounds 1-4 multiplied ONE T = 20 launch by T / 20 and reported 4.2 GB) -> ~0.19 GB per T = 1000 launch
+    assert traffic is not None and 1e8 < traffic < 1e9 and src["file"].startswith("profiles/r") and src["file"].endswith("_traffic.json")
+    assert int(src["round"][1:]) >= 5 and "not measured in this run" in src["note"] and src["bytes_per_launch_fixed"] > 5e7
+    assert abs(b.measured_traffic(40, 128, 2048)[0] - (src["bytes_per_launch_fixed"] + 40 * src["bytes_per_step"])) < 1.0
     assert b.measured_traffic(1000, 7, 2048) == (None, None)          # no profile for that batch: no number
     c = b.power_limited_ceiling()
     assert c["source"].startswith("profiles/r") and 1500 < c["bare_mfma_tflops"] < 2500 and 1000 < c["kernel_mix_tflops"] < c["refill_per_mfma_tflops"] < c["bare_mfma_tflops"]
