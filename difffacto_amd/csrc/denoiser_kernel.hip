@@ -345,7 +345,7 @@ struct HidAct {
 __device__ __forceinline__ h2 pk_f16(float lo, float hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
 // gelu(g) = g Phi(g),  Phi(g) ~ 1/2 + u R(z),  u = g / 2,  z = min(u^2 - m, L^2 - m),  R of degree 5 (minimax fit of g Phi(g) on
 // [-6, 6]: 3.9e-4 in exact arithmetic; evaluated in fp16 with the centred argument z the error of a * gelu(g) is rms 8.5e-4 for
-// a, g ~ N(0, 1.5), tools/fit_gelu_poly.py).  Ten packed instructions per PAIR of values and no transcendental (an exp / rcp
+// a, g ~ N(0, 1.5), tools/experiments/fit_gelu_poly.py).  Ten packed instructions per PAIR of values and no transcendental (an exp / rcp
 // pair is quarter rate and not packed: the sigmoid form cost 6 packed + 4 transcendental instructions per pair = 2.2x the
 // VALU cycles).  g arrives as g / 2 (FF_G_SCALE), a as a / 16 (FF_A_SCALE); fp16 overflow is benign: z saturates at the
 // min, the clamp modifier saturates Phi to [0, 1].
@@ -453,7 +453,7 @@ constexpr int MFMA_PRIO = 0, VALU_PRIO = 3;   // s_setprio inside M / V slots
 
 // M slot of FF record j: h += W2[:, chunk j-1] hid (S3: 8 MFMAs) then a,g = b1[j] + W1[chunk j] xn (S1: 16 MFMAs).
 // The 24 A-fragment units are fetched in batches of eight ds_read_b128 running one batch ahead of the MFMAs.
-// Slot-boundary clock stamps for tools/trace_slots.py; compiled in only with -DDFX_TRACE (the bookkeeping costs
+// Slot-boundary clock stamps for tools/experiments/trace_slots.py; compiled in only with -DDFX_TRACE (the bookkeeping costs
 // ~10 scalar instructions per stamp site even when switched off at run time).
 struct Tracer {
 #ifdef DFX_TRACE
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void issue_record(const KParams &p, DmaState &st, int
 // The DMA of the record three ahead is issued one piece at a time from inside the wave's own M slot, between MFMAs (the two
 // groups' M slots are in anti-phase, so at most four waves issue at a time, one KiB per ~250 cycles).  Issued all at once
 // behind the record's management barrier, the eight waves' 24 KiB hit the texture-address path (64 B/clk) together and
-// every wave sits ~400 cycles in the issue stall on the critical path of the record (slot trace, tools/run_trace.sh).
+// every wave sits ~400 cycles in the issue stall on the critical path of the record (slot trace, tools/experiments/run_trace.sh).
 template <int NW>
 struct Issuer {
   static constexpr int CALLS = PipeCfg<NW>::CALLS;
@@ -1863,7 +1863,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_denoise_pipe_f32(const KParams p
 
   // record boundary: this wave's pieces of the record after next have landed, everybody is done with the slot that is refilled next
   // (ring protocol of k_denoise_pipe), then the pieces of the record three ahead are issued
-#ifdef DFX_TRACE   // phase stamps of waves 0 and 4 (one SIMD) of workgroup 0: tools/trace_f32.py
+#ifdef DFX_TRACE   // phase stamps of waves 0 and 4 (one SIMD) of workgroup 0: tools/experiments/trace_f32.py
   Tracer tr{(p.trace != nullptr && bid == 0 && (wave & 3) == 0) ? p.trace + (size_t)(wave >> 2) * p.trace_cap : nullptr, p.trace_cap, 0};
 #else
   Tracer tr;

@@ -573,7 +573,7 @@ int dfx_furthest_point_sampling_f32(const float *xyz, float *tmp, int32_t *idx, 
     fps_resident_kernel<NT, PPT, LDSC><<<B, NT, sh, st>>>(xyz, idx, N, M, log2bs);                             \
   } while (0)
   // Workgroup shape: the selection loop is a chain of M dependent arg-max reductions whose length is the instructions a wavefront
-  // issues per step — ~8 per point plus the two reduction levels; every size takes the fastest shape of `tools/sweep_fps_shape.py`
+  // issues per step — ~8 per point plus the two reduction levels; every size takes the fastest shape of `tools/experiments/sweep_fps_shape.py`
   // (with the 64-bit reductions, ~70 instructions per wavefront, fewer and fatter wavefronts won: 512 x 16 at N = 8192; with the
   // single-word ones the per-wavefront cost is small again and 1024 x 8 is back in front).
   int nt = 0, ppt = 0;

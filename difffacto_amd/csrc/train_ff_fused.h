@@ -198,7 +198,7 @@ __device__ __forceinline__ void dma256(const void *gbase, unsigned voff4, unsign
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff4), "s"(gbase), "s"(lds_addr) : "memory");
 }
 
-// Phase stamps of a few workgroups (tools/trace_train_ff.py builds with -DDFX_TRACE_FF; never in the shipped library): wave 0 of the
+// Phase stamps of a few workgroups (tools/experiments/trace_train_ff.py builds with -DDFX_TRACE_FF; never in the shipped library): wave 0 of the
 // workgroups whose id is a multiple of FFT_EVERY writes (tag, shader clock) pairs into a host-visible buffer dumped at process exit.
 #ifdef DFX_TRACE_FF
 constexpr int FFT_CAP = 128, FFT_WGS = 64, FFT_EVERY = 29;

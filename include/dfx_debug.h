@@ -63,7 +63,7 @@ void dfx_debug_w1_fold(int mode);
  * dfx_last_kernel_variant() (dfx.h) names the kernel a launch actually took. */
 void dfx_debug_pipe_waves(int nw);
 /* Slot-boundary clock stamps of two wavefronts of workgroup 0 (device buffer of 2*capacity uint64; NULL = off).
- * Only effective in a library built with -DDFX_TRACE (tools/trace_slots.py builds one). */
+ * Only effective in a library built with -DDFX_TRACE (tools/experiments/trace_slots.py builds one). */
 void dfx_debug_trace(void *device_buf, int capacity);
 
 #ifdef __cplusplus

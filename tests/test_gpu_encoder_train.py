@@ -117,7 +117,7 @@ def test_batch_statistics_from_the_product_epilogue_match_the_two_pass_ones(B, N
     for k, a in two["running"].items():
         assert np.abs(fused["running"][k] - a).max() < 1e-6 * max(1.0, np.abs(a).max()), k
     # Gradients: a discontinuous function of the statistics' last bits — a max-pool arg-max or a ReLU unit at ~0 that falls the other way moves
-    # whole entries (tools/ab_bn_stats.py against the CPU oracle: at 8 x 2048 the EPILOGUE path agrees with the oracle to 3.6e-5 of max-abs and the
+    # whole entries (tools/experiments/ab_bn_stats.py against the CPU oracle: at 8 x 2048 the EPILOGUE path agrees with the oracle to 3.6e-5 of max-abs and the
     # two-pass path sits 1.2e-2 away on bn2.bias; at 16 x 1024 both sit 4.8e-2 away on one head bias and 1.3e-5 from each other).  Hence: relative
     # L2 per tensor as for the flows' known kink case, and most tensors to rounding.
     worst, close = 0.0, 0

@@ -105,7 +105,7 @@ FAMILIES = [
     ("denoiser train fwd/bwd vs oracle", lambda a: tt.test_forward_backward_vs_oracle_full_gradients(*a),
      lambda: (ri(1, 6), 32 * ri(1, 24), rb(), rb())),      # the training path takes N % 32 == 0 (include/dfx.h)
     ("bf16 product kernels", lambda a: tt.test_bf16_product_kernels_against_torch(*a), gemm_case),
-    # (against the float64 oracle with the fp32 oracle's own error as the yardstick: tools/pnv2_conditioning.py says why)
+    # (against the float64 oracle with the fp32 oracle's own error as the yardstick: tools/experiments/pnv2_conditioning.py says why)
     ("PointNetV2 train vs f64 oracle", lambda a: pnv2_check(*a), lambda: (ri(2, 8), ri(64, 800))),
     ("prior loss vs oracle", lambda a: tet.test_prior_loss_vs_oracle_other_batch(*a), lambda: (ri(2, 90), False)),
     ("FPS", lambda a: tp.test_fps_matches_oracle(pu, *a), lambda: (lambda n: (ri(1, 4), n, ri(1, min(n, 700))))(ri(1, 6000))),

@@ -6,7 +6,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 run() {
   local name=$1; shift
-  rocprofv3 --pmc "$@" -d $OUT/$name --output-format csv -- python tools/time_pointnet_v2_train.py 128 2048 > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" -d $OUT/$name --output-format csv -- python tools/experiments/time_pointnet_v2_train.py 128 2048 > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" $PAT > $OUT/$name.summary.txt 2>&1
   echo "== pass $name"; cat $OUT/$name.summary.txt

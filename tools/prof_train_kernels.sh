@@ -15,5 +15,5 @@ for r in rows[:24]:
     tot += us
     print("%8.1f us/iter %5d calls/iter %8.1f us/call  %s" % (us, int(r["Calls"]) // it, float(r["AverageNs"]) / 1e3, r["Name"][:110]))
 print("%8.1f us/iter in all %d kernels" % (sum(float(r["TotalDurationNs"]) for r in rows) / it / 1e3, len(rows)))
-print("(the parameter-gradient reductions run on a side stream beside other kernels — k_stem_bwd, k_sum_parts, k_ff_wgrad_finish and whatever they overlap are stretched: the sum exceeds the wall time of an iteration; tools/iter_sequence.py prints the timeline, tools/bench_train.py --streams 0 the single-stream order)")
+print("(the parameter-gradient reductions run on a side stream beside other kernels — k_stem_bwd, k_sum_parts, k_ff_wgrad_finish and whatever they overlap are stretched: the sum exceeds the wall time of an iteration; tools/experiments/iter_sequence.py prints the timeline, tools/bench_train.py --streams 0 the single-stream order)")
 PY

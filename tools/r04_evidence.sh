@@ -34,7 +34,7 @@ python tools/bench_train.py > $O/bench_train.txt 2>&1
 tools/prof_train_kernels.sh $O/kernel_stats_train.csv > $O/kernel_stats_train.txt 2>&1
 tools/prof_train_traffic.sh $O/train_traffic > $O/traffic_train.txt 2>&1
 PMC_PAT=k_ff tools/prof_train_pmc.sh $O/train_pmc > $O/pmc_train_ff.txt 2>&1
-python tools/trace_train_ff.py $O/trace_train_ff.txt > /dev/null 2>&1
+python tools/experiments/trace_train_ff.py $O/trace_train_ff.txt > /dev/null 2>&1
 python tools/bench_pointnet2.py > $O/bench_pointnet2.txt 2>&1
 tools/prof_pointnet2.sh > $O/prof_pointnet2.log 2>&1
 cp gpurun_out/pn2/kernel_stats.csv $O/kernel_stats_pointnet2.csv 2>/dev/null
