@@ -99,6 +99,13 @@ def test_encoder_forward_with_part_aligner_matches_reference():
     got = {k: v.detach().cpu().reshape(expect[k].shape) if isinstance(v, torch.Tensor) else v for k, v in got.items()}
     worst = _compare(got, expect, 2e-4)
     print(f"encoder forward + sample_noise: worst rel err {worst:.2e}; arg-min ids {idx.tolist()}")
+    # AnchorDiffAE.cache_noise (anchor_gen.py:807-815, the cIMLE noise cache of stage 2) = the arg-min candidate of sample_noise: same draws -> same rows
+    model.sample_noise_num = num
+    with replay_draws(draws[1:3]) as queue:
+        cached = model.cache_noise(batch, "cuda")
+    assert not queue
+    ref = expect["sn_noise"][np.arange(expect["sn_noise"].shape[0]), expect["sn_id"]]
+    assert np.array_equal(cached.cpu().numpy(), ref)
 
 
 def test_seedless_sampling_is_fresh_per_call_and_replays_under_manual_seed():
