@@ -2294,6 +2294,338 @@ __global__ void __launch_bounds__(COOP_NW * 64, 2) k_denoise_coop(const KParams 
   }
 }
 
+// ---- k_denoise_coop16 (round 5): the co-operative kernel on SIXTEEN-point tiles (v_mfma_f32_16x16x32_bf16 / _f16).
+// A 2048-point shape is 128 tiles of 16 points instead of 64 of 32: a single shape occupies 128 CUs, two shapes the whole chip, and every VALU phase of a
+// tile's critical path (LayerNorms, softmax, GELU, step boundary: 10.3 k of the 13.5 k cycles of a block in k_denoise_coop) works on half the values per
+// lane; an MFMA is 16 cycles instead of 32.  Same records in memory — no second pack: a 16 x 32 A fragment of this MFMA is TWO 8-byte pieces of the 32 x 32
+// tile the packs hold (the K order of those tiles is the accumulator order, whose groups of four consecutive channels stay together), gathered by address.
+// Layout: lane l = (point j = l & 15, group g = l >> 4); accumulator tile c (0..7), register r (0..3) = channel 16 c + 4 g + r; the B fragment of k-step s
+// (32 channels) is built in-lane from tiles 2 s, 2 s + 1 (element e = register e & 3 of tile 2 s + (e >> 2)), and the gathered A fragments follow that order.
+// The accumulation order over K differs from the 32 x 32 x 16 family (32 channels per MFMA instead of 16), so this variant is NOT bit-identical to the
+// others: it is gated against the exact-fp32 chain and the CPU oracle at the bf16 tolerances (tests/test_gpu_small_batch16.py).
+// Work of a block: phase A (wave 0: attention + LayerNorms), phase H (all 8 waves: chunks w and w + 8 of the hidden layer, both 16-unit halves of a chunk
+// on one wave so that the GELU output is a complete B fragment), phase G (all 8 waves: wave w owns accumulator tile w of h; its 16 W2 fragments sit in the
+// registers round 0 of phase H has freed).  The next block's attention record | c_t row | b2 are fetched by LDS-DMA during phase H into the other half of
+// a double buffer.  One workgroup per CU (128 fragment registers), LDS 77 KiB.
+constexpr int C16_NW = 8, C16_PTS = 16;
+constexpr double C16_ROUND_MS = 1e9;   // ms per round of g_num_cus workgroups at N = 2048, T = 1000 (launch()'s cost model; 1e9 = never chosen automatically until measured)
+constexpr int C16_XN = 0;                                            // 4 x 64 uint4: LN3 output, B fragments of the four k-steps
+constexpr int C16_HID = C16_XN + 4 * 1024;                           // 16 x 64 uint4: GELU output, B fragment of every 32-unit chunk
+constexpr int C16_AT = C16_HID + FF_CHUNKS * 1024;                   // 2 x [attention record 17 KiB | c_t row 1 KiB | b2 1 KiB]
+constexpr int C16_AT_BYTES = asms_bytes(DFX_PREC_BF16) + 2048;
+constexpr int C16_HS = C16_AT + 2 * C16_AT_BYTES;                    // home of h: [tile c (8)][lane] float4 = 8 KiB
+constexpr int C16_CONST = C16_HS + 8 * 1024;                         // chain-invariant operands (as k_denoise_coop): W_in x-columns | pre_norm | W_out | cpart
+constexpr int C16_Z = C16_CONST + 7 * 1024;                          // noise z[3][16] | posterior table row at +512
+constexpr int C16_PS = C16_Z + 1024;                                 // per-point chain state: 13 x 16 floats
+constexpr int C16_TOTAL = C16_PS + 1024;
+static_assert(C16_TOTAL <= 160 * 1024, "LDS budget of the 16-point co-operative kernel");
+static_assert(FF_CHUNKS == 2 * C16_NW && INNER == 128, "two chunks per wavefront, eight accumulator tiles");
+
+__global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams p) {
+  constexpr int PREC = DFX_PREC_BF16;
+  constexpr int TSTRIDE = tile_units(PREC) * 64, AREC = asms_bytes(PREC) / 16;
+  constexpr int TILE_B = TSTRIDE * 16;   // bytes per 32 x 32 tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const long long g0 = (long long)blockIdx.x * C16_PTS;
+  const int s = __builtin_amdgcn_readfirstlane((int)(g0 / p.N));
+  const int n = (int)(g0 - (long long)s * p.N) + j;
+  const int depth = p.d.depth;
+  const bool w0 = wave == 0;
+  float *ps_lds = reinterpret_cast<float *>(pipe_smem + C16_PS);
+  float *s_hs = reinterpret_cast<float *>(pipe_smem + C16_HS);
+  uint4 *s_xn = reinterpret_cast<uint4 *>(pipe_smem + C16_XN);
+  uint4 *s_hid = reinterpret_cast<uint4 *>(pipe_smem + C16_HID);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)pipe_smem);
+  const unsigned voff = lane * 16;
+  // byte offset of this lane's 8-byte piece inside unit 0 of a 32 x 32 tile, for the tile's rows 0..15 (half 0) / 16..31 (half 1); unit 1: + 1024
+  const unsigned aoff0 = (unsigned)((j + 32 * (g & 1)) * 16 + 8 * (g >> 1)), aoff1 = aoff0 + 16 * 16;
+  // index of this lane's four consecutive entries of a per-channel vector in cvec order, for accumulator tile c (channels 16 c + 4 g + 0..3)
+  auto cv = [&](int c) { return (g & 1) * 64 + (c >> 1) * 16 + (c & 1) * 8 + (g >> 1) * 4; };
+  auto gather = [&](const char *tile, unsigned aoff) -> uint4 {   // one 16 x 32 A fragment out of a 32 x 32 tile (global or LDS)
+    const uint2 a = *reinterpret_cast<const uint2 *>(tile + aoff), b = *reinterpret_cast<const uint2 *>(tile + aoff + 1024);
+    return make_uint4(a.x, a.y, b.x, b.y);
+  };
+  auto mfma_bf = [](const uint4 &a, const uint4 &b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  };
+  auto mfma_h = [](const uint4 &a, const uint4 &b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  };
+  auto xg = [](float v) {   // sum over the four lane groups of a point
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+  };
+  auto hs_ptr = [&](int c) -> v4f * { return reinterpret_cast<v4f *>(s_hs + (c * 64 + lane) * 4); };
+  // LayerNorm statistics of h (32 values in-lane + the other three groups of the point): single pass like ln_stats_fast
+  auto ln16 = [&](const v4f (&h)[8], float &mean, float &rstd) {
+    float st = 0.f, qt = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st += h[c][r], qt = fmaf(h[c][r], h[c][r], qt);
+    st = xg(st), qt = xg(qt);
+    mean = st * (1.0f / 128.0f);
+    rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean, mean, qt * (1.0f / 128.0f)), 0.f) + 1e-5f);
+  };
+  // normalised (affine-free) h: the bf16 B fragment of k-step k
+  auto ln_frag = [&](const v4f (&h)[8], int k, float rstd, float nmr) -> uint4 {
+    v8f t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = fmaf(h[2 * k + (e >> 2)][e & 3], rstd, nmr);
+    return __builtin_bit_cast(uint4, __builtin_convertvector(t, v8bf));
+  };
+
+  unsigned vmask = 0;
+  if (w0) {
+    PointState ps0;
+    ps0.live = g == 0;   // the four groups of a point hold the same state; group 0 does the stores (point_init / step_epilogue test `live` and the half-wave)
+    point_init(p, ps0, s, n, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, vmask);
+    pstate_store(ps_lds, j, C16_PTS, ps0, true);
+  }
+  {   // chain-invariant small operands -> LDS
+    float4 *c_winx = reinterpret_cast<float4 *>(pipe_smem + C16_CONST);
+    float2 *c_pregb = reinterpret_cast<float2 *>(pipe_smem + C16_CONST + 2048);
+    float4 *c_wout = reinterpret_cast<float4 *>(pipe_smem + C16_CONST + 3072);
+    float *c_cp = reinterpret_cast<float *>(pipe_smem + C16_CONST + 5120);
+    const int tid = threadIdx.x;
+    if (tid < 128) c_winx[tid] = p.d.win_x[tid], c_pregb[tid] = p.d.pre_gb[tid], c_wout[tid] = p.d.wout[tid];
+    c_cp[tid] = p.cpart[(size_t)s * NCLS * INNER + tid];
+    __syncthreads();
+  }
+  const float4 *winx = reinterpret_cast<const float4 *>(pipe_smem + C16_CONST);
+  const float2 *pregb = reinterpret_cast<const float2 *>(pipe_smem + C16_CONST + 2048);
+  const float4 *wout = reinterpret_cast<const float4 *>(pipe_smem + C16_CONST + 3072);
+  const uint4 *asms_s = p.as_ms + (size_t)s * depth * AREC;
+
+  // proj_in + pre_norm of the chain state -> h's LDS home (wave 0)
+  auto enter_step = [&](const PointState &ps) {
+    v4f h[8];
+    const float *cp = reinterpret_cast<const float *>(pipe_smem + C16_CONST + 5120) + ps.sg * INNER;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const v4f cpv = *reinterpret_cast<const v4f *>(cp + cv(c));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 w = winx[cv(c) + r];
+        h[c][r] = fmaf(w.z, ps.x[2], fmaf(w.y, ps.x[1], fmaf(w.x, ps.x[0], cpv[r])));
+      }
+    }
+    float mean, rstd;
+    ln16(h, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v4f o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2 gb = pregb[cv(c) + r];
+        o[r] = fmaf((h[c][r] - mean) * rstd, gb.x, gb.y);
+      }
+      *hs_ptr(c) = o;
+    }
+  };
+  // the operands of block b at timestep t -> half `buf` of the double buffer: 17 KiB record | c_t row | b2 (19 pieces over waves 1..7)
+  auto fetch_record = [&](int b, int t, int buf) {
+    const BlockPack bp = block_pack(p, b);
+    constexpr int NA = asms_bytes(PREC) / 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int k = i * (C16_NW - 1) + wave - 1;
+      const unsigned dst = lds0 + C16_AT + buf * C16_AT_BYTES + k * 1024;
+      if (k < NA) dma1k_pinned(reinterpret_cast<const char *>(asms_s + (size_t)b * AREC) + k * 1024, voff, dst);
+      else if (k == NA) dma1k_pinned(reinterpret_cast<const char *>(bp.ct + (size_t)t * CT_ROW), voff, dst);
+      else if (k == NA + 1) dma1k_pinned(reinterpret_cast<const char *>(bp.bconst + BCONST_B2_OFF), voff, dst);
+    }
+  };
+
+  if (w0) {
+    PointState ps;
+    pstate_load(ps_lds, j, C16_PTS, ps, false);
+    enter_step(ps);
+  } else {
+    fetch_record(0, step_t(p, 0, s), 0);
+  }
+  uint4 R[32];   // GEMM1 fragments of the wave's two chunks (16 each); phase G: the wave's sixteen W2 fragments in R[0..15]
+  int seq = 0;
+  for (int step = 0; step < p.nsteps; ++step) {
+    const int t = step_t(p, step, s);
+    for (int b = 0; b < depth; ++b, ++seq) {
+      const BlockPack bp = block_pack(p, b);
+      const unsigned char *at = pipe_smem + C16_AT + (seq & 1) * C16_AT_BYTES;
+      if (!w0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's record (requested a block ago) has landed
+      // GEMM1 fragments of chunks `wave` (R[0..15]) and `wave + 8` (R[16..31]): [a | g] x 4 k-steps x 2 halves, in flight through phase A
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const char *ck = pin_ptr(reinterpret_cast<const char *>(bp.chunks + (size_t)(r * C16_NW + wave) * CHUNK_TILES * TSTRIDE));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          R[16 * r + 4 * k + 0] = gather(ck + (0 + k) * TILE_B, aoff0), R[16 * r + 4 * k + 1] = gather(ck + (4 + k) * TILE_B, aoff0);
+          R[16 * r + 4 * k + 2] = gather(ck + (0 + k) * TILE_B, aoff1), R[16 * r + 4 * k + 3] = gather(ck + (4 + k) * TILE_B, aoff1);
+        }
+      }
+      __syncthreads();   // 0: this block's record is in LDS; h's home holds the previous block's result
+      if (w0) {          // ---- phase A
+        v4f h[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) h[c] = *hs_ptr(c);
+        // sim = A_s LN2(h) + sbias: rows 16 rt + 4 g + r = key r of head 4 rt + g; the B fragments are consumed as they are made
+        const float *sb = reinterpret_cast<const float *>(at + 8 * TILE_B);
+        v4f sim[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) sim[rt] = *reinterpret_cast<const v4f *>(sb + (g & 1) * 16 + 8 * rt + 4 * (g >> 1));
+        {
+          float mean, rstd;
+          ln16(h, mean, rstd);
+          const float nmr = -mean * rstd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 xk = ln_frag(h, k, rstd, nmr);
+            sim[0] = mfma_bf(gather(reinterpret_cast<const char *>(at) + k * TILE_B, aoff0), xk, sim[0]);
+            sim[1] = mfma_bf(gather(reinterpret_cast<const char *>(at) + k * TILE_B, aoff1), xk, sim[1]);
+          }
+        }
+        v8f pf;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {   // masked softmax over the four keys (attention.py:195-198), in-lane
+          float sj[4], e[4], sum = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sj[q] = (vmask >> q) & 1u ? sim[rt][q] : -3.402823466e38f;
+          const float m = fmaxf(fmaxf(sj[0], sj[1]), fmaxf(sj[2], sj[3]));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = __expf(sj[q] - m), sum += e[q];
+          const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pf[4 * rt + q] = e[q] * inv;
+        }
+        const uint4 pa = __builtin_bit_cast(uint4, __builtin_convertvector(pf, v8bf));
+        const float *ct = reinterpret_cast<const float *>(at + asms_bytes(PREC));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {   // h += M_s P + c_t
+          h[c] = mfma_bf(gather(reinterpret_cast<const char *>(at) + (4 + (c >> 1)) * TILE_B, (c & 1) ? aoff1 : aoff0), pa, h[c]);
+          const v4f cc = *reinterpret_cast<const v4f *>(ct + cv(c));
+          h[c] += cc;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *hs_ptr(c) = h[c];
+        {
+          float mean, rstd;
+          ln16(h, mean, rstd);
+          const float nmr = -mean * rstd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint4 xk = ln_frag(h, k, rstd, nmr);
+            if (k == 3 && p.d.w1_fold && g == 3) xk.w = (xk.w & 0x0000ffffu) | 0x3f800000u;   // channel 127 = tile 7, row 15: element 7 of k-step 3 carries the constant 1 (bias_slot_one)
+            s_xn[k * 64 + lane] = xk;
+          }
+        }
+      } else if (wave == C16_NW - 1 && b == depth - 1 && p.mode != MODE_EPS) {   // the step's noise and posterior coefficients, ready for wave 0's epilogue
+        float z[3];
+        if (p.noise) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) z[i] = p.noise[(((size_t)step * p.B + s) * 3 + i) * p.N + n];
+        } else {
+          philox_normal3(p.seed, ((unsigned long long)p.shape0 + (unsigned)s) * (unsigned)p.N + (unsigned)n, (unsigned)t, 0u, z);
+        }
+        float *s_z = reinterpret_cast<float *>(pipe_smem + C16_Z);
+        if (g == 0) s_z[j] = z[0], s_z[16 + j] = z[1], s_z[32 + j] = z[2];
+        if (lane < 8) s_z[128 + lane] = p.d.tab[(size_t)t * 8 + lane];
+      }
+      __syncthreads();   // 1: xn3 of this block and h are in LDS
+      // ---- phase H.  The next block's record travels meanwhile (into the other half of the double buffer: nobody reads that half before barrier 0)
+      if (!w0) {
+        const int nb = b + 1 < depth ? b + 1 : 0, nstep = b + 1 < depth ? step : step + 1;
+        if (nstep < p.nsteps) fetch_record(nb, step_t(p, nstep, s), (seq + 1) & 1);
+      }
+      uint4 xq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xq[k] = s_xn[k * 64 + lane];
+      const float *b1t = bp.bconst;   // [u][part][hf][16] in the 32-wide register order (read only by engines without the W1 bias fold)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int u = r * C16_NW + wave;
+        v4f a[2], gg[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          if (p.d.w1_fold) {
+            a[hh] = v4f{0.f, 0.f, 0.f, 0.f}, gg[hh] = a[hh];
+          } else {   // unit 16 hh + 4 g + q of the chunk = entry (g & 1) * 16 + 8 hh + 4 (g >> 1) + q of the [hf][16] table
+            a[hh] = *reinterpret_cast<const v4f *>(b1t + u * 64 + (g & 1) * 16 + 8 * hh + 4 * (g >> 1));
+            gg[hh] = *reinterpret_cast<const v4f *>(b1t + u * 64 + 32 + (g & 1) * 16 + 8 * hh + 4 * (g >> 1));
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            a[hh] = mfma_bf(R[16 * r + 4 * k + 2 * hh + 0], xq[k], a[hh]);
+            gg[hh] = mfma_bf(R[16 * r + 4 * k + 2 * hh + 1], xq[k], gg[hh]);
+          }
+        }
+        if (r == 0) {   // round 0's registers are free: this wave's W2 fragments — accumulator tile `wave`, all sixteen chunks (W2 of chunk c sits in FF record c + FF_SKEW, tiles 8..11)
+          const char *w2 = pin_ptr(reinterpret_cast<const char *>(bp.chunks + (size_t)FF_SKEW * CHUNK_TILES * TSTRIDE) + (8 + (wave >> 1)) * TILE_B);
+          const unsigned ao = (wave & 1) ? aoff1 : aoff0;
+#pragma unroll
+          for (int c = 0; c < FF_CHUNKS; ++c) R[c] = gather(w2 + (size_t)c * CHUNK_TILES * TILE_B, ao);
+        }
+        // packed-fp16 GELU on the eight values of the two halves (gelu16_f16_math on four pairs): hid = a gelu(g) with the pack's scales
+        h2 ap[4], gp[4], y[4], z[4], rr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gp[i] = pk_f16(gg[i >> 1][2 * (i & 1)], gg[i >> 1][2 * (i & 1) + 1]), ap[i] = pk_f16(a[i >> 1][2 * (i & 1)], a[i >> 1][2 * (i & 1) + 1]);
+#define DFX_ST4(expr) _Pragma("unroll") for (int i = 0; i < 4; ++i) { expr; }
+        DFX_ST4(z[i] = __builtin_elementwise_fma(gp[i], gp[i], h2c(-1.62f)));
+        DFX_ST4(y[i] = ap[i] * gp[i]);
+        DFX_ST4(z[i] = __builtin_elementwise_min(z[i], h2c(1.62f)));
+        DFX_ST4(rr[i] = __builtin_elementwise_fma(z[i], h2c(-0.0011402554f), h2c(0.0057853916f)));
+        DFX_ST4(rr[i] = __builtin_elementwise_fma(rr[i], z[i], h2c(-0.0158536041f)));
+        DFX_ST4(rr[i] = __builtin_elementwise_fma(rr[i], z[i], h2c(0.0409006897f)));
+        DFX_ST4(rr[i] = __builtin_elementwise_fma(rr[i], z[i], h2c(-0.1098130657f)));
+        DFX_ST4(rr[i] = __builtin_elementwise_fma(rr[i], z[i], h2c(0.3885767652f)));
+        DFX_ST4(asm("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(z[i]) : "v"(gp[i]), "v"(rr[i])));
+        DFX_ST4(y[i] = y[i] * z[i]);
+#undef DFX_ST4
+        s_hid[u * 64 + lane] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
+                                          __builtin_bit_cast(unsigned, y[3]));
+      }
+      __syncthreads();   // 2: hid of all chunks is in LDS
+      // ---- phase G: wave w accumulates tile w of h over the sixteen chunks, + b2
+      {
+        v4f ht = *hs_ptr(wave);
+#pragma unroll
+        for (int u = 0; u < FF_CHUNKS; ++u) ht = mfma_h(R[u], s_hid[u * 64 + lane], ht);
+        const float *b2 = reinterpret_cast<const float *>(at + asms_bytes(PREC) + 1024);
+        const v4f bb = *reinterpret_cast<const v4f *>(b2 + cv(wave));
+        *hs_ptr(wave) = ht + bb;
+      }
+    }
+    __syncthreads();   // the last block's tiles are in h's home
+    if (w0) {
+      v4f h[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) h[c] = *hs_ptr(c);
+      float mean, rstd;
+      ln16(h, mean, rstd);
+      const float nmr = -mean * rstd;
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 w = wout[cv(c) + r];
+          const float v = fmaf(h[c][r], rstd, nmr);
+          e0 = fmaf(w.x, v, e0), e1 = fmaf(w.y, v, e1), e2 = fmaf(w.z, v, e2);
+        }
+      const float eps[3] = {xg(e0) + p.d.bout[0], xg(e1) + p.d.bout[1], xg(e2) + p.d.bout[2]};
+      PointState ps;
+      ps.s = s, ps.n = n, ps.gid = 0, ps.live = g == 0;
+      pstate_load(ps_lds, j, C16_PTS, ps, true);
+      const float *s_z = reinterpret_cast<const float *>(pipe_smem + C16_Z);
+      const float zr[3] = {s_z[j], s_z[16 + j], s_z[32 + j]};
+      const bool zok = p.mode != MODE_EPS;
+      if (step_epilogue(p, ps, eps, step, t, zok ? zr : nullptr, zok ? s_z + 128 : nullptr)) break;
+      pstate_store(ps_lds, j, C16_PTS, ps, false);
+      if (step + 1 < p.nsteps) enter_step(ps);
+    }
+  }
+}
+
 // ---- k_denoise_coop2: the co-operative kernel with TWO 32-point tiles per workgroup (round 4; batches of 5 .. 8 shapes at N = 2048, i.e. one to two
 // tiles per CU, where k_denoise_coop needs two rounds of workgroups and k_denoise_pipe<2> leaves half of every CU idle).  Same phases, same device
 // functions, same MFMA order per accumulator as k_denoise_coop — bit-identical results — with the work of a block cut this way:
@@ -2617,7 +2949,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     if (cost < best) best = cost, nw = c;
   }
   const bool pipe2 = bf16 && g_force_nw == 64 && tiles(8) * 256 <= 3LL * p.N;   // two tiles per wavefront (k_denoise_pipe2): 256-point workgroup tiles
-  if (g_force_nw > 1 && g_force_nw != 64 && g_force_nw != 16) nw = g_force_nw;
+  if (g_force_nw > 1 && g_force_nw != 64 && g_force_nw != 16 && g_force_nw < 160) nw = g_force_nw;
   if (pipe2) nw = 8;
   const long long wpg = tiles(nw);
   // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
@@ -2629,7 +2961,13 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   // T = 1000 — between one and two rounds of k_denoise_coop (B = 5 .. 8 shapes of 2048 points) the cheapest
   const double coop_cost = rounds_cost(waves, 32.7, 0.0), coop2_cost = rounds_cost((waves + 1) / 2, 48.2, 0.0);
   const bool coop2 = bf16 && !pipe2 && p.N % 64 == 0 && (g_force_nw == 16 || (g_force_nw == 0 && coop2_cost < coop_cost && (!pipe || coop2_cost < best)));
-  if (pipe || coop || coop2 || pipe_f32) {
+  // 16-point tiles (k_denoise_coop16, round 5): 2 x the workgroups of k_denoise_coop at about half the time per round — the fastest choice while the batch
+  // is at most two rounds of it (B <= 4 shapes of 2048 points); works with either W1 pack.  dfx_debug_pipe_waves(160) forces it, (161) rules it out.
+  const long long tiles16 = ((long long)p.B * p.N) / 16;
+  const double coop16_cost = rounds_cost(tiles16, C16_ROUND_MS, 0.0);
+  const bool coop16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && !pipe2 &&
+                      (g_force_nw == 160 || (g_force_nw == 0 && coop16_cost < (coop2 ? coop2_cost : coop ? coop_cost : best)));
+  if (pipe || coop || coop2 || pipe_f32 || coop16) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {
       hipError_t e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<8>), PipeCfg<8>::L_TOTAL);
@@ -2637,6 +2975,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe<2>), PipeCfg<2>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop), CL_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop2), C2_TOTAL);
+      if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_coop16), C16_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe2), P2_LDS);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<8>), PipeCfg<8>::L_TOTAL);
       if (e == hipSuccess) e = set_max_lds(reinterpret_cast<const void *>(k_denoise_pipe_f32<4>), PipeCfg<4>::L_TOTAL);
@@ -2647,7 +2986,8 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   EventTimer tm;
   tm.begin(st);
   const char *variant;
-  if (pipe2) variant = "k_denoise_pipe2", k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
+  if (coop16) variant = "k_denoise_coop16", k_denoise_coop16<<<(int)tiles16, C16_NW * 64, C16_TOTAL, st>>>(p);
+  else if (pipe2) variant = "k_denoise_pipe2", k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
   else if (coop2 && !(g_force_nw == 1)) variant = "k_denoise_coop2", k_denoise_coop2<<<(int)(waves / 2), COOP_NW * 64, C2_TOTAL, st>>>(p);
   else if (coop) variant = "k_denoise_coop", k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
   else if (pipe && nw == 8) variant = "k_denoise_pipe<8>", k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);

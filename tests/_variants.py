@@ -2,15 +2,15 @@
 (include/dfx.h: dfx_last_kernel_variant) — a test whose name claims a kernel checks that the kernel ran."""
 import contextlib
 
-NAMES = {"bf16": {8: "k_denoise_pipe<8>", 4: "k_denoise_pipe<4>", 2: "k_denoise_pipe<2>", 1: "k_denoise_coop", 64: "k_denoise_pipe2", 16: "k_denoise_coop2"},
+NAMES = {"bf16": {8: "k_denoise_pipe<8>", 4: "k_denoise_pipe<4>", 2: "k_denoise_pipe<2>", 1: "k_denoise_coop", 64: "k_denoise_pipe2", 16: "k_denoise_coop2", 160: "k_denoise_coop16"},
          "f32": {8: "k_denoise_pipe_f32<8>", 4: "k_denoise_pipe_f32<4>", 2: "k_denoise_pipe_f32<2>", 1: "k_denoise<f32>"}}
-AUTO = {"bf16": set(NAMES["bf16"].values()) - {"k_denoise_pipe2"} | {"k_denoise<bf16>"},
+AUTO = {"bf16": set(NAMES["bf16"].values()) - {"k_denoise_pipe2"} | {"k_denoise<bf16>"},   # (k_denoise_coop16: the launcher's choice for the smallest batches)
         "f32": set(NAMES["f32"].values())}
 
 
 @contextlib.contextmanager
 def forced(nw):
-    """nw = 8 / 4 / 2 wavefronts per workgroup of the pipelined kernel, 1 = co-operative (bf16) or direct (fp32) kernel, 16 = co-operative with two tiles per workgroup, 64 = pipe2; 0 = automatic."""
+    """nw = 8 / 4 / 2 wavefronts per workgroup of the pipelined kernel, 1 = co-operative (bf16) or direct (fp32) kernel, 16 = co-operative with two tiles per workgroup, 160 = co-operative on 16-point tiles (161 rules that one out), 64 = pipe2; 0 = automatic."""
     from difffacto_amd import _ffi
     _ffi.lib().dfx_debug_pipe_waves(int(nw))
     try:
