@@ -2343,9 +2343,27 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
   const unsigned aoff0 = (unsigned)((j + 32 * (g & 1)) * 16 + 8 * (g >> 1)), aoff1 = aoff0 + 16 * 16;
   // index of this lane's four consecutive entries of a per-channel vector in cvec order, for accumulator tile c (channels 16 c + 4 g + 0..3)
   auto cv = [&](int c) { return (g & 1) * 64 + (c >> 1) * 16 + (c & 1) * 8 + (g >> 1) * 4; };
-  auto gather = [&](const char *tile, unsigned aoff) -> uint4 {   // one 16 x 32 A fragment out of a 32 x 32 tile (global or LDS)
-    const uint2 a = *reinterpret_cast<const uint2 *>(tile + aoff), b = *reinterpret_cast<const uint2 *>(tile + aoff + 1024);
-    return make_uint4(a.x, a.y, b.x, b.y);
+  // One 16 x 32 A fragment out of a 32 x 32 tile = two 8-byte pieces (elements 4 q .. 4 q + 3 of units 0 and 1, q = g >> 1).  From global memory every
+  // lane loads ONE whole 16-byte unit instead — groups 0 / 1 unit 0, groups 2 / 3 unit 1 of the same row — and the two half-waves trade the piece the other
+  // one needs with two v_permlane32_swap: the same bytes in half the load instructions (the first version issued 96 eight-byte loads per wavefront and block;
+  // the CU's address path, shared by its eight wavefronts, took 8 k cycles per block for them).  The address space is spelled out through an integer:
+  // behind pin_ptr's round trip hipcc would emit flat loads, which count against lgkmcnt as well.
+  const unsigned goff0 = (unsigned)((g >> 1) * 1024 + (j + 32 * (g & 1)) * 16), goff1 = goff0 + 16 * 16;
+  auto gather = [&](const char *tile, unsigned goff) -> uint4 {          // goff = goff0 (rows 0..15 of the tile) or goff1 (rows 16..31); the RAW unit: frag_fix() before use
+    typedef const __attribute__((address_space(1))) unsigned long long *gp64;
+    const gp64 q = (gp64)(unsigned long long)(uintptr_t)(tile + goff);
+    const unsigned long long lo = q[0], hi = q[1];
+    return make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+  };
+  auto frag_fix = [](uint4 &f) {   // (applied where the fragment is consumed: at the load site it would wait for the data)
+    const auto r0 = __builtin_amdgcn_permlane32_swap(f.x, f.z, false, false), r1 = __builtin_amdgcn_permlane32_swap(f.y, f.w, false, false);   // x, y of the upper half-wave <-> z, w of the lower
+    f = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  };
+  auto gather_lds = [&](const unsigned char *tile, unsigned aoff) -> uint4 {   // from the attention record's LDS copy
+    typedef const __attribute__((address_space(3))) unsigned long long *lp64;
+    const uintptr_t la = (uintptr_t)(const __attribute__((address_space(3))) unsigned char *)tile + aoff;
+    const unsigned long long a = *(lp64)la, b = *(lp64)(la + 1024);
+    return make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
   };
   auto mfma_bf = [](const uint4 &a, const uint4 &b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
@@ -2447,6 +2465,11 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
     fetch_record(0, step_t(p, 0, s), 0);
   }
   uint4 R[32];   // GEMM1 fragments of the wave's two chunks (16 each); phase G: the wave's sixteen W2 fragments in R[0..15]
+#ifdef DFX_TRACE   // phase stamps of wave 0 (row 0 of the trace buffer) and of wave 5 (row 1) of workgroup 0
+  Tracer tr{(p.trace != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 5)) ? p.trace + (size_t)(wave ? 1 : 0) * p.trace_cap : nullptr, p.trace_cap, 0};
+#else
+  Tracer tr;
+#endif
   int seq = 0;
   for (int step = 0; step < p.nsteps; ++step) {
     const int t = step_t(p, step, s);
@@ -2454,17 +2477,22 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
       const BlockPack bp = block_pack(p, b);
       const unsigned char *at = pipe_smem + C16_AT + (seq & 1) * C16_AT_BYTES;
       if (!w0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's record (requested a block ago) has landed
-      // GEMM1 fragments of chunks `wave` (R[0..15]) and `wave + 8` (R[16..31]): [a | g] x 4 k-steps x 2 halves, in flight through phase A
+      // GEMM1 fragments of chunks `wave` (R[0..15]) and `wave + 8` (R[16..31]): [a | g] x 4 k-steps x 2 halves, requested by every wavefront in front of
+      // barrier 0.  (The CU's address path takes ~16 cycles per wavefront-wide load and is shared by the eight wavefronts: 256 loads = 4 k cycles at the top
+      // of every block.  Requesting waves 1..7's behind the barrier, under wave 0's phase A, was tried: phase A then takes 12.6 k cycles instead of 3.8 k —
+      // its LDS reads and the returning load data share a path — 56 ms per chain instead of 31.8; profiles/r05_small_batch_sweep.txt.)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const char *ck = pin_ptr(reinterpret_cast<const char *>(bp.chunks + (size_t)(r * C16_NW + wave) * CHUNK_TILES * TSTRIDE));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          R[16 * r + 4 * k + 0] = gather(ck + (0 + k) * TILE_B, aoff0), R[16 * r + 4 * k + 1] = gather(ck + (4 + k) * TILE_B, aoff0);
-          R[16 * r + 4 * k + 2] = gather(ck + (0 + k) * TILE_B, aoff1), R[16 * r + 4 * k + 3] = gather(ck + (4 + k) * TILE_B, aoff1);
+          R[16 * r + 4 * k + 0] = gather(ck + (0 + k) * TILE_B, goff0), R[16 * r + 4 * k + 1] = gather(ck + (4 + k) * TILE_B, goff0);
+          R[16 * r + 4 * k + 2] = gather(ck + (0 + k) * TILE_B, goff1), R[16 * r + 4 * k + 3] = gather(ck + (4 + k) * TILE_B, goff1);
         }
       }
+      tr.stamp(10);
       __syncthreads();   // 0: this block's record is in LDS; h's home holds the previous block's result
+      tr.stamp(11);
       if (w0) {          // ---- phase A
         v4f h[8];
 #pragma unroll
@@ -2481,8 +2509,8 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint4 xk = ln_frag(h, k, rstd, nmr);
-            sim[0] = mfma_bf(gather(reinterpret_cast<const char *>(at) + k * TILE_B, aoff0), xk, sim[0]);
-            sim[1] = mfma_bf(gather(reinterpret_cast<const char *>(at) + k * TILE_B, aoff1), xk, sim[1]);
+            sim[0] = mfma_bf(gather_lds(at + k * TILE_B, aoff0), xk, sim[0]);
+            sim[1] = mfma_bf(gather_lds(at + k * TILE_B, aoff1), xk, sim[1]);
           }
         }
         v8f pf;
@@ -2502,7 +2530,7 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
         const float *ct = reinterpret_cast<const float *>(at + asms_bytes(PREC));
 #pragma unroll
         for (int c = 0; c < 8; ++c) {   // h += M_s P + c_t
-          h[c] = mfma_bf(gather(reinterpret_cast<const char *>(at) + (4 + (c >> 1)) * TILE_B, (c & 1) ? aoff1 : aoff0), pa, h[c]);
+          h[c] = mfma_bf(gather_lds(at + (4 + (c >> 1)) * TILE_B, (c & 1) ? aoff1 : aoff0), pa, h[c]);
           const v4f cc = *reinterpret_cast<const v4f *>(ct + cv(c));
           h[c] += cc;
         }
@@ -2531,7 +2559,9 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
         if (g == 0) s_z[j] = z[0], s_z[16 + j] = z[1], s_z[32 + j] = z[2];
         if (lane < 8) s_z[128 + lane] = p.d.tab[(size_t)t * 8 + lane];
       }
+      tr.stamp(12);
       __syncthreads();   // 1: xn3 of this block and h are in LDS
+      tr.stamp(13);
       // ---- phase H.  The next block's record travels meanwhile (into the other half of the double buffer: nobody reads that half before barrier 0)
       if (!w0) {
         const int nb = b + 1 < depth ? b + 1 : 0, nstep = b + 1 < depth ? step : step + 1;
@@ -2544,6 +2574,8 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int u = r * C16_NW + wave;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) frag_fix(R[16 * r + i]);
         v4f a[2], gg[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -2561,7 +2593,7 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
         }
         if (r == 0) {   // round 0's registers are free: this wave's W2 fragments — accumulator tile `wave`, all sixteen chunks (W2 of chunk c sits in FF record c + FF_SKEW, tiles 8..11)
           const char *w2 = pin_ptr(reinterpret_cast<const char *>(bp.chunks + (size_t)FF_SKEW * CHUNK_TILES * TSTRIDE) + (8 + (wave >> 1)) * TILE_B);
-          const unsigned ao = (wave & 1) ? aoff1 : aoff0;
+          const unsigned ao = (wave & 1) ? goff1 : goff0;
 #pragma unroll
           for (int c = 0; c < FF_CHUNKS; ++c) R[c] = gather(w2 + (size_t)c * CHUNK_TILES * TILE_B, ao);
         }
@@ -2584,10 +2616,14 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
         s_hid[u * 64 + lane] = make_uint4(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]),
                                           __builtin_bit_cast(unsigned, y[3]));
       }
+      tr.stamp(14);
       __syncthreads();   // 2: hid of all chunks is in LDS
+      tr.stamp(15);
       // ---- phase G: wave w accumulates tile w of h over the sixteen chunks, + b2
       {
         v4f ht = *hs_ptr(wave);
+#pragma unroll
+        for (int u = 0; u < FF_CHUNKS; ++u) frag_fix(R[u]);
 #pragma unroll
         for (int u = 0; u < FF_CHUNKS; ++u) ht = mfma_h(R[u], s_hid[u * 64 + lane], ht);
         const float *b2 = reinterpret_cast<const float *>(at + asms_bytes(PREC) + 1024);
@@ -2595,7 +2631,9 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
         *hs_ptr(wave) = ht + bb;
       }
     }
+    tr.stamp(16);
     __syncthreads();   // the last block's tiles are in h's home
+    tr.stamp(17);
     if (w0) {
       v4f h[8];
 #pragma unroll
@@ -2619,9 +2657,12 @@ __global__ void __launch_bounds__(C16_NW * 64, 2) k_denoise_coop16(const KParams
       const float *s_z = reinterpret_cast<const float *>(pipe_smem + C16_Z);
       const float zr[3] = {s_z[j], s_z[16 + j], s_z[32 + j]};
       const bool zok = p.mode != MODE_EPS;
+      tr.stamp(18);
       if (step_epilogue(p, ps, eps, step, t, zok ? zr : nullptr, zok ? s_z + 128 : nullptr)) break;
+      tr.stamp(19);
       pstate_store(ps_lds, j, C16_PTS, ps, false);
       if (step + 1 < p.nsteps) enter_step(ps);
+      tr.stamp(20);
     }
   }
 }
@@ -2922,6 +2963,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   p.trace = g_trace;
   p.trace_cap = g_trace_cap;
   constexpr int NW = 4;
+  const int fnw = g_force_nw == 161 ? 0 : g_force_nw;   // 161 = automatic, with k_denoise_coop16 ruled out (A/B of the launcher's choice)
   const long long waves = ((long long)p.B * p.N) / 32;
   const long long grid = (waves + NW - 1) / NW;
   if (grid > 0x7fffffffLL) return set_error(DFX_ERR_INVALID_ARG, "denoiser: B*N too large");
@@ -2948,25 +2990,25 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     const double cost = rounds_cost(tiles(c) * p.B, c == 8 ? 93.5 : c == 4 ? 88.5 : 86.5, c / (8.0 * g_num_cus));
     if (cost < best) best = cost, nw = c;
   }
-  const bool pipe2 = bf16 && g_force_nw == 64 && tiles(8) * 256 <= 3LL * p.N;   // two tiles per wavefront (k_denoise_pipe2): 256-point workgroup tiles
-  if (g_force_nw > 1 && g_force_nw != 64 && g_force_nw != 16 && g_force_nw < 160) nw = g_force_nw;
+  const bool pipe2 = bf16 && fnw == 64 && tiles(8) * 256 <= 3LL * p.N;   // two tiles per wavefront (k_denoise_pipe2): 256-point workgroup tiles
+  if (fnw > 1 && fnw != 64 && fnw != 16 && fnw < 160) nw = fnw;
   if (pipe2) nw = 8;
   const long long wpg = tiles(nw);
   // (~3x faster per point than the direct kernel: taken unless the padding of a small shape eats that factor)
   const bool pipe = bf16 && wpg * nw * 32 <= 3LL * p.N;
   // the exact-fp32 chain: same tiling; ~3x the direct kernel's rate per point, so a padded small shape may still take it
-  const bool pipe_f32 = f32 && g_force_nw != 1 && wpg * nw * 32 <= 3LL * p.N;
-  const bool coop = bf16 && !pipe2 && (g_force_nw == 1 || (g_force_nw == 16 && p.N % 64 != 0) || (g_force_nw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));   // (16 = two tiles per workgroup: needs N % 64 == 0, else this one)
+  const bool pipe_f32 = f32 && fnw != 1 && wpg * nw * 32 <= 3LL * p.N;
+  const bool coop = bf16 && !pipe2 && (fnw == 1 || (fnw == 16 && p.N % 64 != 0) || (fnw == 0 && (pipe ? rounds_cost(waves, 32.7, 0.0) < best : waves <= g_num_cus)));   // (16 = two tiles per workgroup: needs N % 64 == 0, else this one)
   // two tiles per co-operative workgroup (k_denoise_coop2; dfx_debug_pipe_waves(16) forces it): 48.2 ms per round of g_num_cus workgroups at N = 2048,
   // T = 1000 — between one and two rounds of k_denoise_coop (B = 5 .. 8 shapes of 2048 points) the cheapest
   const double coop_cost = rounds_cost(waves, 32.7, 0.0), coop2_cost = rounds_cost((waves + 1) / 2, 48.2, 0.0);
-  const bool coop2 = bf16 && !pipe2 && p.N % 64 == 0 && (g_force_nw == 16 || (g_force_nw == 0 && coop2_cost < coop_cost && (!pipe || coop2_cost < best)));
+  const bool coop2 = bf16 && !pipe2 && p.N % 64 == 0 && (fnw == 16 || (fnw == 0 && coop2_cost < coop_cost && (!pipe || coop2_cost < best)));
   // 16-point tiles (k_denoise_coop16, round 5): 2 x the workgroups of k_denoise_coop at about half the time per round — the fastest choice while the batch
   // is at most two rounds of it (B <= 4 shapes of 2048 points); works with either W1 pack.  dfx_debug_pipe_waves(160) forces it, (161) rules it out.
   const long long tiles16 = ((long long)p.B * p.N) / 16;
   const double coop16_cost = rounds_cost(tiles16, C16_ROUND_MS, 0.0);
   const bool coop16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && !pipe2 &&
-                      (g_force_nw == 160 || (g_force_nw == 0 && coop16_cost < (coop2 ? coop2_cost : coop ? coop_cost : best)));
+                      (fnw == 160 || (fnw == 0 && g_force_nw != 161 && coop16_cost < (coop2 ? coop2_cost : coop ? coop_cost : best)));
   if (pipe || coop || coop2 || pipe_f32 || coop16) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {
@@ -2988,7 +3030,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const char *variant;
   if (coop16) variant = "k_denoise_coop16", k_denoise_coop16<<<(int)tiles16, C16_NW * 64, C16_TOTAL, st>>>(p);
   else if (pipe2) variant = "k_denoise_pipe2", k_denoise_pipe2<<<(int)(wpg * p.B), P2_NW * 64, P2_LDS, st>>>(p);
-  else if (coop2 && !(g_force_nw == 1)) variant = "k_denoise_coop2", k_denoise_coop2<<<(int)(waves / 2), COOP_NW * 64, C2_TOTAL, st>>>(p);
+  else if (coop2 && !(fnw == 1)) variant = "k_denoise_coop2", k_denoise_coop2<<<(int)(waves / 2), COOP_NW * 64, C2_TOTAL, st>>>(p);
   else if (coop) variant = "k_denoise_coop", k_denoise_coop<<<(int)waves, COOP_NW * 64, CL_TOTAL, st>>>(p);
   else if (pipe && nw == 8) variant = "k_denoise_pipe<8>", k_denoise_pipe<8><<<(int)(wpg * p.B), 8 * 64, PipeCfg<8>::L_TOTAL, st>>>(p);
   else if (pipe && nw == 4) variant = "k_denoise_pipe<4>", k_denoise_pipe<4><<<(int)(wpg * p.B), 4 * 64, PipeCfg<4>::L_TOTAL, st>>>(p);
@@ -3125,7 +3167,7 @@ int dfx_masked_mse_f32(const float *target, const float *pred, const float *flag
 }
 
 void dfx_debug_force_direct(int on) { g_force_direct = on != 0; }
-void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1 || nw == 64 || nw == 16) ? nw : 0; }
+void dfx_debug_pipe_waves(int nw) { g_force_nw = (nw == 8 || nw == 4 || nw == 2 || nw == 1 || nw == 64 || nw == 16 || nw == 160 || nw == 161) ? nw : 0; }
 void dfx_debug_trace(void *device_buf, int capacity) {
   g_trace = static_cast<unsigned long long *>(device_buf);
   g_trace_cap = capacity;
