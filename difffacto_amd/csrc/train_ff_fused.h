@@ -63,6 +63,12 @@ struct PackArgs {
   float *b2p;        // [2 hf][4 c][16]
   float keep_a;      // dropout behind the GEGLU (attention.py:84): its scale 1 / (1 - p) rides on the `a` half of W1 / b1 (hid = a gelu(g) is linear in a),
                      // i.e. on the tiles W1a, W1a^T and b1a; 1 when dropout is off.  The kernels then only SELECT (k_ff_wgrad_finish scales dW1a, db1a back)
+  // LayerNorm3's affine is folded into the product behind it (round 5):  W1 (xhat g3 + b3) + b1 = (W1 diag(g3)) xhat + (b1 + W1 b3).  The kernels'
+  // B operand is the plain normalised row xhat3 (bf16) — which is also what LayerNorm3's backward needs, so the backward kernel does not read h1 a
+  // second time — and their dxn3 accumulator holds d xhat3 = g3 o dxn3 directly.  The parameter side follows from G = d[a | g]^T xhat3 (k_ff_wgrad):
+  // dW1 = G diag(g3) + db1 (x) b3,  d gamma3 = sum_o W1[o][.] G[o][.],  d beta3 = sum_o W1[o][.] db1[o]   (k_ff_wgrad_finish, k_ln3_param)
+  const float *g3, *b3;   // (128) each
+  float *b1f;             // (1024) the folded bias in natural order, `a` half times keep_a: k_ff_wgrad's
 };
 
 struct PackBatch {
@@ -73,9 +79,13 @@ struct PackBatch {
 __global__ void k_ff_pack(PackBatch batch) {
   const PackArgs &a = batch.blk[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < NCHUNK * 2 * 2 * 16) {   // b1p
+  if (idx < NCHUNK * 2 * 2 * 16) {   // b1p, b1f: b1 + W1 beta3
     const int r = idx & 15, hf = (idx >> 4) & 1, p = (idx >> 5) & 1, j = idx >> 6;
-    a.b1p[idx] = a.b1[p * FH + 32 * j + rho(r, hf)] * (p == 0 ? a.keep_a : 1.0f);
+    const int row = p * FH + 32 * j + rho(r, hf);
+    float t = a.b1[row];
+    for (int ch = 0; ch < C; ++ch) t = fmaf(a.w1[(size_t)row * C + ch], a.b3[ch], t);
+    t *= p == 0 ? a.keep_a : 1.0f;
+    a.b1p[idx] = t, a.b1f[row] = t;
   }
   if (idx < 2 * 4 * 16) {
     const int r = idx & 15, c = (idx >> 4) & 3, hf = idx >> 6;
@@ -89,8 +99,8 @@ __global__ void k_ff_pack(PackBatch batch) {
   for (int e = 0; e < 8; ++e) {
     float x;
     if (t < T_W2) {                      // W1a / W1g, k-tile c, natural K
-      const int p = t >> 2, c = t & 3;
-      x = a.w1[(size_t)(p * FH + 32 * j + i) * C + 32 * c + k_nat(u, hf, e)] * (p == 0 ? a.keep_a : 1.0f);
+      const int p = t >> 2, c = t & 3, ch = 32 * c + k_nat(u, hf, e);
+      x = a.w1[(size_t)(p * FH + 32 * j + i) * C + ch] * a.g3[ch] * (p == 0 ? a.keep_a : 1.0f);
     } else if (t < T_W2T) {              // W2 row tile ct, K = hidden units in register order
       const int ct = t - T_W2;
       x = a.w2[(size_t)(32 * ct + i) * FH + 32 * j + k_reg(u, hf, e)];
@@ -99,7 +109,7 @@ __global__ void k_ff_pack(PackBatch batch) {
       x = a.w2[(size_t)(32 * c + k_nat(u, hf, e)) * FH + 32 * j + i];
     } else {                             // W1a^T / W1g^T: rows = channels 32 ct + i, K = hidden units in register order
       const int p = (t - T_W1AT) >> 2, ct = (t - T_W1AT) & 3;
-      x = a.w1[(size_t)(p * FH + 32 * j + k_reg(u, hf, e)) * C + 32 * ct + i] * (p == 0 ? a.keep_a : 1.0f);
+      x = a.w1[(size_t)(p * FH + 32 * j + k_reg(u, hf, e)) * C + 32 * ct + i] * a.g3[32 * ct + i] * (p == 0 ? a.keep_a : 1.0f);
     }
     v[e] = (__bf16)x;
   }
@@ -425,6 +435,31 @@ __device__ __forceinline__ uint4 ln_frag(const v8f &xcu, int c, int u, int hf, c
   return __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
 }
 
+// the plain normalised row as a bf16 fragment (LayerNorm3: the affine part rides on W1 / b1, PackArgs)
+__device__ __forceinline__ uint4 xhat_frag(const v8f &xcu, float mu, float rstd) {
+  v8f y;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[e] = (xcu[e] - mu) * rstd;
+  return __builtin_bit_cast(uint4, __builtin_convertvector(y, v8bf));
+}
+// bf16 B-operand fragments of a row -> the same values as fp32 in the accumulator layout (rows_to_acc on packed pairs: dwords (0, 2) and (1, 3) of
+// a fragment trade half-waves, i.e. elements (m, 4 + m) -> registers (8 u + m, 8 u + 4 + m), two elements per swap)
+__device__ __forceinline__ void frags_to_acc(const uint4 (&f)[4][2], v16f (&d)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned w[4] = {f[c][u].x, f[c][u].y, f[c][u].z, f[c][u].w};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const auto r = __builtin_amdgcn_permlane32_swap(w[h], w[2 + h], false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        d[c][8 * u + 2 * h] = __builtin_bit_cast(float, r0 << 16), d[c][8 * u + 2 * h + 1] = __builtin_bit_cast(float, r0 & 0xffff0000u);
+        d[c][8 * u + 4 + 2 * h] = __builtin_bit_cast(float, r1 << 16), d[c][8 * u + 4 + 2 * h + 1] = __builtin_bit_cast(float, r1 & 0xffff0000u);
+      }
+    }
+}
+
 // x * sigmoid(k(x)), k(x) = x (c1 + c3 x^2); returns gelu and d gelu / dx
 __device__ __forceinline__ void gelu_fd(float x, float &f, float &d) {
   const float x2 = x * x;
@@ -587,15 +622,16 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     for (int w = 0; w < 8; ++w) dmw[w] = dmk[w * 64];
   }
   float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
-  float *gbs = reinterpret_cast<float *>(ff_smem + TAB_GB3);
+  float *dump = reinterpret_cast<float *>(ff_smem + TAB_GB3);   // 1 KiB nobody reads
   float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
   float *b2s = reinterpret_cast<float *>(ff_smem + TAB_B2);
-  // tables: threads 0 .. 127 (waves 0, 1) fetch gamma3 | beta3 | b_o of their channel, the others gamma2 | beta2 | b2 — unconditional loads
+  // tables: every thread fetches gamma2 | beta2 of its channel, threads 0 .. 127 (waves 0, 1) b_o, the others b2 — unconditional loads
   // through selected pointers (a branch here costs a wait for the rows: hipcc resolves the write-after-write on the other path with vmcnt(0))
   const int tx = threadIdx.x, tc = tx & (C - 1);
   const bool lo_half = wave < NW / 2;
-  const float *tp0 = lo_half ? a.g3 : at ? a.g2 : a.g3, *tp1 = lo_half ? a.b3 : at ? a.b2n : a.b3;
-  const float *tp2 = lo_half ? (at ? a.bo : a.g3) : (!BWD ? a.b2p : a.g3);
+  // (LayerNorm3's affine rides on W1 / b1: no table for it.  Without the attention sub-block the loads go to a valid dummy, b1p)
+  const float *tp0 = at ? a.g2 : a.b1p, *tp1 = at ? a.b2n : a.b1p;
+  const float *tp2 = lo_half ? (at ? a.bo : a.b1p) : (!BWD ? a.b2p : a.b1p);
   const float tv0 = tp0[tc], tv1 = tp1[tc], tv2 = tp2[tc];
   dma1k(reinterpret_cast<const char *>(a.b1p) + wave * 1024, voff, lds0 + TAB_B1 + wave * 1024);
   if (BWD) {
@@ -617,7 +653,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ONE round trip: rows, tables, attention fragments, the first two chunks / items
   {
-    float *d0 = lo_half ? gbs : gb2, *d2 = lo_half ? gb2 + 2 * C : b2s;
+    float *d0 = lo_half ? gb2 : dump, *d2 = lo_half ? gb2 + 2 * C : b2s;   // waves 0, 1: gamma2 | beta2 | b_o; waves 2, 3: b2 (their copies of gamma2 | beta2 go to the dump)
     d0[tc] = tv0, d0[C + tc] = tv1, d2[tc] = tv2;
   }
   __syncthreads();
@@ -687,13 +723,12 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   } else if (!BWD) {
     rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
   }
-  // LayerNorm3 on this lane's row of h1 (one copy of the code for all paths: in both branches hipcc hoisted the gamma / beta reads above the
-  // branch — and spilled them)
+  // LayerNorm3 on this lane's row of h1: statistics and the plain normalised row as bf16 fragments (gamma3 / beta3 ride on W1 / b1, PackArgs)
   ln_stats(x, mu, rstd);
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xn[c][u] = ln_frag(x[c][u], c, u, hf, gbs, mu, rstd);
+    for (int u = 0; u < 2; ++u) xn[c][u] = xhat_frag(x[c][u], mu, rstd);
   uint4 dhb[4][2];
   if (BWD) {
 #pragma unroll
@@ -885,7 +920,6 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
   }
   v16f xh[4], dv[4];
-  load_rows_acc(a.h1 + rowbase, m_h1, xh);
   load_rows_acc(a.dh + rowbase, m_dh, dv);
   unsigned attw[2] = {0, 0};
   if (DROP && at) attw[0] = dmk[8 * 64], attw[1] = dmk[9 * 64];   // the to_out site's bits of this tile (same batch of loads)
@@ -898,30 +932,27 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
     return v;
   };
-  // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)): dh1 = dh + rstd (dy g - mean(dy g)
-  // - xhat mean(dy g xhat)), and the column sums of dy xhat / dy over the workgroup's points for d gamma3 / d beta3 ----
-  // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
-  // [channel][point] from the accumulator layout, read back 16 points of one channel per lane.
+  // ---- LayerNorm3 backward on the accumulators (register r of tile c = channel 32 c + rho(r, hf)).  acc holds d xhat3 (gamma3 rides on W1^T), and
+  // xhat3 is the loop's own B operand turned into the accumulator layout (bf16: no second read of h1):
+  //     dh1 = dh + rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+  // d gamma3 / d beta3 come from the weight-gradient side (k_ln3_param); the column sum over the workgroup's points left here is d b2 ----
+  frags_to_acc(xn, xh);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4f g = *reinterpret_cast<const v4f *>(gbs + 32 * c + 8 * q + 4 * hf);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        xh[c][4 * q + m] = (xh[c][4 * q + m] - mu) * rstd;
-        const float dg = acc[c][4 * q + m] * g[m];
-        s1 += dg;
-        s2 = fmaf(dg, xh[c][4 * q + m], s2);
-      }
+    for (int r = 0; r < 16; ++r) {
+      s1 += acc[c][r];
+      s2 = fmaf(acc[c][r], xh[c][r], s2);
     }
   s1 += xhalf(s1), s2 += xhalf(s2);
   s1 *= (1.0f / C), s2 *= (1.0f / C);
   FFT(4);
+  // The sums run over the lanes; a per-wave LDS tile (the chunk buffers are free now) turns 32 points x 32 channels around: written
+  // [channel][point] from the accumulator layout, read back 16 points of one channel per lane.
   constexpr int TROW = 36;   // floats per tile row: 16-byte aligned rows, conflict-free column reads
   float *tt = reinterpret_cast<float *>(ff_smem) + wave * 32 * TROW;
-  float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][NQ][128]
+  float *cred = reinterpret_cast<float *>(ff_smem) + NW * 32 * TROW;   // [NW][NQ][128]; rows 0, 1 (d gamma3, d beta3 until round 5) are unused
   static_assert((NW * 32 * TROW + NW * 6 * C) * 4 <= AT_OFF_BWD, "column-sum tiles overlap the attention fragments");
   const int NQ = at ? 6 : 3;
   const float keep = live ? 1.f : 0.f;
@@ -940,25 +971,18 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // dh1 replaces dh in dv, tile by tile
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    v16f gx, d1c;
+    colsum(dv[c], 2, c);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int ch = 32 * c + 8 * q + 4 * hf;
-      const v4f g = *reinterpret_cast<const v4f *>(gbs + ch);
       v4f o;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = 4 * q + m;
-        gx[r] = acc[c][r] * xh[c][r];
-        o[m] = dv[c][r] + rstd * (acc[c][r] * g[m] - s1 - xh[c][r] * s2);
-        d1c[r] = o[m];
+        o[m] = dv[c][r] + rstd * (acc[c][r] - s1 - xh[c][r] * s2);
+        dv[c][r] = o[m];
       }
-      if (live && !at) *reinterpret_cast<v4f *>(a.dh1 + rowbase + (pj * C + ch)) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
+      if (live && !at) *reinterpret_cast<v4f *>(a.dh1 + rowbase + (pj * C + 32 * c + 8 * q + 4 * hf)) = o;   // (with the attention fused in, dh1 leaves as fragments: pk2)
     }
-    colsum(gx, 0, c);
-    colsum(acc[c], 1, c);
-    colsum(dv[c], 2, c);
-    dv[c] = d1c;
   }
   FFT(5);
   if (at) {
@@ -1089,7 +1113,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   }
   FFT(7);
   __syncthreads();
-  for (int i = threadIdx.x; i < NQ * C; i += NW * 64) {
+  for (int i = 2 * C + threadIdx.x; i < NQ * C; i += NW * 64) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) t += cred[(w * NQ + i / C) * C + i % C];
@@ -1114,14 +1138,13 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 // Partials per (slab, chunk) are summed by k_ff_wgrad_finish in slab order.
 struct FwArgs {
   const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
-  const float *b1;       // (1024)
+  const float *b1;       // (1024) the FOLDED bias PackArgs::b1f (b1 + W1 beta3, `a` half times keep_a)
   const uint4 *pk;       // [R / 32][2][4][2][64]
   float *part;           // [nslab][NCHUNK][12][16][64] fp32 gradient tiles in accumulator layout
   float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
   long long ntiles;      // R / 32
   int nslab;
   const unsigned *dmask; // k_ff_wgrad<true>: the forward's dropout bits (FfArgs::dmask); words 0 .. 7 of a tile (2 KiB) travel with the tile
-  float keep_a;          // 1 / (1 - p): b1a here (the W1a fragments carry it already, PackArgs::keep_a)
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
@@ -1192,7 +1215,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
         }
     }
-    const float ba = a.b1[32 * j + pj] * (DROP ? a.keep_a : 1.0f), bg = a.b1[FH + 32 * j + pj];
+    const float ba = a.b1[32 * j + pj], bg = a.b1[FH + 32 * j + pj];
     float sa = 0.f, sg = 0.f;
     // dropout bits in this orientation (unit pj of chunk j on the lane, point 8 q + 4 half + m in register 4 q + m): the forward's lane of that point is
     // (point, (pj >> 2) & 1), its bit 16 (j & 1) + 4 (pj >> 3) + (pj & 3) of word j >> 1 — four consecutive lanes' words per 16-byte LDS read
@@ -1315,10 +1338,14 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
 // sums the slabs in order and scatters the tiles: gradient tile (which, c) of chunk j, register r, lane (i, hf) = unit rho(r, hf) of the
 // chunk, channel 32 c + i
 struct FwFinishArgs {
-  const float *part, *bpart;
+  float *part;              // in: the slab partials; out (slab 0's tiles 4 .. 11): G = d[a | g]^T xhat3 summed, for k_ln3_param
+  const float *bpart;
   float *dw1, *db1, *dw2;   // (1024, 128), (1024), (128, 512)
   int nslab;
-  float keep_a;             // dropout: the `a` half's gradients were accumulated against keep_a a (PackArgs::keep_a): d W1a, d b1a get the factor back; 1 otherwise
+  float keep_a;             // dropout: the `a` half's gradients were accumulated against keep_a a (PackArgs::keep_a): G_a, d b1a get the factor back; 1 otherwise
+  const float *g3, *b3;     // LayerNorm3's affine, folded into W1 / b1 by k_ff_pack: dW1 = G diag(g3) + db1 (x) b3
+  const float *w1;          // (1024, 128) fp32 master weights, for k_ln3_param
+  float *dg3, *db3;         // (128) each: d gamma3 = sum_o W1[o][.] G[o][.],  d beta3 = sum_o W1[o][.] db1[o]
 };
 struct FwFinishBatch {   // one launch for all transformer blocks (blockIdx.y): block i's partials wait in block i's own buffers
   FwFinishArgs blk[DFX_MAX_DEPTH];
@@ -1331,9 +1358,18 @@ __global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
     float t = 0.f;
     for (int s = 0; s < a.nslab; ++s) t += a.part[(size_t)s * NT + idx];
     const int lane = idx & 63, r = (idx >> 6) & 15, tile = (idx >> 10) % 12, j = idx / (12 * 1024);
-    const int unit = 32 * j + rho(r, lane >> 5), ch = 32 * (tile & 3) + (lane & 31);
-    if (tile < 4) a.dw2[(size_t)ch * FH + unit] = t;
-    else a.dw1[(size_t)((tile < 8 ? 0 : FH) + unit) * C + ch] = tile < 8 ? t * a.keep_a : t;
+    const int ru = rho(r, lane >> 5), unit = 32 * j + ru, ch = 32 * (tile & 3) + (lane & 31);
+    if (tile < 4) {
+      a.dw2[(size_t)ch * FH + unit] = t;
+    } else {
+      const int p = tile < 8 ? 0 : 1;
+      const float kp = p == 0 ? a.keep_a : 1.0f;
+      float b = 0.f;   // d b1 of this row (the 32 lanes of a unit read the same words)
+      for (int s = 0; s < a.nslab; ++s) b += a.bpart[(size_t)s * NCHUNK * 64 + j * 64 + p * 32 + ru];
+      t *= kp;
+      a.part[idx] = t;   // (slab 0: this thread's own element, read above)
+      a.dw1[(size_t)(p * FH + unit) * C + ch] = fmaf(t, a.g3[ch], b * kp * a.b3[ch]);
+    }
   } else if (idx < NT + NCHUNK * 64) {
     const int k = idx - NT, j = k >> 6, p = (k >> 5) & 1, i = k & 31;
     float t = 0.f;
@@ -1341,10 +1377,35 @@ __global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
     a.db1[p * FH + 32 * j + i] = p == 0 ? t * a.keep_a : t;
   }
 }
+// LayerNorm3's parameter gradients from the weight-gradient side (behind k_ff_wgrad_finish): workgroup (c, block) owns 32 channels; thread (i, grp)
+// walks 128 of the 1024 rows of G (tile layout, FwFinishArgs::part) and W1, the eight groups are summed in order
+__global__ __launch_bounds__(256) void k_ln3_param(FwFinishBatch batch) {
+  const FwFinishArgs &a = batch.blk[blockIdx.y];
+  __shared__ float red[2][8][32];
+  const int c = blockIdx.x, i = threadIdx.x & 31, grp = threadIdx.x >> 5, ch = 32 * c + i;
+  float sg = 0.f, sb = 0.f;
+  for (int k = grp * 128; k < grp * 128 + 128; ++k) {   // k = ((p 16 + j) 16 + r) 2 + hf
+    const int hf = k & 1, r = (k >> 1) & 15, j = (k >> 5) & 15, p = k >> 9;
+    const int row = p * FH + 32 * j + rho(r, hf);
+    const float w = a.w1[(size_t)row * C + ch];
+    sg = fmaf(w, a.part[(size_t)((j * 12 + 4 + 4 * p + c) * 16 + r) * 64 + 32 * hf + i], sg);
+    sb = fmaf(w, a.db1[row], sb);
+  }
+  red[0][grp][i] = sg, red[1][grp][i] = sb;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[which][g][i];
+    (which ? a.db3 : a.dg3)[ch] = t;
+  }
+}
 inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
 inline void launch_ff_wgrad_finish(hipStream_t st, const FwFinishBatch &f, int depth) {
   const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
   k_ff_wgrad_finish<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(f);
+  k_ln3_param<<<dim3(C / 32, depth), 256, 0, st>>>(f);
 }
 template <bool DROP>
 inline int launch_ff_wgrad_t(hipStream_t st, const FwArgs &a) {

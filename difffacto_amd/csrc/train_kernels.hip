@@ -193,6 +193,7 @@ struct SumOuts {
 __global__ __launch_bounds__(1024) void k_sum_parts_multi(const float *__restrict__ part, SumOuts outs, int nparts, int cols, int ld_part) {
   __shared__ float red[32][32];
   const int per = cols / 32, which = blockIdx.x / per, c = (blockIdx.x % per) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  if (!outs.o[which]) return;   // (a row of the partials nobody wants: the whole workgroup leaves)
   const float *src = part + which * cols + c;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int p = q;
@@ -219,6 +220,7 @@ struct SumJobs {
 __global__ __launch_bounds__(1024) void k_sum_parts_jobs(SumJobs jobs, int nparts, int cols, int ld_part) {
   __shared__ float red[32][32];
   const int per = cols / 32, job = blockIdx.x / per, b = job / 6, which = job % 6, c = (blockIdx.x % per) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  if (!jobs.o[b][which]) return;   // (a row of the partials nobody wants: the whole workgroup leaves)
   const float *src = jobs.part[b] + which * cols + c;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int p = q;
@@ -1696,7 +1698,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
   for (int i = 0; i < depth; ++i) {
     w.ff_frags[i] = c.take<uint4>(dfx::ffused::pack_bytes_frags() / sizeof(uint4));
-    w.ff_b1p[i] = c.take<float>(dfx::ffused::B1P_FLOATS);
+    w.ff_b1p[i] = c.take<float>(2 * dfx::ffused::B1P_FLOATS);   // the folded bias twice: in the chunk loop's order, and in natural order (PackArgs::b1f)
     w.ff_b2p[i] = c.take<float>(dfx::ffused::B2P_FLOATS);
   }
   for (int i = 0; i < depth; ++i) w.at_frags[i] = c.take<uint4>((size_t)B * dfx::afused::SHAPE_U4);
@@ -2123,7 +2125,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     dfx::ffused::PackBatch pb{};
     for (int i = 0; i < wt->depth; ++i)
       pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i],
-                                        dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f};
+                                        dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, wt->blk[i].norm3_w, wt->blk[i].norm3_b,
+                                        w.ff_b1p[i] + dfx::ffused::B1P_FLOATS};
     dfx::ffused::launch_pack(st, pb, wt->depth);
   } else {
     k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
@@ -2285,7 +2288,6 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
         fa.hin = a.hin, fa.dh_in = w.dh;
         fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
-      const float keep_a = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
       if (dropout_p > 0.f) {   // the bits the forward left in a.p (ff_fused() admits dropout only with the attention inside these kernels)
         fa.dk = dfx::drop_key(dropout_seed, dropout_p), fa.site_att = (unsigned)(2 * i), fa.site_ff = (unsigned)(2 * i + 1);
         fa.dmask = reinterpret_cast<unsigned *>(a.p);
@@ -2299,12 +2301,12 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       const int groups = (int)dfx::ffused::ff_groups(B, N);
       // (with the attention's input gradient in the same kernel, the six column sums of every block are one launch behind the loop)
       if (!dx_in_ff)
-        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart[i], SumOuts{{mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
+        k_sum_parts_multi<<<3 * C / 32, 1024, 0, st>>>(w.cpart[i], SumOuts{{nullptr, nullptr, mut(gw.ff2_b), nullptr}}, groups, C, 3 * C);
       // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide; the slab partials of every
       // block are summed in one launch behind the loop
       {
-        dfx::ffused::FwArgs wa{w.ff_frags[i], bw.ff0_b, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i], R / 32, w.ffw_slabs,
-                               dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr, keep_a};
+        dfx::ffused::FwArgs wa{w.ff_frags[i], w.ff_b1p[i] + dfx::ffused::B1P_FLOATS, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i],
+                               R / 32, w.ffw_slabs, dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr};
         if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
@@ -2367,11 +2369,12 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     for (int i = 0; i < wt->depth; ++i) {
       const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
       fb.blk[i] = dfx::ffused::FwFinishArgs{w.ffw_part[i], w.ffw_bpart[i], mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs,
-                                            dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f};
+                                            dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, bw.norm3_w, bw.norm3_b, bw.ff0_w,
+                                            mut(gw.norm3_w), mut(gw.norm3_b)};   // (d gamma3 / d beta3: k_ln3_param behind the slab sums)
       ub.blk[i] = dfx::afused::UnfoldArgs{w.at_part[i], w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
                                           mut(gw.to_q), mut(gw.to_out_w), w.at_sum[i], B, w.at_split, LDKV0};
       sj.part[i] = w.cpart[i];
-      float *o6[6] = {mut(gw.norm3_w), mut(gw.norm3_b), mut(gw.ff2_b), mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b)};
+      float *o6[6] = {nullptr, nullptr, mut(gw.ff2_b), mut(gw.norm2_w), mut(gw.norm2_b), mut(gw.to_out_b)};   // (rows 0, 1 of the partials are unused)
       for (int q = 0; q < 6; ++q) sj.o[i][q] = o6[q];
     }
     // the chain towards the context gradient (unfold_kv -> d Wk / d Wv / d ctx -> time-embedding MLP) stays on the caller's stream; the
