@@ -1335,77 +1335,85 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       out[((8 + c) * 16 + r) * 64] = dWg[c][r];
     }
 }
-// sums the slabs in order and scatters the tiles: gradient tile (which, c) of chunk j, register r, lane (i, hf) = unit rho(r, hf) of the
-// chunk, channel 32 c + i
+// The slab partials of k_ff_wgrad -> the gradients (three launches for all blocks, launch_ff_wgrad_finish)
 struct FwFinishArgs {
-  float *part;              // in: the slab partials; out (slab 0's tiles 4 .. 11): G = d[a | g]^T xhat3 summed, for k_ln3_param
-  const float *bpart;
+  const float *part, *bpart;
   float *dw1, *db1, *dw2;   // (1024, 128), (1024), (128, 512)
   int nslab;
   float keep_a;             // dropout: the `a` half's gradients were accumulated against keep_a a (PackArgs::keep_a): G_a, d b1a get the factor back; 1 otherwise
   const float *g3, *b3;     // LayerNorm3's affine, folded into W1 / b1 by k_ff_pack: dW1 = G diag(g3) + db1 (x) b3
-  const float *w1;          // (1024, 128) fp32 master weights, for k_ln3_param
-  float *dg3, *db3;         // (128) each: d gamma3 = sum_o W1[o][.] G[o][.],  d beta3 = sum_o W1[o][.] db1[o]
+  const float *w1;          // (1024, 128) fp32 master weights: d gamma3 = sum_o W1[o][.] G[o][.],  d beta3 = sum_o W1[o][.] db1[o]
+  float *lnpart;            // [NCHUNK * 8 * 4 workgroups of k_ff_wgrad_finish][2][32] their partial sums of the two, summed by k_ln3_param
+  float *dg3, *db3;         // (128) each
 };
 struct FwFinishBatch {   // one launch for all transformer blocks (blockIdx.y): block i's partials wait in block i's own buffers
   FwFinishArgs blk[DFX_MAX_DEPTH];
 };
-__global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
+constexpr int LNPART_FLOATS = NCHUNK * 8 * 4 * 64;
+// d b1 first (k_ff_wgrad_finish needs a row's value for every element of the row): workgroup = chunk, thread = (quarter of the slabs, a / g, unit);
+// the quarters are summed in order
+__global__ __launch_bounds__(256) void k_ff_bsum(FwFinishBatch batch) {
   const FwFinishArgs &a = batch.blk[blockIdx.y];
-  const int idx = blockIdx.x * 256 + threadIdx.x;   // over NCHUNK * 12 * 1024 tile elements, then NCHUNK * 64 bias sums
-  constexpr int NT = NCHUNK * 12 * 1024;
-  if (idx < NT) {
-    float t = 0.f;
-    for (int s = 0; s < a.nslab; ++s) t += a.part[(size_t)s * NT + idx];
-    const int lane = idx & 63, r = (idx >> 6) & 15, tile = (idx >> 10) % 12, j = idx / (12 * 1024);
-    const int ru = rho(r, lane >> 5), unit = 32 * j + ru, ch = 32 * (tile & 3) + (lane & 31);
-    if (tile < 4) {
-      a.dw2[(size_t)ch * FH + unit] = t;
-    } else {
-      const int p = tile < 8 ? 0 : 1;
-      const float kp = p == 0 ? a.keep_a : 1.0f;
-      float b = 0.f;   // d b1 of this row (the 32 lanes of a unit read the same words)
-      for (int s = 0; s < a.nslab; ++s) b += a.bpart[(size_t)s * NCHUNK * 64 + j * 64 + p * 32 + ru];
-      t *= kp;
-      a.part[idx] = t;   // (slab 0: this thread's own element, read above)
-      a.dw1[(size_t)(p * FH + unit) * C + ch] = fmaf(t, a.g3[ch], b * kp * a.b3[ch]);
-    }
-  } else if (idx < NT + NCHUNK * 64) {
-    const int k = idx - NT, j = k >> 6, p = (k >> 5) & 1, i = k & 31;
-    float t = 0.f;
-    for (int s = 0; s < a.nslab; ++s) t += a.bpart[(size_t)s * NCHUNK * 64 + k];
+  __shared__ float red[4][64];
+  const int j = blockIdx.x, k = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int per = (a.nslab + 3) / 4, s1 = (q + 1) * per < a.nslab ? (q + 1) * per : a.nslab;
+  float t = 0.f;
+#pragma unroll 8
+  for (int s = q * per; s < s1; ++s) t += a.bpart[(size_t)s * NCHUNK * 64 + j * 64 + k];
+  red[q][k] = t;
+  __syncthreads();
+  if (q == 0) {
+    const int p = k >> 5, i = k & 31;
+    t = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     a.db1[p * FH + 32 * j + i] = p == 0 ? t * a.keep_a : t;
   }
 }
-// LayerNorm3's parameter gradients from the weight-gradient side (behind k_ff_wgrad_finish): workgroup (c, block) owns 32 channels; thread (i, grp)
-// walks 128 of the 1024 rows of G (tile layout, FwFinishArgs::part) and W1, the eight groups are summed in order
-__global__ __launch_bounds__(256) void k_ln3_param(FwFinishBatch batch) {
+// sums the slabs in order and scatters the tiles: gradient tile (which, c) of chunk j, register r, lane (i, hf) = unit rho(r, hf) of the
+// chunk, channel 32 c + i.  A workgroup = (chunk, tile, four registers): 8 rows x 32 channels
+__global__ __launch_bounds__(256) void k_ff_wgrad_finish(FwFinishBatch batch) {
   const FwFinishArgs &a = batch.blk[blockIdx.y];
   __shared__ float red[2][8][32];
-  const int c = blockIdx.x, i = threadIdx.x & 31, grp = threadIdx.x >> 5, ch = 32 * c + i;
-  float sg = 0.f, sb = 0.f;
-  for (int k = grp * 128; k < grp * 128 + 128; ++k) {   // k = ((p 16 + j) 16 + r) 2 + hf
-    const int hf = k & 1, r = (k >> 1) & 15, j = (k >> 5) & 15, p = k >> 9;
-    const int row = p * FH + 32 * j + rho(r, hf);
-    const float w = a.w1[(size_t)row * C + ch];
-    sg = fmaf(w, a.part[(size_t)((j * 12 + 4 + 4 * p + c) * 16 + r) * 64 + 32 * hf + i], sg);
-    sb = fmaf(w, a.db1[row], sb);
+  const int tile = (blockIdx.x >> 2) % 12, j = blockIdx.x / 48;   // (wave-uniform)
+  const int idx = blockIdx.x * 256 + threadIdx.x;                 // over NCHUNK * 12 * 1024 tile elements
+  constexpr int NT = NCHUNK * 12 * 1024;
+  float t = 0.f;
+  for (int s = 0; s < a.nslab; ++s) t += a.part[(size_t)s * NT + idx];
+  const int lane = idx & 63, r = (idx >> 6) & 15;
+  const int unit = 32 * j + rho(r, lane >> 5), ch = 32 * (tile & 3) + (lane & 31);
+  if (tile < 4) {
+    a.dw2[(size_t)ch * FH + unit] = t;
+    return;
   }
-  red[0][grp][i] = sg, red[1][grp][i] = sb;
+  const int row = (tile < 8 ? 0 : FH) + unit;
+  const float g = tile < 8 ? t * a.keep_a : t, b = a.db1[row], w = a.w1[(size_t)row * C + ch];
+  a.dw1[(size_t)row * C + ch] = fmaf(g, a.g3[ch], b * a.b3[ch]);
+  const int q = threadIdx.x >> 5;   // (register, half-wave) of the workgroup's eight rows
+  red[0][q][lane & 31] = w * g, red[1][q][lane & 31] = w * b;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5;
-    float t = 0.f;
+    const int which = threadIdx.x >> 5, i = threadIdx.x & 31;
+    float u = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += red[which][g][i];
-    (which ? a.db3 : a.dg3)[ch] = t;
+    for (int k = 0; k < 8; ++k) u += red[which][k][i];
+    a.lnpart[((size_t)(j * 8 + tile - 4) * 4 + (blockIdx.x & 3)) * 64 + threadIdx.x] = u;
   }
+}
+// LayerNorm3's parameter gradients: channel tile c gets the partials of the workgroups of tiles 4 + c and 8 + c, in order
+__global__ __launch_bounds__(64) void k_ln3_param(FwFinishBatch batch) {
+  const FwFinishArgs &a = batch.blk[blockIdx.y];
+  const int c = blockIdx.x, which = threadIdx.x >> 5, i = threadIdx.x & 31;
+  float t = 0.f;
+  for (int j = 0; j < NCHUNK; ++j)
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t += a.lnpart[((size_t)(j * 8 + 4 * p + c) * 4 + q) * 64 + threadIdx.x];
+  (which ? a.db3 : a.dg3)[32 * c + i] = t;
 }
 inline int wgrad_slabs(long long ntiles) { return (int)(ntiles < 64 ? ntiles : 64); }
 inline void launch_ff_wgrad_finish(hipStream_t st, const FwFinishBatch &f, int depth) {
-  const int total = NCHUNK * 12 * 1024 + NCHUNK * 64;
-  k_ff_wgrad_finish<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(f);
-  k_ln3_param<<<dim3(C / 32, depth), 256, 0, st>>>(f);
+  k_ff_bsum<<<dim3(NCHUNK, depth), 256, 0, st>>>(f);
+  k_ff_wgrad_finish<<<dim3(NCHUNK * 12 * 4, depth), 256, 0, st>>>(f);
+  k_ln3_param<<<dim3(C / 32, depth), 64, 0, st>>>(f);
 }
 template <bool DROP>
 inline int launch_ff_wgrad_t(hipStream_t st, const FwArgs &a) {

@@ -1625,7 +1625,7 @@ struct TrainWs {
   float *at_part[DFX_MAX_DEPTH], *at_sum[DFX_MAX_DEPTH], *cpart[DFX_MAX_DEPTH];   // per block: summed / unfolded behind the block loop, one launch each
   int at_split;
   // weight-stationary feed-forward gradients (k_ff_wgrad): per-slab partial tiles
-  float *ffw_part[DFX_MAX_DEPTH], *ffw_bpart[DFX_MAX_DEPTH];
+  float *ffw_part[DFX_MAX_DEPTH], *ffw_bpart[DFX_MAX_DEPTH], *ffw_lnpart[DFX_MAX_DEPTH];
   int ffw_slabs;
   // keys / values of all blocks in one product: packed weights (and transposed), k | v of every block side by side, their gradients
   float *wkv, *wkvT, *kv, *dkv, *dwkv;
@@ -1711,6 +1711,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
     w.cpart[i] = c.take<float>(a > b ? a : b);
     w.ffw_part[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
     w.ffw_bpart[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
+    w.ffw_lnpart[i] = c.take<float>(dfx::ffused::LNPART_FLOATS);
   }
   w.wkv = c.take<float>((size_t)2 * depth * C * CTXP);
   w.wkvT = c.take<float>((size_t)2 * depth * C * CTXP);
@@ -2370,7 +2371,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       const dfx_block_weights &bw = wt->blk[i], &gw = grads->blk[i];
       fb.blk[i] = dfx::ffused::FwFinishArgs{w.ffw_part[i], w.ffw_bpart[i], mut(gw.ff0_w), mut(gw.ff0_b), mut(gw.ff2_w), w.ffw_slabs,
                                             dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, bw.norm3_w, bw.norm3_b, bw.ff0_w,
-                                            mut(gw.norm3_w), mut(gw.norm3_b)};   // (d gamma3 / d beta3: k_ln3_param behind the slab sums)
+                                            w.ffw_lnpart[i], mut(gw.norm3_w), mut(gw.norm3_b)};   // (d gamma3 / d beta3: k_ln3_param behind the slab sums)
       ub.blk[i] = dfx::afused::UnfoldArgs{w.at_part[i], w.kv + 2 * i * C, w.kv + (2 * i + 1) * C, bw.to_q, bw.to_out_w, w.dkv + 2 * i * C, w.dkv + (2 * i + 1) * C,
                                           mut(gw.to_q), mut(gw.to_out_w), w.at_sum[i], B, w.at_split, LDKV0};
       sj.part[i] = w.cpart[i];
