@@ -460,6 +460,38 @@ __device__ __forceinline__ void frags_to_acc(const uint4 (&f)[4][2], v16f (&d)[4
     }
 }
 
+constexpr int HL_LO_U4 = 8 * 64;   // bf16-pair tiles (TL_DH_HL below): uint4 offset of the lo half within a tile
+// One channel tile (accumulator layout, fp32) of a row-shaped tensor as a bf16 pair, see TL_DH_HL: hi in the B-operand layout (frags_to_acc backwards:
+// the packed pairs (8 u + 2 h, +1) and (8 u + 4 + 2 h, +1) trade half-waves), lo = bf16(v - hi) in place
+__device__ __forceinline__ void store_hl(uint4 *tile_lane, int c, const v16f &v, bool live) {
+  unsigned hp[8], lp[8];   // packed pairs (2 d, 2 d + 1)
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    const v2f x = {v[2 * d], v[2 * d + 1]};
+    hp[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, v2bf));
+    const v2f r = {x[0] - __builtin_bit_cast(float, hp[d] << 16), x[1] - __builtin_bit_cast(float, hp[d] & 0xffff0000u)};
+    lp[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, v2bf));
+  }
+  uint4 hb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    unsigned w[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const auto r = __builtin_amdgcn_permlane32_swap(hp[4 * u + h], hp[4 * u + 2 + h], false, false);
+      w[h] = r[0], w[2 + h] = r[1];
+    }
+    hb[u] = uint4{w[0], w[1], w[2], w[3]};
+  }
+  if (live) {
+    tile_lane[(c * 2 + 0) * 64] = hb[0], tile_lane[(c * 2 + 1) * 64] = hb[1];
+    tile_lane[HL_LO_U4 + (c * 2 + 0) * 64] = uint4{lp[0], lp[1], lp[2], lp[3]};
+    tile_lane[HL_LO_U4 + (c * 2 + 1) * 64] = uint4{lp[4], lp[5], lp[6], lp[7]};
+  }
+}
+
 // x * sigmoid(k(x)), k(x) = x (c1 + c3 x^2); returns gelu and d gelu / dx
 __device__ __forceinline__ void gelu_fd(float x, float &f, float &d) {
   const float x2 = x * x;
@@ -543,7 +575,15 @@ __device__ __forceinline__ void load_rows_acc(const float *__restrict__ hrow, in
 //   B-operand layout, block (c, u), element e of lane (pj, hf) = channel 32 c + 16 u + 8 hf + e     -> ((c 2 + u) 2 + e / 4) 256 + lane 4 + e % 4
 //   accumulator layout, register 4 q + m of tile c, lane (pj, hf) = channel 32 c + 8 q + 4 hf + m  -> ((c 2 + q / 2) 2 + hf) 256 + (pj + 32 (q & 1)) 4 + m
 // (the same element either way).  Measured: k_ff<true> 356 -> 334 us, k_ff<false> 180 -> 165 us per block.
-enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16 };
+enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16, TL_DH_HL = 32, TL_DHIN_HL = 64 };
+// ---- The gradient between two blocks' backward kernels as a bf16 PAIR (round 5, TL_DH_HL / TL_DHIN_HL): hi = bf16(dh) and lo = bf16(dh - hi), i.e. dh to
+// 2^-17 relative, in the tile's own 16 KiB: [hi: 8 blocks (c, u) of 1 KiB, the bf16 B-operand fragments themselves][lo: 8 blocks (c, k) of 1 KiB in the
+// accumulator layout, registers 8 k .. 8 k + 7 of tile c as 8 bf16 per lane].  The backward kernel wants dh twice — rounded to bf16 as the operand of
+// d hid = W2^T dh in front of the chunk loop, and in full behind it for dh1 = dh + ... — and cannot hold it across the loop: as fp32 that was 2 x 512 B
+// per point, now 256 B (hi, which goes straight into the MFMA and is turned into the accumulator layout with permlane swaps behind the loop) + 256 B
+// (lo).  k_ff_wgrad reads the same hi blocks as its dh fragments (FwArgs::dhf), so k_ff<true> writes only the xhat3 half of FfArgs::pk: 768 B per
+// point and block less traffic.  The ends of the stack (the head's output, the stem's input) stay fp32 row-major.
+
 struct RowMap {   // per tensor: one lane offset for each register layout (floats), tiled or not
   bool tiled;
   unsigned lb, la;
@@ -612,7 +652,17 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // ---- prologue, memory side: this lane's rows first (the oldest requests come back first), then the tables, then the ring ----
   v8f x[4][2], xd[4][2];
   load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
-  if (BWD) load_rows(a.dh + rowbase, m_dh, xd);
+  const bool hl_in = BWD && (a.tiled & TL_DH_HL), hl_out = BWD && (a.tiled & TL_DHIN_HL);
+  uint4 dhb[4][2];
+  if (BWD) {
+    if (hl_in) {   // the bf16 fragments themselves
+      const uint4 *hp = reinterpret_cast<const uint4 *>(a.dh + rowbase) + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dhb[c][0] = hp[(c * 2 + 0) * 64], dhb[c][1] = hp[(c * 2 + 1) * 64];
+    } else {
+      load_rows(a.dh + rowbase, m_dh, xd);
+    }
+  }
   // dropout: this tile's bit words (one lane = one point half, the forward's mapping); the backward holds the eight feed-forward words across the loop
   unsigned *dmk = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE + lane : nullptr;
   const unsigned long long prow = (unsigned long long)(rowbase / C) + pj;   // this lane's row of the (R, .) tensors
@@ -729,23 +779,26 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int u = 0; u < 2; ++u) xn[c][u] = xhat_frag(x[c][u], mu, rstd);
-  uint4 dhb[4][2];
   if (BWD) {
+    if (!hl_in) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) dhb[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(xd[c][u], v8bf));
+        for (int u = 0; u < 2; ++u) dhb[c][u] = __builtin_bit_cast(uint4, __builtin_convertvector(xd[c][u], v8bf));
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    // the tile for k_ff_wgrad: xn3 and dh as bf16 B-operand fragments (points on the lanes), 16 KiB of whole 1 KiB stores (left in flight)
+    // the tile for k_ff_wgrad: xhat3 and dh as bf16 B-operand fragments (points on the lanes), whole 1 KiB stores (left in flight); a bf16-pair
+    // gradient's hi half IS the second set: k_ff_wgrad reads it in place
     if (live) {
       uint4 *pk = a.pk + (size_t)(rowbase / (32 * C)) * PK_TILE_U4 + lane;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
-        pk[(PK_DH * 8 + c * 2 + 0) * 64] = dhb[c][0], pk[(PK_DH * 8 + c * 2 + 1) * 64] = dhb[c][1];
+      for (int c = 0; c < 4; ++c) pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
+      if (!hl_in) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pk[(PK_DH * 8 + c * 2 + 0) * 64] = dhb[c][0], pk[(PK_DH * 8 + c * 2 + 1) * 64] = dhb[c][1];
       }
     }
   } else {
@@ -920,7 +973,26 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
   }
   v16f xh[4], dv[4];
-  load_rows_acc(a.dh + rowbase, m_dh, dv);
+  if (hl_in) {   // dh = hi (the loop's own operand, turned into the accumulator layout) + lo (8 x 16 bytes per lane)
+    const uint4 *lp = reinterpret_cast<const uint4 *>(a.dh + rowbase) + HL_LO_U4 + lane;
+    uint4 lo[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lo[c][0] = lp[(c * 2 + 0) * 64], lo[c][1] = lp[(c * 2 + 1) * 64];
+    frags_to_acc(dhb, dv);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned w[4] = {lo[c][k].x, lo[c][k].y, lo[c][k].z, lo[c][k].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          dv[c][8 * k + 2 * d] += __builtin_bit_cast(float, w[d] << 16);
+          dv[c][8 * k + 2 * d + 1] += __builtin_bit_cast(float, w[d] & 0xffff0000u);
+        }
+      }
+  } else {
+    load_rows_acc(a.dh + rowbase, m_dh, dv);
+  }
   unsigned attw[2] = {0, 0};
   if (DROP && at) attw[0] = dmk[8 * 64], attw[1] = dmk[9 * 64];   // the to_out site's bits of this tile (same batch of loads)
   // gradient in front of the to_out dropout = selected, scaled gradient at h1 (channel tile c)
@@ -1092,7 +1164,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const v16f dx = dxn2(c);
-      v16f gx;
+      v16f gx, ov;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int ch = 32 * c + 8 * q + 4 * hf;
@@ -1104,8 +1176,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
           gx[r] = dx[r] * xh[c][r];
           o[m] = dv[c][r] + rstd2 * (dx[r] * g[m] - t1 - xh[c][r] * t2);
         }
-        if (live) *reinterpret_cast<v4f *>(a.dh_in + rowbase + m_dhin.a(c, q)) = o;
+        if (hl_out) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) ov[4 * q + m] = o[m];
+        } else if (live) {
+          *reinterpret_cast<v4f *>(a.dh_in + rowbase + m_dhin.a(c, q)) = o;
+        }
       }
+      if (hl_out) store_hl(reinterpret_cast<uint4 *>(a.dh_in + rowbase) + lane, c, ov, live);
       colsum(gx, 3, c);
       colsum(dx, 4, c);
       colsum(att_drop(dv[c], c), 5, c);   // d b_o
@@ -1145,6 +1223,8 @@ struct FwArgs {
   long long ntiles;      // R / 32
   int nslab;
   const unsigned *dmask; // k_ff_wgrad<true>: the forward's dropout bits (FfArgs::dmask); words 0 .. 7 of a tile (2 KiB) travel with the tile
+  const uint4 *dhf;      // optional: the block's incoming gradient as bf16-pair tiles (TL_DH_HL) — their hi halves are the dh fragments, the PK_DH
+                         // half of pk is then unwritten
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
@@ -1178,7 +1258,9 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // iteration k requests tile k + 2: two 1 KiB pieces per wavefront
   auto stage = [&](int k) {
     if (k + 2 < nt) {
-      const char *src = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
+      // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
+      const char *src = wave >= WG_NW / 2 && a.dhf ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + 2) * PK_TILE_U4) - 8192
+                                                   : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
 #pragma unroll
       for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
       if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront

@@ -2264,9 +2264,10 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   DFX_HIP_TRY(hipMemsetAsync(w.dctx, 0, sizeof(float) * (size_t)BJ * CTXP, st));
   bool stem_done = false;
   const bool dx_in_ff_all = t_attn_in_ff;
+  float *dh_cur = w.dh;   // the gradient of the residual stream: where the next kernel on the way back finds it
   auto stem_backward = [&](hipStream_t s, float *part) {   // pre_norm, proj_in (fused ends): reads w.dh, the input rows and the weights
     const int nb = (int)((R + STEM_ROWS - 1) / STEM_ROWS);
-    k_stem_bwd<<<nb, 256, 0, s>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, part, R);
+    k_stem_bwd<<<nb, 256, 0, s>>>(dh_cur, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, part, R);
     k_sum_parts<<<C * 13 / 32, 1024, 0, s>>>(part, mut(grads->proj_in_w), nb, C * 13, 2048);
     k_sum_parts_multi<<<3 * C / 32, 1024, 0, s>>>(part + C * 13, SumOuts{{mut(grads->proj_in_b), mut(grads->pre_norm_w), mut(grads->pre_norm_b), nullptr}}, nb, C, 2048);
   };
@@ -2280,13 +2281,19 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // backward -> dh1; hid, d[a | g] and xn3 leave the kernel once, as bf16, for the two weight-gradient products
       dfx::ffused::FfArgs fa{};
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
-      fa.h1 = a.h1, fa.dh = w.dh, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart[i], fa.R = R, fa.B = B, fa.N = N;
-      if (t_attn_in_ff)   // the layouts the forward left behind; the gradient is row-major where the head wrote it and where the stem reads it
-        fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN | dfx::ffused::TL_DHIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_DH : 0);
-      const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 -> w.dh2 for the parameter kernel, dh -> w.dh)
+      fa.h1 = a.h1, fa.dh = dh_cur, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart[i], fa.R = R, fa.B = B, fa.N = N;
+      const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 leaves as fragments for the parameter kernel)
+      // With the attention inside, the gradient travels between the blocks as bf16-pair tiles (train_ff_fused.h, TL_DH_HL), alternating between w.dh
+      // and w.dh2 (k_ff_wgrad reads block i's INCOMING gradient after k_ff<true> has written the outgoing one); it is fp32 row-major where the head
+      // wrote it and where the stem reads it (dh_cur behind the loop)
+      const bool hl_in = dx_in_ff && i + 1 < wt->depth, hl_out = dx_in_ff && i > 0;
+      const float *dh_in_blk = dh_cur;
+      if (t_attn_in_ff)   // + the layouts the forward left behind
+        fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN | dfx::ffused::TL_DHIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_DH : 0) |
+                   (hl_in ? dfx::ffused::TL_DH_HL : 0) | (hl_out ? dfx::ffused::TL_DHIN_HL : 0);
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
-        fa.hin = a.hin, fa.dh_in = w.dh;
+        fa.hin = a.hin, fa.dh_in = dh_cur = (dh_cur == w.dh ? w.dh2 : w.dh);
         fa.pk2 = reinterpret_cast<uint4 *>(w.dq);   // xn2 / dh1 as fragments for the parameter kernel (w.dq: free in this path)
       }
       if (dropout_p > 0.f) {   // the bits the forward left in a.p (ff_fused() admits dropout only with the attention inside these kernels)
@@ -2307,7 +2314,8 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // block are summed in one launch behind the loop
       {
         dfx::ffused::FwArgs wa{w.ff_frags[i], w.ff_b1p[i] + dfx::ffused::B1P_FLOATS, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i],
-                               R / 32, w.ffw_slabs, dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr};
+                               R / 32, w.ffw_slabs, dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr,
+                               hl_in ? reinterpret_cast<const uint4 *>(dh_in_blk) : nullptr};
         if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
@@ -2406,7 +2414,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
     if ((rc = wgrad(st, w, w.dh2, C, w.xin, XIN, mut(grads->proj_in_w), mut(grads->proj_in_b), C, XIN, 13, R))) return rc;
   }
   // gradient at the input rows (optional; w.dh = the gradient behind pre_norm is final and row-major on either path)
-  if (d_x || d_variances) k_stem_dx<<<2048, 256, 0, st>>>(w.dh, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, d_x, d_variances, N, R);
+  if (d_x || d_variances) k_stem_dx<<<2048, 256, 0, st>>>(dh_cur, w.xin, wt->proj_in_w, wt->proj_in_b, wt->pre_norm_w, d_x, d_variances, N, R);
   // context -> part codes, (mean, var), time embedding MLP
   k_ctx_bwd<<<(B * CTX + 255) / 256, 256, 0, st>>>(w.dctx, d_ctx_code, d_ctx_mv, w.dte_out, B);
   if ((rc = wgrad(st, w, w.dte_out, TE, w.te_hid, TEH, mut(grads->te2_w), mut(grads->te2_b), TE, TEH, TEH, B))) return rc;
