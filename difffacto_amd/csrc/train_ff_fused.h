@@ -575,7 +575,13 @@ __device__ __forceinline__ void load_rows_acc(const float *__restrict__ hrow, in
 //   B-operand layout, block (c, u), element e of lane (pj, hf) = channel 32 c + 16 u + 8 hf + e     -> ((c 2 + u) 2 + e / 4) 256 + lane 4 + e % 4
 //   accumulator layout, register 4 q + m of tile c, lane (pj, hf) = channel 32 c + 8 q + 4 hf + m  -> ((c 2 + q / 2) 2 + hf) 256 + (pj + 32 (q & 1)) 4 + m
 // (the same element either way).  Measured: k_ff<true> 356 -> 334 us, k_ff<false> 180 -> 165 us per block.
-enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16, TL_DH_HL = 32, TL_DHIN_HL = 64 };
+enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16, TL_DH_HL = 32, TL_DHIN_HL = 64, TL_H1_FRAG = 128 };
+// ---- h1 as the backward wants it (round 5, TL_H1_FRAG; forward with the attention sub-block inside).  The backward kernels need two things of h1: the bf16
+// fragments of xhat3 = LayerNorm3's normalised row (k_ff<true>'s B operand and, turned around, LayerNorm3's backward; k_ff_wgrad's tiles) and the row's
+// 1 / std.  So the forward stores exactly those in the tile's 16 KiB — [xhat3: 8 blocks (c, u) of 1 KiB = the PK_XN set][rstd: 32 floats] — instead of
+// the fp32 rows: 260 B per point written and read instead of 512, bit-identical operands (the backward rounded the same fp32 values to bf16), no
+// LayerNorm statistics in the backward's prologue, and k_ff<true> no longer writes the xhat3 half of FfArgs::pk (k_ff_wgrad reads these tiles).
+constexpr int H1F_RSTD = 2048;   // float offset of the tile's 32 rstd values
 // ---- The gradient between two blocks' backward kernels as a bf16 PAIR (round 5, TL_DH_HL / TL_DHIN_HL): hi = bf16(dh) and lo = bf16(dh - hi), i.e. dh to
 // 2^-17 relative, in the tile's own 16 KiB: [hi: 8 blocks (c, u) of 1 KiB, the bf16 B-operand fragments themselves][lo: 8 blocks (c, k) of 1 KiB in the
 // accumulator layout, registers 8 k .. 8 k + 7 of tile c as 8 bf16 per lane].  The backward kernel wants dh twice — rounded to bf16 as the operand of
@@ -651,7 +657,17 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   FFT(1);
   // ---- prologue, memory side: this lane's rows first (the oldest requests come back first), then the tables, then the ring ----
   v8f x[4][2], xd[4][2];
-  load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
+  const bool h1f = a.tiled & TL_H1_FRAG;
+  uint4 xn[4][2];
+  float mu, rstd = 0.f;
+  if (BWD && h1f) {   // what the forward left: the xhat3 fragments and 1 / std of this lane's row
+    const uint4 *hp = reinterpret_cast<const uint4 *>(a.h1 + rowbase) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xn[c][0] = hp[(c * 2 + 0) * 64], xn[c][1] = hp[(c * 2 + 1) * 64];
+    rstd = (a.h1 + rowbase)[H1F_RSTD + pj];
+  } else {
+    load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
+  }
   const bool hl_in = BWD && (a.tiled & TL_DH_HL), hl_out = BWD && (a.tiled & TL_DHIN_HL);
   uint4 dhb[4][2];
   if (BWD) {
@@ -708,9 +724,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   }
   __syncthreads();
   FFT(16);
-  // B operand of the products over the channels: xn3 = LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
-  uint4 xn[4][2];
-  float mu, rstd;
+  // B operand of the products over the channels: xhat3 of LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
   if (!BWD && at) {
     // attention sub-block in registers: h1 = hin + M_s softmax(A_s LN2(hin)) + b_o, then straight on to LayerNorm3
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
       acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
       }
-      if (live) {
+      if (live && !h1f) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<v4f *>(a.h1_out + rowbase + m_h1.a(ct, q)) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
@@ -774,11 +788,19 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
   }
   // LayerNorm3 on this lane's row of h1: statistics and the plain normalised row as bf16 fragments (gamma3 / beta3 ride on W1 / b1, PackArgs)
-  ln_stats(x, mu, rstd);
+  if (!(BWD && h1f)) {
+    ln_stats(x, mu, rstd);
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xn[c][u] = xhat_frag(x[c][u], mu, rstd);
+      for (int u = 0; u < 2; ++u) xn[c][u] = xhat_frag(x[c][u], mu, rstd);
+  }
+  if (!BWD && at && h1f && live) {   // h1 for the backward kernels: these fragments and 1 / std (TL_H1_FRAG)
+    uint4 *hp = reinterpret_cast<uint4 *>(a.h1_out + rowbase) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hp[(c * 2 + 0) * 64] = xn[c][0], hp[(c * 2 + 1) * 64] = xn[c][1];
+    if (hf == 0) (a.h1_out + rowbase)[H1F_RSTD + pj] = rstd;
+  }
   if (BWD) {
     if (!hl_in) {
 #pragma unroll
@@ -794,8 +816,10 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     // gradient's hi half IS the second set: k_ff_wgrad reads it in place
     if (live) {
       uint4 *pk = a.pk + (size_t)(rowbase / (32 * C)) * PK_TILE_U4 + lane;
+      if (!h1f) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
+        for (int c = 0; c < 4; ++c) pk[(PK_XN * 8 + c * 2 + 0) * 64] = xn[c][0], pk[(PK_XN * 8 + c * 2 + 1) * 64] = xn[c][1];
+      }
       if (!hl_in) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) pk[(PK_DH * 8 + c * 2 + 0) * 64] = dhb[c][0], pk[(PK_DH * 8 + c * 2 + 1) * 64] = dhb[c][1];
@@ -1217,14 +1241,14 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 struct FwArgs {
   const uint4 *frags;    // the k_ff_pack fragments: tiles T_W1A, T_W1G, T_W2T of each chunk are this kernel's B operands
   const float *b1;       // (1024) the FOLDED bias PackArgs::b1f (b1 + W1 beta3, `a` half times keep_a)
-  const uint4 *pk;       // [R / 32][2][4][2][64]
+  const uint4 *pk;       // [R / 32][2][4][2][64]: set PK_XN = the xhat3 fragments (k_ff<true>'s pk, or the forward's h1 tiles, TL_H1_FRAG: same place in the tile)
   float *part;           // [nslab][NCHUNK][12][16][64] fp32 gradient tiles in accumulator layout
   float *bpart;          // [nslab][NCHUNK][2][32] column sums of da, dg
   long long ntiles;      // R / 32
   int nslab;
   const unsigned *dmask; // k_ff_wgrad<true>: the forward's dropout bits (FfArgs::dmask); words 0 .. 7 of a tile (2 KiB) travel with the tile
-  const uint4 *dhf;      // optional: the block's incoming gradient as bf16-pair tiles (TL_DH_HL) — their hi halves are the dh fragments, the PK_DH
-                         // half of pk is then unwritten
+  const uint4 *dhf;      // the dh fragments: tiles of 16 KiB whose FIRST 8 KiB they are — the block's incoming gradient as bf16-pair tiles (TL_DH_HL: the hi
+                         // halves), or k_ff<true>'s pk + the offset of its PK_DH set
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
@@ -1259,8 +1283,8 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   auto stage = [&](int k) {
     if (k + 2 < nt) {
       // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
-      const char *src = wave >= WG_NW / 2 && a.dhf ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + 2) * PK_TILE_U4) - 8192
-                                                   : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
+      const char *src = wave >= WG_NW / 2 ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + 2) * PK_TILE_U4) - 8192
+                                          : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
 #pragma unroll
       for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
       if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront

@@ -2154,7 +2154,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R, fa.B = B, fa.N = N;
       // tile-major rows between the fused kernels (train_ff_fused.h): everything but the stem's output and the head's input
-      if (t_attn_in_ff) fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_H2 : 0);
+      // (+ h1 itself only as what the backward kernels want of it: the xhat3 fragments and 1 / std, TL_H1_FRAG)
+      if (t_attn_in_ff) fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_H2 : 0) | dfx::ffused::TL_H1_FRAG;
       if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.h1_out = a.h1;
@@ -2290,7 +2291,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       const float *dh_in_blk = dh_cur;
       if (t_attn_in_ff)   // + the layouts the forward left behind
         fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN | dfx::ffused::TL_DHIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_DH : 0) |
-                   (hl_in ? dfx::ffused::TL_DH_HL : 0) | (hl_out ? dfx::ffused::TL_DHIN_HL : 0);
+                   (hl_in ? dfx::ffused::TL_DH_HL : 0) | (hl_out ? dfx::ffused::TL_DHIN_HL : 0) | dfx::ffused::TL_H1_FRAG;
       if (dx_in_ff) {
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.dh_in = dh_cur = (dh_cur == w.dh ? w.dh2 : w.dh);
@@ -2313,9 +2314,10 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       // dW1, db1, dW2: weight-stationary, hid and d[a | g] recomputed from the tiles k_ff<true> left in w.dwide; the slab partials of every
       // block are summed in one launch behind the loop
       {
-        dfx::ffused::FwArgs wa{w.ff_frags[i], w.ff_b1p[i] + dfx::ffused::B1P_FLOATS, reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i],
+        dfx::ffused::FwArgs wa{w.ff_frags[i], w.ff_b1p[i] + dfx::ffused::B1P_FLOATS,
+                               dx_in_ff ? reinterpret_cast<const uint4 *>(a.h1) : reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i],
                                R / 32, w.ffw_slabs, dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr,
-                               hl_in ? reinterpret_cast<const uint4 *>(dh_in_blk) : nullptr};
+                               hl_in ? reinterpret_cast<const uint4 *>(dh_in_blk) : reinterpret_cast<const uint4 *>(w.dwide) + dfx::ffused::PK_TILE_U4 / 2};
         if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
