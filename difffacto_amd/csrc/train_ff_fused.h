@@ -682,11 +682,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   // dropout: this tile's bit words (one lane = one point half, the forward's mapping); the backward holds the eight feed-forward words across the loop
   unsigned *dmk = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE + lane : nullptr;
   const unsigned long long prow = (unsigned long long)(rowbase / C) + pj;   // this lane's row of the (R, .) tensors
-  unsigned dmw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (BWD && DROP) {
-#pragma unroll
-    for (int w = 0; w < 8; ++w) dmw[w] = dmk[w * 64];
-  }
+  unsigned dmw = 0;   // forward: the word being assembled; backward: the word of chunks (j & ~1, + 1), requested at the top of every second chunk
   float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
   float *dump = reinterpret_cast<float *>(ff_smem + TAB_GB3);   // 1 KiB nobody reads
   float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);   // LayerNorm2 affine | to_out bias (attention sub-block fused in)
@@ -841,8 +837,12 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     // forward: chunk j + 2 -> the slot of chunk j - 1 (every wave is past it); backward: item 2 j + 2 -> the slot of item 2 j - 1
     if (!BWD) {
       if (j + NBUF - 1 < NCHUNK) stage_chunk<BWD>(a.frags, j + NBUF - 1, lds0 + ((j + NBUF - 1) % NBUF) * BUF_BYTES, wave, voff);
-    } else if (2 * j + 2 < 2 * NCHUNK) {
-      stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
+    } else {
+      // dropout: this lane's bit word of chunks (j, j + 1), requested IN FRONT of the item's pieces — operations complete in order, so the counted
+      // wait at the item boundary below (at most the newest pieces outstanding) covers it; one register instead of the tile's eight words
+      // (inline asm: hipcc's own wait for a load it knows would be vmcnt(0) at the first use — behind the NEXT item's pieces)
+      if (DROP && !(j & 1)) asm volatile("global_load_dword %0, %1, off" : "=v"(dmw) : "v"(dmk + (j >> 1) * 64) : "memory");
+      if (2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
     }
     const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (BWD ? (2 * j) % 3 : j % NBUF) * BUF_BYTES) + lane;
     auto frag = [&](int t, int u) -> uint4 { return fr[(lt<BWD>(t) * 2 + u) * 64]; };
@@ -882,8 +882,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
         unsigned w[4][2];
         drop_words(a.dk, a.site_ff, prow * (FH / 8) + 4 * j, hf, w);
         const unsigned bits = drop_apply(hv, w, a.dk.thr);
-        dmw[0] = (j & 1) ? dmw[0] | (bits << 16) : bits;
-        if ((j & 1) && live) dmk[(j >> 1) * 64] = dmw[0];   // (a store in flight only tightens the counted waits below: operations complete in order)
+        dmw = (j & 1) ? dmw | (bits << 16) : bits;
+        if ((j & 1) && live) dmk[(j >> 1) * 64] = dmw;   // (a store in flight only tightens the counted waits below: operations complete in order)
       }
       const uint4 h0 = pack8(hv, 0), h1 = pack8(hv, 1);
 #pragma unroll
@@ -918,8 +918,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3.  The boundary sits in FRONT
       // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
       FFT(10);
-      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");
       FFT(11);
       __syncthreads();
       FFT(12);
@@ -931,8 +931,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       for (int i = 0; i < 8; ++i) P[i] = f2(i);
       __builtin_amdgcn_sched_barrier(0);
       if (DROP) {   // d hid in front of the dropout = selected d hid behind it (the scale rides on `a` and on W1a^T)
-        const unsigned sel = j < 8 ? (j < 4 ? (j < 2 ? dmw[0] : dmw[1]) : (j < 6 ? dmw[2] : dmw[3])) : (j < 12 ? (j < 10 ? dmw[4] : dmw[5]) : (j < 14 ? dmw[6] : dmw[7]));
-        drop_select(dhid, (j & 1) ? sel >> 16 : sel);
+        drop_select(dhid, (j & 1) ? dmw >> 16 : dmw);
       }
       // ---- GEGLU backward on the registers ----
       v16f da, dg;
@@ -1336,6 +1335,12 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       v16f av, gv, dv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
+      uint4 mq[4];
+      if (DROP) {   // the tile's bit words first: they travel under the 24 MFMAs instead of behind them
+        const unsigned *mk = reinterpret_cast<const unsigned *>(fw_smem + WG_MASK + (k % 3) * 2048) + dm_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mq[q] = *reinterpret_cast<const uint4 *>(mk + 8 * q);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1348,14 +1353,12 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       if (k < 12) FFT(14);
       unsigned keepm[16];
       if (DROP) {
-        const unsigned *mk = reinterpret_cast<const unsigned *>(fw_smem + WG_MASK + (k % 3) * 2048) + dm_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint4 mq = *reinterpret_cast<const uint4 *>(mk + 8 * q);
-          const unsigned wq[4] = {mq.x, mq.y, mq.z, mq.w};
+          const unsigned wq[4] = {mq[q].x, mq[q].y, mq[q].z, mq[q].w};
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            keepm[4 * q + m] = 0u - ((wq[m] >> dm_bit) & 1u);   // all ones = kept
+            keepm[4 * q + m] = (unsigned)__builtin_amdgcn_sbfe((int)wq[m], dm_bit, 1);   // v_bfe_i32: all ones = kept
             const float dvr = dv[4 * q + m];   // (copies: a bit_cast applied to a vector-element expression reads element 0)
             dv[4 * q + m] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, dvr) & keepm[4 * q + m]);
           }
