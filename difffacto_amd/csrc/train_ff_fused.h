@@ -504,6 +504,26 @@ __device__ __forceinline__ float gelu_f(float x) {
   const float e = __builtin_amdgcn_exp2f(x * fmaf(-0.100125614f, x * x, -2.30876530f));
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// The same arithmetic on PAIRS of accumulator registers (round 5): gfx950's packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) do two
+// lanes' worth of an fp32 operation per issue slot — same IEEE results, half the VALU slots; only exp2 / rcp stay one element per instruction.  The loops
+// of the three feed-forward kernels spend as many SIMD cycles on this arithmetic as on their MFMAs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float c) { return v2f{c, c}; }
+__device__ __forceinline__ v2f exp2_2(v2f x) { return v2f{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
+__device__ __forceinline__ v2f rcp_2(v2f x) { return v2f{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
+__device__ __forceinline__ void gelu_fd2(v2f x, v2f &f, v2f &d) {
+  const v2f x2 = x * x;
+  const v2f e = exp2_2(x * __builtin_elementwise_fma(splat2(-0.100125614f), x2, splat2(-2.30876530f)));
+  const v2f s = rcp_2(splat2(1.0f) + e);
+  f = x * s;
+  d = __builtin_elementwise_fma(f * (splat2(1.0f) - s), __builtin_elementwise_fma(splat2(0.20820537f), x2, splat2(1.60031416f)), s);
+}
+__device__ __forceinline__ v2f gelu_f2(v2f x) {
+  const v2f e = exp2_2(x * __builtin_elementwise_fma(splat2(-0.100125614f), x * x, splat2(-2.30876530f)));
+  return x * rcp_2(splat2(1.0f) + e);
+}
+__device__ __forceinline__ v2f pair(const v16f &v, int i) { return v2f{v[2 * i], v[2 * i + 1]}; }
+__device__ __forceinline__ void set_pair(v16f &v, int i, v2f x) { v[2 * i] = x[0], v[2 * i + 1] = x[1]; }
 
 constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
 // per 32-point tile, for k_ff_wgrad: two sets of fragments [4 c][2 u][64 lanes] (8 KiB each) in memory; k_ff_wgrad derives the
@@ -876,7 +896,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       v16f hv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = av[r] * gelu_f(gv[r]);
+      for (int i = 0; i < 8; ++i) set_pair(hv, i, pair(av, i) * gelu_f2(pair(gv, i)));
       if (DROP) {
         // dropout behind the GEGLU (attention.py:84): element (row, unit 32 j + 8 q + 4 hf + m) = group row * 64 + 4 j + q of the site; the scale rides on `a`
         unsigned w[4][2];
@@ -936,11 +956,12 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
       // ---- GEGLU backward on the registers ----
       v16f da, dg;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float f, d;
-        gelu_fd(gv[r], f, d);
-        da[r] = dhid[r] * f;
-        dg[r] = dhid[r] * av[r] * d;
+      for (int i = 0; i < 8; ++i) {
+        v2f f, d;
+        gelu_fd2(pair(gv, i), f, d);
+        const v2f dh2 = pair(dhid, i);
+        set_pair(da, i, dh2 * f);
+        set_pair(dg, i, dh2 * pair(av, i) * d);
       }
       const uint4 a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1366,7 +1387,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       }
       v16f hv, da, dg;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) {   // (scalar fp32 here: the packed forms of gelu_fd2 made this kernel 5 % SLOWER — 236 -> 249 us — the producer's chain is serial)
         float f, d;
         gelu_fd(gv[r], f, d);
         const float hr = av[r] * f;
