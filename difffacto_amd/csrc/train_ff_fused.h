@@ -1277,8 +1277,9 @@ constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chun
 // LDS: the tiles ([xn3 | dh] fragments, 16 KiB) travel in a ring of three slots, two tiles ahead of the producers (L2 latency under load
 // is longer than one tile's arithmetic); the consumers turn tile k around (two MFMAs with a 0/1 selection matrix per 32 x 32 tile, exact)
 // into one of two 16 KiB slots while they multiply tile k - 1
-constexpr int WG_RING_A = 0, WG_RING_T = 3 * 16384, WG_RING = 5 * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
-constexpr int WG_MASK = WG_LDS, WG_LDS_DROP = WG_LDS + 3 * 2048;   // dropout: the tiles' bit words (2 KiB each) in a ring of their own, same three slots
+constexpr int WG_SLOTS = 3;
+constexpr int WG_RING_A = 0, WG_RING_T = WG_SLOTS * 16384, WG_RING = (WG_SLOTS + 2) * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
+constexpr int WG_MASK = WG_LDS, WG_LDS_DROP = WG_LDS + WG_SLOTS * 2048;   // dropout: the tiles' bit words (2 KiB each) in a ring of their own, same slots
 template <bool DROP>
 __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char fw_smem[];   // 3 tiles x 32 KiB | 2 x 4 chunks x 6 KiB of hid / da / dg fragments
@@ -1300,21 +1301,23 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
   const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
   // iteration k requests tile k + 2: two 1 KiB pieces per wavefront
+  constexpr int AHEAD = WG_SLOTS - 1;
   auto stage = [&](int k) {
-    if (k + 2 < nt) {
+    if (k + AHEAD < nt) {
       // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
-      const char *src = wave >= WG_NW / 2 ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + 2) * PK_TILE_U4) - 8192
-                                          : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + 2) * PK_TILE_U4);
+      const char *src = wave >= WG_NW / 2 ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + AHEAD) * PK_TILE_U4) - 8192
+                                          : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + AHEAD) * PK_TILE_U4);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + 2) % 3) * 16384 + (wave * 2 + q) * 1024);
+      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + AHEAD) % WG_SLOTS) * 16384 + (wave * 2 + q) * 1024);
       if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront
-        dma256(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + 2) * DM_TILE) + wave * 256, lane * 4, lds0 + WG_MASK + ((k + 2) % 3) * 2048 + wave * 256);
+        dma256(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + AHEAD) * DM_TILE) + wave * 256, lane * 4,
+               lds0 + WG_MASK + ((k + AHEAD) % WG_SLOTS) * 2048 + wave * 256);
     }
   };
-  // top of iteration k: everything requested before iteration k - 1 has landed (loads complete in order; the last iterations request
-  // nothing: drain)
+  // top of iteration k: everything requested before iteration k - 1 has landed, i.e. tiles <= k (loads complete in order; the last iterations
+  // request nothing: drain)
   auto arrive = [&](int k) {
-    if (k + 1 < nt) {
+    if (k + AHEAD - 1 < nt) {
       if (DROP) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // stretch, and neither role needs more than 256 registers.
   FFT_INIT2(a, consumer ? 3 : 2, consumer ? WG_CHUNKS * 64 : 0);
   FFT(1);
-  stage(-2), stage(-1);   // tiles 0, 1
+  for (int k = -AHEAD; k < 0; ++k) stage(k);   // tiles 0, 1
   if (!consumer) {
     uint4 w1a[4][2], w1g[4][2], w2t[4][2];
     {
@@ -1346,22 +1349,11 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     // dropout bits in this orientation (unit pj of chunk j on the lane, point 8 q + 4 half + m in register 4 q + m): the forward's lane of that point is
     // (point, (pj >> 2) & 1), its bit 16 (j & 1) + 4 (pj >> 3) + (pj & 3) of word j >> 1 — four consecutive lanes' words per 16-byte LDS read
     const int dm_off = (j >> 1) * 64 + 32 * ((pj >> 2) & 1) + 4 * (lane >> 5), dm_bit = 16 * (j & 1) + 4 * (pj >> 3) + (pj & 3);
-    for (int k = 0; k <= nt; ++k) {
-      if (k < 24) FFT(10);
-      arrive(k);   // tile k has landed; everybody is done with tile k - 1's producer half and tile k - 2's consumer half and fragments
-      if (k < 24) FFT(11);
-      stage(k);
-      if (k == nt) break;
-      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
-      v16f av, gv, dv;
+    // 24 MFMAs of tile k: [a | g]^T = xhat3 W1^T + b1, d hid^T = dh W2
+    auto mm = [&](int k, v16f &av, v16f &gv, v16f &dv) {
+      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384) + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
-      uint4 mq[4];
-      if (DROP) {   // the tile's bit words first: they travel under the 24 MFMAs instead of behind them
-        const unsigned *mk = reinterpret_cast<const unsigned *>(fw_smem + WG_MASK + (k % 3) * 2048) + dm_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = *reinterpret_cast<const uint4 *>(mk + 8 * q);
-      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1371,12 +1363,16 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           gv = mfma(x, w1g[c][u], gv);
           dv = mfma(tl[(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
         }
-      if (k < 12) FFT(14);
+    };
+    // GEGLU forward / backward on tile k's accumulators -> six fragments in LDS
+    auto act = [&](int k, const v16f &av, const v16f &gv, v16f &dv) {
       unsigned keepm[16];
       if (DROP) {
+        const unsigned *mk = reinterpret_cast<const unsigned *>(fw_smem + WG_MASK + (k % WG_SLOTS) * 2048) + dm_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const unsigned wq[4] = {mq[q].x, mq[q].y, mq[q].z, mq[q].w};
+          const uint4 mq = *reinterpret_cast<const uint4 *>(mk + 8 * q);
+          const unsigned wq[4] = {mq.x, mq.y, mq.z, mq.w};
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             keepm[4 * q + m] = (unsigned)__builtin_amdgcn_sbfe((int)wq[m], dm_bit, 1);   // v_bfe_i32: all ones = kept
@@ -1385,22 +1381,42 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
           }
         }
       }
-      v16f hv, da, dg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {   // (scalar fp32 here: the packed forms of gelu_fd2 made this kernel 5 % SLOWER — 236 -> 249 us — the producer's chain is serial)
-        float f, d;
-        gelu_fd(gv[r], f, d);
-        const float hr = av[r] * f;
-        hv[r] = DROP ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hr) & keepm[r]) : hr;
-        da[r] = dv[r] * f;
-        dg[r] = dv[r] * av[r] * d;
-        sa += da[r], sg += dg[r];
-      }
-      if (k < 12) FFT(12);
       uint4 *po = packs + ((k & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
-      po[0 * 64] = pack8(hv, 0), po[1 * 64] = pack8(hv, 1), po[2 * 64] = pack8(da, 0), po[3 * 64] = pack8(da, 1);
-      po[4 * 64] = pack8(dg, 0), po[5 * 64] = pack8(dg, 1);
-      if (k < 12) FFT(13);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {   // (half a tile at a time: eight values of each of the three products alive, not sixteen)
+        v8f hv, da, dg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // (scalar fp32 here: the packed forms of gelu_fd2 made this kernel 5 % SLOWER — 236 -> 249 us)
+          const int r = 8 * u + e;
+          float f, d;
+          gelu_fd(gv[r], f, d);
+          const float hr = av[r] * f;
+          hv[e] = DROP ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hr) & keepm[r]) : hr;
+          da[e] = dv[r] * f;
+          dg[e] = dv[r] * av[r] * d;
+          sa += da[e], sg += dg[e];
+        }
+        po[(0 + u) * 64] = __builtin_bit_cast(uint4, __builtin_convertvector(hv, v8bf));
+        po[(2 + u) * 64] = __builtin_bit_cast(uint4, __builtin_convertvector(da, v8bf));
+        po[(4 + u) * 64] = __builtin_bit_cast(uint4, __builtin_convertvector(dg, v8bf));
+      }
+    };
+    // (Round 5, measured and dropped: running the 24 MFMAs — or just GEMM1's 16 — of tile k + 1 beside the GEGLU arithmetic of tile k in the SAME wavefront,
+    // two accumulator sets, four ring slots: 230 -> 249 us per block left to hipcc's order, 292-297 us with a forced MFMA : VALU interleave — VALU
+    // beside MFMAs of one wavefront is an anti-lever on this part; the producer / consumer split across two wavefronts is what overlaps them.)
+    {
+      for (int k = 0; k <= nt; ++k) {
+        if (k < 24) FFT(10);
+        arrive(k);   // tile k has landed; everybody is done with tile k - 1's producer half and tile k - 2's consumer half and fragments
+        if (k < 24) FFT(11);
+        stage(k);
+        if (k == nt) break;
+        v16f av, gv, dv;
+        mm(k, av, gv, dv);
+        if (k < 12) FFT(14);
+        act(k, av, gv, dv);
+        if (k < 12) FFT(13);
+      }
     }
     FFT(3);
     sa += xhalf(sa), sg += xhalf(sg);   // the two half-waves hold different points of the same unit
@@ -1429,7 +1445,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     if (k < 12) FFT(21);
     stage(k);
     if (k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
-      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % 3) * 16384) + lane;
+      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384) + lane;
       uint4 *to = reinterpret_cast<uint4 *>(fw_smem + WG_RING_T + (k & 1) * 16384) + lane;
       v16f z;
 #pragma unroll
