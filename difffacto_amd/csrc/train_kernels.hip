@@ -769,7 +769,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ hfin
 constexpr int HEAD_PART = 672;
 __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps, const float *__restrict__ hfin, const float *__restrict__ g,
                                                    const float *__restrict__ be, const float *__restrict__ W, float *__restrict__ dh,
-                                                   float *__restrict__ part, int N, long long R) {
+                                                   float *__restrict__ part, int N, long long R, bool hl) {
+  // hl: dh leaves as the bf16-pair tiles the fused backward kernels pass between the blocks (train_ff_fused.h, TL_DH_HL) instead of fp32 rows
   __shared__ float red[8][HEAD_PART];
   const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const v4f gv = reinterpret_cast<const v4f *>(g)[l], bv = reinterpret_cast<const v4f *>(be)[l];
@@ -793,7 +794,21 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps
     const v4f dyg = dhn * gv;
     const float s1 = sum32(dyg[0] + dyg[1] + dyg[2] + dyg[3]) * (1.0f / C);
     const float s2 = sum32(dyg[0] * xh[0] + dyg[1] * xh[1] + dyg[2] * xh[2] + dyg[3] * xh[3]) * (1.0f / C);
-    reinterpret_cast<v4f *>(dh + r * C)[l] = rstd * (dyg - s1 - xh * s2);
+    const v4f o = rstd * (dyg - s1 - xh * s2);
+    if (!hl) {
+      reinterpret_cast<v4f *>(dh + r * C)[l] = o;
+    } else {
+      // this thread's channels 4 l .. 4 l + 3 of point pj = r % 32: hi = element 4 (l & 1) .. of block (c, u) = (l >> 3, (l >> 2) & 1), half-wave (l >> 1) & 1;
+      // lo = registers 4 q .. 4 q + 3, q = (l >> 1) & 3, of accumulator tile c in half-wave l & 1 (block (c, q >> 1), second half of the tile)
+      typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+      const v4bf hi = __builtin_convertvector(o, v4bf);
+      const v4f rem = o - __builtin_convertvector(hi, v4f);
+      const v4bf lo = __builtin_convertvector(rem, v4bf);
+      char *tile = reinterpret_cast<char *>(dh + (r & ~31LL) * C);
+      const int pj = (int)(r & 31), c = l >> 3, q = (l >> 1) & 3;
+      *reinterpret_cast<uint2 *>(tile + ((c * 2 + ((l >> 2) & 1)) * 64 + pj + 32 * ((l >> 1) & 1)) * 16 + 8 * (l & 1)) = __builtin_bit_cast(uint2, hi);
+      *reinterpret_cast<uint2 *>(tile + 8192 + ((c * 2 + (q >> 1)) * 64 + pj + 32 * (l & 1)) * 16 + 8 * (q & 1)) = __builtin_bit_cast(uint2, lo);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -2244,7 +2259,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
   if (fused_ends) {
     const int nb = (int)((R + HEAD_ROWS - 1) / HEAD_ROWS);
     float *hp = w.hn;
-    k_head_bwd<<<nb, 256, 0, st>>>(d_eps, w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, w.dh, hp, N, R);
+    k_head_bwd<<<nb, 256, 0, st>>>(d_eps, w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, w.dh, hp, N, R, t_attn_in_ff);
     head_sums = [&, nb, hp](hipStream_t s) {
       k_sum_parts<<<3 * C / 32, 1024, 0, s>>>(hp, mut(grads->proj_out_w), nb, 3 * C, HEAD_PART);
       k_sum_parts_multi<<<2 * C / 32, 1024, 0, s>>>(hp + 3 * C, SumOuts{{mut(grads->post_norm_w), mut(grads->post_norm_b), nullptr, nullptr}}, nb, C, HEAD_PART);
@@ -2284,10 +2299,10 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
       fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
       fa.h1 = a.h1, fa.dh = dh_cur, fa.pk = reinterpret_cast<uint4 *>(w.dwide), fa.dh1 = w.dh2, fa.cpart = w.cpart[i], fa.R = R, fa.B = B, fa.N = N;
       const bool dx_in_ff = t_attn_in_ff;   // the attention's input gradient in the same kernel (dh1 leaves as fragments for the parameter kernel)
-      // With the attention inside, the gradient travels between the blocks as bf16-pair tiles (train_ff_fused.h, TL_DH_HL), alternating between w.dh
-      // and w.dh2 (k_ff_wgrad reads block i's INCOMING gradient after k_ff<true> has written the outgoing one); it is fp32 row-major where the head
-      // wrote it and where the stem reads it (dh_cur behind the loop)
-      const bool hl_in = dx_in_ff && i + 1 < wt->depth, hl_out = dx_in_ff && i > 0;
+      // With the attention inside, the gradient travels from the head through the blocks as bf16-pair tiles (train_ff_fused.h, TL_DH_HL), alternating
+      // between w.dh and w.dh2 (k_ff_wgrad reads block i's INCOMING gradient after k_ff<true> has written the outgoing one); block 0 writes the fp32
+      // rows the stem reads (dh_cur behind the loop)
+      const bool hl_in = dx_in_ff, hl_out = dx_in_ff && i > 0;   // (k_head_bwd writes the pair format too; block 0 hands fp32 rows to the stem)
       const float *dh_in_blk = dh_cur;
       if (t_attn_in_ff)   // + the layouts the forward left behind
         fa.tiled = dfx::ffused::TL_H1 | (i > 0 ? dfx::ffused::TL_HIN | dfx::ffused::TL_DHIN : 0) | (i + 1 < wt->depth ? dfx::ffused::TL_DH : 0) |
@@ -2318,6 +2333,7 @@ int dfx_denoiser_train_backward(const dfx_denoiser_weights *wt, void *workspace,
                                dx_in_ff ? reinterpret_cast<const uint4 *>(a.h1) : reinterpret_cast<const uint4 *>(w.dwide), w.ffw_part[i], w.ffw_bpart[i],
                                R / 32, w.ffw_slabs, dropout_p > 0.f ? reinterpret_cast<const unsigned *>(a.p) : nullptr,
                                hl_in ? reinterpret_cast<const uint4 *>(dh_in_blk) : reinterpret_cast<const uint4 *>(w.dwide) + dfx::ffused::PK_TILE_U4 / 2};
+        // (without the attention inside — dfx_debug_train_fused(2) — k_ff<true> reads fp32 rows and leaves both fragment sets in w.dwide)
         if (dfx::ffused::launch_ff_wgrad(st, wa)) return dfx::set_error(DFX_ERR_HIP, "train: feed-forward weight-gradient launch");
       }
       // attention + LayerNorm2 (train_attn_fused.h): parameter side first (reads dh1 = w.dh2), then dh -> w.dh
