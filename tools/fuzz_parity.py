@@ -29,7 +29,7 @@ import test_gpu_pointnet2 as tp  # noqa: E402
 import test_gpu_train as tt  # noqa: E402
 from difffacto_amd import synth  # noqa: E402
 from difffacto_amd.pointnet2_ops import pointnet2_utils as pu  # noqa: E402
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "experiments"))
 from pnv2_conditioning import check_case as pnv2_check  # noqa: E402
 
 W = synth.make_denoiser_weights(seed=0)
@@ -125,7 +125,7 @@ FAMILIES = [
     ("f32 pipelined = direct fp32 kernel: bit-identical", lambda a: td.test_f32_pipelined_chain_is_bit_identical_to_the_direct_kernel(W, *a),
      lambda: (32 * ri(3, 100),)),
     ("fused vs layer-by-layer training FF", lambda a: tt.test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(*a),
-     lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 3), n))(32 * ri(1, 40))),
+     lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 3), n, (0.2, ri(1, 10 ** 6)) if rb() else None))(32 * ri(1, 40))),   # (B, N, dropout: round 5)
 ]
 
 for name in ("test_fps_matches_oracle", "test_ball_query_matches_oracle"):
