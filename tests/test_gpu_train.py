@@ -208,6 +208,42 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout):
     assert e_loss < 6e-4 and e_eps < 1e-2, (e_loss, e_eps)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_fused_path_at_other_depths(depth):
+    """The fused backward passes the gradient between the blocks through two alternating buffers (bf16-pair tiles; the head writes the
+    first, block 0 hands fp32 rows to the stem — in w.dh or w.dh2 depending on the depth's parity) and batches the finishing kernels over the
+    blocks: depths 1, 2 and 4 (the shipped network has 5) against the layer-by-layer bf16 kernels, the gates of the depth-5 test."""
+    from difffacto_amd import _ffi, synth
+    B, N = 2, 224
+    rng = np.random.Generator(np.random.PCG64(600 + depth))
+    W = synth.make_denoiser_weights(8, depth=depth)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=23, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+             flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+    fused = _run(c, True, precision="bf16")
+    _ffi.lib().dfx_debug_train_fused(0)
+    try:
+        layer = _run(c, True, precision="bf16")
+    finally:
+        _ffi.lib().dfx_debug_train_fused(1)
+    assert set(fused["grads"]) == set(layer["grads"]) and any(not np.array_equal(fused["grads"][k], layer["grads"][k]) for k in layer["grads"])
+    e_eps = np.abs(fused["eps"] - layer["eps"]).max()
+    worst, at = 0.0, None
+    for k, gr in layer["grads"].items():
+        e = np.abs(fused["grads"][k] - gr).max() / max(np.abs(gr).max(), 1e-30)
+        if e > worst:
+            worst, at = e, k
+    print(f"depth {depth}: fused vs layer-by-layer eps max-abs {e_eps:.1e}, gradients worst max-norm {worst:.1e} ({at})")
+    assert e_eps < 1e-2 and worst < 2e-2, (e_eps, worst, at)
+
+
 def test_layernorm3_fold_with_awkward_affine_parameters():
     """Round 5: the fused kernels fold LayerNorm3's affine into W1 / b1 (W1 diag(g3), b1 + W1 b3) and take d gamma3 / d beta3 / dW1 from the
     weight-gradient side (G = d[a|g]^T xhat3: dW1 = G diag(g3) + db1 (x) b3, d gamma3 = sum_o W1 o G, d beta3 = sum_o W1[o][.] db1[o]).
