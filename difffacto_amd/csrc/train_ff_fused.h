@@ -73,10 +73,26 @@ struct PackArgs {
 
 struct PackBatch {
   PackArgs blk[DFX_MAX_DEPTH];   // blockIdx.y = transformer block: every block's weights in one launch
+  // blockIdx.y == depth (optional, head_tab != nullptr): the head for the last block's forward kernel (TL_HEAD) — proj_out with post_norm's affine
+  // folded in: tab[k][ch] = W_out[k][ch] gamma[ch] (3 x 128), tab[384 + k] = b_out[k] + sum_ch W_out[k][ch] beta[ch]
+  int depth;
+  const float *head_w, *head_b, *head_g, *head_be;
+  float *head_tab;   // HEAD_TAB_FLOATS
 };
+constexpr int HEAD_TAB_FLOATS = 3 * C + 4;
 
 // one thread per (chunk, tile, unit, lane)
 __global__ void k_ff_pack(PackBatch batch) {
+  if ((int)blockIdx.y == batch.depth) {   // the head's table: one workgroup
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) batch.head_tab[i] = batch.head_w[i] * batch.head_g[i % C];
+    if (threadIdx.x < 3) {
+      float t = batch.head_b[threadIdx.x];
+      for (int ch = 0; ch < C; ++ch) t = fmaf(batch.head_w[threadIdx.x * C + ch], batch.head_be[ch], t);
+      batch.head_tab[3 * C + threadIdx.x] = t;
+    }
+    return;
+  }
   const PackArgs &a = batch.blk[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < NCHUNK * 2 * 2 * 16) {   // b1p, b1f: b1 + W1 beta3
@@ -153,6 +169,10 @@ struct FfArgs {
   DropKey dk;
   unsigned site_att, site_ff;
   unsigned *dmask;
+  // the head inside the LAST block's forward kernel (TL_HEAD; round 5): eps = W_out post_norm(h2) + b_out from the accumulators (table: PackBatch::head_tab),
+  // and h2 leaves only as what k_head_bwd wants of it — the bf16 fragments of post_norm's normalised row + 1 / std, in h2's own tiles (TL_H1_FRAG's format)
+  const float *head_tab;
+  float *eps;            // (B, 3, N)
 #ifdef DFX_TRACE_FF
   unsigned long long *trace;
 #endif
@@ -463,6 +483,27 @@ __device__ __forceinline__ void frags_to_acc(const uint4 (&f)[4][2], v16f (&d)[4
 constexpr int HL_LO_U4 = 8 * 64;   // bf16-pair tiles (TL_DH_HL below): uint4 offset of the lo half within a tile
 // One channel tile (accumulator layout, fp32) of a row-shaped tensor as a bf16 pair, see TL_DH_HL: hi in the B-operand layout (frags_to_acc backwards:
 // the packed pairs (8 u + 2 h, +1) and (8 u + 4 + 2 h, +1) trade half-waves), lo = bf16(v - hi) in place
+// one channel tile (accumulator layout, fp32) -> its two bf16 B-operand fragments (frags_to_acc backwards)
+__device__ __forceinline__ void acc_to_frags(const v16f &v, uint4 (&hb)[2]) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+  unsigned hp[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const v2f x = {v[2 * d], v[2 * d + 1]};
+    hp[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, v2bf));
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    unsigned w[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const auto r = __builtin_amdgcn_permlane32_swap(hp[4 * u + h], hp[4 * u + 2 + h], false, false);
+      w[h] = r[0], w[2 + h] = r[1];
+    }
+    hb[u] = uint4{w[0], w[1], w[2], w[3]};
+  }
+}
 __device__ __forceinline__ void store_hl(uint4 *tile_lane, int c, const v16f &v, bool live) {
   unsigned hp[8], lp[8];   // packed pairs (2 d, 2 d + 1)
 #pragma unroll
@@ -595,7 +636,7 @@ __device__ __forceinline__ void load_rows_acc(const float *__restrict__ hrow, in
 //   B-operand layout, block (c, u), element e of lane (pj, hf) = channel 32 c + 16 u + 8 hf + e     -> ((c 2 + u) 2 + e / 4) 256 + lane 4 + e % 4
 //   accumulator layout, register 4 q + m of tile c, lane (pj, hf) = channel 32 c + 8 q + 4 hf + m  -> ((c 2 + q / 2) 2 + hf) 256 + (pj + 32 (q & 1)) 4 + m
 // (the same element either way).  Measured: k_ff<true> 356 -> 334 us, k_ff<false> 180 -> 165 us per block.
-enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16, TL_DH_HL = 32, TL_DHIN_HL = 64, TL_H1_FRAG = 128 };
+enum { TL_HIN = 1, TL_H1 = 2, TL_H2 = 4, TL_DH = 8, TL_DHIN = 16, TL_DH_HL = 32, TL_DHIN_HL = 64, TL_H1_FRAG = 128, TL_HEAD = 256 };
 // ---- h1 as the backward wants it (round 5, TL_H1_FRAG; forward with the attention sub-block inside).  The backward kernels need two things of h1: the bf16
 // fragments of xhat3 = LayerNorm3's normalised row (k_ff<true>'s B operand and, turned around, LayerNorm3's backward; k_ff_wgrad's tiles) and the row's
 // 1 / std.  So the forward stores exactly those in the tile's 16 KiB — [xhat3: 8 blocks (c, u) of 1 KiB = the PK_XN set][rstd: 32 floats] — instead of
@@ -996,6 +1037,57 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   }
   FFT(3);
   if (!BWD) {
+    if (a.tiled & TL_HEAD) {
+      // post_norm + proj_out on the accumulators (two-pass statistics like k_head_fwd's ln_row); xhat replaces h2 in acc
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += acc[c][r];
+      sm += xhalf(sm);
+      const float mup = sm * (1.0f / C);
+      float qs = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[c][r] - mup;
+          qs = fmaf(d, d, qs);
+        }
+      qs += xhalf(qs);
+      const float rstdp = 1.0f / sqrtf(qs * (1.0f / C) + LN_EPS);
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = 32 * c + 8 * q + 4 * hf;
+          const v4f w0 = *reinterpret_cast<const v4f *>(a.head_tab + ch), w1 = *reinterpret_cast<const v4f *>(a.head_tab + C + ch);
+          const v4f w2 = *reinterpret_cast<const v4f *>(a.head_tab + 2 * C + ch);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float xh = (acc[c][4 * q + m] - mup) * rstdp;
+            acc[c][4 * q + m] = xh;
+            e0 = fmaf(xh, w0[m], e0), e1 = fmaf(xh, w1[m], e1), e2 = fmaf(xh, w2[m], e2);
+          }
+        }
+      e0 += xhalf(e0), e1 += xhalf(e1), e2 += xhalf(e2);
+      if (!live) return;
+      if (hf == 0) {
+        float *ep = a.eps + (size_t)s * 3 * a.N + ti * 32 + pj;
+        ep[0] = e0 + a.head_tab[3 * C], ep[a.N] = e1 + a.head_tab[3 * C + 1], ep[2 * (size_t)a.N] = e2 + a.head_tab[3 * C + 2];
+        (a.h2 + rowbase)[H1F_RSTD + pj] = rstdp;
+      }
+      uint4 *hp = reinterpret_cast<uint4 *>(a.h2 + rowbase) + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint4 hb[2];
+        acc_to_frags(acc[c], hb);
+        hp[(c * 2 + 0) * 64] = hb[0], hp[(c * 2 + 1) * 64] = hb[1];
+      }
+      FFT(9);
+      return;
+    }
     if (!live) return;
     float *out = a.h2 + rowbase;
 #pragma unroll
@@ -1579,9 +1671,10 @@ inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) { return a.dmask ? l
 
 inline size_t pack_bytes_frags() { return (size_t)NCHUNK * CHUNK_U4 * sizeof(uint4); }
 
-inline void launch_pack(hipStream_t st, const PackBatch &b, int depth) {
+inline void launch_pack(hipStream_t st, PackBatch &b, int depth) {
   const int total = NCHUNK * TILES * 128;
-  k_ff_pack<<<dim3((total + 255) / 256, depth), 256, 0, st>>>(b);
+  b.depth = depth;
+  k_ff_pack<<<dim3((total + 255) / 256, depth + (b.head_tab ? 1 : 0)), 256, 0, st>>>(b);
 }
 // workgroups of k_ff<*> (= rows of the backward's column-sum partials): one shape per workgroup
 inline long long ff_groups(int B, int N) { return (long long)B * ((N / 32 + NW_BWD - 1) / NW_BWD); }

@@ -785,7 +785,16 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ deps
     const float d0 = deps[(bb * 3 + 0) * N + n], d1 = deps[(bb * 3 + 1) * N + n], d2 = deps[(bb * 3 + 2) * N + n];
     v4f xh;
     float rstd;
-    ln_row(hfin + r * C, l, xh, rstd);
+    if (!hl) {
+      ln_row(hfin + r * C, l, xh, rstd);
+    } else {   // the last block's forward kernel left the normalised row as bf16 fragments + 1 / std (train_ff_fused.h, TL_HEAD): this thread's four channels
+      const char *tile = reinterpret_cast<const char *>(hfin + (r & ~31LL) * C);
+      const int pj = (int)(r & 31), c = l >> 3;
+      const uint2 hv = *reinterpret_cast<const uint2 *>(tile + ((c * 2 + ((l >> 2) & 1)) * 64 + pj + 32 * ((l >> 1) & 1)) * 16 + 8 * (l & 1));
+      xh = v4f{__builtin_bit_cast(float, hv.x << 16), __builtin_bit_cast(float, hv.x & 0xffff0000u), __builtin_bit_cast(float, hv.y << 16),
+               __builtin_bit_cast(float, hv.y & 0xffff0000u)};
+      rstd = reinterpret_cast<const float *>(tile)[dfx::ffused::H1F_RSTD + pj];
+    }
     const v4f hn = xh * gv + bv;
     const v4f dhn = d0 * w0 + d1 * w1 + d2 * w2;
     a0 += d0 * hn, a1 += d1 * hn, a2 += d2 * hn;
@@ -1640,7 +1649,7 @@ struct TrainWs {
   float *at_part[DFX_MAX_DEPTH], *at_sum[DFX_MAX_DEPTH], *cpart[DFX_MAX_DEPTH];   // per block: summed / unfolded behind the block loop, one launch each
   int at_split;
   // weight-stationary feed-forward gradients (k_ff_wgrad): per-slab partial tiles
-  float *ffw_part[DFX_MAX_DEPTH], *ffw_bpart[DFX_MAX_DEPTH], *ffw_lnpart[DFX_MAX_DEPTH];
+  float *ffw_part[DFX_MAX_DEPTH], *ffw_bpart[DFX_MAX_DEPTH], *ffw_lnpart[DFX_MAX_DEPTH], *head_tab;
   int ffw_slabs;
   // keys / values of all blocks in one product: packed weights (and transposed), k | v of every block side by side, their gradients
   float *wkv, *wkvT, *kv, *dkv, *dwkv;
@@ -1727,6 +1736,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
     w.ffw_part[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 12 * 1024);
     w.ffw_bpart[i] = c.take<float>((size_t)w.ffw_slabs * dfx::ffused::NCHUNK * 64);
     w.ffw_lnpart[i] = c.take<float>(dfx::ffused::LNPART_FLOATS);
+    if (i == 0) w.head_tab = c.take<float>(512);   // (>= dfx::ffused::HEAD_TAB_FLOATS)
   }
   w.wkv = c.take<float>((size_t)2 * depth * C * CTXP);
   w.wkvT = c.take<float>((size_t)2 * depth * C * CTXP);
@@ -2143,6 +2153,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i],
                                         dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, wt->blk[i].norm3_w, wt->blk[i].norm3_b,
                                         w.ff_b1p[i] + dfx::ffused::B1P_FLOATS};
+    if (t_attn_in_ff)   // + the head's table: the last block's forward kernel computes eps itself
+      pb.head_w = wt->proj_out_w, pb.head_b = wt->proj_out_b, pb.head_g = wt->post_norm_w, pb.head_be = wt->post_norm_b, pb.head_tab = w.head_tab;
     dfx::ffused::launch_pack(st, pb, wt->depth);
   } else {
     k_pad_cols<<<(C * XIN + 255) / 256, 256, 0, st>>>(wt->proj_in_w, w.wpad, C, 13, XIN);
@@ -2174,6 +2186,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       if (t_attn_in_ff) {   // attention sub-block inside the feed-forward kernel's prologue: h1 computed from hin, written once
         fa.at_frags = w.at_frags[i], fa.valid = w.valid, fa.g2 = bw.norm2_w, fa.b2n = bw.norm2_b, fa.bo = bw.to_out_b;
         fa.hin = a.hin, fa.h1_out = a.h1;
+        if (i + 1 == wt->depth) fa.tiled |= dfx::ffused::TL_HEAD, fa.head_tab = w.head_tab, fa.eps = eps;   // post_norm + proj_out in this kernel's epilogue
         if (dropout_p > 0.f) {   // the two sites of block i (the layer-by-layer path's numbering); bits -> a.p (R x 32 floats, unused by the fused path; 80 B per point needed)
           fa.dk = dfx::drop_key(dropout_seed, dropout_p), fa.site_att = (unsigned)(2 * i), fa.site_ff = (unsigned)(2 * i + 1);
           fa.dmask = reinterpret_cast<unsigned *>(a.p);
@@ -2211,7 +2224,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     if ((rc = lin(st, a.hid, FH, bw.ff2_w, bw.ff2_b, hout, C, R, C, FH, a.h1, C, bf))) return rc;
   }
   if (fused_ends) {
-    k_head_fwd<<<2048, 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, wt->proj_out_b, eps, N, R);
+    if (!t_attn_in_ff) k_head_fwd<<<2048, 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, wt->proj_out_w, wt->proj_out_b, eps, N, R);
   } else {
     k_ln_fwd<false><<<(int)((R + 7) / 8), 256, 0, st>>>(w.hfin, wt->post_norm_w, wt->post_norm_b, w.hn, w.st_post, R);
     k_eps_fwd<<<(int)((R + 7) / 8), 256, 0, st>>>(w.hn, wt->proj_out_w, wt->proj_out_b, eps, N, R);
