@@ -123,6 +123,7 @@ SIGNATURES = {
     "dfx_debug_dropout_factors": (_I, [_U64, _I, _F, _P, ctypes.c_longlong, _P]),
     "dfx_debug_train_fused": (None, [_I]),
     "dfx_debug_train_streams": (None, [_I]),
+    "dfx_debug_lin_split_k": (None, [_I]),
     "dfx_debug_bn_fused_stats": (None, [_I]),
     "dfx_debug_stats_merge": (None, [_P, _I, _I, _P]),
     "dfx_debug_rowmap": (None, [_I, _P, _P]),

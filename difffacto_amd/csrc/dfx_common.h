@@ -59,13 +59,15 @@ inline hipError_t set_max_lds(const void *kernel, int bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// A second HIP stream per device for work that is off the caller's critical path (the training step's context branch and its
+// A second HIP stream per (device, caller's stream) for work that is off the caller's critical path (the training step's context branch and its
 // parameter-gradient reductions: small-grid kernels that leave most of the chip idle when they run one after the other on the caller's
 // stream).  Every entry point that uses it forks from and joins back into the caller's stream before it returns, so the caller sees plain
-// stream-ordered behaviour (and a stream capture of the caller's stream captures the side work with it).  Events come from a per-device
-// ring, one per fork / join, so that concurrent calls on different caller streams never wait on each other's records.
+// stream-ordered behaviour (and a stream capture of the caller's stream captures the side work with it).  Events come from the pair's own
+// ring, one per fork / join; calls on different caller streams (or host threads with streams of their own) share nothing — not the side stream, so not
+// each other's capture state either.
 struct SideStream {
   hipStream_t main = nullptr, side = nullptr;
+  void *impl = nullptr;       // the (device, caller's stream) pair's side stream + event ring
   bool on = false;
   bool pending = false;       // forked and not joined since: the destructor joins (an entry point's early error return must not leave side work
                               // running against a workspace the caller may free, nor a stream capture with an unjoined fork — ADVICE r4)

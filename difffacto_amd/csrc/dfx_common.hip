@@ -2,7 +2,9 @@
 #include "dfx_common.h"
 
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace dfx {
 
@@ -19,6 +21,9 @@ int set_error(int code, const char *fmt, ...) {
 }
 
 bool g_event_timing = false;
+namespace lin {
+int g_lin_split_k = -1;
+}
 float g_last_ms = -1.0f;
 const char *g_last_variant = "";
 
@@ -51,13 +56,20 @@ struct DevSide {
   std::atomic<unsigned> next{0};
 };
 std::mutex g_side_mu;
-DevSide *g_side[256] = {};
+// One side stream + event ring per (device, caller's stream) — ADVICE r4: with one per device, independent calls on different streams or host threads were
+// serialised through it, and a caller under stream capture put the shared stream into capture mode under everybody else's launches.  (At most 64 pairs
+// get their own; whoever comes later shares the device's first one.)
+std::map<std::pair<int, hipStream_t>, DevSide *> g_side;
+DevSide *g_side_first[256] = {};
 
-DevSide *dev_side() {
+DevSide *dev_side(hipStream_t caller) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return nullptr;
   std::lock_guard<std::mutex> lk(g_side_mu);
-  if (g_side[dev]) return g_side[dev];
+  const auto key = std::make_pair(dev, caller);
+  const auto it = g_side.find(key);
+  if (it != g_side.end()) return it->second;
+  if (g_side.size() >= 64 && g_side_first[dev]) return g_side_first[dev];
   DevSide *d = new DevSide;
   if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) {
     delete d;
@@ -65,7 +77,8 @@ DevSide *dev_side() {
   }
   for (hipEvent_t &e : d->ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;   // (leaks a few handles on a broken device)
-  g_side[dev] = d;
+  g_side[key] = d;
+  if (!g_side_first[dev]) g_side_first[dev] = d;
   return d;
 }
 hipEvent_t next_event(DevSide *d) { return d->ev[d->next.fetch_add(1, std::memory_order_relaxed) & 63]; }
@@ -75,15 +88,16 @@ int SideStream::open(hipStream_t caller, bool enable) {
   main = side = caller;
   on = false;
   if (!enable) return DFX_OK;
-  DevSide *d = dev_side();
-  if (!d) return set_error(DFX_ERR_HIP, "side stream: cannot create the per-device stream / events");
+  DevSide *d = dev_side(caller);
+  if (!d) return set_error(DFX_ERR_HIP, "side stream: cannot create the side stream / events");
+  impl = d;
   side = d->st;
   on = true;
   return DFX_OK;
 }
 int SideStream::fork() {
   if (!on) return DFX_OK;
-  hipEvent_t e = next_event(dev_side());
+  hipEvent_t e = next_event(static_cast<DevSide *>(impl));
   DFX_HIP_TRY(hipEventRecord(e, main));
   DFX_HIP_TRY(hipStreamWaitEvent(side, e, 0));
   pending = true;
@@ -91,7 +105,7 @@ int SideStream::fork() {
 }
 int SideStream::join() {
   if (!on) return DFX_OK;
-  hipEvent_t e = next_event(dev_side());
+  hipEvent_t e = next_event(static_cast<DevSide *>(impl));
   pending = false;
   DFX_HIP_TRY(hipEventRecord(e, side));
   DFX_HIP_TRY(hipStreamWaitEvent(main, e, 0));
@@ -180,6 +194,7 @@ int dfx_abi_version(void) { return DFX_ABI_VERSION; }
 const char *dfx_last_error(void) { return dfx::err_buf(); }
 
 void dfx_set_event_timing(int enable) { dfx::g_event_timing = enable != 0; }
+void dfx_debug_lin_split_k(int mode) { dfx::lin::g_lin_split_k = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
 
 float dfx_last_kernel_ms(void) { return dfx::g_last_ms; }
 

@@ -11,6 +11,8 @@
 
 namespace dfx {
 namespace lin {
+extern int g_lin_split_k;   // -1 automatic (by tile count), 0 never, 1 whenever K >= 128 (dfx_debug_lin_split_k)
+
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -434,7 +436,12 @@ inline void launch(hipStream_t st, int groups, const LinArgs &a) {
   // at most one tile per CU and a long K: four wavefronts per tile (split-K) — the call is a chain of round trips, not of MFMAs (measured per call of
   // the latent sampler at B = 128: flows 7.1 / 8.8 / 13.7 -> 6.4 / 7.9 / 11.1 us, the aligner's K = 1024 projection 20.3 -> 14.1; with 384-512 tiles
   // the split costs 1-2 us instead)
-  if ((long long)grid.x * grid.y * groups <= 256 && a.K >= 128) k_lin<EPI, 4><<<grid, 256, 0, st>>>(a);
+  // (the split regroups the fp32 sum over K, and the choice depends on the call's row count: results of the few-row calls — the latent front end, the
+  // time-embedding MLP — are reproducible for a given batch size, not across batch sizes.  dfx_debug_lin_split_k(1) takes the split whenever K >= 128,
+  // whatever the tile count — one grouping for every batch size, for sharded runs that must match a single-process run bit for bit; 0 never splits)
+  const int mode = g_lin_split_k;
+  const bool split = a.K >= 128 && (mode == 1 || (mode < 0 && (long long)grid.x * grid.y * groups <= 256));
+  if (split) k_lin<EPI, 4><<<grid, 256, 0, st>>>(a);
   else k_lin<EPI><<<grid, 64, 0, st>>>(a);
 }
 

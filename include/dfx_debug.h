@@ -34,6 +34,10 @@ void dfx_debug_stats_merge(const float *values, int n, int chunk, float *out3);
 /* Host-side table of the fused training kernels' row addressing inside a 32-point tile (tiled = 1: the tile-major layout between the fused
  * kernels; 0: row-major): float offset of (point, channel) through the B-operand-layout and the accumulator-layout accessors; [32][128] int32 each. */
 void dfx_debug_rowmap(int tiled, int *out_b, int *out_a);
+/* The few-row fp32 products (latent front end, time-embedding MLP; mfma_linear.h) split their sum over K across four wavefronts when the call has at
+ * most 256 output tiles — a different grouping of the same fp32 terms, chosen by the call's row count.  mode 1: split whenever K >= 128 (one grouping for
+ * every batch size: sharded runs reproduce a single-process run's latents bit for bit whatever the shard size); 0: never; -1: automatic (default). */
+void dfx_debug_lin_split_k(int mode);
 /* Debug / A-B switch: 1 keeps the EMD auction's state in global memory for every n (default 0: in LDS when n <= 2688). */
 void dfx_debug_emd_state_global(int on);
 /* Debug / sweep: workgroup shape of the register-resident FPS kernel (threads in {256, 512, 1024} x points per thread in {2..32},

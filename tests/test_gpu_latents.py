@@ -68,6 +68,29 @@ def test_sample_latents_vs_oracle_full_batch(sampler):
     _close(out["params"], ref["ctx"][1])
 
 
+def test_latents_of_a_shard_match_the_full_batch_bit_for_bit_with_one_k_grouping(sampler):
+    """The few-row fp32 products of the front end split their K sum over four wavefronts when a call has few tiles (mfma_linear.h): the grouping, and
+    with it the last bits, follows the batch size.  dfx_debug_lin_split_k(1) fixes ONE grouping for every batch size: the latents of shapes 32..47
+    computed alone (a rank's shard) are then the bits of the same shapes inside the batch of 128; integer outputs always are."""
+    from difffacto_amd import _ffi
+    S, K, N = 128, 2, 256
+    rng = np.random.Generator(np.random.PCG64(41))
+    w = rng.standard_normal((S, 256, 4)).astype(np.float32)
+    an = rng.standard_normal((S * K, 32)).astype(np.float32)
+    _, _, _, valid = synth.make_latents(S, seed=41)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    lo, hi = 32, 48
+    _ffi.lib().dfx_debug_lin_split_k(1)
+    try:
+        full = sampler.sample_latents(cu(w), cu(an), cu(valid), K=K, npoints=N)
+        part = sampler.sample_latents(cu(w[lo:hi]), cu(an[lo * K:hi * K]), cu(valid[lo:hi]), K=K, npoints=N)
+    finally:
+        _ffi.lib().dfx_debug_lin_split_k(-1)
+    for k in ("part_code", "mean", "logvar", "mean_per_point", "logvar_per_point", "params", "seg_mask"):
+        a, b = full[k].cpu().numpy()[lo * K:hi * K], part[k].cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a, b), (k, float(np.abs(a.astype(np.float64) - b).max()))
+
+
 def test_given_part_code_and_ragged_sizes(sampler):
     """part_code given (flows skipped, part_encoders.py:1053), S=1 / S=33 (partial 32-row tiles), K=1."""
     from oracle import latents as ol
