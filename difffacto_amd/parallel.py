@@ -100,7 +100,9 @@ def probe_gather(device=None):
     """Day-one guard for a collective library this code has not met yet: every rank tries ONE tiny rooted gather; if it raises on
     any rank (agreed through an all_reduce(MIN) of the success flags, so that all ranks switch together), gather_clouds() uses
     all_gather from then on.  Returns {"gather": mode in use, "fallback": None or the first error text}.  A collective that HANGS
-    cannot be rescued from inside the process; DFX_GATHER=all_gather skips the rooted gather altogether."""
+    cannot be rescued from inside the process — that includes a gather that raises on ONE rank only: the others wait inside it until the
+    process group's timeout (init_process_group(timeout=...)) before they reach the agreement all_reduce (ADVICE r4);
+    DFX_GATHER=all_gather skips the rooted gather altogether."""
     global _MODE_OVERRIDE
     if not dist.is_initialized() or dist.get_world_size() == 1 or _gather_mode() == "all_gather":
         return {"gather": _gather_mode(), "fallback": None}
