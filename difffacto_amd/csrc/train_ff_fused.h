@@ -1,16 +1,19 @@
-// Fused GEGLU feed-forward of a transformer block for the TRAINING path (train_kernels.hip, bf16 matrix products, dropout off), with the
+// Fused GEGLU feed-forward of a transformer block for the TRAINING path (train_kernels.hip, bf16 matrix products, dropout on or off), with the
 // block's LayerNorms and — optionally, FfArgs::at_frags — its attention sub-block in the same kernels:
 //
-//   forward    [h1 = hin + M_s softmax(A_s LN2(hin)) + b_o]   h2 = h1 + W2 (a * gelu(g)) + b2,   [a | g] = W1 LN3(h1) + b1
-//   backward   given dh2:  d[a | g], dxn3 = W1^T d[a | g],  dh1 = dh2 + LN3'(dxn3)   [dh_in = dh1 + LN2'(A_s^T dsim)]      (attention.py:50-57, 77-94,
-//              column sums for the LayerNorm / bias gradients; the tile's xn3 / dh as bf16 fragments for k_ff_wgrad               179-204, 296-306)
-//   k_ff_wgrad dW1, db1, dW2 by a weight-stationary recompute of hid and d[a | g]
+//   forward    [h1 = hin + M_s softmax(A_s LN2(hin)) + b_o]   h2 = h1 + W2 (a * gelu(g)) + b2,   [a | g] = W1' xhat3(h1) + b1'   (LayerNorm3's affine
+//              rides on W1' = W1 diag(gamma3), b1' = b1 + W1 beta3: PackArgs)  [last block: eps = W_out post_norm(h2) + b_out, TL_HEAD]
+//   backward   given dh2:  d[a | g], d xhat3 = W1'^T d[a | g],  dh1 = dh2 + LN3'(d xhat3)   [dh_in = dh1 + LN2'(A_s^T dsim)]      (attention.py:50-57, 77-94,
+//              column sums for the bias / LayerNorm2 gradients; xn2 / dh1 as bf16 fragments for k_attn_bwd_param                    179-204, 296-306)
+//   k_ff_wgrad dW1, db1, dW2 (and through them d gamma3 / d beta3) by a weight-stationary recompute of hid and d[a | g]
 //
 // Same structure as the sampling kernel: one wavefront = 32 points, channels on the MFMA M axis, points on the lanes, the
 // 1024-wide [a | g] and the 512-wide hidden activation live in accumulator registers one 32-unit chunk at a time and never
 // touch HBM.  The layer-by-layer path wrote [a | g] (2 KB / point), hid (1 KB), d hid (2 KB) and d[a | g] (2 KB) per block and read
-// each of them back once or twice: ~22 KB per point and block; these kernels move ~1.5 KB (forward: hin in, h1 and h2 out) + ~4.5 KB
-// (backward: h1, dh twice each, hin in; dh1, dh_in, 0.5 KB of fragments out).
+// each of them back once or twice: ~22 KB per point and block.  These kernels (round 5) move per point and block: forward 512 B in (hin), 772 B out
+// (h2; the xhat3 fragments + 1 / std that are all the backward wants of h1, TL_H1_FRAG); backward 1284 B in (those fragments, the incoming gradient as a
+// bf16 pair hi + lo, TL_DH_HL, hin) and 1024 B out (xn2 / dh1 fragments, the outgoing gradient pair); k_ff_wgrad reads the xhat3 fragments and the
+// gradient's hi halves in place.  Round 4: 1.5 KB + 4.1 KB (h1 and dh as fp32, read twice each by the backward, fragments written for k_ff_wgrad).
 // A sum over the points (weight gradients) needs the points on the K axis of the MFMA, i.e. along the registers, and here they are on
 // the lanes: hence the second kernel, which recomputes hid and d[a | g] in the transposed orientation from the fragments.
 //
