@@ -61,8 +61,8 @@ def analyse(path, out):
                 for tag, v in seg.items():
                     tot[f"  loop seg ending at tag {tag}"].append(v)
                 if k == 1:
-                    span(3, 4, "epilogue a: second read of h1, LN3 statistics")
-                    span(4, 5, "epilogue b: second read of dh, LN3 backward, 3 x 4 column sums")
+                    span(3, 4, "epilogue a: gradient lo halves in, xhat3 / dh into the accumulator layout, LN3 sums")
+                    span(4, 5, "epilogue b: LN3 backward, 4 column sums (d b2)")
                     span(5, 6, "epilogue c: read hin, LN2, sim (8 MFMA), xhat2")
                     span(6, 7, "epilogue d: softmax, dP (8 MFMA), dxn2 (8 MFMA), LN2 backward, stores, 3 x 4 column sums")
                     span(7, 8, "epilogue e: workgroup reduction + last stores landed")
