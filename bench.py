@@ -325,7 +325,7 @@ def stage1_iteration(B, N, iters=16, encoder_precision="f32", dropout=0.0):
     for _ in range(3):   # (short samples of this loop scatter by +-5 %: 12.2 ms over 24 iterations read 12.5 .. 13.8 over 4 .. 8)
         it()
     samples = []
-    for _ in range(2):   # two samples of `iters` iterations, the faster one is the figure: this loop is host-launch-bound (~11 ms of python +
+    for _ in range(3):   # three samples of `iters` iterations, the fastest one is the figure: this loop is host-launch-bound (~11 ms of python +
         torch.cuda.synchronize()   # ~600 launches per iteration) and one sample in ten reads 30-40 % high on a busy host (r05: 15.1 vs 11.1 ms)
         t0 = time.perf_counter()
         for _ in range(iters):
