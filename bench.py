@@ -325,8 +325,8 @@ def stage1_iteration(B, N, iters=16, encoder_precision="f32", dropout=0.0):
     for _ in range(3):   # (short samples of this loop scatter by +-5 %: 12.2 ms over 24 iterations read 12.5 .. 13.8 over 4 .. 8)
         it()
     samples = []
-    for _ in range(3):   # three samples of `iters` iterations, the fastest one is the figure: this loop is host-launch-bound (~11 ms of python +
-        torch.cuda.synchronize()   # ~600 launches per iteration) and one sample in ten reads 30-40 % high on a busy host (r05: 15.1 vs 11.1 ms)
+    for _ in range(3):   # three samples of `iters` iterations, the fastest one is the figure: ~470 launches per iteration, 6.7 ms of host enqueue time against
+        torch.cuda.synchronize()   # ~10 ms of GPU time (tools/experiments/stage1_host_time.py); samples differ by +-0.7 ms, one in ten reads 30-40 % high (r05: 15.1 vs 11.1 ms)
         t0 = time.perf_counter()
         for _ in range(iters):
             it()
