@@ -191,7 +191,8 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout):
     if dropout is not None:   # dropout did something, and a different seed gives different factors on the fused path
         plain = _run(c, True, precision="bf16")
         other = _run(c, True, precision="bf16", dropout=(dropout[0], dropout[1] + 1))
-        assert abs(plain["loss"] - fused["loss"]) > 1e-4 and abs(other["loss"] - fused["loss"]) > 1e-6
+        # (on eps, not on the scalar loss: two dropout patterns can land on the same loss to five digits — tools/fuzz_parity.py found B = 5, N = 160, seed 717135)
+        assert np.abs(plain["eps"] - fused["eps"]).max() > 1e-3 and np.abs(other["eps"] - fused["eps"]).max() > 1e-3
     e_eps = np.abs(fused["eps"] - layer["eps"]).max()
     worst_max = worst_l2 = 0.0
     for k, gr in layer["grads"].items():
