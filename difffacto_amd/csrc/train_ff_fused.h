@@ -694,13 +694,17 @@ constexpr int AT_OFF_BWD = 32768;
 // forward's prologue, ~6 in the backward's and ~45 in its epilogue — 58 % of a backward wavefront's life.  Now: rows first, tables and ring
 // behind them, ONE wait; attention fragments through LDS (LDS-DMA, no registers); the epilogue's second reads as two batches.  Vector-memory
 // operations complete in issue order (loads, stores and LDS-DMA alike), so stores may stay in flight across the counted waits of the loop.
+// The body of k_ff / k_ff_fwd_chain.  `first`: the lane's rows come from memory; otherwise (forward chain, blocks behind the first) they are `hc`, the
+// previous block's output, still in the accumulator registers it was computed in.  `hc` leaves with this block's output (forward).
 template <bool BWD, bool DROP>
-__global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
+__device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (&hc)[4]) {
   constexpr int NW = nw_of<BWD>();
   static_assert(NW == 4 && NW * 64 == 2 * C && FWD_TILES == BWD_TILES && B1P_FLOATS * 4 == NW * 1024, "table staging below assumes 256 threads");
   constexpr int BUF_BYTES = (BWD ? BWD_TILES : FWD_TILES) * 2048;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ff_smem[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));   // (opaque per call: in the chain hipcc otherwise hoists every lane-derived offset out of the block loop and keeps ~40 registers alive)
+  const int lane = lane_, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hf = lane >> 5, pj = lane & 31;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ff_smem);
   const unsigned voff = lane * 16;
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) xn[c][0] = hp[(c * 2 + 0) * 64], xn[c][1] = hp[(c * 2 + 1) * 64];
     rstd = (a.h1 + rowbase)[H1F_RSTD + pj];
-  } else {
+  } else if (BWD || first) {
     load_rows((BWD || !at ? a.h1 : a.hin) + rowbase, BWD || !at ? m_h1 : m_hin, x);   // (one load site: selected pointer and map, no branch)
   }
   const bool hl_in = BWD && (a.tiled & TL_DH_HL), hl_out = BWD && (a.tiled & TL_DHIN_HL);
@@ -786,6 +790,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   FFT(16);
   // B operand of the products over the channels: xhat3 of LN3(h1) (bf16, natural K order) and, backward, dh rounded to bf16
   v16f acc[4];   // forward: the residual stream h; backward: dxn3
+  if (!BWD && !first) acc_to_rows(hc, x);   // (chained forward: this block's input rows = the previous block's output, never re-read)
   if (!BWD && at) {
     // attention sub-block in registers: h1 = hin + M_s softmax(A_s LN2(hin)) + b_o, then straight on to LayerNorm3
     const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + 2 * BUF_BYTES) + lane;
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
     }
     softmax_regs(sim, vmask);
     const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
-    rows_to_acc(x, acc);
+    rows_to_acc(x, acc);   // (also in the chain: keeping hc alive through the attention prologue beside x costs 64 registers)
     unsigned attw = 0;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -1040,6 +1045,8 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   }
   FFT(3);
   if (!BWD) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hc[c] = acc[c];   // (dead in the single-block kernel)
     if (a.tiled & TL_HEAD) {
       // post_norm + proj_out on the accumulators (two-pass statistics like k_head_fwd's ln_row); xhat replaces h2 in acc
       float sm = 0.f;
@@ -1340,6 +1347,26 @@ __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   FFT(8);
+}
+
+template <bool BWD, bool DROP>
+__global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
+  v16f hc[4];
+  ff_run<BWD, DROP>(a, true, hc);
+}
+// The forward of ALL blocks in one launch (round 5): a point's way through the network depends on no other point (the attention's keys / values are the
+// four context tokens, folded into A_s / M_s), so a wavefront takes its 32 points through block after block with the residual stream in its accumulator
+// registers — as the sampling kernel does.  Every block still WRITES its output rows (the backward recomputes LayerNorm2 from them), but nobody reads them
+// back in the forward: 512 B per point and block less traffic, and the prologue's wait for the rows (a quarter of a single-block workgroup's life) is
+// paid once.  Same arithmetic on the same values as five launches of k_ff<false>: bit-identical.
+struct FfChain {
+  FfArgs blk[DFX_MAX_DEPTH];
+  int n;
+};
+template <bool DROP>
+__global__ __launch_bounds__(NW_FWD * 64, 2) void k_ff_fwd_chain(FfChain ch) {
+  v16f hc[4];
+  for (int b = 0; b < ch.n; ++b) ff_run<false, DROP>(ch.blk[b], b == 0, hc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1697,6 +1724,21 @@ inline int launch_ff_t(hipStream_t st, const FfArgs &a) {
 #endif
   return 0;
 }
+template <bool DROP>
+inline int launch_ff_chain_t(hipStream_t st, const FfChain &c) {
+  static PerDeviceOnce attrs;
+  if (attrs.run([] { return set_max_lds(reinterpret_cast<const void *>(k_ff_fwd_chain<DROP>), FF_LDS); }) != hipSuccess) return -1;
+  const long long groups = ff_groups(c.blk[0].B, c.blk[0].N);
+#ifdef DFX_TRACE_FF
+  FfChain ct = c;
+  for (int b = 0; b < c.n; ++b) ct.blk[b].trace = ff_trace_buffer();
+  k_ff_fwd_chain<DROP><<<(int)groups, NW_FWD * 64, FF_LDS, st>>>(ct);
+#else
+  k_ff_fwd_chain<DROP><<<(int)groups, NW_FWD * 64, FF_LDS, st>>>(c);
+#endif
+  return 0;
+}
+inline int launch_ff_chain(hipStream_t st, const FfChain &c) { return c.blk[0].dmask ? launch_ff_chain_t<true>(st, c) : launch_ff_chain_t<false>(st, c); }
 // dropout (FfArgs::dmask set) takes the DROP instantiations; the p = 0 kernels are the ones of round 4, untouched
 template <bool BWD>
 inline int launch_ff(hipStream_t st, const FfArgs &a) { return a.dmask ? launch_ff_t<BWD, true>(st, a) : launch_ff_t<BWD, false>(st, a); }

@@ -2169,6 +2169,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     dfx::afused::k_attn_fold<<<dim3(B, wt->depth), 256, 0, sc>>>(fo);
   }
   if ((rc = ss.join())) return rc;
+  dfx::ffused::FfChain chain{};
   for (int i = 0; i < wt->depth; ++i) {
     const dfx_block_weights &bw = wt->blk[i];
     BlockAct &a = w.blk[i];
@@ -2196,6 +2197,14 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
         aa.frags = w.at_frags[i], aa.valid = w.valid, aa.g2 = bw.norm2_w, aa.b2 = bw.norm2_b, aa.bo = bw.to_out_b;
         aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
         dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
+      }
+      if (t_attn_in_ff) {   // all blocks in ONE launch (k_ff_fwd_chain): collected here, launched behind the last one
+        chain.blk[i] = fa;
+        if (i + 1 == wt->depth) {
+          chain.n = wt->depth;
+          if (dfx::ffused::launch_ff_chain(st, chain)) return dfx::set_error(DFX_ERR_HIP, "train: fused forward chain launch");
+        }
+        continue;
       }
       if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
       continue;
