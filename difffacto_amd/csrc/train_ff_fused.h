@@ -1429,11 +1429,12 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
       const char *src = wave >= WG_NW / 2 ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + AHEAD) * PK_TILE_U4) - 8192
                                           : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + AHEAD) * PK_TILE_U4);
+      const unsigned slot = __builtin_amdgcn_readfirstlane((unsigned)((k + AHEAD) % WG_SLOTS));   // (wave-uniform: the LDS address goes through m0)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + ((k + AHEAD) % WG_SLOTS) * 16384 + (wave * 2 + q) * 1024);
+      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + slot * 16384 + (wave * 2 + q) * 1024);
       if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront
         dma256(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + AHEAD) * DM_TILE) + wave * 256, lane * 4,
-               lds0 + WG_MASK + ((k + AHEAD) % WG_SLOTS) * 2048 + wave * 256);
+               lds0 + WG_MASK + slot * 2048 + wave * 256);
     }
   };
   // top of iteration k: everything requested before iteration k - 1 has landed, i.e. tiles <= k (loads complete in order; the last iterations

@@ -2198,6 +2198,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
         aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
         dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
       }
+#ifndef DFX_TRACE_FF   // (the phase-trace build stamps single-block launches)
       if (t_attn_in_ff) {   // all blocks in ONE launch (k_ff_fwd_chain): collected here, launched behind the last one
         chain.blk[i] = fa;
         if (i + 1 == wt->depth) {
@@ -2206,6 +2207,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
         }
         continue;
       }
+#endif
       if (dfx::ffused::launch_ff<false>(st, fa)) return dfx::set_error(DFX_ERR_HIP, "train: fused feed-forward launch");
       continue;
     }
