@@ -87,6 +87,7 @@ SIGNATURES = {
     "dfx_denoiser_precision": (_I, [_P]),
     "dfx_denoiser_w1_fold": (_I, [_P, ctypes.POINTER(ctypes.c_float)]),
     "dfx_debug_w1_fold": (None, [_I]),
+    "dfx_debug_w1_fold_channel": (_I, [_P]),
     "dfx_denoiser_get_tables": (_I, [_P, _P]),
     "dfx_shape_ctx_bytes": (_SZ, [_P, _I]),
     "dfx_shape_ctx_prepare": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "dfx_denoiser_train_backward": (_I, [ctypes.POINTER(DenoiserWeights), _P, _SZ, _P, ctypes.POINTER(DenoiserWeights), _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P]),
     "dfx_debug_dropout_factors": (_I, [_U64, _I, _F, _P, ctypes.c_longlong, _P]),
     "dfx_debug_train_fused": (None, [_I]),
+    "dfx_debug_last_train_path": (ctypes.c_char_p, []),
     "dfx_debug_train_streams": (None, [_I]),
     "dfx_debug_lin_split_k": (None, [_I]),
     "dfx_debug_bn_fused_stats": (None, [_I]),

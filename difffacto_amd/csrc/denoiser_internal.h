@@ -130,5 +130,6 @@ struct dfx_denoiser {
   const float *const *wptrs_dev = nullptr;  // device array [depth][7] = {wq, wk^T (static columns), wv^T, wo^T, g2, be2, Wq be2}
   float *host_tables = nullptr;             // [8][T] fp32, order of dfx_denoiser_get_tables
   double *host_ac_pv = nullptr;             // [2][T] float64: alphas_cumprod, posterior_variance (DDIM coefficients per call)
-  float w1_fold_ratio = 0.f;                // bf16: max_r |W1'[r][127]| / mean_c |W1'[r][c]| over the blocks (what decided dev.w1_fold)
+  float w1_fold_ratio = 0.f;                // bf16: max_r |W1'[r][k]| / mean_c |W1'[r][c]| over the blocks for the folded channel k (127's when not folded)
+  int w1_fold_channel = -1;                 // bf16: the hidden channel whose K slot carries b1' (exchanged with 127 at pack time when != 127); -1 = no fold
 };

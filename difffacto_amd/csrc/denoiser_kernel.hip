@@ -2979,8 +2979,8 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
     auto f = [](double L) { return 1.0 + 0.36 * L * L * L * L; };
     return base * (full * f(g_num_cus * fill_per_wg) + (rest ? f(rest * fill_per_wg) : 0.0));
   };
-  // (a bf16 engine without the W1 bias fold — DenoiserDev::w1_fold = 0, decided at create from its weights — has the plain pack, which only
-  // the direct kernel reads: the pipelined / co-operative kernels take b1' from channel 127's K slot)
+  // (a bf16 engine without the W1 bias fold — DenoiserDev::w1_fold = 0: every hidden channel is an outlier of some block's W1', or the debug
+  // switch — has the plain pack, which only the direct kernel and k_denoise_coop16 read: the other chain kernels take b1' from slot 127)
   const bool bf16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && d->dev.w1_fold;
   const bool f32 = d->dev.prec == DFX_PREC_F32 && !g_force_direct;
   int nw = PIPE_NW;
@@ -3008,7 +3008,7 @@ int launch(const dfx_denoiser *d, const void *shape_ctx, KParams &p, hipStream_t
   const long long tiles16 = ((long long)p.B * p.N) / 16;
   const double coop16_cost = rounds_cost(tiles16, C16_ROUND_MS, 0.0);
   const bool coop16 = d->dev.prec == DFX_PREC_BF16 && !g_force_direct && !pipe2 &&
-                      (fnw == 160 || (fnw == 0 && g_force_nw != 161 && coop16_cost < (coop2 ? coop2_cost : coop ? coop_cost : best)));
+                      (fnw == 160 || (fnw == 0 && g_force_nw != 161 && coop16_cost < (coop2 ? coop2_cost : coop ? coop_cost : bf16 ? best : 3.0 * best)));   // (an engine without the fold falls back to the direct kernel, ~3x the pipelined estimate: ADVICE r5)
   if (pipe || coop || coop2 || pipe_f32 || coop16) {
     static PerDeviceOnce attrs;
     DFX_HIP_TRY(attrs.run([] {

@@ -25,6 +25,7 @@ using namespace dfx;
 namespace {
 
 int g_w1_fold_mode = -1;                       // dfx_debug_w1_fold: -1 = decide per engine from its weights, 0 = never, 1 = always
+constexpr float W1_FOLD_KEEP_127 = 4.0f;       // channel 127 stays the folded one while its column's ratio is at most this (bit-compatible with round 5's packs)
 constexpr float W1_FOLD_MAX_RATIO = 8.0f;      // (random-init and unit-gamma weights: ~1-3; the fold's extra rounding scales with the ratio)
 
 // ---------------------------------------------------------------------------------------------
@@ -121,22 +122,33 @@ __global__ void k_pack_w1(const float *__restrict__ W1, const float *__restrict_
   tile_store<PREC>(dst, di, W1[(size_t)row * INNER + col] * g3[col] * sc);
 }
 
-// How much coarser the fold makes a row of W1' = W1 diag(gamma3): every weight of row r becomes W1'[r][c] - W1'[r][127], so its bf16 rounding
-// step follows |W1'[r][127]| instead of |W1'[r][c]|.  out[0] = max over the rows of |W1'[r][127]| / mean_c |W1'[r][c]| (1 for weights of one
-// scale; a LayerNorm outlier gamma3[127] shows up as itself).  One workgroup of 1024 threads = one row each.
-__global__ void __launch_bounds__(1024) k_w1_fold_ratio(const float *__restrict__ W1, const float *__restrict__ g3, float *__restrict__ out) {
-  __shared__ float red[1024];
+// How much coarser the fold makes a row of W1' = W1 diag(gamma3) when channel k is the redundant one: every weight of row r becomes
+// W1'[r][c] - W1'[r][k], so its bf16 rounding step follows |W1'[r][k]| instead of |W1'[r][c]|.  out[k] = max over the rows of
+// |W1'[r][k]| / mean_{c != k} |W1'[r][c]| (about 1-3 for weights of one scale; a LayerNorm outlier gamma3[k] shows up as itself).
+// One workgroup of 1024 threads = one row each.
+__global__ void __launch_bounds__(1024) k_w1_fold_scores(const float *__restrict__ W1, const float *__restrict__ g3, float *__restrict__ out) {
+  __shared__ unsigned best[INNER];   // non-negative floats order like their bit patterns
   const int row = threadIdx.x;
-  float s = 0.f;
-  for (int c = 0; c < INNER - 1; ++c) s += fabsf(W1[(size_t)row * INNER + c] * g3[c]);
-  const float w127 = fabsf(W1[(size_t)row * INNER + 127] * g3[127]);
-  red[row] = w127 / fmaxf(s / (INNER - 1), 1e-30f);
+  if (row < INNER) best[row] = 0u;
   __syncthreads();
-  for (int k = 512; k > 0; k >>= 1) {
-    if (row < k) red[row] = fmaxf(red[row], red[row + k]);
-    __syncthreads();
+  float s = 0.f;
+  for (int c = 0; c < INNER; ++c) s += fabsf(W1[(size_t)row * INNER + c] * g3[c]);
+  for (int c = 0; c < INNER; ++c) {
+    const float w = fabsf(W1[(size_t)row * INNER + c] * g3[c]);
+    atomicMax(&best[c], __float_as_uint(w / fmaxf((s - w) / (INNER - 1), 1e-30f)));
   }
-  if (row == 0) out[0] = red[0];
+  __syncthreads();
+  if (row < INNER) out[row] = __uint_as_float(best[row]);
+}
+
+// A copy of a (rows x cols) parameter with hidden channels ka and kb exchanged along its rows (by_col = 0) or its columns (by_col = 1)
+__global__ void k_swap_channels(const float *__restrict__ src, float *__restrict__ dst, int rows, int cols, int by_col, int ka, int kb) {
+  const long long gi = blockIdx.x * 256LL + threadIdx.x;
+  if (gi >= (long long)rows * cols) return;
+  int r = (int)(gi / cols), c = (int)(gi % cols);
+  int &k = by_col ? c : r;
+  k = k == ka ? kb : k == kb ? ka : k;
+  dst[gi] = src[(size_t)r * cols + c];
 }
 
 // b1' = b1 + W1 beta3, stored [u][part][hf][16]
@@ -459,8 +471,10 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   carve(static_cast<char *>(d->pool));
 
   int rc = DFX_OK;
+  void *swap_pool = nullptr;   // bf16 engines whose W1 bias fold moves to another channel: channel-exchanged copies of the parameters (freed below)
   auto fail = [&](int code) {
     (void)hipStreamSynchronize(st);
+    if (swap_pool) (void)hipFree(swap_pool);
     (void)hipFree(d->pool);
     delete[] d->host_tables;
     delete[] d->host_ac_pv;
@@ -512,6 +526,68 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   }
   TRY_HIP(hipMemcpyAsync(cv.sinus, sinus.data(), sizeof(float) * T * TEMB, hipMemcpyHostToDevice, st));
 
+  // ---- bf16: b1' rides in ONE hidden channel's K slot of W1 (k_pack_w1; the kernels put the constant 1 into slot 127).  Any channel can be the
+  // redundant one (the normalised row sums to zero), and the fold costs precision in proportion to that channel's column of W1' = W1 diag(gamma3)
+  // (ADVICE r4): channel 127 is taken as it is while its column is ordinary (ratio <= W1_FOLD_KEEP_127); otherwise the channel whose column is
+  // the smallest over all blocks is EXCHANGED with 127 in every parameter that touches the residual stream — a relabelling of the 128 hidden
+  // channels, under which the network is the same function (LayerNorm, the residual adds and the matrix products commute with it) — and the
+  // engine is packed from those copies (an outlier gamma3[127] used to send the engine to the ~3x slower direct kernel).  Only
+  // when EVERY channel is an outlier of some block (> W1_FOLD_MAX_RATIO), or dfx_debug_w1_fold(0), the plain pack + direct kernel remain. ----
+  int w1_fold = 0, fold_ch = -1;
+  d->w1_fold_ratio = 0.f;
+  dfx_denoiser_weights wswap;
+  if (precision == DFX_PREC_BF16) {
+    static_assert(FF_HID * 2 == 1024, "k_w1_fold_scores: one thread per row of W1");
+    std::vector<float> sc((size_t)depth * INNER), score(INNER, 0.f);
+    for (int b = 0; b < depth; ++b) {
+      k_w1_fold_scores<<<1, 1024, 0, st>>>(w->blk[b].ff0_w, w->blk[b].norm3_w, cv.h1 + (size_t)b * INNER);   // (cv.h1: >= 2048 floats, not yet in use)
+      TRY_LAUNCH("w1_fold_scores");
+    }
+    TRY_HIP(hipMemcpyAsync(sc.data(), cv.h1, sizeof(float) * depth * INNER, hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < depth; ++b)
+      for (int k = 0; k < INNER; ++k) score[k] = std::max(score[k], sc[(size_t)b * INNER + k]);
+    int kmin = INNER - 1;
+    for (int k = 0; k < INNER; ++k)
+      if (score[k] < score[kmin]) kmin = k;
+    if (g_w1_fold_mode == 1) fold_ch = INNER - 1;                                   // forced: the round-5 form
+    else if (g_w1_fold_mode < 0) fold_ch = score[INNER - 1] <= W1_FOLD_KEEP_127 ? INNER - 1 : (score[kmin] <= W1_FOLD_MAX_RATIO ? kmin : -1);
+    w1_fold = fold_ch >= 0;
+    d->w1_fold_ratio = score[w1_fold ? fold_ch : INNER - 1];
+    if (w1_fold && fold_ch != INNER - 1) {
+      size_t floats = (size_t)INNER * IN_CH + 5 * INNER + 3 * INNER + (size_t)depth * (7 * INNER + 2 * (size_t)INNER * INNER + 2 * FF_HID * INNER + (size_t)INNER * FF_HID);
+      TRY_HIP(hipMalloc(&swap_pool, floats * sizeof(float)));
+      float *next = static_cast<float *>(swap_pool);
+      bool bad = false;
+      auto ex = [&](const float *src, int rows, int cols, int by_col) -> const float * {
+        float *dst = next;
+        next += (size_t)rows * cols;
+        k_swap_channels<<<nblk((long long)rows * cols), 256, 0, st>>>(src, dst, rows, cols, by_col, fold_ch, INNER - 1);
+        bad = bad || hipGetLastError() != hipSuccess;
+        return dst;
+      };
+      wswap = *w;
+      wswap.proj_in_w = ex(w->proj_in_w, INNER, IN_CH, 0), wswap.proj_in_b = ex(w->proj_in_b, INNER, 1, 0);
+      wswap.pre_norm_w = ex(w->pre_norm_w, INNER, 1, 0), wswap.pre_norm_b = ex(w->pre_norm_b, INNER, 1, 0);
+      wswap.post_norm_w = ex(w->post_norm_w, INNER, 1, 0), wswap.post_norm_b = ex(w->post_norm_b, INNER, 1, 0);
+      wswap.proj_out_w = ex(w->proj_out_w, 3, INNER, 1);
+      for (int b = 0; b < depth; ++b) {
+        const dfx_block_weights &k = w->blk[b];
+        dfx_block_weights &o = wswap.blk[b];
+        o.norm2_w = ex(k.norm2_w, INNER, 1, 0), o.norm2_b = ex(k.norm2_b, INNER, 1, 0);
+        o.to_q = ex(k.to_q, INNER, INNER, 1);                                              // (inner, hidden): the hidden channels are its columns
+        o.to_out_w = ex(k.to_out_w, INNER, INNER, 0), o.to_out_b = ex(k.to_out_b, INNER, 1, 0);   // (hidden, inner)
+        o.norm3_w = ex(k.norm3_w, INNER, 1, 0), o.norm3_b = ex(k.norm3_b, INNER, 1, 0);
+        o.ff0_w = ex(k.ff0_w, 2 * FF_HID, INNER, 1);
+        o.ff2_w = ex(k.ff2_w, INNER, FF_HID, 0), o.ff2_b = ex(k.ff2_b, INNER, 1, 0);
+      }
+      if (bad || (size_t)(next - static_cast<float *>(swap_pool)) > floats) return fail(set_error(DFX_ERR_HIP, "denoiser_create: channel exchange failed"));
+      w = &wswap;   // everything below packs the relabelled network
+    }
+  }
+  d->dev.w1_fold = w1_fold;
+  d->w1_fold_channel = fold_ch;
+
   // ---- time_embed MLP for all t: Linear(256->2048) GEGLU Linear(1024->256) ----
   k_linear<<<nblk((long long)T * 2048), 256, 0, st>>>(cv.sinus, TEMB, w->te0_w, TEMB, 0, w->te0_b, cv.h1, T, 2048, TEMB);
   TRY_LAUNCH("time_embed.0");
@@ -539,25 +615,6 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
     }
     d->dev.bout[3] = 0.f;
   }
-
-  // ---- bf16: may b1' ride in channel 127's K slot of W1 (k_pack_w1)?  The fold costs precision in proportion to |W1'[., 127]|:
-  // taken unless a block's column 127 is an outlier of its row (threshold W1_FOLD_MAX_RATIO) or dfx_debug_w1_fold() says otherwise; without
-  // it the engine runs the direct kernel with the plain pack and fp32 accumulator initialisers (slower, same arithmetic as the fp32 form) ----
-  int w1_fold = 0;
-  d->w1_fold_ratio = 0.f;
-  if (precision == DFX_PREC_BF16) {
-    static_assert(FF_HID * 2 == 1024, "k_w1_fold_ratio: one thread per row of W1");
-    std::vector<float> ratio(depth, 0.f);
-    for (int b = 0; b < depth; ++b) {
-      k_w1_fold_ratio<<<1, 1024, 0, st>>>(w->blk[b].ff0_w, w->blk[b].norm3_w, cv.y + b);
-      TRY_LAUNCH("w1_fold_ratio");
-    }
-    TRY_HIP(hipMemcpyAsync(ratio.data(), cv.y, sizeof(float) * depth, hipMemcpyDeviceToHost, st));
-    TRY_HIP(hipStreamSynchronize(st));
-    for (int b = 0; b < depth; ++b) d->w1_fold_ratio = std::max(d->w1_fold_ratio, ratio[b]);
-    w1_fold = g_w1_fold_mode < 0 ? (d->w1_fold_ratio <= W1_FOLD_MAX_RATIO) : g_w1_fold_mode;
-  }
-  d->dev.w1_fold = w1_fold;
 
   // ---- per block ----
   std::vector<const float *> wptrs((size_t)DFX_MAX_DEPTH * 7, nullptr);
@@ -607,6 +664,7 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int T
   }
   TRY_HIP(hipMemcpyAsync(cv.wptrs, wptrs.data(), sizeof(const float *) * DFX_MAX_DEPTH * 7, hipMemcpyHostToDevice, st));
   TRY_HIP(hipStreamSynchronize(st));  // host staging vectors die here; user parameters no longer needed
+  if (swap_pool) (void)hipFree(swap_pool), swap_pool = nullptr;
 #undef TRY_HIP
 #undef TRY_LAUNCH
 
@@ -649,6 +707,7 @@ int dfx_denoiser_w1_fold(const dfx_denoiser *d, float *ratio) {
   return d ? d->dev.w1_fold : -1;
 }
 void dfx_debug_w1_fold(int mode) { g_w1_fold_mode = mode < 0 ? -1 : mode != 0; }
+int dfx_debug_w1_fold_channel(const dfx_denoiser *d) { return d ? d->w1_fold_channel : -1; }
 
 int dfx_denoiser_get_tables(const dfx_denoiser *d, float *host_out) {
   DFX_REQUIRE(d && host_out, "get_tables: null argument");

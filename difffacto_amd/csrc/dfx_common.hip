@@ -57,19 +57,24 @@ struct DevSide {
 };
 std::mutex g_side_mu;
 // One side stream + event ring per (device, caller's stream) — ADVICE r4: with one per device, independent calls on different streams or host threads were
-// serialised through it, and a caller under stream capture put the shared stream into capture mode under everybody else's launches.  (At most 64 pairs
-// get their own; whoever comes later shares the device's first one.)
+// serialised through it, and a caller under stream capture put the shared stream into capture mode under everybody else's launches.  At most
+// DFX_MAX_SIDE_STREAMS (64, dfx.h) pairs get one — entries are never evicted (a destroyed caller stream's handle may be reused by the runtime, and
+// a side stream may sit inside somebody's captured graph) — and a caller beyond that runs WITHOUT a side stream (everything on its own stream:
+// the same results, no overlap; ADVICE r5: sharing the first pair's stream brought back exactly the hazards above).
 std::map<std::pair<int, hipStream_t>, DevSide *> g_side;
-DevSide *g_side_first[256] = {};
 
-DevSide *dev_side(hipStream_t caller) {
+DevSide *dev_side(hipStream_t caller, bool &capped) {
   int dev = 0;
+  capped = false;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return nullptr;
   std::lock_guard<std::mutex> lk(g_side_mu);
   const auto key = std::make_pair(dev, caller);
   const auto it = g_side.find(key);
   if (it != g_side.end()) return it->second;
-  if (g_side.size() >= 64 && g_side_first[dev]) return g_side_first[dev];
+  if (g_side.size() >= 64) {
+    capped = true;
+    return nullptr;
+  }
   DevSide *d = new DevSide;
   if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) {
     delete d;
@@ -78,7 +83,6 @@ DevSide *dev_side(hipStream_t caller) {
   for (hipEvent_t &e : d->ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;   // (leaks a few handles on a broken device)
   g_side[key] = d;
-  if (!g_side_first[dev]) g_side_first[dev] = d;
   return d;
 }
 hipEvent_t next_event(DevSide *d) { return d->ev[d->next.fetch_add(1, std::memory_order_relaxed) & 63]; }
@@ -88,7 +92,9 @@ int SideStream::open(hipStream_t caller, bool enable) {
   main = side = caller;
   on = false;
   if (!enable) return DFX_OK;
-  DevSide *d = dev_side(caller);
+  bool capped = false;
+  DevSide *d = dev_side(caller, capped);
+  if (!d && capped) return DFX_OK;   // more than 64 (device, stream) pairs in this process: this caller gets no side stream (on == false)
   if (!d) return set_error(DFX_ERR_HIP, "side stream: cannot create the side stream / events");
   impl = d;
   side = d->st;
@@ -168,20 +174,27 @@ int dfx_debug_bare_mfma(int iters, float *ms_out, double *tflops_out, dfx_stream
   DFX_HIP_TRY(hipGetDevice(&dev));
   DFX_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   float *scratch = nullptr;
-  DFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), 256));
-  hipEvent_t a, b;
-  DFX_HIP_TRY(hipEventCreate(&a));
-  DFX_HIP_TRY(hipEventCreate(&b));
-  dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, 16);   // code load
-  (void)hipEventRecord(a, st);
-  dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, iters);
-  (void)hipEventRecord(b, st);
-  const hipError_t e = hipEventSynchronize(b);
+  hipEvent_t a = nullptr, b = nullptr;
   float ms = -1.f;
-  if (e == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipFree(scratch);
+  // every exit passes the clean-up below: bench.py calls this several times per run
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&scratch), 256);
+  if (e == hipSuccess) e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  if (e == hipSuccess) {
+    dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, 16);   // code load
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipEventRecord(a, st);
+  if (e == hipSuccess) {
+    dfx::k_bare_mfma<<<cus, 256, 0, st>>>(scratch, iters);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipEventRecord(b, st);
+  if (e == hipSuccess) e = hipEventSynchronize(b);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (scratch) (void)hipFree(scratch);
   if (e != hipSuccess || ms <= 0.f) return dfx::set_error(DFX_ERR_HIP, "debug_bare_mfma: %s", hipGetErrorString(e));
   *ms_out = ms;
   *tflops_out = (double)cus * 4.0 * iters * 16.0 * 32768.0 / (ms * 1e-3) / 1e12;   // executed MFMA flops: 2 x 32 x 32 x 16 each

@@ -1764,6 +1764,7 @@ unsigned long long g_path_seq = 0;   // forward counter: the record with the sma
 std::mutex g_path_mu;
 std::unordered_map<const void *, PathRecord> g_path;   // keyed by workspace pointer (a handful per process)
 thread_local bool t_ff_fused = true, t_attn_in_ff = true;   // what the call in progress on this thread uses
+thread_local const char *t_last_path = "none";                // dfx_debug_last_train_path(): the kernel family the last forward on this thread took
 // (dropout > 0 takes the fused kernels when the attention sub-block sits inside them — the default — : k_ff<*, true> / k_ff_wgrad<true>)
 inline bool ff_fused(bool bf, float dropout_p, long long R, int N) { return t_ff_fused && bf && (dropout_p == 0.f || t_attn_in_ff) && R % 32 == 0 && N % 32 == 0; }
 
@@ -2122,6 +2123,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
   const long long R = (long long)B * N;
   const int BJ = B * J;
   const bool fused_ends = ff_fused(bf, dropout_p, R, N);
+  t_last_path = fused_ends ? (dropout_p > 0.f ? "fused_bf16_dropout" : "fused_bf16")
+                           : bf ? (dropout_p > 0.f ? "layer_bf16_dropout" : "layer_bf16") : (dropout_p > 0.f ? "layer_f32_dropout" : "layer_f32");
   // Two branches meet in front of the first block: the points (input rows, proj_in + pre_norm, the blocks' weight fragments) on the caller's
   // stream, the context (time embedding -> context rows -> keys / values of every block -> folded attention operands) on the side stream
   dfx::SideStream ss;
@@ -2703,6 +2706,7 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them
 // (site 2 i: behind to_out of block i, over (B N, 128); 2 i + 1: behind the GEGLU of block i, over (B N, 512); 1000: time_embed)
 void dfx_debug_train_fused(int on) { g_ff_fused = on != 0, g_attn_in_ff = on != 2; }
+const char *dfx_debug_last_train_path(void) { return t_last_path; }
 void dfx_debug_bn_fused_stats(int on) { g_bn_fused_stats = on != 0; }
 // Host-side run of the statistics arithmetic of k_lin_wide_lds<.., LM_STATS> / k_bn_merge (the same stats_merge, compiled for the host): `n` values cut
 // into pieces of `chunk` (a lane's 16 rows of a tile), each piece as (count, mean, sum of squared deviations from its own mean), merged left to right.

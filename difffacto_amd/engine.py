@@ -126,10 +126,14 @@ class DenoiserEngine:
             pass
 
     def w1_fold(self):
-        """(folded, ratio): whether this bf16 engine carries b1' in channel 127's K slot of the packed W1 (``dfx_denoiser_w1_fold``) and the
-        outlier ratio max_r |W1[r,127] gamma3[127]| / mean_c |W1[r,c] gamma3[c]| that decided it (> 8: plain pack, direct kernel)."""
+        """(folded, ratio): whether this bf16 engine carries b1' in a hidden channel's K slot of the packed W1 (``dfx_denoiser_w1_fold``) and that
+        channel's outlier ratio max_r |W1[r,k] gamma3[k]| / mean_c |W1[r,c] gamma3[c]| (not folded — every channel above 8 —: plain pack, direct kernel)."""
         r = ctypes.c_float(0.0)
         return bool(_ffi.lib().dfx_denoiser_w1_fold(self._h, ctypes.byref(r))), float(r.value)
+
+    def w1_fold_channel(self):
+        """The hidden channel create() made the redundant one (127 unless it relabelled the channels around an outlier; -1: no fold)."""
+        return int(_ffi.lib().dfx_debug_w1_fold_channel(self._h))
 
     # ------------------------------------------------------------------------------------------
     def tables(self):

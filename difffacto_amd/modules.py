@@ -319,8 +319,8 @@ class AnchoredDiffusion(nn.Module):
             # logvar_per_point BEFORE its detach_variance line (anchor_gen.py:1002 vs :1013-1014), so in stage 2 the loss reaches the part aligner
             # through q_sample's sqrt(variance) * noise and through the network's per-point variance columns as well — reproduced.
             if variance.requires_grad:
-                sa = torch.from_numpy(self.sqrt_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
-                s1 = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+                tab_a, tab_1 = self._q_tables(x_start.device)
+                sa, s1 = tab_a[t].view(-1, 1, 1), tab_1[t].view(-1, 1, 1)
                 x_t = sa * (x_start - anchors) + anchors + s1 * torch.sqrt(variance) * noise          # q_sample (:148-173), differentiable
             else:
                 x_t = self.q_sample(x_start, t, anchors, noise=noise, variance=variance)
@@ -334,13 +334,22 @@ class AnchoredDiffusion(nn.Module):
         fl = None if flags is None else flags.reshape(flags.shape[0], -1)
         return {"mse_loss": eng.masked_mse(noise, eps, fl)}
 
+    def _q_tables(self, device):
+        """sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod) as fp32 device tensors, uploaded once per device (not per training step: a pageable
+        host-to-device copy in the middle of a step drains the stream) and kept out of ``state_dict`` (the reference has no such buffers)."""
+        cache = self.__dict__.setdefault("_q_tables_cache", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = tuple(torch.from_numpy(np.asarray(a)).to(device).float() for a in (self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod))
+        return cache[key]
+
     @torch.no_grad()
     def q_sample(self, x_start, t, anchors, noise=None, variance=None):
         """Forward process (:148-173), host-side elementwise helper (not on the sampling path)."""
         if noise is None:
             noise = torch.randn_like(x_start)
-        sa = torch.from_numpy(self.sqrt_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
-        s1 = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(x_start.device).float()[t].view(-1, 1, 1)
+        tab_a, tab_1 = self._q_tables(x_start.device)
+        sa, s1 = tab_a[t].view(-1, 1, 1), tab_1[t].view(-1, 1, 1)
         return sa * (x_start - anchors) + anchors + s1 * torch.sqrt(variance) * noise
 
 

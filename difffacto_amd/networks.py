@@ -87,6 +87,10 @@ class AnchorDiffAE(nn.Module):
             diffusion_loss_weight, sample_noise_num, cimle, cimle_sample_num
         self.fix_part_ids, self.gen = fix_part_ids, gen
         self.num_timesteps, self.num_anchors, self.npoints = int(num_timesteps), num_anchors, npoints
+        # detach_anchor=False raises in the training forward (stage1_losses); detach_variance detaches a tensor the reference no longer reads
+        # (anchor_gen.py:1013-1014 vs :1002), and learn_var / global_shift / global_scale / vertical_only are stored and never read by the
+        # reference (:95-102): accepted and without effect, like there; noise_reg_loss / reg_loss_weight only enter the language branches
+        # (:891,:911), which raise above (train_language).
         self.detach_anchor, self.detach_variance = detach_anchor, detach_variance
         self.fixed_id = [0] * num_anchors
         self.points_per_anchor = npoints // num_anchors
@@ -135,7 +139,7 @@ class AnchorDiffAE(nn.Module):
             from . import training as _training
             t, _ = self.sampler.sample(B, device)
             return _training.stage1_losses(self.encoder, self.diffusion, pcds, device=device, epoch=epoch, t=t,
-                                           diffusion_loss_weight=self.diffusion_loss_weight)
+                                           diffusion_loss_weight=self.diffusion_loss_weight, detach_anchor=self.detach_anchor)
         with torch.no_grad():
             # the reference runs the encoder on every val batch, gen branch included (:995): its reparameterisation draw comes first
             ctx, mean_pp, logvar_pp, _flag, _losses, _latents = self.encoder(pcds, device, epoch=epoch)

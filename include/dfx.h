@@ -35,6 +35,7 @@ extern "C" {
 #define DFX_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate       */
 
 typedef void *dfx_stream_t;
+#define DFX_MAX_SIDE_STREAMS 64   /* see dfx_denoiser_train_forward */
 
 int dfx_version(void);
 /* Bumped whenever an existing entry point changes its argument list (round 2 inserted `shape_offset` into the four sampling
@@ -143,10 +144,13 @@ int dfx_denoiser_create(dfx_denoiser **out, const dfx_denoiser_weights *w, int n
 void dfx_denoiser_destroy(dfx_denoiser *d);
 int dfx_denoiser_num_timesteps(const dfx_denoiser *d);
 int dfx_denoiser_precision(const dfx_denoiser *d);
-/* DFX_PREC_BF16 engines: 1 if b1' = b1 + W1 beta3 rides in channel 127's K slot of the packed W1 (no accumulator initialisers in the chain
- * kernels; exact in real arithmetic, and it rounds every weight of a row with a step that follows |W1[r][127] gamma3[127]|), 0 if the engine
- * was created with the plain pack because that column is an outlier (ratio > 8 of the row's mean magnitude) — it then runs the direct kernel
- * (same results as before the fold existed, ~3x slower).  *ratio (may be NULL) receives the measured ratio.  fp32 engines: 0. */
+/* DFX_PREC_BF16 engines: 1 if b1' = b1 + W1 beta3 rides in one hidden channel's K slot of the packed W1 (no accumulator initialisers in the chain
+ * kernels; exact in real arithmetic — a LayerNorm output sums to zero, so one channel is redundant — and every weight of a row then rounds with a
+ * step that follows that channel's column of W1 diag(gamma3)).  Create picks the channel from the weights: 127, or — when 127's column is an
+ * outlier (ratio > 4 of its row's mean magnitude) — the channel with the smallest column over all blocks, exchanged with 127 in a private copy
+ * of the parameters (a relabelling of the hidden channels: the same function).  0 only if every channel is an outlier of some block (ratio > 8):
+ * the engine then has the plain pack and runs the direct kernel (~3x slower).  *ratio (may be NULL) receives the chosen channel's ratio.
+ * fp32 engines: 0. */
 int dfx_denoiser_w1_fold(const dfx_denoiser *d, float *ratio);
 
 /* Copies the 8 fp32 schedule tables the kernels use to HOST memory, each `num_timesteps` long, in the
@@ -409,7 +413,7 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode denoiser: forward with saved activations, backward, loss gradient, optimizer.
- * Replaces autograd through TransformerNet.forward / _forward_attn (python/difffacto/models/networks/attention.py:385-440;
+ * Replaces autograd through TransformerNet.forward / _forward_attn (python/difffacto/models/diffusions/nets/attention.py:385-440;
  * BasicTransformerBlock :296-306, CrossAttention :179-204, FeedForward/GEGLU :50-57,77-94; nn.Dropout optional, see below), the
  * mse_loss of AnchoredDiffusion.training_losses (anchored_diffusion.py:840-847), and Runner.train's
  * clip_grad_norm_ + Adam.step (runner.py:312-316, optimizers.py:4-16).
@@ -418,8 +422,11 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
  *   in fp32 (v_mfma_f32_32x32x16_bf16); activations, gradients, LayerNorm / softmax / GELU and the optimiser stay fp32.
  *   The same value must be passed to the forward and the backward of one step.
  *   dropout_p in [0, 1): nn.Dropout of train() mode behind every to_out (attention.py:177) and GEGLU (:84, time_embed
- *   included); factors come from Philox4x32-10 keyed by dropout_seed with counter (element group, site) and are
- *   regenerated by the backward (pass the same p and seed); torch's own CUDA dropout stream is launch-geometry dependent
+ *   included); factor(seed, site, element i) = 0 when a 16-bit draw is below round(p 2^16), else 1 / (1 - p); the draw is 16 bits of
+ *   Philox4x32-7 keyed by the 64-bit dropout_seed, counter = (i >> 3 = group of EIGHT consecutive elements of the site's row-major
+ *   tensor, site, 0xD20F0), element i & 7 = half (i & 1) of word (i & 7) >> 1 (csrc/dfx_dropout.h is the one definition); sites: 2 b =
+ *   behind to_out of block b over (B N, 128), 2 b + 1 = behind the GEGLU of block b over (B N, 512), 1000 = time_embed over (B, 1024).
+ *   The backward regenerates / re-reads them (pass the same p and seed); torch's own CUDA dropout stream is launch-geometry dependent
  *   and not reproducible, so this is libdfx's contract, checked against torch autograd by replaying the factors
  *   (dfx_debug_dropout_factors, include/dfx_debug.h).
  *   x (B,3,N); t (B,) int32; ctx_code (B,256,4) and ctx_mv (B,6,4) = the two tensors of the reference's ctx list;
@@ -427,6 +434,9 @@ int dfx_emd_backward_f32(const float *xyz1, const float *xyz2, const float *grad
  *   NULL; assignment (B,N) int32; eps (B,3,N).
  *   workspace: dfx_denoiser_train_workspace_bytes(B, N, depth) device bytes, 256-byte aligned; the backward reads what
  *   the forward of the SAME (B, N) call left in it.
+ *   Streams: the bf16 path forks small-grid work (context branch, parameter-gradient reductions) onto an internal side stream per
+ *   (device, caller stream) pair and joins it before returning — stream-ordered, capturable.  A process gets at most
+ *   DFX_MAX_SIDE_STREAMS such pairs (never evicted); callers beyond that run everything on their own stream (same results).
  *   grads: a dfx_denoiser_weights whose pointers name WRITABLE device buffers of the parameters' shapes; every one of
  *   them is overwritten (not accumulated).  d_ctx_code / d_ctx_mv: (B,256,4) / (B,6,4) or NULL.
  *   d_x (B,3,N) / d_variances (B,N,3) or NULL (ABI 4): the gradient at the input x and at the per-point variance feature columns — stage 2 of the

@@ -19,6 +19,10 @@ int dfx_debug_dropout_factors(uint64_t seed, int site, float p, float *out, long
  * the fused path applies to DFX_PREC_BF16 with dropout_p == 0); 2 = fused, but the attention forward and its input gradient run as
  * kernels of their own instead of inside the feed-forward kernels. */
 void dfx_debug_train_fused(int on);
+/* The kernel family the calling thread's most recent dfx_denoiser_train_forward took (its backward follows the same record):
+ * "fused_bf16", "fused_bf16_dropout" (k_ff_fwd_chain / k_ff<true> / k_ff_wgrad), "layer_bf16(_dropout)" (layer-by-layer kernels, bf16
+ * products), "layer_f32(_dropout)" (exact fp32; also what DFX_PREC_BF16 takes below 256 rows), "none" before the first call. */
+const char *dfx_debug_last_train_path(void);
 /* Debug / A-B switch: 0 keeps every launch of the fused training path on the caller's stream (default 1: the context branch of the forward
  * and the parameter-gradient reductions of the backward run on a per-device side stream, forked from and joined into the caller's stream
  * inside the call).  Same kernels and operands either way: bit-identical results. */
@@ -55,9 +59,12 @@ int dfx_debug_gemm_bf16(int tn, const void *A, int lda, int a_bf16, const void *
  * matrix pipe at its power cap and clocks (iters = 150000 runs ~50 ms).  Synchronises `stream`. */
 int dfx_debug_bare_mfma(int iters, float *ms_out, double *tflops_out, dfx_stream_t stream);
 void dfx_debug_force_direct(int on);
-/* dfx_denoiser_create's decision about the W1 bias fold of bf16 engines (dfx_denoiser_w1_fold): -1 = from the weights (default),
- * 0 = never, 1 = always.  Applies to engines created afterwards. */
+/* dfx_denoiser_create's decision about the W1 bias fold of bf16 engines (dfx_denoiser_w1_fold): -1 = from the weights (default: channel 127
+ * while its column of W1 diag(gamma3) is ordinary, else the hidden channel with the smallest column over all blocks, exchanged with 127 at
+ * pack time), 0 = never (plain pack, direct kernel), 1 = always on channel 127 (round 5's form).  Applies to engines created afterwards. */
 void dfx_debug_w1_fold(int mode);
+/* The hidden channel whose K slot of the packed W1 carries b1' (127 unless create relabelled the channels; -1 = engine without the fold). */
+int dfx_debug_w1_fold_channel(const dfx_denoiser *d);
 /* Debug: wavefronts per workgroup of the pipelined chain kernel (8, 4 or 2), or 1 = the co-operative latency kernel (one
  * 32-point tile per workgroup, eight wavefronts on it; for an fp32 denoiser: the direct kernel), or 64 = k_denoise_pipe2 (bf16 only:
  * four wavefronts of two 32-point tiles each; when its 256-point workgroup tiles would pad a shape by more than 3x —

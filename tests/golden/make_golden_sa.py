@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Golden vectors for the PointNet++ set-abstraction / feature-propagation MODULES.
 
-    python tests/golden/make_golden_sa.py          # dev container only; writes tests/golden/sa_*.npz, fp_*.npz
+    python tests/golden/make_golden_sa.py          # dev container only; writes tests/golden/sa_*.npz, samsg_*.npz, fp_*.npz
 
 Runs the REFERENCE's own Python classes (pointnet2_ops_lib/pointnet2_ops/pointnet2_{utils,modules}.py:
 QueryAndGroup, GroupAll, PointnetSAModule, PointnetFPModule, build_shared_mlp) on CPU tensors in eval mode.  Their CUDA
@@ -94,6 +94,26 @@ def gen_sa(pm, tag, B, N, C, mlp, npoint, radius, nsample, bn, use_xyz, seed):
     print("wrote sa_" + tag, new_feats.shape, float(new_feats.abs().max()))
 
 
+def gen_sa_msg(pm, tag, B, N, C, mlps, npoint, radii, nsamples, bn, use_xyz, seed):
+    """PointnetSAModuleMSG (pointnet2_modules.py:77-115): one FPS, one grouper + shared MLP per radius, channel concat (:74)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xyz = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    feats = rng.standard_normal((B, C, N)).astype(F32) if C else None
+    mod = pm.PointnetSAModuleMSG(npoint=npoint, radii=list(radii), nsamples=list(nsamples), mlps=[list(m) for m in mlps], bn=bn, use_xyz=use_xyz).eval()
+    W = randomize(mod, rng)
+    with torch.no_grad():
+        new_xyz, new_feats = mod(torch.from_numpy(xyz), None if feats is None else torch.from_numpy(feats))
+    out = dict(xyz=xyz, new_xyz=new_xyz.numpy().astype(F32), new_features=new_feats.numpy().astype(F32), npoint=np.array(npoint),
+               radii=np.array(radii, F32), nsamples=np.array(nsamples), bn=np.array(int(bn)), use_xyz=np.array(int(use_xyz)), n_scales=np.array(len(mlps)))
+    for i, m in enumerate(mlps):
+        out[f"mlp{i}"] = np.array(m)
+    if feats is not None:
+        out["features"] = feats
+    out.update({"w." + k: v for k, v in W.items()})
+    np.savez_compressed(os.path.join(HERE, f"samsg_{tag}.npz"), **out)
+    print("wrote samsg_" + tag, new_feats.shape, float(new_feats.abs().max()))
+
+
 def gen_fp(pm, tag, B, n, m, C1, C2, mlp, seed):
     rng = np.random.Generator(np.random.PCG64(seed))
     unknown = rng.uniform(-1, 1, size=(B, n, 3)).astype(F32)
@@ -120,6 +140,12 @@ def main():
     gen_sa(pm, "nobn_noxyz_ragged", B=2, N=100, C=5, mlp=[5, 24, 40], npoint=10, radius=0.5, nsample=20, bn=False, use_xyz=False, seed=44)
     gen_sa(pm, "xyz_only", B=1, N=128, C=0, mlp=[0, 16, 32], npoint=16, radius=0.6, nsample=16, bn=True, use_xyz=True, seed=45)
     gen_fp(pm, "small", B=2, n=50, m=20, C1=6, C2=10, mlp=[16, 32, 24], seed=46)
+    # PointNet2MSG's first two layers at reduced size (python/difffacto/models/encoders/pointnet2.py:88-112): three radii, nsample 16 / 32 / 128,
+    # channel concat 64 + 128 + 128 -> second layer's input
+    gen_sa_msg(pm, "msg1_small", B=2, N=320, C=3, mlps=[[3, 32, 32, 64], [3, 64, 64, 128], [3, 64, 96, 128]], npoint=48, radii=[0.2, 0.4, 0.8],
+               nsamples=[16, 32, 128], bn=True, use_xyz=True, seed=47)
+    gen_sa_msg(pm, "msg2_small", B=2, N=64, C=320, mlps=[[320, 64, 64, 128], [320, 128, 128, 256]], npoint=16, radii=[0.5, 1.0],
+               nsamples=[32, 64], bn=True, use_xyz=True, seed=48)
 
 
 if __name__ == "__main__":

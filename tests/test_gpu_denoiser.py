@@ -468,19 +468,46 @@ def test_f32_pipelined_chain_is_bit_identical_to_the_direct_kernel(W, N):
             assert torch.equal(x, y), (k, i, (x - y).abs().max().item())
 
 
-def test_w1_bias_fold_backs_off_on_an_outlier_channel_and_is_selectable(W):
-    """the bf16 pack carries b1' in channel 127's K slot of W1 and subtracts W1[., 127] gamma3[127] from every other column — exact in
-    real arithmetic, but every weight of a row then rounds with a step that follows that column.  dfx_denoiser_create measures the column
-    (dfx_denoiser_w1_fold) and keeps the plain pack + fp32 accumulator initialisers (direct kernel) when it is an outlier; dfx_debug_w1_fold
-    forces either form.  Checked against the exact fp32 engine on the N = 2048 golden inputs:
-      * synthetic weights: folded by default (ratio ~1-3), forced-plain agrees with fp32 within the bf16 gate as well;
-      * gamma3[127] of block 2 times 64: NOT folded, error within the same gate; forcing the fold on those weights is measurably worse."""
+def _tile_golden(g, reps):
+    return {k: np.concatenate([g[k]] * reps, axis=0) for k in ("part_code", "mean", "logvar", "valid", "x", "seg")}
+
+
+def trained_like(W, seed=5):
+    """Synthetic weights with the statistics trained LayerNorm gains tend to have: heavy-tailed gamma (log-normal, sigma 0.5) with a few
+    outlier channels per LayerNorm (x 16 .. x 64, channel 127 of norm3 among them in two blocks) and non-zero beta."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Wt = {k: v.copy() for k, v in W.items()}
+    for k in Wt:
+        if ".norm" in k or k.startswith(("pre_norm", "post_norm")):
+            if k.endswith(".weight"):
+                Wt[k] = (Wt[k] * np.exp(0.5 * rng.standard_normal(128))).astype(np.float32)
+                Wt[k][rng.choice(127, size=3, replace=False)] *= rng.choice([16.0, 32.0, 64.0], size=3).astype(np.float32)
+            else:
+                Wt[k] = (Wt[k] + 0.3 * rng.standard_normal(128)).astype(np.float32)
+    Wt["transformer_blocks.1.norm3.weight"][127] *= 32.0
+    Wt["transformer_blocks.3.norm3.weight"][127] *= 64.0
+    return Wt
+
+
+def test_w1_bias_fold_moves_to_another_channel_around_an_outlier_and_is_selectable(W):
+    """The bf16 pack carries b1' in ONE hidden channel's K slot of W1 and subtracts that channel's column of W1 diag(gamma3) from every other
+    column — exact in real arithmetic (a LayerNorm output sums to zero), but every weight of a row then rounds with a step that follows
+    that column.  Round 5 backed off to the plain pack + the ~3x slower direct kernel when channel 127's column was an outlier
+    (VERDICT r5 weak #8); round 6: dfx_denoiser_create exchanges 127 with the hidden channel whose column is the smallest over all blocks
+    (a relabelling of the residual stream's channels: the same function), so the fold — and the pipelined / co-operative kernels — stay.
+    Checked against the exact fp32 engine on the N = 2048 golden inputs (B = 1: co-operative kernel) and 64 copies of them (pipelined):
+      * synthetic weights: folded on 127 by default (ratio ~1-3); forced-plain agrees with fp32 within the bf16 gate as well;
+      * gamma3[127] of block 2 times 64: folded on ANOTHER channel, the fast kernels, error <= the plain pack's; forcing the fold onto 127
+        (dfx_debug_w1_fold(1), round 5's form) on those weights is measurably worse;
+      * heavy-tailed "trained-like" gains with several outlier channels: folded, fast kernels, within the plain pack's error."""
     from difffacto_amd import _ffi
     from difffacto_amd.engine import last_kernel_variant
-    g = np.load(os.path.join(GOLDEN, "denoiser_eps_B1_N2048.npz"))
-    x, seg, t = torch.from_numpy(g["x"]), torch.from_numpy(g["seg"]), int(g["ts"][0])
+    g1 = dict(np.load(os.path.join(GOLDEN, "denoiser_eps_B1_N2048.npz")))
+    t = int(g1["ts"][0])
 
-    def err(Wx, mode):
+    def err(Wx, mode, reps=1):
+        g = _tile_golden(g1, reps)
+        x, seg = torch.from_numpy(g["x"]), torch.from_numpy(g["seg"])
         _ffi.lib().dfx_debug_w1_fold(mode)
         try:
             eb = _engine(Wx, 10, "bf16")
@@ -490,22 +517,33 @@ def test_w1_bias_fold_backs_off_on_an_outlier_channel_and_is_selectable(W):
         out = eb.eps(_prep(eb, g), x, seg, t).cpu().numpy()
         variant = last_kernel_variant()
         ref = ef.eps(_prep(ef, g), x, seg, t).cpu().numpy()
-        return float(np.abs(out - ref).max()), eb.w1_fold(), variant, float(np.abs(ref).max())
+        assert all(np.array_equal(out[0], out[i]) for i in range(1, reps))
+        return float(np.abs(out - ref).max()), eb.w1_fold(), eb.w1_fold_channel(), variant, float(np.abs(ref).max())
 
-    e_def, (folded, ratio), variant, scale = err(W, -1)
-    assert folded and ratio < 8 and variant != "k_denoise<bf16>", (folded, ratio, variant)   # (B = 1: the co-operative chain kernel)
-    e_plain, (folded_p, _), variant_p, _ = err(W, 0)
-    assert not folded_p and variant_p == "k_denoise<bf16>"
+    e_def, (folded, ratio), ch, variant, scale = err(W, -1)
+    assert folded and ch == 127 and ratio < 4 and variant != "k_denoise<bf16>", (folded, ch, ratio, variant)   # (B = 1: a co-operative chain kernel)
+    e_plain, (folded_p, _), ch_p, variant_p, _ = err(W, 0)
+    assert not folded_p and ch_p == -1 and variant_p in ("k_denoise<bf16>", "k_denoise_coop16"), variant_p
     assert e_def <= TOL_BF16_EPS and e_plain <= TOL_BF16_EPS, (e_def, e_plain)
     Wo = {k: v.copy() for k, v in W.items()}
     Wo["transformer_blocks.2.norm3.weight"][127] *= 64.0
-    e_auto, (folded_o, ratio_o), variant_o, scale_o = err(Wo, -1)
-    assert not folded_o and ratio_o > 8 and variant_o == "k_denoise<bf16>", (folded_o, ratio_o, variant_o)
-    e_forced, (folded_f, _), _, _ = err(Wo, 1)
-    assert folded_f
-    print(f"W1 bias fold: synthetic weights ratio {ratio:.2f}: folded {e_def:.2e} / plain {e_plain:.2e} (|eps| {scale:.2f}); "
-          f"gamma3[127] x 64 (ratio {ratio_o:.1f}): auto = plain {e_auto:.2e}, forced fold {e_forced:.2e} (|eps| {scale_o:.2f})")
+    e_auto, (folded_o, ratio_o), ch_o, variant_o, scale_o = err(Wo, -1)
+    assert folded_o and ch_o not in (127, -1) and ratio_o < 4 and variant_o not in ("k_denoise<bf16>",), (folded_o, ch_o, ratio_o, variant_o)
+    e_auto64, _, _, variant_o64, _ = err(Wo, -1, reps=64)
+    assert variant_o64 == "k_denoise_pipe<8>", variant_o64            # the headline kernel, not the direct one
+    e_oplain, (folded_op, _), _, _, _ = err(Wo, 0)
+    e_forced, (folded_f, ratio_f), ch_f, _, _ = err(Wo, 1)
+    assert folded_f and ch_f == 127 and ratio_f > 8 and not folded_op
+    Wt = trained_like(W)
+    e_t, (folded_t, ratio_t), ch_t, variant_t, scale_t = err(Wt, -1, reps=64)
+    e_tplain, _, _, _, _ = err(Wt, 0)
+    assert folded_t and ch_t not in (127, -1) and variant_t == "k_denoise_pipe<8>", (folded_t, ch_t, ratio_t, variant_t)
+    print(f"W1 bias fold: synthetic weights (channel {ch}, ratio {ratio:.2f}): folded {e_def:.2e} / plain {e_plain:.2e} (|eps| {scale:.2f}); "
+          f"gamma3[127] x 64: moved to channel {ch_o} (ratio {ratio_o:.2f}) {e_auto:.2e} [{variant_o}], x64 shapes {e_auto64:.2e} [{variant_o64}], "
+          f"plain {e_oplain:.2e}, forced onto 127 (ratio {ratio_f:.1f}) {e_forced:.2e} (|eps| {scale_o:.2f}); "
+          f"trained-like gains: channel {ch_t} (ratio {ratio_t:.2f}) {e_t:.2e} [{variant_t}] / plain {e_tplain:.2e} (|eps| {scale_t:.2f})")
     # measured (r05): synthetic weights folded 3.5e-3 / plain 2.0e-3; outlier weights plain 7.7e-3 (the outlier channel's own bf16 rounding, in any
-    # bf16 formulation) / forced fold 1.4e-1 -> the back-off is worth a factor ~19 there
-    assert e_auto <= 2 * TOL_BF16_EPS, e_auto
+    # bf16 formulation) / forced fold on 127 1.4e-1.  The moved fold must stay within 1.5x of the plain pack on the same weights (and the 2x gate).
+    assert e_auto <= 2 * TOL_BF16_EPS and e_auto <= 1.5 * e_oplain + 1e-3 and e_auto64 <= 2 * TOL_BF16_EPS, (e_auto, e_oplain, e_auto64)
     assert e_forced > 5 * e_auto, (e_forced, e_auto)
+    assert e_t <= 1.5 * e_tplain + 1e-3 * scale_t, (e_t, e_tplain, scale_t)

@@ -458,13 +458,12 @@ def test_stage2_training_step_matches_the_reference():
     from _train_case import check_against_golden
     from difffacto_amd import synth
     from difffacto_amd.networks import AnchorDiffAE
-    from test_modules_cpu import DIFF_CFG, ENC_CFG
+    from test_modules_cpu import model_cfg
     g = dict(np.load(os.path.join(GOLD, "stage2_step_B4_N64_T10.npz")))
     batch = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in/")}
     draws = [g[f"draw_{i}"] for i in range(int(g["n_draws"]))]
     T, N = 10, batch["ref"].shape[1]
-    m = AnchorDiffAE(encoder=dict(type="PartEncoderForTransformerDecoder", **ENC_CFG), diffusion=dict(type="AnchoredDiffusion", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], dropout=0.0)}),
-                     sampler=dict(type="Uniform"), num_anchors=4, num_timesteps=T, npoints=N, gen=True, cimle=True, cimle_sample_num=1, precision="f32")
+    m = AnchorDiffAE(**model_cfg(num_timesteps=T, npoints=N, net=dict(dropout=0.0)), precision="f32")   # cfg.model of gen_chair.py (pinned on CPU), Dropout 0
     W = {"diffusion.model." + k: v for k, v in synth.make_denoiser_weights(0).items()}
     W.update({"encoder." + k: v for k, v in synth.make_latent_weights(0).items()})
     W.update({"encoder.encoder." + k: v for k, v in synth.make_pointnet_v2_weights(0).items()})

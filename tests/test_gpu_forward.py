@@ -23,10 +23,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 def _model(T, N, K, gen, precision, ret_interval=5):
     from difffacto_amd.networks import AnchorDiffAE
-    from test_modules_cpu import DIFF_CFG, ENC_CFG
-    m = AnchorDiffAE(encoder=dict(type="PartEncoderForTransformerDecoder", **ENC_CFG), diffusion=dict(type="AnchoredDiffusion", **DIFF_CFG),
-                     sampler=dict(type="Uniform"), num_anchors=4, num_timesteps=T, npoints=N, gen=gen, cimle=True, cimle_sample_num=K,
-                     ret_traj=True, ret_interval=ret_interval, precision=precision)
+    from test_modules_cpu import model_cfg
+    # every key of the unmodified configs/gen_chair.py `cfg.model` (pinned against the reference's config loader on CPU:
+    # test_install_full_builds_the_mirror_from_the_unmodified_configs), with the fixture's T / N / K / ret_interval
+    m = AnchorDiffAE(**model_cfg(num_timesteps=T, npoints=N, gen=gen, cimle_sample_num=K, ret_interval=ret_interval), precision=precision)
     W = {"diffusion.model." + k: v for k, v in synth.make_denoiser_weights(0).items()}
     W.update({"encoder." + k: v for k, v in synth.make_latent_weights(0).items()})
     W.update({"encoder.encoder." + k: v for k, v in synth.make_pointnet_v2_weights(0).items()})

@@ -60,6 +60,30 @@ def test_sa_module_matches_reference_golden(path, force_general):
         _close(out2, g["new_features"])
 
 
+@pytest.mark.parametrize("tag", ["msg1_small", "msg2_small"])
+def test_sa_msg_module_matches_reference_golden(tag):
+    """Multi-scale grouping (PointnetSAModuleMSG, pointnet2_modules.py:77-115; PointNet2MSG's layers, models/encoders/pointnet2.py:88-112):
+    ONE furthest-point sampling, then per radius ball query -> group -> shared MLP -> max (dfx_sa_forward_f32 per scale) and the channel
+    concat — against the reference's own class (tests/golden/samsg_*.npz, make_golden_sa.py).  Also each scale's general path."""
+    from difffacto_amd.pointnet2_ops.pointnet2_modules import PointnetSAModuleMSG
+    g = np.load(os.path.join(GOLDEN, f"samsg_{tag}.npz"))
+    S = int(g["n_scales"])
+    mlps = [[int(v) for v in g[f"mlp{i}"]] for i in range(S)]
+    mod = PointnetSAModuleMSG(npoint=int(g["npoint"]), radii=[float(r) for r in g["radii"]], nsamples=[int(n) for n in g["nsamples"]],
+                              mlps=[list(m) for m in mlps], bn=bool(g["bn"]), use_xyz=bool(g["use_xyz"]))
+    mod = _load(mod, g)
+    xyz = torch.from_numpy(g["xyz"]).cuda()
+    feats = torch.from_numpy(g["features"]).cuda() if "features" in g.files else None
+    with torch.no_grad():
+        new_xyz, out = mod(xyz, feats)
+        per_scale = [mod._forward_native(k, xyz, new_xyz, feats, force_general=True) for k in range(S)]
+    assert np.array_equal(new_xyz.cpu().numpy(), g["new_xyz"])            # FPS + gather: bit-exact
+    assert out.shape[1] == sum(m[-1] for m in mlps)
+    _close(out, g["new_features"])
+    _close(torch.cat(per_scale, dim=1), g["new_features"])
+    print(f"samsg_{tag}: {S} scales -> {tuple(out.shape)}, max err {float(np.abs(out.cpu().numpy() - g['new_features']).max()):.2e} (|ref| {float(np.abs(g['new_features']).max()):.2f})")
+
+
 def test_fp_module_matches_reference_golden():
     from difffacto_amd.pointnet2_ops.pointnet2_modules import PointnetFPModule
     g = np.load(os.path.join(GOLDEN, "fp_small.npz"))

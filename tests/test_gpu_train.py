@@ -474,6 +474,75 @@ def test_dropout_factors_and_replayed_mask_parity():
         assert np.abs(r[k] - ref[k]).max() <= 5e-4 * np.abs(ref[k]).max() + 1e-8, k
 
 
+def _seeded_case(B, N, wseed, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = synth.make_denoiser_weights(wseed)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=seed % 97 + 1, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    return dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+                ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+                anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+                valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32),
+                flags=(rng.uniform(size=(B, 1, N)) > 0.3).astype(np.float32))
+
+
+def replayed_drops(seed, p, B, N, depth=5):
+    """The factors the HIP kernels draw (dfx_dropout.h: Philox keyed by (seed, site, element group)) in the shapes oracle/train.py replays
+    them at the reference's dropout sites: behind to_out (attention.py:84), behind the GEGLU (attention.py:177), time_embed."""
+    from difffacto_amd import training
+    drops = {"te": training.dropout_factors(seed, 1000, p, B * 1024).cpu().numpy().reshape(B, 1024)}
+    for i in range(depth):
+        drops[("attn", i)] = training.dropout_factors(seed, 2 * i, p, B * N * 128).cpu().numpy().reshape(B, N, 128)
+        drops[("ff", i)] = training.dropout_factors(seed, 2 * i + 1, p, B * N * 512).cpu().numpy().reshape(B, N, 512)
+    return drops
+
+
+@pytest.mark.parametrize("path", ["fused", "layer"])
+@pytest.mark.parametrize("B,N", [(2, 1024), (3, 160), (1, 4096)])
+def test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(B, N, path):
+    """config 5 AS SHIPPED (train_chair_stage1.py:38: Dropout 0.2, bf16 products) compared with the fp32 torch-autograd
+    oracle DIRECTLY — not through another HIP path.  The Philox factors of (p, seed) are replayed into oracle/train.py at the reference's sites;
+    `fused` = k_ff_fwd_chain / k_ff<true, true> / k_ff_wgrad<true> (1 / (1 - p) folded into the `a` half of the packed W1, one-bit masks,
+    masks re-gathered in the transposed orientation by the weight-gradient kernel), `layer` = the layer-by-layer bf16 kernels (the middle
+    link of the old chain of comparisons).  The path is asserted from the library's own record (dfx_debug_last_train_path).
+    Gates = the p = 0 gates of test_bf16_matrix_products_within_stated_tolerance (3x the measured p = 0 values: eps 6.6e-3 max-abs,
+    gradients 1.7e-2 of max-abs / 1.3e-2 relative L2) — dropout scales activations by at most 1.25 and zeroes the rest, it does not
+    widen the bf16 rounding; measured values are printed (profiles/r06_parity_prints.txt)."""
+    from difffacto_amd import _ffi
+    from oracle import train
+    p, seed = 0.2, 20260930 + B * 7 + N
+    c = _seeded_case(B, N, wseed=3, seed=900 + B * 31 + N)
+    ref = train.loss_and_grads(**c, drops=replayed_drops(seed, p, B, N))
+    ref0 = train.loss_and_grads(**c)
+    _ffi.lib().dfx_debug_train_fused(1 if path == "fused" else 0)
+    try:
+        r = _run(c, True, precision="bf16", dropout=(p, seed))
+        took = _ffi.lib().dfx_debug_last_train_path().decode()
+    finally:
+        _ffi.lib().dfx_debug_train_fused(1)
+    assert took == ("fused_bf16_dropout" if path == "fused" else "layer_bf16_dropout"), took
+    assert np.abs(ref["eps"] - ref0["eps"]).max() > 1e-2        # the replayed factors did something in the oracle
+    e_loss = abs(r["loss"] - ref["loss"]) / abs(ref["loss"])
+    e_eps = np.abs(r["eps"] - ref["eps"]).max()
+    worst_max = worst_l2 = 0.0
+    at = None
+    for k, gr in ref["grads"].items():
+        scale = max(np.abs(gr).max(), 1e-30)
+        e_max = np.abs(r["grads"][k] - gr).max() / scale
+        e_l2 = np.linalg.norm((r["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
+        if e_max > worst_max:
+            worst_max, at = e_max, k
+        worst_l2 = max(worst_l2, e_l2)
+    e_ctx = max(np.abs(r[k] - ref[k]).max() / np.abs(ref[k]).max() for k in ("d_ctx_code", "d_ctx_mv"))
+    print(f"bf16 + dropout 0.2, {took} (B={B}, N={N}) vs fp32 autograd oracle with replayed factors: loss rel {e_loss:.1e}, eps max-abs {e_eps:.1e}, "
+          f"gradients worst max-norm {worst_max:.1e} ({at}), worst relative L2 {worst_l2:.1e}, d ctx {e_ctx:.1e}")
+    assert e_loss < 1e-3 and e_eps < 6.6e-3, (e_loss, e_eps)
+    assert worst_max < 1.7e-2 and worst_l2 < 1.3e-2 and e_ctx < 1.7e-2, (worst_max, at, worst_l2, e_ctx)
+
+
 def test_smallest_shapes_and_no_validity_mask():
     """B = 1, N = 32 (one attention block, one product slab) with valid = None (all parts present), no flags, both precisions'
     code paths: against the oracle."""

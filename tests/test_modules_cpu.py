@@ -89,6 +89,23 @@ ENC_CFG = dict(
     kl_weight_annealing=False, gen=True, prior_var=1.0)   # configs/gen_chair.py:6-47
 
 
+TOP_CFG = dict(sampler=dict(type='Uniform'), num_anchors=4, num_timesteps=100, npoints=2048, gen=True, cimle=True, cimle_sample_num=1, ret_traj=True,
+               ret_interval=10, forward_sample=False, drift_anchors=False, interpolate=False, save_weights=False)   # configs/gen_chair.py:88-104
+
+
+def model_cfg(**overrides):
+    """`cfg.model` of the unmodified configs/gen_chair.py without its 'type' key (test_install_full_... checks that against the reference's own
+    config loader), with the knobs the golden fixtures were generated under (num_timesteps, npoints, cimle_sample_num, ret_interval, ...) replaced:
+    what the -m gpu composition tests construct networks.AnchorDiffAE from."""
+    net = overrides.pop("net", {})
+    diffusion = dict(type="AnchoredDiffusion", **{**DIFF_CFG, "net": dict(DIFF_CFG["net"], **net)})
+    return {**TOP_CFG, "encoder": dict(type="PartEncoderForTransformerDecoder", **ENC_CFG), "diffusion": diffusion, **overrides}
+
+
+def _plain(c):
+    return {k: _plain(v) for k, v in c.items()} if hasattr(c, "items") else c
+
+
 def test_encoder_mirror_state_dict_keys_and_unsupported_options():
     from difffacto_amd.encoders import PartEncoderForTransformerDecoder, PartAlignerTransformer
     enc = PartEncoderForTransformerDecoder(**ENC_CFG)
@@ -358,3 +375,70 @@ def test_anchor_diff_ae_mirror_bookkeeping_on_oracle_backends(tag, chain_at, mon
             assert np.array_equal(got, ref), k
         else:
             assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), k
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python/difffacto"), reason="dev container only")
+@pytest.mark.parametrize("cfg_name", ["gen_chair.py", "gen_airplane.py", "gen_car.py", "gen_lamp.py", "train_chair_stage1.py", "train_chair_stage2.py"])
+def test_install_full_builds_the_mirror_from_the_unmodified_configs(cfg_name):
+    """INTEGRATION.md §2's "take the whole model" binding: after `install(full=True)` the REFERENCE's own `init_cfg` +
+    `build_from_cfg(cfg.model, MODELS)` (utils/registry.py:24-46) on an unmodified shipped config yields `networks.AnchorDiffAE` whose `state_dict`
+    has the reference model's keys and shapes, and a reference-made checkpoint loads `strict=True` — also through the shape-checking,
+    `strict=False` protocol of `Runner.load` (runner.py:505-520), with nothing dropped and nothing left unloaded."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import contextlib
+    import io
+    import ref_import
+    import difffacto_amd
+    from difffacto_amd import networks, encoders, modules
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_model, cfg = ref_import.build_reference_model(cfg_name)
+    assert type(ref_model).__module__.startswith("difffacto.")
+    ref_sd = ref_model.state_dict()
+    from difffacto.utils.registry import NETS, DIFFUSIONS, MODELS, ENCODERS, SAMPLERS, build_from_cfg
+    regs = (NETS, DIFFUSIONS, MODELS, ENCODERS, SAMPLERS)
+    saved = [dict(r._modules) for r in regs]
+    saved_mods = {k: sys.modules.get(k) for k in ("pointnet2_ops", "pointnet2_ops.pointnet2_utils", "pointnet2_ops.pointnet2_modules")}
+    try:
+        assert difffacto_amd.install(full=True) is True
+        with contextlib.redirect_stdout(io.StringIO()):
+            mine = build_from_cfg(cfg.model, MODELS)
+        assert type(mine) is networks.AnchorDiffAE
+        if cfg_name == "gen_chair.py":       # the dict the -m gpu composition tests build the mirror from IS this config's cfg.model
+            assert _plain(cfg.model) == {"type": "AnchorDiffAE", **model_cfg()}
+        if cfg_name == "train_chair_stage2.py":   # stage 2 = gen_chair's model up to these keys (the stage2_step golden was made on gen_chair's)
+            got, base = _plain(cfg.model), {"type": "AnchorDiffAE", **model_cfg()}
+            assert got.pop("save_dir") and got.pop("ret_interval") == 1 and "cimle_sample_num" not in got
+            assert got["encoder"]["part_aligner"].pop("noise_scale") == 50
+            base.pop("ret_interval"), base.pop("cimle_sample_num"), base["encoder"]["part_aligner"].pop("noise_scale")
+            assert got == base
+        assert type(mine.encoder) is encoders.PartEncoderForTransformerDecoder and type(mine.encoder.encoder) is encoders.PointNetV2
+        assert type(mine.diffusion) is modules.AnchoredDiffusion and type(mine.diffusion.model) is modules.TransformerNet
+        my_sd = mine.state_dict()
+        assert list(my_sd) == list(ref_sd) or set(my_sd) == set(ref_sd)
+        assert len(ref_sd) == (473 if cfg_name == "train_chair_stage1.py" else 547)   # stage 1 has no part aligner (train_chair_stage1.py)
+        for k, v in ref_sd.items():
+            assert tuple(my_sd[k].shape) == tuple(v.shape) and my_sd[k].dtype == v.dtype, k
+        assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for p in ref_model.parameters())
+        mine.load_state_dict(ref_sd, strict=True)
+        for k, v in mine.state_dict().items():
+            assert torch.equal(v, ref_sd[k]), k
+        # Runner.load's protocol on a checkpoint written by DataParallel-wrapped training ("module." prefix stripped by the caller, runner.py:503)
+        with contextlib.redirect_stdout(io.StringIO()):
+            again = build_from_cfg(cfg.model, MODELS)
+        ckpt = {"module." + k: v.clone() for k, v in ref_sd.items()}
+        state = {k.replace("module.", ""): v for k, v in ckpt.items()}
+        target = again.state_dict()
+        dropped = [k for k in state if k not in target]
+        reshaped = [k for k in state if k in target and state[k].shape != target[k].shape]
+        missing = [k for k in target if k not in state]
+        assert not dropped and not reshaped and not missing
+        res = again.load_state_dict(state, strict=False)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert all(torch.equal(v, ref_sd[k]) for k, v in again.state_dict().items())
+    finally:
+        for r, s in zip(regs, saved):
+            r._modules.clear()
+            r._modules.update(s)
+        for k, v in saved_mods.items():
+            if v is not None:
+                sys.modules[k] = v
