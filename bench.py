@@ -248,12 +248,21 @@ def train_iteration(Wnp, B, N, iters=10):
 
         step = [0]
 
+        last = {}
+
         def it(p=0.0):
             opt.zero_grad()
             step[0] += 1
             drop = (p, 7000 + step[0]) if p > 0 else None     # a fresh Philox key per step, like the module API draws one (modules.TransformerNet._forward_train)
-            training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16", dropout=drop), None).backward()
+            loss = training.masked_mse(noise, training.denoiser_train_forward(P, *a, precision="bf16", dropout=drop), None)
+            loss.backward()
+            last["loss"] = loss.detach()
             opt.step()
+
+        def check_finite(tag):   # after the timed loop (outside it): the last loss, every gradient and every updated parameter
+            if not (bool(torch.isfinite(last["loss"])) and all(bool(torch.isfinite(v.grad).all()) and bool(torch.isfinite(v).all()) for v in P.values())):
+                raise FloatingPointError(f"train_iteration[{tag}]: non-finite loss / gradient / parameter")
+            return float(last["loss"])
 
         def timed(p):
             for _ in range(3):   # (the block runs behind the chain sweeps: three warm-ups and ten timed iterations keep a 20 ms sample's noise out of the line)
@@ -266,9 +275,11 @@ def train_iteration(Wnp, B, N, iters=10):
             return (time.perf_counter() - t0) / iters * 1e3
 
         ms = timed(0.0)
+        loss_p0 = check_finite("p=0")
         ms_p02 = timed(0.2)    # configs/train_chair_stage1.py:38 as shipped: nn.Dropout(0.2) behind every to_out and GEGLU, in the fused kernels (k_ff<*, true>)
         out = {"what": "denoiser forward + backward + clip + Adam, bf16 matrix products, fp32 master weights (tools/bench_train.py)",
-               "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters, "dropout": 0.0,
+               "ms": ms, "shapes_per_s": B / ms * 1e3, "batch": B, "npoints": N, "iters": iters, "dropout": 0.0, "finite": True,
+               "last_loss": loss_p0, "last_loss_dropout_0.2": check_finite("p=0.2"),
                "dropout_0.2": {"ms": ms_p02, "shapes_per_s": B / ms_p02 * 1e3, "vs_dropout_0": ms_p02 / ms,
                                "what": "the same iteration with the shipped dropout = 0.2 (Philox factors drawn in the fused forward kernel, one bit per element kept for the backward kernels)"}}
         del P, a, noise, opt
@@ -501,11 +512,14 @@ def chain_line(params, names, B, N, T, precision, dev, noise_scale=100.0, launch
         wall_ms = (time.perf_counter() - t0) / launches * 1e3
         ok = all(bool(torch.isfinite(p).all()) for p in preds)   # every timed launch
         ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.last_chain_events]))
+        from difffacto_amd.engine import last_kernel_variant
+        variant, fold = last_kernel_variant(), (eng.w1_fold() + (eng.w1_fold_channel(),) if precision == "bf16" else None)
         eng.close()
         ach = flops_per_step(N) * T * B / (ms * 1e-3) / 1e12
         return {"batch": B, "npoints": N, "num_timesteps": T, "dtype": precision, "noise_scale": noise_scale, "kernel_ms": ms,
                 "shapes_per_s": B / ms * 1e3, "wall_ms": wall_ms, "wall_shapes_per_s": B / wall_ms * 1e3, "achieved_tflops": ach,
-                "frac": ach / PEAK_TFLOPS[precision], "launches": launches, "finite": ok}
+                "frac": ach / PEAK_TFLOPS[precision], "launches": launches, "finite": ok, "kernel_variant": variant,
+                **({} if fold is None else {"w1_fold": {"folded": fold[0], "ratio": round(fold[1], 3), "channel": fold[2]}})}
     except Exception as e:
         return {"error": repr(e)[:200]}
 
@@ -531,6 +545,16 @@ def sweep_block(params, names, precision, dev, T):
     for name, ns, n, b in (("gen_airplane", 50.0, 2048, 128), ("gen_car", 50.0, 8192, 128), ("gen_lamp", 10.0, 2048, 128),
                            ("gen_chair_B1024", 100.0, 2048, 1024)):
         out[name] = chain_line(params, names, b, n, T, precision, dev, noise_scale=ns)
+    # a checkpoint-like hazard: LayerNorm gain outlier in the channel the W1 bias fold used to sit on — round 5 sent such an
+    # engine to the ~3x slower direct kernel; since round 6 dfx_denoiser_create moves the fold to another hidden channel and the headline kernel stays
+    po = dict(params)
+    g3 = params["transformer_blocks.2.norm3.weight"].clone()
+    g3[127] *= 64.0
+    po["transformer_blocks.2.norm3.weight"] = g3
+    out["outlier_weights"] = chain_line(po, names, 128, 2048, T, precision, dev)
+    if isinstance(out["outlier_weights"], dict) and isinstance(out.get("gen_lamp"), dict) and "kernel_ms" in out["outlier_weights"] and "kernel_ms" in out["gen_lamp"]:
+        out["outlier_weights"]["what"] = "gen_chair B = 128 with transformer_blocks.2.norm3.weight[127] x 64"
+        out["outlier_weights"]["vs_ordinary_weights"] = out["outlier_weights"]["kernel_ms"] / out["gen_lamp"]["kernel_ms"]   # (same B, N, T, kernel)
     if isinstance(out.get("gen_car"), dict):
         out["gen_car"].update(fps_line(dev))   # the evaluation protocol's FPS 8192 -> 2048 leg, next to the sampling it follows
     return out
