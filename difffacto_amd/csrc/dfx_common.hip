@@ -76,7 +76,13 @@ DevSide *dev_side(hipStream_t caller, bool &capped) {
     return nullptr;
   }
   DevSide *d = new DevSide;
+#ifdef DFX_SIDE_LOWPRIO
+  int plo = 0, phi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&plo, &phi);   // (lowest, greatest): numerically lower = higher priority
+  if (hipStreamCreateWithPriority(&d->st, hipStreamNonBlocking, plo) != hipSuccess) {
+#else
   if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) {
+#endif
     delete d;
     return nullptr;
   }

@@ -34,6 +34,7 @@
 #pragma once
 #include "dfx_common.h"
 #include "dfx_dropout.h"
+#include <type_traits>
 
 namespace dfx {
 namespace ffused {
@@ -45,11 +46,24 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 
 constexpr int C = 128, FH = 512, NCHUNK = FH / 32;
-constexpr int TILES = 24;                         // tiles per chunk in the pack
+// Round 6: the FORWARD kernel computes hid = a gelu(g) with the sampling kernel's transcendental-free packed-fp16 polynomial (gelu16_f16 below) and feeds
+// GEMM2 as an fp16 product (v_mfma_f32_32x32x16_f16) — the fp32 sigmoid form cost 6 packed-fp32 + 4 quarter-rate instructions per PAIR of values, and
+// packed fp32 VALU serialises against the matrix pipe the SIMD's other wavefront is feeding (denoiser_kernel.hip's notes; ablation profiles/r06_ab_train.txt:
+// the forward without any GELU arithmetic runs 716 -> 607 us).  It reads its OWN twelve tiles of a chunk (T_F*): W1a scaled by FWD_A_SCALE, W1g by
+// FWD_G_SCALE (the polynomial works on u = g / 2; a g / 32 stays inside the fp16 range) and W2 as fp16 times the inverse of their product — exact
+// powers of two.  The backward kernels keep the bf16 tiles 0..23 and the fp32 sigmoid form (their gradients multiply fp32 values that fp16 cannot hold).
+#ifndef DFX_FF_FWD_F16
+#define DFX_FF_FWD_F16 1
+#endif
+constexpr bool FWD_F16 = DFX_FF_FWD_F16 != 0;
+constexpr float FWD_A_SCALE = 0.0625f, FWD_G_SCALE = 0.5f;
+constexpr int TILES = FWD_F16 ? 36 : 24;          // tiles per chunk in the pack
 constexpr int TILE_U4 = 128;                      // uint4 per tile (2 units x 64 lanes)
-constexpr int CHUNK_U4 = TILES * TILE_U4;         // 3072 uint4 = 48 KiB
-constexpr int FWD_TILES = 12, BWD_TILES = 12;     // LDS slot size in tiles.  forward: tiles 0..11 of a chunk; backward: see stage_item
-enum { T_W1A = 0, T_W1G = 4, T_W2 = 8, T_W2T = 12, T_W1AT = 16, T_W1GT = 20 };
+constexpr int CHUNK_U4 = TILES * TILE_U4;         // 4608 uint4 = 72 KiB (48 KiB without the forward's own tiles)
+constexpr int FWD_TILES = 12, BWD_TILES = 12;     // LDS slot size in tiles.  forward: tiles FWD_TILE0 .. + 11 of a chunk; backward: see stage_item
+enum { T_W1A = 0, T_W1G = 4, T_W2 = 8, T_W2T = 12, T_W1AT = 16, T_W1GT = 20, T_FW1A = 24, T_FW1G = 28, T_FW2 = 32 };
+constexpr int FWD_TILE0 = FWD_F16 ? T_FW1A : 0;   // first tile of the forward's slot image (within it: W1a 0..3, W1g 4..7, W2 8..11 either way)
+constexpr int PACK_RECORDS = FWD_F16 ? NCHUNK + 1 : NCHUNK;   // chunk records in the pack (the forward's skew needs a 17th for the last W2)
 
 __host__ __device__ inline int rho(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 // K index (0..31) held by unit u, element e of a lane in half hf
@@ -72,6 +86,7 @@ struct PackArgs {
   // dW1 = G diag(g3) + db1 (x) b3,  d gamma3 = sum_o W1[o][.] G[o][.],  d beta3 = sum_o W1[o][.] db1[o]   (k_ff_wgrad_finish, k_ln3_param)
   const float *g3, *b3;   // (128) each
   float *b1f;             // (1024) the folded bias in natural order, `a` half times keep_a: k_ff_wgrad's
+  float *b1ps;            // [NCHUNK][2 parts][2 hf][16] = b1p with the forward's scales (FWD_A_SCALE / FWD_G_SCALE): the forward kernel's table
 };
 
 struct PackBatch {
@@ -105,13 +120,15 @@ __global__ void k_ff_pack(PackBatch batch) {
     for (int ch = 0; ch < C; ++ch) t = fmaf(a.w1[(size_t)row * C + ch], a.b3[ch], t);
     t *= p == 0 ? a.keep_a : 1.0f;
     a.b1p[idx] = t, a.b1f[row] = t;
+    a.b1ps[idx] = t * (p == 0 ? FWD_A_SCALE : FWD_G_SCALE);
   }
   if (idx < 2 * 4 * 16) {
     const int r = idx & 15, c = (idx >> 4) & 3, hf = idx >> 6;
     a.b2p[idx] = a.b2[32 * c + rho(r, hf)];
   }
-  if (idx >= NCHUNK * TILES * 2 * 64) return;
+  if (idx >= PACK_RECORDS * TILES * 2 * 64) return;
   const int lane = idx & 63, u = (idx >> 6) & 1, t = (idx >> 7) % TILES, j = idx / (TILES * 128);
+  if (j == NCHUNK && t < T_FW2) return;   // the forward's 17th record: only its W2 tiles (hidden chunk 15) are read
   const int i = lane & 31, hf = lane >> 5;
   __bf16 v[8];
 #pragma unroll
@@ -126,9 +143,18 @@ __global__ void k_ff_pack(PackBatch batch) {
     } else if (t < T_W1AT) {             // W2^T: rows = hidden units, k-tile c over the channels, natural K
       const int c = t - T_W2T;
       x = a.w2[(size_t)(32 * c + k_nat(u, hf, e)) * FH + 32 * j + i];
-    } else {                             // W1a^T / W1g^T: rows = channels 32 ct + i, K = hidden units in register order
+    } else if (t < T_FW1A) {             // W1a^T / W1g^T: rows = channels 32 ct + i, K = hidden units in register order
       const int p = (t - T_W1AT) >> 2, ct = (t - T_W1AT) & 3;
       x = a.w1[(size_t)(p * FH + 32 * j + k_reg(u, hf, e)) * C + 32 * ct + i] * a.g3[32 * ct + i] * (p == 0 ? a.keep_a : 1.0f);
+    } else if (t < T_FW2) {              // the forward's W1a / W1g: tiles 0..7 times the fp16 scales (bf16, exact)
+      const int p = (t - T_FW1A) >> 2, c = (t - T_FW1A) & 3, ch = 32 * c + k_nat(u, hf, e);
+      x = a.w1[(size_t)(p * FH + 32 * j + i) * C + ch] * a.g3[ch] * (p == 0 ? a.keep_a * FWD_A_SCALE : FWD_G_SCALE);
+    } else {                             // the forward's W2: tile 8 + ct as FP16, times 1 / (FWD_A_SCALE FWD_G_SCALE) — of hidden chunk j - 1: the forward's
+      const int ct = t - T_FW2;          // records are SKEWED (record j = W1 of chunk j + W2 of chunk j - 1: one uninterrupted MFMA burst per record, ff_fwd)
+      x = j == 0 ? 0.f : a.w2[(size_t)(32 * ct + i) * FH + 32 * (j - 1) + k_reg(u, hf, e)] * (1.0f / (FWD_A_SCALE * FWD_G_SCALE));
+      const _Float16 h = (_Float16)x;
+      v[e] = __builtin_bit_cast(__bf16, h);
+      continue;
     }
     v[e] = (__bf16)x;
   }
@@ -234,14 +260,17 @@ __device__ __forceinline__ void dma256(const void *gbase, unsigned voff4, unsign
 // Phase stamps of a few workgroups (tools/experiments/trace_train_ff.py builds with -DDFX_TRACE_FF; never in the shipped library): wave 0 of the
 // workgroups whose id is a multiple of FFT_EVERY writes (tag, shader clock) pairs into a host-visible buffer dumped at process exit.
 #ifdef DFX_TRACE_FF
-constexpr int FFT_CAP = 128, FFT_WGS = 64, FFT_EVERY = 29;
+constexpr int FFT_CAP = 320, FFT_WGS = 64, FFT_EVERY = 29;
 struct FfTrace {
   unsigned long long *buf;
   int n;
-  __device__ __forceinline__ void init(unsigned long long *base, int kernel_slot, int thread = 0) {
+  // `append` > 0: a later block of the forward chain keeps stamping behind the previous blocks' entries (their count); the first block clears the row
+  __device__ __forceinline__ void init(unsigned long long *base, int kernel_slot, int thread = 0, int append = 0) {
     const int wg = blockIdx.x;
     buf = (base && wg % FFT_EVERY == 0 && wg / FFT_EVERY < FFT_WGS && (int)threadIdx.x == thread) ? base + ((size_t)kernel_slot * FFT_WGS + wg / FFT_EVERY) * FFT_CAP : nullptr;
-    n = 0;
+    n = append;
+    if (buf && !append)
+      for (int i = 0; i < FFT_CAP; ++i) buf[i] = 0;
   }
   __device__ __forceinline__ void stamp(int tag) {
     if (buf && n < FFT_CAP) {
@@ -278,10 +307,14 @@ inline unsigned long long *ff_trace_buffer() {
   return buf;
 }
 #define FFT_INIT(args, slot) FfTrace fft; fft.init((args).trace, slot)
+#define FFT_INIT_CHAIN(args, slot, append) FfTrace fft; fft.init((args).trace, slot, 0, append)
+#define FFT_COUNT(var) var = fft.n
 #define FFT_INIT2(args, slot, thread) FfTrace fft; fft.init((args).trace, slot, thread)
 #define FFT(tag) fft.stamp(tag)
 #else
 #define FFT_INIT(args, slot)
+#define FFT_INIT_CHAIN(args, slot, append)
+#define FFT_COUNT(var)
 #define FFT_INIT2(args, slot, thread)
 #define FFT(tag)
 #endif
@@ -569,6 +602,46 @@ __device__ __forceinline__ v2f gelu_f2(v2f x) {
 __device__ __forceinline__ v2f pair(const v16f &v, int i) { return v2f{v[2 * i], v[2 * i + 1]}; }
 __device__ __forceinline__ void set_pair(v16f &v, int i, v2f x) { v[2 * i] = x[0], v[2 * i + 1] = x[1]; }
 
+// ---- the sampling kernel's packed-fp16 GEGLU (denoiser_kernel.hip: gelu16_f16_cvt / gelu16_f16_math, fit: tools/experiments/fit_gelu_poly.py), for the
+// FORWARD kernel: gelu(g) = g Phi(g), Phi(g) ~ 1/2 + u R(z), u = g / 2, z = min(u^2 - m, L^2 - m), R of degree 5 (3.9e-4 in exact arithmetic on [-6, 6];
+// rms 8.5e-4 on a gelu(g) in fp16).  Ten packed instructions per pair of values, no transcendental, and v_pk_*_f16 does not contend with the matrix pipe.
+// Inputs: a / 16 and g / 2 (the forward's tiles are scaled); output hid / 32 as the two fp16 B fragments of GEMM2 (pack8's element order: registers 8 u ..).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ h2 pk_f16(float lo, float hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ h2 h2c(float v) { return h2{(_Float16)v, (_Float16)v}; }
+// (a, g) -> packed fp16 first: after these sixteen conversions the accumulators are dead and their next initialisers can be fetched underneath the arithmetic
+__device__ __forceinline__ void geglu16_f16_cvt(const v16f &a, const v16f &g, h2 (&aa)[8], h2 (&gg)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gg[i] = pk_f16(g[2 * i], g[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) aa[i] = pk_f16(a[2 * i], a[2 * i + 1]);
+}
+__device__ __forceinline__ void geglu16_f16_math(const h2 (&aa)[8], const h2 (&gg)[8], uint4 (&hid)[2]) {
+  h2 y[8], z[8], r[8];
+  // stage by stage over the eight pairs: eight independent instructions between two dependent ones (a dependent v_pk_* costs a wait state on gfx950)
+#define DFX_STAGE(expr)                                   \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) { expr; } \
+  __builtin_amdgcn_sched_barrier(0)
+  __builtin_amdgcn_sched_barrier(0);
+  DFX_STAGE(z[i] = __builtin_elementwise_fma(gg[i], gg[i], h2c(-1.62f)));
+  DFX_STAGE(y[i] = aa[i] * gg[i]);
+  DFX_STAGE(z[i] = __builtin_elementwise_min(z[i], h2c(1.62f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(z[i], h2c(-0.0011402554f), h2c(0.0057853916f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(-0.0158536041f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(0.0409006897f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(-0.1098130657f)));
+  DFX_STAGE(r[i] = __builtin_elementwise_fma(r[i], z[i], h2c(0.3885767652f)));
+  DFX_STAGE(asm("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(z[i]) : "v"(gg[i]), "v"(r[i])));   // Phi
+  DFX_STAGE(y[i] = y[i] * z[i]);
+#undef DFX_STAGE
+  hid[0] = uint4{__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), __builtin_bit_cast(unsigned, y[2]), __builtin_bit_cast(unsigned, y[3])};
+  hid[1] = uint4{__builtin_bit_cast(unsigned, y[4]), __builtin_bit_cast(unsigned, y[5]), __builtin_bit_cast(unsigned, y[6]), __builtin_bit_cast(unsigned, y[7])};
+}
+__device__ __forceinline__ v16f mfma_f16(const uint4 &a, const uint4 &b, v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+}
+
 constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
 // per 32-point tile, for k_ff_wgrad: two sets of fragments [4 c][2 u][64 lanes] (8 KiB each) in memory; k_ff_wgrad derives the
 // transposed sets (PK_XNT, PK_DHT: channels on the lanes, points along the registers) in LDS
@@ -596,6 +669,12 @@ __device__ __forceinline__ void stage_chunk(const uint4 *frags, int j, unsigned 
     const int spiece = BWD && piece >= 16 ? piece + 8 : piece;           // backward skips tiles 8..11 (W2)
     dma1k(src + spiece * 1024, voff, lds_buf + piece * 1024);
   }
+}
+// ff_fwd's record j: the forward's own twelve tiles of pack record j (T_FW1A ..: scaled W1a | W1g of chunk j, fp16 W2 of chunk j - 1)
+__device__ __forceinline__ void stage_record_fwd(const uint4 *frags, int j, unsigned lds_buf, int wave, unsigned voff) {
+  const char *src = reinterpret_cast<const char *>(frags + (size_t)j * CHUNK_U4) + FWD_TILE0 * 2048;
+#pragma unroll
+  for (int k = 0; k < FWD_TILES * 2 / NW_FWD; ++k) dma1k(src + (k * NW_FWD + wave) * 1024, voff, lds_buf + (k * NW_FWD + wave) * 1024);
 }
 
 // Backward: a chunk streams as two items through a ring of three 24 KiB slots — item 2 j = [W1a | W1g | W2^T] of chunk j (tiles 0..7 and
@@ -697,7 +776,7 @@ constexpr int AT_OFF_BWD = 32768;
 // The body of k_ff / k_ff_fwd_chain.  `first`: the lane's rows come from memory; otherwise (forward chain, blocks behind the first) they are `hc`, the
 // previous block's output, still in the accumulator registers it was computed in.  `hc` leaves with this block's output (forward).
 template <bool BWD, bool DROP>
-__device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (&hc)[4]) {
+__device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (&hc)[4], int &trace_n) {
   constexpr int NW = nw_of<BWD>();
   static_assert(NW == 4 && NW * 64 == 2 * C && FWD_TILES == BWD_TILES && B1P_FLOATS * 4 == NW * 1024, "table staging below assumes 256 threads");
   constexpr int BUF_BYTES = (BWD ? BWD_TILES : FWD_TILES) * 2048;
@@ -721,7 +800,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
   const bool at = a.at_frags != nullptr;
 
   constexpr int PIECES = FWD_TILES * 2 / NW;   // forward: LDS-DMA instructions per wave and chunk
-  FFT_INIT(a, BWD ? 1 : 0);
+  FFT_INIT_CHAIN(a, BWD ? 1 : 0, !BWD && !first ? trace_n : 0);   // (trace builds: the chain's later blocks append)
   FFT(1);
   // ---- prologue, memory side: this lane's rows first (the oldest requests come back first), then the tables, then the ring ----
   v8f x[4][2], xd[4][2];
@@ -848,7 +927,9 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       }
     }
     acc_to_rows(acc, x);   // h1 in the B-operand layout for LayerNorm3
+    FFT(17);
     __syncthreads();       // everybody is done with the attention fragments: slot 2 takes chunk 2 at the top of the loop
+    FFT(18);
   } else if (!BWD) {
     rows_to_acc(x, acc);   // h1 in the accumulator layout, from the same read
   }
@@ -945,7 +1026,11 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       __builtin_amdgcn_sched_barrier(0);
       v16f hv;
 #pragma unroll
+#ifdef DFX_ABL_FWD_GELU   // (ablation builds only, tools/experiments/ab_train_variants.sh: wrong numbers, the loop without its GELU arithmetic)
+      for (int i = 0; i < 8; ++i) set_pair(hv, i, pair(av, i) * pair(gv, i));
+#else
       for (int i = 0; i < 8; ++i) set_pair(hv, i, pair(av, i) * gelu_f2(pair(gv, i)));
+#endif
       if (DROP) {
         // dropout behind the GEGLU (attention.py:84): element (row, unit 32 j + 8 q + 4 hf + m) = group row * 64 + 4 j + q of the site; the scale rides on `a`
         unsigned w[4][2];
@@ -1007,7 +1092,11 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         v2f f, d;
+#ifdef DFX_ABL_BWD_GELU
+        f = pair(gv, i), d = splat2(1.0f);
+#else
         gelu_fd2(pair(gv, i), f, d);
+#endif
         const v2f dh2 = pair(dhid, i);
         set_pair(da, i, dh2 * f);
         set_pair(dg, i, dh2 * pair(av, i) * d);
@@ -1096,8 +1185,10 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
         hp[(c * 2 + 0) * 64] = hb[0], hp[(c * 2 + 1) * 64] = hb[1];
       }
       FFT(9);
+      FFT_COUNT(trace_n);
       return;
     }
+    FFT_COUNT(trace_n);
     if (!live) return;
     float *out = a.h2 + rowbase;
 #pragma unroll
@@ -1106,6 +1197,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<v4f *>(out + m_h2.a(c, q)) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
     FFT(9);
+    FFT_COUNT(trace_n);
     return;
   }
   // ---- backward epilogue.  The ring is idle (every wave is behind the loop's last barrier): the shape's [A_s | M_s^T | A_s^T] fragments are
@@ -1349,10 +1441,330 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
   FFT(8);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The forward of one block, round 6 (FWD_F16): the sampling kernel's slot structure on the training kernel's rows.
+//   * records are SKEWED: record j = [W1a | W1g of hidden chunk j | W2 of chunk j - 1] (k_ff_pack), so an iteration is ONE uninterrupted burst of 24 MFMAs
+//     (GEMM2 of chunk j - 1, GEMM1 of chunk j) behind ONE stretch of VALU (the GEGLU of chunk j - 1): 17 iterations, the first without GEMM2, the last
+//     without GEMM1;
+//   * the burst's first eight A fragments are requested at the TOP of the iteration, in front of the GEGLU arithmetic, which hides their LDS round trip
+//     (the unskewed loop paid it in front of every GEMM1: ~15 % of a chunk); the rest go through the ring of eight registers, refilled in place;
+//   * the GEGLU is the packed-fp16 polynomial (geglu16_f16) and GEMM2 an fp16 product; b1 of chunk j is fetched underneath it (the accumulators
+//     are dead once converted);
+//   * in the chain, the NEXT block's tables, attention fragments and first two records are requested behind this block's last barrier, in front of
+//     its row stores (`next` / `has_next` / `staged`): the next block's first wait finds most of them landed.
+// Same rows, same tile layouts, same dropout bits as ff_run<false>; the attention sub-block and LayerNorm3 are its code.
+template <bool DROP>
+__device__ __forceinline__ void ff_fwd(const FfArgs &a, const FfArgs &next, const bool has_next, const bool first, const bool staged, v16f (&hc)[4], float (&tv)[3],
+                                       int &trace_n) {
+  constexpr int NW = NW_FWD, NREC = NCHUNK + 1;
+  static_assert(NW == 4 && B1P_FLOATS * 4 == NW * 1024, "table staging below assumes 256 threads");
+  constexpr int BUF_BYTES = FWD_TILES * 2048, PIECES = FWD_TILES * 2 / NW;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ff_smem[];
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));   // (opaque per call: see ff_run)
+  const int lane = lane_, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = lane >> 5, pj = lane & 31;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ff_smem);
+  const unsigned voff = lane * 16;
+  const int tps = a.N / 32, gps = (tps + NW - 1) / NW;
+  const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x / gps);
+  int ti = ((int)blockIdx.x - s * gps) * NW + wave;
+  const bool live = ti < tps;
+  if (!live) ti = tps - 1;
+  const long long rowbase = ((long long)s * a.N + ti * 32) * C;
+  const RowMap m_hin(a.tiled & TL_HIN, lane, pj, hf), m_h1(a.tiled & TL_H1, lane, pj, hf), m_h2(a.tiled & TL_H2, lane, pj, hf);
+  const bool h1f = a.tiled & TL_H1_FRAG;
+  FFT_INIT_CHAIN(a, 0, !first ? trace_n : 0);
+  FFT(1);
+  // what a block's prologue requests through LDS-DMA: b1 table, [A_s | M_s] of the shape -> slot 2, records 0 and 1 -> slots 0 and 1
+  auto stage_prologue = [&](const FfArgs &b) {
+    dma1k(reinterpret_cast<const char *>(b.b1p) + wave * 1024, voff, lds0 + TAB_B1 + wave * 1024);
+    const char *src = reinterpret_cast<const char *>(b.at_frags + (size_t)s * SHAPE_U4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma1k(src + (k * NW + wave) * 1024, voff, lds0 + 2 * BUF_BYTES + (k * NW + wave) * 1024);
+    stage_record_fwd(b.frags, 0, lds0, wave, voff);
+    stage_record_fwd(b.frags, 1, lds0 + BUF_BYTES, wave, voff);
+  };
+  v8f x[4][2];
+  if (first) load_rows(a.hin + rowbase, m_hin, x);
+  const unsigned long long prow = (unsigned long long)(rowbase / C) + pj;
+  unsigned *dmk = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE + lane : nullptr;
+  float *b1s = reinterpret_cast<float *>(ff_smem + TAB_B1);
+  float *dump = reinterpret_cast<float *>(ff_smem + TAB_GB3);
+  float *gb2 = reinterpret_cast<float *>(ff_smem + TAB_GB2);
+  float *b2s = reinterpret_cast<float *>(ff_smem + TAB_B2);
+  const int tc = threadIdx.x & (C - 1);
+  const bool lo_half = wave < NW / 2;
+  // tables: gamma2 | beta2 of the thread's channel, b_o (waves 0, 1) or b2 (waves 2, 3) — in `tv`, fetched here or by the previous block's tail
+  auto load_tables = [&](const FfArgs &b) {
+    const float *tp2 = lo_half ? b.bo : b.b2p;
+    tv[0] = b.g2[tc], tv[1] = b.b2n[tc], tv[2] = tp2[tc];
+  };
+  if (!staged) {
+    load_tables(a);
+    stage_prologue(a);
+  }
+  unsigned vmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
+  // ONE round trip (first block: rows, tables, attention fragments, two records).  Behind a previous block the requests were made in front of its
+  // sixteen row stores, which may stay in flight (operations complete in order: "at most the sixteen newest outstanding" = everything requested landed)
+  if (staged && live) asm volatile("s_waitcnt vmcnt(16)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2])::"memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2])::"memory");
+  {
+    float *d0 = lo_half ? gb2 : dump, *d2 = lo_half ? gb2 + 2 * C : b2s;
+    d0[tc] = tv[0], d0[C + tc] = tv[1], d2[tc] = tv[2];
+  }
+  __syncthreads();
+  FFT(16);
+  v16f acc[4];
+  if (!first) acc_to_rows(hc, x);
+  uint4 xn[4][2];
+  float mu, rstd;
+  {
+    // ---- attention sub-block in registers (ff_run<false>'s code): h1 = hin + [dropout] (M_s softmax(A_s LN2(hin)) + b_o) ----
+    const uint4 *fl = reinterpret_cast<const uint4 *>(ff_smem + 2 * BUF_BYTES) + lane;
+    v16f sim = zero16();
+    {
+      float mu2, rstd2;
+      ln_stats(x, mu2, rstd2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sim = mfma(fl[F_AS * SET_U4 + (c * 2 + u) * 64], ln_frag(x[c][u], c, u, hf, gb2, mu2, rstd2), sim);
+    }
+    softmax_regs(sim, vmask);
+    const uint4 p0 = pack8(sim, 0), p1 = pack8(sim, 1);
+    rows_to_acc(x, acc);
+    unsigned attw = 0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      if (DROP) {
+        v16f t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f b = *reinterpret_cast<const v4f *>(gb2 + 2 * C + 32 * ct + 8 * q + 4 * hf);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) t[4 * q + m] = b[m];
+        }
+        t = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, t);
+        t = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, t);
+        unsigned w[4][2];
+        drop_words(a.dk, a.site_att, prow * (C / 8) + 4 * ct, hf, w);
+        const unsigned bits = drop_apply(t, w, a.dk.thr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = fmaf(a.dk.keep, t[r], acc[ct][r]);
+        attw |= bits << (16 * (ct & 1));
+        if (ct & 1) {
+          if (live) dmk[(8 + (ct >> 1)) * 64] = attw;
+          attw = 0;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f b = *reinterpret_cast<const v4f *>(gb2 + 2 * C + 32 * ct + 8 * q + 4 * hf);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[ct][4 * q + m] += b[m];
+        }
+        acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 0) * 64], p0, acc[ct]);
+        acc[ct] = mfma(fl[F_MS * SET_U4 + (ct * 2 + 1) * 64], p1, acc[ct]);
+      }
+      if (live && !h1f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<v4f *>(a.h1_out + rowbase + m_h1.a(ct, q)) = v4f{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+      }
+    }
+    acc_to_rows(acc, x);
+    FFT(17);
+    __syncthreads();   // everybody is done with the attention fragments: slot 2 takes record 2 at the top of the loop
+    FFT(18);
+  }
+  ln_stats(x, mu, rstd);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xn[c][u] = xhat_frag(x[c][u], mu, rstd);
+  if (h1f && live) {
+    uint4 *hp = reinterpret_cast<uint4 *>(a.h1_out + rowbase) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hp[(c * 2 + 0) * 64] = xn[c][0], hp[(c * 2 + 1) * 64] = xn[c][1];
+    if (hf == 0) (a.h1_out + rowbase)[H1F_RSTD + pj] = rstd;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    v16f b2;
+    load16(b2, b2s + hf * 64 + c * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] += b2[r];
+  }
+  FFT(2);
+
+  // ---- the skewed loop: iteration j = [top: record j + 2 requested, first eight fragments of the burst requested] [V: GEGLU of chunk j - 1, b1 of
+  // chunk j] [M: GEMM2 of chunk j - 1 (8 MFMAs), GEMM1 of chunk j (16)] [record j + 1 landed, barrier] ----
+  v16f av, gv;
+  unsigned dmw = 0;
+  auto step = [&](const int j, auto s2_, auto s1_, auto stage_) {
+    constexpr bool S2 = decltype(s2_)::value, S1 = decltype(s1_)::value, STAGE = decltype(stage_)::value;   // STAGE: record j + 2 exists
+    constexpr int NM = (S2 ? 8 : 0) + (S1 ? 16 : 0);
+    // this wave's six pieces of record j + 2 (-> the slot of record j - 1: everybody is past it) are issued from INSIDE the burst, one behind every fourth
+    // MFMA, where issue slots are free — six back-to-back LDS-DMA instructions at the top cost the wave ~100 cycles each (MI355X_MICROARCH.md)
+    const char *dsrc = reinterpret_cast<const char *>(a.frags + (size_t)(j + 2) * CHUNK_U4) + FWD_TILE0 * 2048 + wave * 1024;
+    const unsigned ddst = lds0 + ((j + 2) % NBUF) * BUF_BYTES + wave * 1024;
+    const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (j % NBUF) * BUF_BYTES) + lane;
+    // A fragment of MFMA m of the burst: GEMM2 (row tile m & 3, unit m >> 2) first, then GEMM1 MFMA e (k-tile e >> 2, unit (e >> 1) & 1, a / g = e & 1)
+    auto fm = [&](int m) -> uint4 {
+      if (S2 && m < 8) return fr[((T_W2 + (m & 3)) * 2 + (m >> 2)) * 64];
+      const int e = m - (S2 ? 8 : 0);
+      return fr[((((e & 1) ? T_W1G : T_W1A) + (e >> 2)) * 2 + ((e >> 1) & 1)) * 64];
+    };
+    uint4 P[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P[i] = fm(i);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 hh[2];
+    h2 aa[8], gg[8];
+    if (S2) {
+      if (DROP) {   // dropout behind the GEGLU of chunk j - 1 (attention.py:84), selected on `a`: element (row, unit 32 (j - 1) + 8 q + 4 hf + m) = group row * 64 + 4 (j - 1) + q
+        const int jj = j - 1;
+        unsigned w[4][2];
+        drop_words(a.dk, a.site_ff, prow * (FH / 8) + 4 * jj, hf, w);
+        const unsigned bits = drop_apply(av, w, a.dk.thr);
+        dmw = (jj & 1) ? dmw | (bits << 16) : bits;
+        if ((jj & 1) && live) dmk[(jj >> 1) * 64] = dmw;
+      }
+      geglu16_f16_cvt(av, gv, aa, gg);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S1) {
+      load16(av, b1s + ((j * 2 + 0) * 2 + hf) * 16);
+      load16(gv, b1s + ((j * 2 + 1) * 2 + hf) * 16);
+    }
+    if (S2) {   // (pinned here: LLVM otherwise sinks the arithmetic into the burst)
+      geglu16_f16_math(aa, gg, hh);
+      asm volatile("" : "+v"(hh[0].x), "+v"(hh[0].y), "+v"(hh[0].z), "+v"(hh[0].w), "+v"(hh[1].x), "+v"(hh[1].y), "+v"(hh[1].z), "+v"(hh[1].w));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      if (S2 && m < 8) {
+        acc[m & 3] = mfma_f16(P[m & 7], hh[m >> 2], acc[m & 3]);
+      } else {
+        const int e = m - (S2 ? 8 : 0);
+        if (e & 1) gv = mfma(P[m & 7], xn[e >> 2][(e >> 1) & 1], gv);
+        else av = mfma(P[m & 7], xn[e >> 2][(e >> 1) & 1], av);
+      }
+      if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k)
+          if (m == (k * NM) / PIECES) dma1k(dsrc + k * NW * 1024, voff, ddst + k * NW * 1024);
+      }
+      if (m + 8 < NM) P[m & 7] = fm(m + 8);
+    }
+#pragma unroll
+    for (int m = 0; m < NM - 8; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FFT(13);
+    if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // record j + 1 has landed; record j + 2's pieces may be out
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FFT(14);
+    __syncthreads();
+    FFT(15);
+  };
+  static_assert(NREC == NCHUNK + 1, "records 0 .. NCHUNK");
+  step(0, std::false_type{}, std::true_type{}, std::true_type{});
+#pragma unroll 1
+  for (int j = 1; j < NCHUNK - 1; ++j) step(j, std::true_type{}, std::true_type{}, std::true_type{});
+  step(NCHUNK - 1, std::true_type{}, std::true_type{}, std::false_type{});
+  step(NCHUNK, std::true_type{}, std::false_type{}, std::false_type{});
+  FFT(3);
+  // the ring and the tables are idle from here: the next block's prologue requests travel under this block's row stores
+  if (has_next) {
+    load_tables(next);
+    stage_prologue(next);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) hc[c] = acc[c];
+  if (a.tiled & TL_HEAD) {
+    // post_norm + proj_out on the accumulators (ff_run<false>'s code)
+    float sm = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm += acc[c][r];
+    sm += xhalf(sm);
+    const float mup = sm * (1.0f / C);
+    float qs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc[c][r] - mup;
+        qs = fmaf(d, d, qs);
+      }
+    qs += xhalf(qs);
+    const float rstdp = 1.0f / sqrtf(qs * (1.0f / C) + LN_EPS);
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = 32 * c + 8 * q + 4 * hf;
+        const v4f w0 = *reinterpret_cast<const v4f *>(a.head_tab + ch), w1 = *reinterpret_cast<const v4f *>(a.head_tab + C + ch);
+        const v4f w2 = *reinterpret_cast<const v4f *>(a.head_tab + 2 * C + ch);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float xh = (acc[c][4 * q + m] - mup) * rstdp;
+          acc[c][4 * q + m] = xh;
+          e0 = fmaf(xh, w0[m], e0), e1 = fmaf(xh, w1[m], e1), e2 = fmaf(xh, w2[m], e2);
+        }
+      }
+    e0 += xhalf(e0), e1 += xhalf(e1), e2 += xhalf(e2);
+    if (live) {
+      if (hf == 0) {
+        float *ep = a.eps + (size_t)s * 3 * a.N + ti * 32 + pj;
+        ep[0] = e0 + a.head_tab[3 * C], ep[a.N] = e1 + a.head_tab[3 * C + 1], ep[2 * (size_t)a.N] = e2 + a.head_tab[3 * C + 2];
+        (a.h2 + rowbase)[H1F_RSTD + pj] = rstdp;
+      }
+      uint4 *hp = reinterpret_cast<uint4 *>(a.h2 + rowbase) + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint4 hb[2];
+        acc_to_frags(acc[c], hb);
+        hp[(c * 2 + 0) * 64] = hb[0], hp[(c * 2 + 1) * 64] = hb[1];
+      }
+    }
+    FFT(9);
+    FFT_COUNT(trace_n);
+    return;
+  }
+  if (live) {
+    float *out = a.h2 + rowbase;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v4f *>(out + m_h2.a(c, q)) = v4f{acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+  }
+  FFT(9);
+  FFT_COUNT(trace_n);
+}
+
 template <bool BWD, bool DROP>
 __global__ __launch_bounds__(nw_of<BWD>() * 64, 2) void k_ff(FfArgs a) {
   v16f hc[4];
-  ff_run<BWD, DROP>(a, true, hc);
+  int tn = 0;
+  if constexpr (!BWD && FWD_F16) {
+    if (a.at_frags) {   // (the attention sub-block inside: every shipped launch; dfx_debug_train_fused(2) keeps the round-5 body)
+      float tv[3];
+      ff_fwd<DROP>(a, a, false, true, false, hc, tv, tn);
+      return;
+    }
+  }
+  ff_run<BWD, DROP>(a, true, hc, tn);
 }
 // The forward of ALL blocks in one launch (round 5): a point's way through the network depends on no other point (the attention's keys / values are the
 // four context tokens, folded into A_s / M_s), so a wavefront takes its 32 points through block after block with the residual stream in its accumulator
@@ -1366,7 +1778,13 @@ struct FfChain {
 template <bool DROP>
 __global__ __launch_bounds__(NW_FWD * 64, 2) void k_ff_fwd_chain(FfChain ch) {
   v16f hc[4];
-  for (int b = 0; b < ch.n; ++b) ff_run<false, DROP>(ch.blk[b], b == 0, hc);
+  int tn = 0;   // (trace builds only)
+  if constexpr (FWD_F16) {
+    float tv[3];
+    for (int b = 0; b < ch.n; ++b) ff_fwd<DROP>(ch.blk[b], ch.blk[b + 1 < ch.n ? b + 1 : b], b + 1 < ch.n, b == 0, b > 0, hc, tv, tn);
+  } else {
+    for (int b = 0; b < ch.n; ++b) ff_run<false, DROP>(ch.blk[b], b == 0, hc, tn);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1512,7 +1930,11 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
         for (int e = 0; e < 8; ++e) {   // (scalar fp32 here: the packed forms of gelu_fd2 made this kernel 5 % SLOWER — 236 -> 249 us)
           const int r = 8 * u + e;
           float f, d;
+#ifdef DFX_ABL_WG_ACT
+          f = gv[r], d = 1.0f;
+#else
           gelu_fd(gv[r], f, d);
+#endif
           const float hr = av[r] * f;
           hv[e] = DROP ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hr) & keepm[r]) : hr;
           da[e] = dv[r] * f;
@@ -1700,10 +2122,10 @@ inline int launch_ff_wgrad_t(hipStream_t st, const FwArgs &a) {
 }
 inline int launch_ff_wgrad(hipStream_t st, const FwArgs &a) { return a.dmask ? launch_ff_wgrad_t<true>(st, a) : launch_ff_wgrad_t<false>(st, a); }
 
-inline size_t pack_bytes_frags() { return (size_t)NCHUNK * CHUNK_U4 * sizeof(uint4); }
+inline size_t pack_bytes_frags() { return (size_t)PACK_RECORDS * CHUNK_U4 * sizeof(uint4); }
 
 inline void launch_pack(hipStream_t st, PackBatch &b, int depth) {
-  const int total = NCHUNK * TILES * 128;
+  const int total = PACK_RECORDS * TILES * 128;
   b.depth = depth;
   k_ff_pack<<<dim3((total + 255) / 256, depth + (b.head_tab ? 1 : 0)), 256, 0, st>>>(b);
 }

@@ -1722,7 +1722,7 @@ size_t carve(TrainWs &w, void *base, int B, int N, int depth) {
   w.apart = c.take<float>((size_t)B * (N / 32) * 2 * J * C);
   for (int i = 0; i < depth; ++i) {
     w.ff_frags[i] = c.take<uint4>(dfx::ffused::pack_bytes_frags() / sizeof(uint4));
-    w.ff_b1p[i] = c.take<float>(2 * dfx::ffused::B1P_FLOATS);   // the folded bias twice: in the chunk loop's order, and in natural order (PackArgs::b1f)
+    w.ff_b1p[i] = c.take<float>(3 * dfx::ffused::B1P_FLOATS);   // the folded bias three times: in the chunk loop's order, in natural order (PackArgs::b1f), and with the forward's fp16 scales (b1ps)
     w.ff_b2p[i] = c.take<float>(dfx::ffused::B2P_FLOATS);
   }
   for (int i = 0; i < depth; ++i) w.at_frags[i] = c.take<uint4>((size_t)B * dfx::afused::SHAPE_U4);
@@ -2155,7 +2155,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
     for (int i = 0; i < wt->depth; ++i)
       pb.blk[i] = dfx::ffused::PackArgs{wt->blk[i].ff0_w, wt->blk[i].ff0_b, wt->blk[i].ff2_w, wt->blk[i].ff2_b, w.ff_frags[i], w.ff_b1p[i], w.ff_b2p[i],
                                         dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, wt->blk[i].norm3_w, wt->blk[i].norm3_b,
-                                        w.ff_b1p[i] + dfx::ffused::B1P_FLOATS};
+                                        w.ff_b1p[i] + dfx::ffused::B1P_FLOATS, w.ff_b1p[i] + 2 * dfx::ffused::B1P_FLOATS};
     if (t_attn_in_ff)   // + the head's table: the last block's forward kernel computes eps itself
       pb.head_w = wt->proj_out_w, pb.head_b = wt->proj_out_b, pb.head_g = wt->post_norm_w, pb.head_be = wt->post_norm_b, pb.head_tab = w.head_tab;
     dfx::ffused::launch_pack(st, pb, wt->depth);
@@ -2182,7 +2182,8 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
       // the whole block in two launches (train_attn_fused.h, train_ff_fused.h): h1 = hin + attention(LN2(hin)), hout = h1 + FF(LN3(h1));
       // q, P, att, xn2, xn3, [a | g], hid never exist in memory
       dfx::ffused::FfArgs fa{};
-      fa.frags = w.ff_frags[i], fa.b1p = w.ff_b1p[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
+      fa.frags = w.ff_frags[i], fa.b2p = w.ff_b2p[i], fa.g3 = bw.norm3_w, fa.b3 = bw.norm3_b;
+      fa.b1p = w.ff_b1p[i] + (dfx::ffused::FWD_F16 && t_attn_in_ff ? 2 * dfx::ffused::B1P_FLOATS : 0);   // ff_fwd's table: scaled like its W1 tiles (PackArgs::b1ps)
       fa.h1 = a.h1, fa.h2 = hout, fa.R = R, fa.B = B, fa.N = N;
       // tile-major rows between the fused kernels (train_ff_fused.h): everything but the stem's output and the head's input
       // (+ h1 itself only as what the backward kernels want of it: the xhat3 fragments and 1 / std, TL_H1_FRAG)
@@ -2201,7 +2202,7 @@ int dfx_denoiser_train_forward(const dfx_denoiser_weights *wt, void *workspace, 
         aa.h = a.hin, aa.h1 = a.h1, aa.N = N, aa.R = R;
         dfx::afused::k_attn_fwd_fused<<<(int)((R / 32 + dfx::afused::NW - 1) / dfx::afused::NW), dfx::afused::NW * 64, 0, st>>>(aa);
       }
-#ifndef DFX_TRACE_FF   // (the phase-trace build stamps single-block launches)
+#if !defined(DFX_TRACE_FF) || defined(DFX_TRACE_FF_CHAIN)   // (the phase-trace build stamps single-block launches unless asked for the chain)
       if (t_attn_in_ff) {   // all blocks in ONE launch (k_ff_fwd_chain): collected here, launched behind the last one
         chain.blk[i] = fa;
         if (i + 1 == wt->depth) {

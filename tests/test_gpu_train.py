@@ -321,7 +321,11 @@ def test_attention_inside_the_feed_forward_kernels_matches_the_separate_attentio
     for k, gr in apart["grads"].items():
         worst = max(worst, np.abs(inside["grads"][k] - gr).max() / max(np.abs(gr).max(), 1e-30))
     print(f"attention inside vs beside the feed-forward kernels: eps max-abs {e_eps:.1e}, gradients worst max-norm {worst:.1e}")
-    assert e_eps < 1e-5 and worst < 4e-3
+    # Round 6: the default forward (ff_fwd) evaluates the GEGLU with the sampling kernel's packed-fp16 polynomial and GEMM2 as an fp16 product; the
+    # separate-attention variant keeps round 5's forward body (fp32 sigmoid form, bf16 GEMM2): the two forwards now differ by the distance between
+    # the two GELU formulations — measured eps 1.7e-3, gradients 2.0e-3 of max-abs (gates at 3x / 2x; both forwards sit inside the bf16 gates against the
+    # fp32 oracle, test_bf16_matrix_products_within_stated_tolerance).  Until round 5: identical eps (< 1e-5).
+    assert e_eps < 5e-3 and worst < 4e-3
 
 
 def test_fused_training_step_is_bit_reproducible():
