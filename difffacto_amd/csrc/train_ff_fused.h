@@ -654,6 +654,28 @@ constexpr int NW_BWD = 4;   // wavefronts per workgroup, backward: 128 points; t
 constexpr int NW_FWD = DFX_FF_NW_FWD;   // forward: 128 points and 77 KiB of LDS, TWO workgroups per CU — one's row loads / stores run under the other's chunk loop
 template <bool BWD> constexpr int nw_of() { return BWD ? NW_BWD : NW_FWD; }
 constexpr int NBUF = 3;   // LDS chunk buffers: the stream runs two chunks ahead of the compute
+#ifndef DFX_FF_BWD_SPREAD
+#define DFX_FF_BWD_SPREAD 0   // (measured round 6, same box: 279.3 vs 278.0 us per block — no gain in the backward; the forward keeps its spread)
+#endif
+// s_setprio experiments (round 6, same-box A/Bs, profiles/r06_ab_train_prio.txt): raising a wavefront's priority inside its VALU stretch (the sampling
+// kernel runs its V slots at 3) helps the forward (652 -> 637 us) and HURTS the backward (278 -> 283 per block) and the weight-gradient kernel's
+// producer (224 -> 244): there the other wavefront of the SIMD is the one feeding the matrix pipe
+#ifndef DFX_FF_VPRIO_FWD
+#define DFX_FF_VPRIO_FWD 3
+#endif
+#ifndef DFX_FF_VPRIO_BWD
+#define DFX_FF_VPRIO_BWD 0
+#endif
+#ifndef DFX_FF_MPRIO_BWD
+#define DFX_FF_MPRIO_BWD 0   // priority inside the backward's MFMA bursts
+#endif
+#ifndef DFX_WG_PPRIO
+#define DFX_WG_PPRIO 0       // k_ff_wgrad: producer's GEGLU arithmetic
+#endif
+#ifndef DFX_WG_CPRIO
+#define DFX_WG_CPRIO 0       // k_ff_wgrad: consumer's 24-MFMA stretch
+#endif
+constexpr bool BWD_SPREAD = DFX_FF_BWD_SPREAD != 0;   // backward: ring pieces issued inside the MFMA bursts (see the loop)
 // (measured, B = 128 x 2048, backward / forward per block: 8 waves x 3 buffers 441 / 161 us; 4 waves x 2 buffers, two workgroups
 // per CU, 513 / 161 us; 8 x 2: 662 / 182 us)
 
@@ -992,8 +1014,17 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       // wait at the item boundary below (at most the newest pieces outstanding) covers it; one register instead of the tile's eight words
       // (inline asm: hipcc's own wait for a load it knows would be vmcnt(0) at the first use — behind the NEXT item's pieces)
       if (DROP && !(j & 1)) asm volatile("global_load_dword %0, %1, off" : "=v"(dmw) : "v"(dmk + (j >> 1) * 64) : "memory");
-      if (2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
+      if (!BWD_SPREAD && 2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
     }
+    // Round 6 (BWD_SPREAD): the wave's pieces of the next chunk's two items are issued from INSIDE the two MFMA bursts, one behind every fourth MFMA (six
+    // of item 2 j + 2 in the first burst, four of item 2 j + 3 in the second) instead of back to back in front of them, where each LDS-DMA instruction
+    // cost the wave ~100 cycles of issue (MI355X_MICROARCH.md).  Same slots, same counted waits.  The last chunk has nothing to request: its pieces go
+    // to a 1 KiB dump nobody reads (no branch in the bursts).
+    const bool nxt = j + 1 < NCHUNK;
+    const char *isrc = reinterpret_cast<const char *>(a.frags + (size_t)(nxt ? j + 1 : j) * CHUNK_U4) + wave * 1024;
+    const unsigned idst0 = nxt ? lds0 + ((2 * j + 2) % 3) * BUF_BYTES + wave * 1024 : lds0 + TAB_GB3;
+    const unsigned idst1 = nxt ? lds0 + ((2 * j + 3) % 3) * BUF_BYTES + wave * 1024 : lds0 + TAB_GB3;
+    const unsigned istep = nxt ? 4096u : 0u;
     const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (BWD ? (2 * j) % 3 : j % NBUF) * BUF_BYTES) + lane;
     auto frag = [&](int t, int u) -> uint4 { return fr[(lt<BWD>(t) * 2 + u) * 64]; };
     // ---- [a | g] = b1 + W1 xn3 ----
@@ -1055,11 +1086,16 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
 #pragma unroll
       for (int r = 0; r < 16; ++r) dhid[r] = 0.f;
       __builtin_amdgcn_sched_barrier(0);
+      if (DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(DFX_FF_MPRIO_BWD);
 #pragma unroll
       for (int m = 0; m < 24; ++m) {
         if (m >= 16) dhid = mfma(P[m & 7], dhb[(m - 16) >> 1][(m - 16) & 1], dhid);
         else if (m & 1) gv = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], gv);
         else av = mfma(P[m & 7], xn[m >> 2][(m >> 1) & 1], av);
+        if (BWD_SPREAD && m % 4 == 0) {   // piece k of item 2 j + 2 (tiles 0..7, 12..15 of the next chunk): destination KiB 4 k + wave, source KiB + 8 from 16 on
+          const int k = m / 4;
+          dma1k(isrc + (k < 4 ? k * 4 : k * 4 + 8) * 1024, voff, idst0 + k * istep);
+        }
         if (m + 8 < 24) P[m & 7] = f1(m + 8);
       }
 #pragma unroll
@@ -1072,12 +1108,13 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       // top of this chunk, may still be out), every wave is done with item 2 j -> its slot takes item 2 j + 3.  The boundary sits in FRONT
       // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
       FFT(10);
+      if (DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(0);
       if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");
       FFT(11);
       __syncthreads();
       FFT(12);
-      if (2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
+      if (!BWD_SPREAD && 2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
       const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
       // second burst, MFMA m: row tile ct = m & 3, operand q = m >> 2 (W1a^T unit 0, unit 1, W1g^T unit 0, unit 1: the order per accumulator)
       auto f2 = [&](int m) -> uint4 { return fr2[(lt<BWD>(((m >> 2) < 2 ? T_W1AT : T_W1GT) + (m & 3)) * 2 + ((m >> 2) & 1)) * 64]; };
@@ -1088,6 +1125,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
         drop_select(dhid, (j & 1) ? dmw >> 16 : dmw);
       }
       // ---- GEGLU backward on the registers ----
+      if (DFX_FF_VPRIO_BWD) __builtin_amdgcn_s_setprio(DFX_FF_VPRIO_BWD);
       v16f da, dg;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1103,11 +1141,14 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       }
       const uint4 a0 = pack8(da, 0), a1 = pack8(da, 1), g0 = pack8(dg, 0), g1 = pack8(dg, 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (DFX_FF_VPRIO_BWD) __builtin_amdgcn_s_setprio(0);
+      if (DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(DFX_FF_MPRIO_BWD);
       // ---- dxn3 += W1a^T da + W1g^T dg ----
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int q = m >> 2;
         acc[m & 3] = mfma(P[m & 7], q == 0 ? a0 : q == 1 ? a1 : q == 2 ? g0 : g1, acc[m & 3]);
+        if (BWD_SPREAD && m % 4 == 0) dma1k(isrc + (32 + m) * 1024, voff, idst1 + (m / 4) * istep);   // piece m / 4 of item 2 j + 3 (tiles 16..23)
         if (m + 8 < 16) P[m & 7] = f2(m + 8);
       }
 #pragma unroll
@@ -1117,6 +1158,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (BWD && DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(0);
     // chunk j + 1 must have landed: loads complete in order, so "at most PIECES outstanding" leaves only chunk j + 2's pieces
     // (whatever the order between loads and the backward's stores); no new pieces in the last two iterations -> drain
     FFT(13);
@@ -1624,6 +1666,7 @@ __device__ __forceinline__ void ff_fwd(const FfArgs &a, const FfArgs &next, cons
     __builtin_amdgcn_sched_barrier(0);
     uint4 hh[2];
     h2 aa[8], gg[8];
+    if (DFX_FF_VPRIO_FWD) __builtin_amdgcn_s_setprio(DFX_FF_VPRIO_FWD);
     if (S2) {
       if (DROP) {   // dropout behind the GEGLU of chunk j - 1 (attention.py:84), selected on `a`: element (row, unit 32 (j - 1) + 8 q + 4 hf + m) = group row * 64 + 4 (j - 1) + q
         const int jj = j - 1;
@@ -1644,6 +1687,7 @@ __device__ __forceinline__ void ff_fwd(const FfArgs &a, const FfArgs &next, cons
       geglu16_f16_math(aa, gg, hh);
       asm volatile("" : "+v"(hh[0].x), "+v"(hh[0].y), "+v"(hh[0].z), "+v"(hh[0].w), "+v"(hh[1].x), "+v"(hh[1].y), "+v"(hh[1].z), "+v"(hh[1].w));
     }
+    if (DFX_FF_VPRIO_FWD) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -1959,7 +2003,9 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
         v16f av, gv, dv;
         mm(k, av, gv, dv);
         if (k < 12) FFT(14);
+        if (DFX_WG_PPRIO) __builtin_amdgcn_s_setprio(DFX_WG_PPRIO);
         act(k, av, gv, dv);
+        if (DFX_WG_PPRIO) __builtin_amdgcn_s_setprio(0);
         if (k < 12) FFT(13);
       }
     }
@@ -2006,6 +2052,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_T + ((k - 1) & 1) * 16384) - 16 * 64 + lane;   // (index the slot by PK_XNT, PK_DHT)
     const uint4 *pi = packs + (((k - 1) & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
     const uint4 h0 = pi[0 * 64], h1 = pi[1 * 64], a0 = pi[2 * 64], a1 = pi[3 * 64], g0 = pi[4 * 64], g1 = pi[5 * 64];
+    if (DFX_WG_CPRIO) __builtin_amdgcn_s_setprio(DFX_WG_CPRIO);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 x0 = tl[(PK_XNT * 8 + c * 2 + 0) * 64], x1 = tl[(PK_XNT * 8 + c * 2 + 1) * 64];
@@ -2014,6 +2061,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       dWa[c] = mfma(a1, x1, mfma(a0, x0, dWa[c]));
       dWg[c] = mfma(g1, x1, mfma(g0, x0, dWg[c]));
     }
+    if (DFX_WG_CPRIO) __builtin_amdgcn_s_setprio(0);
     if (k < 12) FFT(23);
   }
   float *out = a.part + ((size_t)slab * NCHUNK + j) * 12 * 1024 + lane;

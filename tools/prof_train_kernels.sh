@@ -2,7 +2,7 @@
 # Per-kernel time of the training iteration (GPU box): tools/prof_train_kernels.sh [out.csv]   (kernel-trace only, no counters)
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$(realpath -m ${1:-$R/gpurun_out/train_kernel_stats.csv})
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kst
-rocprofv3 --kernel-trace --stats -d /tmp/kst --output-format csv -- python $R/tools/bench_train.py > /tmp/kst.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kst --output-format csv -- python $R/tools/bench_train.py $BENCH_ARGS > /tmp/kst.log 2>&1
 F=$(find /tmp/kst -name "*kernel_stats.csv" | head -1)
 mkdir -p $(dirname $OUT); cp $F $OUT
 python - "$OUT" <<'PY'
