@@ -212,7 +212,12 @@ constexpr int DM_WORDS = 10, DM_TILE = DM_WORDS * 64;   // dwords per 32-point t
 // 4 hf .. 4 hf + 3 of every group (accumulator layout: register 4 q + m = element 8 q + 4 hf + m), so the pair computes each group ONCE (half hf
 // takes groups hf and hf + 2) and trades the halves with four v_permlane32_swap.  w[q] = the two words (4 draws) of this lane's elements of group q.
 __device__ __forceinline__ void drop_words(const DropKey &k, unsigned site, unsigned long long g8, int hf, unsigned (&w)[4][2]) {
+#ifdef DFX_ABL_DROP_RNG   // (ablation builds only: wrong factors, no Philox rounds)
+  const unsigned q = (unsigned)g8 * 2654435761u + site;
+  uint4 A = make_uint4(q, q ^ k.k0, q + k.k1, q ^ 0x9E3779B9u), B = make_uint4(q + 1, q ^ k.k1, q + k.k0, q ^ 0xBB67AE85u);
+#else
   uint4 A = drop_group(k, site, g8 + hf), B = drop_group(k, site, g8 + hf + 2);
+#endif
   auto swap = [](unsigned &lo, unsigned &hi) {   // -> lo = [lo of the low half-wave | hi of the low half-wave], hi = [lo of the high | hi of the high]
     const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
     lo = r[0], hi = r[1];

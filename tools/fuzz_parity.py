@@ -126,6 +126,10 @@ FAMILIES = [
      lambda: (32 * ri(3, 100),)),
     ("fused vs layer-by-layer training FF", lambda a: tt.test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(*a),
      lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 3), n, (0.2, ri(1, 10 ** 6)) if rb() else None))(32 * ri(1, 40))),   # (B, N, dropout: round 5)
+    # round 6: config 5 as shipped (bf16 products + Dropout 0.2) against the fp32 autograd oracle DIRECTLY, Philox factors replayed at the reference's
+    # sites; both bf16 paths (fused kernels / layer-by-layer), the path asserted from the library's record
+    ("bf16 + dropout vs oracle (replayed factors)", lambda a: tt.test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(*a),
+     lambda: (lambda n: (max(1, -(-256 // n)) + ri(0, 2), n, "fused" if rb() else "layer"))(32 * ri(1, 48))),
 ]
 
 for name in ("test_fps_matches_oracle", "test_ball_query_matches_oracle"):
