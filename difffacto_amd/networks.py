@@ -118,7 +118,9 @@ class AnchorDiffAE(nn.Module):
     def cache_noise(self, pcds, device, eval_whole=False):
         """anchor_gen.py:807-815 (cIMLE noise caching of stage 2): the best of ``sample_noise_num`` aligner noises per shape."""
         if eval_whole:
-            _unsupported("cache_noise(eval_whole=True)")
+            # (the reference's own eval_whole branch cannot run: it unpacks FIVE values from the encoder's six-tuple, anchor_gen.py:819 vs
+            # part_encoders.py:1254 — ValueError before any arithmetic; no shipped config sets eval_whole: nothing to mirror)
+            _unsupported("cache_noise(eval_whole=True) (the reference's branch raises ValueError at anchor_gen.py:819)")
         noise, idx = self.encoder.sample_noise(pcds, device, self.sample_noise_num)
         return noise[torch.arange(noise.shape[0], device=noise.device), idx]
 
