@@ -63,6 +63,15 @@ class PointNetV2Weights(ctypes.Structure):
                [(n, (c_fp * 2) * 2) for n in ("head_bn_w", "head_bn_b", "head_bn_mean", "head_bn_var")]
 
 
+DFX_MLP_MAX_LAYERS = 4
+
+
+class SharedMlpTrain(ctypes.Structure):
+    """dfx_shared_mlp_train (include/dfx.h): the PointNet++ shared MLP in training mode."""
+    _fields_ = [("layers", ctypes.c_int), ("ch", ctypes.c_int * (DFX_MLP_MAX_LAYERS + 1))] + \
+               [(n, c_fp * DFX_MLP_MAX_LAYERS) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var")] + [("bn_eps", ctypes.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/dfx.h declares
 _I, _F, _P, _U64, _SZ, _D = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_double
 SIGNATURES = {
@@ -112,6 +121,9 @@ SIGNATURES = {
     "dfx_shared_mlp_is_fused": (_I, [_P]),
     "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfx_fp_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfx_shared_mlp_train_workspace_bytes": (_SZ, [ctypes.POINTER(SharedMlpTrain), _I, _I, _I]),
+    "dfx_shared_mlp_train_forward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dfx_shared_mlp_train_backward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, ctypes.POINTER(SharedMlpTrain), _P, _I, _I, _I, _I, _P]),
     "dfx_emd_workspace_bytes": (_SZ, [_I, _I]),
     "dfx_emd_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "dfx_emd_backward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

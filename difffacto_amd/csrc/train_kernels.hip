@@ -2082,6 +2082,124 @@ int lin_g4(hipStream_t st, const float *X, int ldx, long long x_gs, const float 
   return dfx::check_launch("train: grouped linear");
 }
 
+
+// ---- shared MLP of the PointNet++ layers in training mode (dfx_shared_mlp_train_*; pointnet2_modules.py:9-19, :62-70): the grouped tensor as rows,
+// then PointNetV2's building blocks (lin, bn_fwd / bn_bwd with batch statistics, wgrad), a max over the neighbourhood with its arg-max ----
+// x (B, Cc, L) -> rows (B L, ldr) [c < Cc; the padding columns Cc .. ldr - 1 are zeroed], one 32 x 32 tile per workgroup through LDS (both sides coalesced)
+__global__ void k_smt_to_rows(const float *__restrict__ x, float *__restrict__ rows, int Cc, long long L, int ldr) {
+  __shared__ float tile[32][33];
+  const float *xb = x + (size_t)blockIdx.z * Cc * L;
+  float *rb = rows + (size_t)blockIdx.z * L * ldr;
+  const long long l0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) tile[k][tx] = (c0 + k < Cc && l0 + tx < L) ? xb[(size_t)(c0 + k) * L + l0 + tx] : 0.f;
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (l0 + k < L && c0 + tx < ldr) rb[(size_t)(l0 + k) * ldr + c0 + tx] = tile[tx][k];
+}
+// rows (B L, ldr) -> x (B, Cc, L)
+__global__ void k_smt_from_rows(const float *__restrict__ rows, float *__restrict__ x, int Cc, long long L, int ldr) {
+  __shared__ float tile[32][33];
+  const float *rb = rows + (size_t)blockIdx.z * L * ldr;
+  float *xb = x + (size_t)blockIdx.z * Cc * L;
+  const long long l0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) tile[k][tx] = (l0 + k < L && c0 + tx < Cc) ? rb[(size_t)(l0 + k) * ldr + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < Cc && l0 + tx < L) xb[(size_t)(c0 + k) * L + l0 + tx] = tile[tx][k];
+}
+// max over the ns rows of a group (F.max_pool2d over nsample: the FIRST maximum wins, like torch's CPU / CUDA pooling kernels on ties): y (G ns, Cc) ->
+// out (B, Cc, M) with G = B M, arg (G, Cc) = the winning row of the group
+__global__ void k_smt_pool_fwd(const float *__restrict__ y, float *__restrict__ out, int32_t *__restrict__ arg, int M, int ns, int Cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long g = blockIdx.y;
+  if (c >= Cc) return;
+  const float *p = y + (size_t)g * ns * Cc + c;
+  float best = p[0];
+  int at = 0;
+  for (int s = 1; s < ns; ++s) {
+    const float v = p[(size_t)s * Cc];
+    if (v > best || (v != v && best == best)) best = v, at = s;   // (a NaN wins, as in torch)
+  }
+  const long long b = g / M, m = g % M;
+  out[((size_t)b * Cc + c) * M + m] = best;
+  arg[(size_t)g * Cc + c] = at;
+}
+// dy (G ns, Cc) = d_out (B, Cc, M) at the group's winning row, zero elsewhere
+__global__ void k_smt_pool_bwd(const float *__restrict__ d_out, const int32_t *__restrict__ arg, float *__restrict__ dy, int M, int ns, int Cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long g = blockIdx.y;
+  if (c >= Cc) return;
+  const long long b = g / M, m = g % M;
+  const float v = d_out[((size_t)b * Cc + c) * M + m];
+  const int at = arg[(size_t)g * Cc + c];
+  float *p = dy + (size_t)g * ns * Cc + c;
+  for (int s = 0; s < ns; ++s) p[(size_t)s * Cc] = s == at ? v : 0.f;
+}
+// a layer without BatchNorm: y = relu(z) (z already carries the convolution's bias), dz = dy (z > 0)
+__global__ void k_smt_relu(const float *__restrict__ z, float *__restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fmaxf(z[i], 0.f);
+}
+__global__ void k_smt_relu_bwd(const float *__restrict__ dy, const float *__restrict__ z, float *__restrict__ dz, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = z[i] > 0.f ? dy[i] : 0.f;
+}
+struct SmtWs {
+  float *rows0, *z[DFX_MLP_MAX_LAYERS], *y[DFX_MLP_MAX_LAYERS], *mean[DFX_MLP_MAX_LAYERS], *rstd[DFX_MLP_MAX_LAYERS];
+  int32_t *arg;
+  float *dA, *dB, *wpad, *wT, *dwpad;
+  PnWs pn;   // (bn_fwd / bn_bwd take their scratch — pb, sums — from a PnWs)
+  int cp0;   // ch[0] rounded up to a multiple of 8 (K of the products is consumed 8 at a time)
+};
+size_t carve_smt(SmtWs &w, void *base, const dfx_shared_mlp_train *t, long long R, long long G) {
+  Carver c{static_cast<char *>(base)};
+  w.cp0 = (t->ch[0] + 7) / 8 * 8;
+  w.rows0 = c.take<float>((size_t)R * w.cp0);
+  int cmax = w.cp0;
+  size_t wmax = 0;
+  for (int l = 0; l < t->layers; ++l) {
+    const int co = t->ch[l + 1], ci = l == 0 ? w.cp0 : t->ch[l];
+    w.z[l] = c.take<float>((size_t)R * co);
+    w.y[l] = c.take<float>((size_t)R * co);
+    w.mean[l] = c.take<float>(co);
+    w.rstd[l] = c.take<float>(co);
+    cmax = std::max(cmax, co);
+    wmax = std::max(wmax, (size_t)co * ci);
+  }
+  w.arg = c.take<int32_t>((size_t)G * t->ch[t->layers]);
+  w.dA = c.take<float>((size_t)R * cmax);
+  w.dB = c.take<float>((size_t)R * cmax);
+  w.wpad = c.take<float>(wmax);
+  w.wT = c.take<float>(wmax);
+  w.dwpad = c.take<float>(wmax);
+  w.pn.sums = c.take<float>(4 * 1024);
+  const size_t nslab = (size_t)((R + BN_SLAB - 1) / BN_SLAB);
+  size_t pf = nslab * 2 * (size_t)cmax;                                 // BatchNorm column-sum partials
+  pf = std::max(pf, (size_t)nslabs(R) * wmax);                         // weight-gradient partials
+  w.pn.pb.part_floats = pf;
+  w.pn.pb.part = c.take<float>(pf);
+  w.pn.pb.bpart_floats = (size_t)2048 * 1024;
+  w.pn.pb.bpart = c.take<float>(w.pn.pb.bpart_floats);
+  return c.off;
+}
+int check_smt(const dfx_shared_mlp_train *t, const void *ws, size_t ws_bytes, int B, int M, int ns, const char *what) {
+  DFX_REQUIRE(t && ws, "%s: null argument", what);
+  DFX_REQUIRE(t->layers >= 1 && t->layers <= DFX_MLP_MAX_LAYERS, "%s: 1..%d layers", what, DFX_MLP_MAX_LAYERS);
+  DFX_REQUIRE(B >= 1 && M >= 1 && ns >= 1 && (long long)B * M * ns < (1ll << 31), "%s: bad sizes", what);
+  DFX_REQUIRE(t->ch[0] >= 1, "%s: no input channels", what);
+  for (int l = 0; l < t->layers; ++l) {
+    DFX_REQUIRE(t->ch[l + 1] >= 4 && t->ch[l + 1] % 4 == 0 && t->ch[l + 1] <= 1024, "%s: layer %d: %d output channels (multiple of 4, <= 1024)", what, l, t->ch[l + 1]);
+    DFX_REQUIRE(t->conv_w[l], "%s: layer %d: null weight", what, l);
+    DFX_REQUIRE(t->bn_w[l] ? (t->bn_b[l] != nullptr) : true, "%s: layer %d: BatchNorm weight without bias", what, l);
+  }
+  SmtWs w;
+  const size_t need = carve_smt(w, nullptr, t, (long long)B * M * ns, (long long)B * M);
+  DFX_REQUIRE(ws_bytes >= need, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+  DFX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "%s: workspace must be 256-byte aligned", what);
+  return DFX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -2702,6 +2820,96 @@ int dfx_prior_loss_backward(const float *const *flow, int flow_depth, int flow_h
   if (d_part_code) k_flow_scatter<<<(Rf * ZD + 255) / 256, 256, 0, st>>>(dy, d_part_code, B);
   g_prec = prec_saved;
   return dfx::check_launch("prior_loss_backward");
+}
+
+// ---- PointNet++ shared MLP, training mode ----
+size_t dfx_shared_mlp_train_workspace_bytes(const dfx_shared_mlp_train *t, int B, int M, int ns) {
+  if (!t || t->layers < 1 || t->layers > DFX_MLP_MAX_LAYERS || B < 1 || M < 1 || ns < 1) return 0;
+  SmtWs w;
+  return carve_smt(w, nullptr, t, (long long)B * M * ns, (long long)B * M);
+}
+
+int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *t, void *workspace, size_t workspace_bytes, const float *x, float *out, int B, int M,
+                                 int ns, int pool, float momentum, dfx_stream_t stream) {
+  int rc = check_smt(t, workspace, workspace_bytes, B, M, ns, "shared_mlp_train_forward");
+  if (rc) return rc;
+  DFX_REQUIRE(x && out, "shared_mlp_train_forward: null tensor");
+  const int prec_saved = g_prec;
+  g_prec = DFX_PREC_F32;
+  hipStream_t st = dfx::as_stream(stream);
+  const long long G = (long long)B * M, R = G * ns, L = (long long)M * ns;
+  SmtWs w;
+  carve_smt(w, workspace, t, R, G);
+  k_smt_to_rows<<<dim3((unsigned)((L + 31) / 32), (w.cp0 + 31) / 32, B), 256, 0, st>>>(x, w.rows0, t->ch[0], L, w.cp0);
+  const float *in = w.rows0;
+  int K = w.cp0;
+  for (int l = 0; l < t->layers; ++l) {
+    const int co = t->ch[l + 1];
+    const float *W = t->conv_w[l];
+    if (l == 0 && w.cp0 != t->ch[0]) {
+      k_pad_cols<<<(co * w.cp0 + 255) / 256, 256, 0, st>>>(t->conv_w[0], w.wpad, co, t->ch[0], w.cp0);
+      W = w.wpad;
+    }
+    if ((rc = lin(st, in, K, W, t->conv_b[l], w.z[l], co, R, co, K))) break;
+    if (t->bn_w[l]) {
+      if ((rc = bn_fwd(st, w.pn, w.z[l], R, co, t->bn_w[l], t->bn_b[l], t->bn_mean[l], t->bn_var[l], momentum, t->bn_eps, w.mean[l], w.rstd[l], w.y[l], true))) break;
+    } else {
+      k_smt_relu<<<(int)((R * co + 255) / 256), 256, 0, st>>>(w.z[l], w.y[l], R * co);
+    }
+    in = w.y[l], K = co;
+  }
+  g_prec = prec_saved;
+  if (rc) return rc;
+  const int cl = t->ch[t->layers];
+  if (pool) k_smt_pool_fwd<<<dim3((cl + 63) / 64, (unsigned)G), 64, 0, st>>>(in, out, w.arg, M, ns, cl);
+  else k_smt_from_rows<<<dim3((unsigned)((L + 31) / 32), (cl + 31) / 32, B), 256, 0, st>>>(in, out, cl, L, cl);
+  return dfx::check_launch("shared_mlp_train_forward");
+}
+
+int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *t, void *workspace, size_t workspace_bytes, const float *d_out,
+                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, dfx_stream_t stream) {
+  int rc = check_smt(t, workspace, workspace_bytes, B, M, ns, "shared_mlp_train_backward");
+  if (rc) return rc;
+  DFX_REQUIRE(d_out && grads, "shared_mlp_train_backward: null argument");
+  for (int l = 0; l < t->layers; ++l)
+    DFX_REQUIRE(grads->conv_w[l] && (t->conv_b[l] ? grads->conv_b[l] != nullptr : true) && (t->bn_w[l] ? grads->bn_w[l] && grads->bn_b[l] : true),
+                "shared_mlp_train_backward: null gradient buffer in layer %d", l);
+  const int prec_saved = g_prec;
+  g_prec = DFX_PREC_F32;
+  hipStream_t st = dfx::as_stream(stream);
+  const long long G = (long long)B * M, R = G * ns, L = (long long)M * ns;
+  SmtWs w;
+  carve_smt(w, workspace, t, R, G);
+  const int cl = t->ch[t->layers];
+  float *dy = w.dA, *other = w.dB;
+  if (pool) k_smt_pool_bwd<<<dim3((cl + 63) / 64, (unsigned)G), 64, 0, st>>>(d_out, w.arg, dy, M, ns, cl);
+  else k_smt_to_rows<<<dim3((unsigned)((L + 31) / 32), (cl + 31) / 32, B), 256, 0, st>>>(d_out, dy, cl, L, cl);
+  for (int l = t->layers - 1; l >= 0 && !rc; --l) {
+    const int co = t->ch[l + 1], ci = l == 0 ? w.cp0 : t->ch[l], ci_valid = t->ch[l];
+    const float *xin = l == 0 ? w.rows0 : w.y[l - 1];
+    float *dz = other;
+    if (t->bn_w[l]) {
+      rc = bn_bwd(st, w.pn, dy, t->bn_b[l], w.z[l], R, co, t->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true);
+    } else {
+      k_smt_relu_bwd<<<(int)((R * co + 255) / 256), 256, 0, st>>>(dy, w.z[l], dz, R * co);
+    }
+    if (rc) break;
+    if ((rc = wgrad(st, w.pn.pb, dz, co, xin, ci, mut(grads->conv_w[l]), t->conv_b[l] ? mut(grads->conv_b[l]) : nullptr, co, ci, ci_valid, R))) break;
+    if (l > 0 || d_x) {   // d (input rows) = dz W
+      const float *W = t->conv_w[l];
+      if (ci != ci_valid) {
+        k_pad_cols<<<(co * ci + 255) / 256, 256, 0, st>>>(t->conv_w[l], w.wpad, co, ci_valid, ci);
+        W = w.wpad;
+      }
+      transpose(st, W, w.wT, co, ci);   // (ci, co)
+      if ((rc = lin(st, dz, co, w.wT, nullptr, dy, ci, R, ci, co))) break;   // (dy's buffer is free: dz has been formed)
+    }
+    // next layer down: its dy is what was just written into `dy`; dz's buffer becomes the scratch
+  }
+  g_prec = prec_saved;
+  if (rc) return rc;
+  if (d_x) k_smt_from_rows<<<dim3((unsigned)((L + 31) / 32), (t->ch[0] + 31) / 32, B), 256, 0, st>>>(dy, d_x, t->ch[0], L, w.cp0);
+  return dfx::check_launch("shared_mlp_train_backward");
 }
 
 // The dropout factors (0 or 1 / (1 - p)) of `n` consecutive elements of a site, as the training kernels apply them

@@ -7,8 +7,10 @@ In inference (``module.eval()`` under ``torch.no_grad()``) the grouping, the sha
 (Conv2d 1x1 + BatchNorm2d with running statistics + ReLU) and the max over the neighbourhood run in
 libdfx as well (``dfx_sa_forward_f32`` / ``dfx_fp_forward_f32``: one fused launch for the SA1 / SA2
 shapes of PointNet2SSG); the module's torch parameters are only read (so checkpoints load unchanged).
-When gradients or batch statistics are needed (``train()`` or grad mode) the MLP runs through the
-module's own torch layers on the device, as in the reference.
+In ``train()`` mode (round 6) the shared MLP with BATCH-statistics BatchNorm, its running-statistics update, the max
+and their gradients run in libdfx too (``dfx_shared_mlp_train_forward`` / ``_backward`` behind an autograd Function;
+the grouping / interpolation already had native gradient kernels).  Only ``eval()`` with gradients enabled, and stacks
+the training kernels do not serve (an output width that is not a multiple of 4), run the module's own torch layers.
 """
 import ctypes
 from typing import List, Optional, Tuple
@@ -104,6 +106,120 @@ def _inference(module: nn.Module) -> bool:
     return not module.training and not torch.is_grad_enabled()
 
 
+def _train_native_ok(seq: nn.Sequential) -> bool:
+    """The training-mode kernels (dfx_shared_mlp_train_*) serve build_shared_mlp stacks of <= 4 layers whose output widths are multiples of 4, fp32 on
+    the GPU, with BatchNorm in train() mode (batch statistics); anything else stays on the module's torch layers."""
+    try:
+        layers = _NativeMLP(seq).layers
+    except NotImplementedError:
+        return False
+    if not 1 <= len(layers) <= _ffi.DFX_MLP_MAX_LAYERS:
+        return False
+    for conv, bn in layers:
+        if conv.out_channels % 4 or conv.out_channels > 1024 or conv.weight.dtype != torch.float32 or not conv.weight.is_cuda:
+            return False
+        if bn is not None and (not bn.training or not bn.affine or not bn.track_running_stats or bn.momentum is None):
+            return False
+    return True
+
+
+class _SharedMLPTrainFn(torch.autograd.Function):
+    """y = [max over nsample of] mlp(x) for a build_shared_mlp stack in TRAINING mode on libdfx (dfx_shared_mlp_train_forward / _backward): what autograd
+    through nn.Conv2d(1x1) / nn.BatchNorm2d (batch statistics, running-statistics update) / ReLU / F.max_pool2d computes in the reference
+    (pointnet2_modules.py:9-19, :62-70).  x (B, C, M, ns) -> (B, C_out, M) if pool else (B, C_out, M, ns)."""
+
+    @staticmethod
+    def forward(ctx, x, pool, layers, *params):
+        pu._chk(x, "grouped features", torch.float32)
+        B, C, M, ns = x.shape
+        L = len(layers)
+        desc = _ffi.SharedMlpTrain()
+        desc.layers = L
+        desc.ch[0] = C
+        keep, k, slots = [], 0, []
+        for l, (conv, bn) in enumerate(layers):
+            desc.ch[l + 1] = conv.out_channels
+            w = params[k].detach().reshape(conv.out_channels, conv.in_channels).contiguous()
+            k += 1
+            keep.append(w)
+            desc.conv_w[l] = w.data_ptr()
+            slot = {"w": (tuple(params[k - 1].shape), w.numel())}
+            if conv.bias is not None:
+                b = params[k].detach().contiguous()
+                k += 1
+                keep.append(b)
+                desc.conv_b[l] = b.data_ptr()
+                slot["b"] = conv.out_channels
+            if bn is not None:
+                g, be = params[k].detach().contiguous(), params[k + 1].detach().contiguous()
+                k += 2
+                keep += [g, be]
+                desc.bn_w[l], desc.bn_b[l] = g.data_ptr(), be.data_ptr()
+                desc.bn_mean[l], desc.bn_var[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                desc.bn_eps = float(bn.eps)
+                slot["bn"] = conv.out_channels
+            slots.append(slot)
+        momentum = next((float(bn.momentum) for _, bn in layers if bn is not None), -1.0)
+        lib = _ffi.lib()
+        nbytes = lib.dfx_shared_mlp_train_workspace_bytes(ctypes.byref(desc), B, M, ns)
+        if nbytes == 0:
+            raise RuntimeError("dfx_shared_mlp_train_workspace_bytes: unsupported configuration")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+        wsp = (ws.data_ptr() + 255) & ~255
+        cout = layers[-1][0].out_channels
+        out = torch.empty((B, cout, M) if pool else (B, cout, M, ns), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dfx_shared_mlp_train_forward(ctypes.byref(desc), ctypes.c_void_p(wsp), nbytes, _ffi.ptr(x), _ffi.ptr(out), B, M, ns, int(bool(pool)),
+                                                  momentum, _ffi.current_stream())
+        _ffi.check(rc, "dfx_shared_mlp_train_forward")
+        for _, bn in layers:
+            if bn is not None and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        ctx.desc, ctx.keep, ctx.ws, ctx.wsp, ctx.nbytes, ctx.slots, ctx.dims, ctx.pool = desc, keep, ws, wsp, nbytes, slots, (B, C, M, ns), bool(pool)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, C, M, ns = ctx.dims
+        d_out = d_out.contiguous()
+        dev = d_out.device
+        g = _ffi.SharedMlpTrain()
+        g.layers = ctx.desc.layers
+        grads = []
+        for l, slot in enumerate(ctx.slots):
+            shape, n = slot["w"]
+            dw = torch.empty(n, dtype=torch.float32, device=dev)
+            g.conv_w[l] = dw.data_ptr()
+            grads.append(dw.view(shape))
+            if "b" in slot:
+                db = torch.empty(slot["b"], dtype=torch.float32, device=dev)
+                g.conv_b[l] = db.data_ptr()
+                grads.append(db)
+            if "bn" in slot:
+                dg, dbe = torch.empty(slot["bn"], dtype=torch.float32, device=dev), torch.empty(slot["bn"], dtype=torch.float32, device=dev)
+                g.bn_w[l], g.bn_b[l] = dg.data_ptr(), dbe.data_ptr()
+                grads += [dg, dbe]
+        d_x = torch.empty(B, C, M, ns, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(dev):
+            rc = _ffi.lib().dfx_shared_mlp_train_backward(ctypes.byref(ctx.desc), ctypes.c_void_p(ctx.wsp), ctx.nbytes, _ffi.ptr(d_out), ctypes.byref(g), _ffi.ptr(d_x),
+                                                          B, M, ns, int(ctx.pool), _ffi.current_stream())
+        _ffi.check(rc, "dfx_shared_mlp_train_backward")
+        return (d_x, None, None, *grads)
+
+
+def shared_mlp_train(seq: nn.Sequential, x: torch.Tensor, pool: bool) -> torch.Tensor:
+    """``mlp(x)`` [+ max over the last axis] of a ``build_shared_mlp`` stack in training mode on libdfx (see ``_SharedMLPTrainFn``)."""
+    layers = _NativeMLP(seq).layers
+    params = []
+    for conv, bn in layers:
+        params.append(conv.weight)
+        if conv.bias is not None:
+            params.append(conv.bias)
+        if bn is not None:
+            params += [bn.weight, bn.bias]
+    return _SharedMLPTrainFn.apply(x.contiguous(), pool, layers, *params)
+
+
 class _PointnetSAModuleBase(nn.Module):
     """FPS -> gather centres -> per scale: group -> shared MLP -> max over the neighbourhood
     (pointnet2_modules.py:22-74)."""
@@ -156,7 +272,10 @@ class _PointnetSAModuleBase(nn.Module):
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if _inference(self):
                 pooled.append(self._forward_native(k, xyz, new_xyz, features))
-            else:
+            elif self.training and xyz.is_cuda and _train_native_ok(mlp):
+                # train(): grouping (libdfx, with its gradient kernels) -> Conv2d 1x1 + BatchNorm2d (batch statistics) + ReLU -> max, natively (round 6)
+                pooled.append(shared_mlp_train(mlp, grouper(xyz, new_xyz, features), pool=True))
+            else:   # eval() with gradients enabled (BatchNorm on its running statistics under autograd), or a stack the training kernels do not serve
                 nbh = mlp(grouper(xyz, new_xyz, features))   # (B, mlp[-1], npoint, nsample)
                 pooled.append(nbh.amax(dim=3))               # max_pool2d over nsample, squeezed
         return new_xyz, torch.cat(pooled, dim=1)
@@ -226,4 +345,6 @@ class PointnetFPModule(nn.Module):
             weight = inv / inv.sum(dim=2, keepdim=True)
             interp = pu.three_interpolate(known_feats, idx, weight)
         stacked = interp if unknow_feats is None else torch.cat([interp, unknow_feats], dim=1)
+        if self.training and stacked.is_cuda and _train_native_ok(self.mlp):
+            return shared_mlp_train(self.mlp, stacked.unsqueeze(-1), pool=False).squeeze(-1)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

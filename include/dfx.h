@@ -320,7 +320,7 @@ int dfx_aligner_train_backward(const dfx_latent_weights *w, void *workspace, siz
  * (pointnet2_ops_lib/pointnet2_ops/pointnet2_utils.py:296-333, :349-381) + build_shared_mlp's Conv2d 1x1 +
  * BatchNorm2d + ReLU stack (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:9-19) + max_pool2d over nsample
  * (:62-70), and PointnetFPModule.forward (:170-209).  BatchNorm uses its running statistics (folded into the
- * convolution at create time); training-mode statistics are not this path.
+ * convolution at create time); training mode: dfx_shared_mlp_train_* below.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dfx_shared_mlp dfx_shared_mlp; /* opaque; owns folded/packed weights + a grow-only workspace */
 
@@ -345,6 +345,33 @@ int dfx_sa_forward_f32(dfx_shared_mlp *h, const float *xyz, const float *new_xyz
  * known_feats (B,C2,m) [(B,C2,1) when known is NULL] -> out (B, C_out, n). */
 int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *known, const float *unknow_feats,
                        const float *known_feats, float *out, int B, int n, int m, int C1, int C2, dfx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The same shared MLP in TRAINING mode (round 6): build_shared_mlp's Conv2d 1x1 [+ BatchNorm2d with BATCH statistics and the running-
+ * statistics update of nn.BatchNorm2d: momentum, unbiased variance] + ReLU stack over a grouped tensor, + max over nsample
+ * (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:9-19, :62-70; PointnetFPModule's mlp :170-209 with pool = 0), forward with saved
+ * activations and backward — what autograd through nn.Conv2d / nn.BatchNorm2d / F.max_pool2d computes in the reference.  Exact fp32.
+ *   x (B, ch[0], M, ns) = the grouper's output (QueryAndGroup / GroupAll through dfx_group_points, or the interpolated + skip features with
+ *   ns = 1); out (B, ch[layers], M) when pool != 0, else (B, ch[layers], M, ns).  ch[l] % 4 == 0 for l >= 1; layers <= DFX_MLP_MAX_LAYERS.
+ *   conv_b[l] == NULL when the layer has BatchNorm (bn_w[l] != NULL); bn_mean / bn_var: running statistics, updated IN PLACE by the forward
+ *   when momentum >= 0.  grads: the same struct whose conv_w / conv_b / bn_w / bn_b name WRITABLE buffers of the parameters' shapes.
+ *   d_x (B, ch[0], M, ns) or NULL.  workspace: dfx_shared_mlp_train_workspace_bytes, 256-byte aligned; the backward reads what the forward of
+ *   the SAME (B, M, ns) call left in it.
+ * ------------------------------------------------------------------------------------------ */
+#define DFX_MLP_MAX_LAYERS 4
+typedef struct dfx_shared_mlp_train {
+  int layers;
+  int ch[DFX_MLP_MAX_LAYERS + 1];
+  const float *conv_w[DFX_MLP_MAX_LAYERS], *conv_b[DFX_MLP_MAX_LAYERS];
+  const float *bn_w[DFX_MLP_MAX_LAYERS], *bn_b[DFX_MLP_MAX_LAYERS];
+  float *bn_mean[DFX_MLP_MAX_LAYERS], *bn_var[DFX_MLP_MAX_LAYERS];
+  float bn_eps;
+} dfx_shared_mlp_train;
+size_t dfx_shared_mlp_train_workspace_bytes(const dfx_shared_mlp_train *w, int B, int M, int ns);
+int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *w, void *workspace, size_t workspace_bytes, const float *x, float *out, int B, int M,
+                                 int ns, int pool, float momentum, dfx_stream_t stream);
+int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *w, void *workspace, size_t workspace_bytes, const float *d_out,
+                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, dfx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * PointNetV2 masked max-pool part encoder, eval mode — python/difffacto/models/encoders/pointnet.py:124-213

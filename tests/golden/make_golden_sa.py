@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Golden vectors for the PointNet++ set-abstraction / feature-propagation MODULES.
 
-    python tests/golden/make_golden_sa.py          # dev container only; writes tests/golden/sa_*.npz, samsg_*.npz, fp_*.npz
+    python tests/golden/make_golden_sa.py          # dev container only; writes tests/golden/sa_*.npz, samsg_*.npz, fp_*.npz, satrain_*.npz, fptrain_*.npz
 
 Runs the REFERENCE's own Python classes (pointnet2_ops_lib/pointnet2_ops/pointnet2_{utils,modules}.py:
 QueryAndGroup, GroupAll, PointnetSAModule, PointnetFPModule, build_shared_mlp) on CPU tensors in eval mode.  Their CUDA
@@ -114,6 +114,63 @@ def gen_sa_msg(pm, tag, B, N, C, mlps, npoint, radii, nsamples, bn, use_xyz, see
     print("wrote samsg_" + tag, new_feats.shape, float(new_feats.abs().max()))
 
 
+def _train_step(mod, inputs, rng):
+    """train() forward + backward of a reference module on CPU: out, a random upstream gradient, parameter gradients, input gradients,
+    BatchNorm running statistics behind the forward."""
+    mod.train()
+    W0 = {k: v.numpy().copy() for k, v in mod.state_dict().items() if not k.endswith("num_batches_tracked")}
+    res = mod(*inputs)
+    out = res[1] if isinstance(res, tuple) else res
+    gout = rng.standard_normal(tuple(out.shape)).astype(F32)
+    out.backward(torch.from_numpy(gout))
+    d = {"new_features": out.detach().numpy().astype(F32), "gout": gout}
+    d.update({"w." + k: v for k, v in W0.items()})
+    d.update({"g." + k: p.grad.numpy().astype(F32) for k, p in mod.named_parameters()})
+    d.update({"after." + k: v.numpy().copy() for k, v in mod.state_dict().items() if "running_" in k})
+    return res, d
+
+
+def gen_sa_train(pm, tag, B, N, C, mlps, npoint, radii, nsamples, bn, use_xyz, seed):
+    """PointnetSAModule(MSG) in train() mode (BatchNorm2d on batch statistics, autograd through grouping / conv / max_pool2d) — the reference's Python
+    classes over the C-oracle shim, whose *_grad entry points serve the backward."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xyz = rng.uniform(-1, 1, size=(B, N, 3)).astype(F32)
+    feats = rng.standard_normal((B, C, N)).astype(F32) if C else None
+    mod = pm.PointnetSAModuleMSG(npoint=npoint, radii=list(radii), nsamples=list(nsamples), mlps=[list(m) for m in mlps], bn=bn, use_xyz=use_xyz)
+    randomize(mod, rng)
+    tx = torch.from_numpy(xyz).requires_grad_(True)
+    tf = None if feats is None else torch.from_numpy(feats).requires_grad_(True)
+    res, out = _train_step(mod, (tx, tf), rng)
+    out.update(dict(xyz=xyz, npoint=np.array(-1 if npoint is None else npoint), radii=np.array([0.0 if r is None else r for r in radii], F32),
+                    nsamples=np.array([-1 if n is None else n for n in nsamples]), bn=np.array(int(bn)), use_xyz=np.array(int(use_xyz)), n_scales=np.array(len(mlps))))
+    if res[0] is not None:
+        out["new_xyz"] = res[0].detach().numpy().astype(F32)
+    if tx.grad is not None:
+        out["d_xyz"] = tx.grad.numpy().astype(F32)
+    for i, m in enumerate(mlps):
+        out[f"mlp{i}"] = np.array(m)
+    if feats is not None:
+        out["features"], out["d_features"] = feats, tf.grad.numpy().astype(F32)
+    np.savez_compressed(os.path.join(HERE, f"satrain_{tag}.npz"), **out)
+    print("wrote satrain_" + tag, out["new_features"].shape, float(np.abs(out["new_features"]).max()))
+
+
+def gen_fp_train(pm, tag, B, n, m, C1, C2, mlp, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    unknown = rng.uniform(-1, 1, size=(B, n, 3)).astype(F32)
+    known = rng.uniform(-1, 1, size=(B, m, 3)).astype(F32)
+    uf = rng.standard_normal((B, C1, n)).astype(F32)
+    kf = rng.standard_normal((B, C2, m)).astype(F32)
+    mod = pm.PointnetFPModule(mlp=list(mlp))
+    randomize(mod, rng)
+    tu, tk = torch.from_numpy(uf).requires_grad_(True), torch.from_numpy(kf).requires_grad_(True)
+    _, out = _train_step(mod, (torch.from_numpy(unknown), torch.from_numpy(known), tu, tk), rng)
+    out.update(dict(unknown=unknown, known=known, unknow_feats=uf, known_feats=kf, mlp=np.array(mlp), d_unknow_feats=tu.grad.numpy().astype(F32),
+                    d_known_feats=tk.grad.numpy().astype(F32)))
+    np.savez_compressed(os.path.join(HERE, f"fptrain_{tag}.npz"), **out)
+    print("wrote fptrain_" + tag, out["new_features"].shape)
+
+
 def gen_fp(pm, tag, B, n, m, C1, C2, mlp, seed):
     rng = np.random.Generator(np.random.PCG64(seed))
     unknown = rng.uniform(-1, 1, size=(B, n, 3)).astype(F32)
@@ -146,6 +203,11 @@ def main():
                nsamples=[16, 32, 128], bn=True, use_xyz=True, seed=47)
     gen_sa_msg(pm, "msg2_small", B=2, N=64, C=320, mlps=[[320, 64, 64, 128], [320, 128, 128, 256]], npoint=16, radii=[0.5, 1.0],
                nsamples=[32, 64], bn=True, use_xyz=True, seed=48)
+    # train() mode (round 6): batch-statistics BatchNorm + autograd, the layers' native training kernels (dfx_shared_mlp_train_*) are checked against these
+    gen_sa_train(pm, "ssg_small", B=3, N=160, C=4, mlps=[[4, 32, 32, 64]], npoint=24, radii=[0.5], nsamples=[16], bn=True, use_xyz=True, seed=51)
+    gen_sa_train(pm, "msg_small", B=2, N=128, C=6, mlps=[[6, 16, 32], [6, 32, 48]], npoint=16, radii=[0.4, 0.8], nsamples=[8, 24], bn=True, use_xyz=True, seed=52)
+    gen_sa_train(pm, "nobn_groupall", B=2, N=40, C=5, mlps=[[5, 24, 40]], npoint=None, radii=[None], nsamples=[None], bn=False, use_xyz=False, seed=53)
+    gen_fp_train(pm, "small", B=2, n=50, m=20, C1=6, C2=10, mlp=[16, 32, 24], seed=54)
 
 
 if __name__ == "__main__":

@@ -193,3 +193,105 @@ def test_fused_set_abstraction_variants_vs_general(B, N, npoint, nsample, mlp):
     assert torch.equal(out_f, again)
     _close(out_f, out_g)
     _close(out_f, out_t.detach())
+
+
+# ---- train() mode (round 6): the shared MLP with batch-statistics BatchNorm, the max and their gradients on libdfx (dfx_shared_mlp_train_*) against goldens the
+# reference's own classes produced under autograd (tests/golden/satrain_*.npz, fptrain_*.npz: make_golden_sa.py).  fp32 sums in another order than torch's,
+# a BatchNorm in between: 2e-4 x max(1, |ref|) on outputs / running statistics, gradients 5e-4 of their max-abs (measured ~1e-5). ----
+def _load_train(module, g):
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    for k in module.state_dict():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = module.state_dict()[k]
+    module.load_state_dict(sd)
+    return module.cuda().train()
+
+
+def _check_train(mod, g, out, extra):
+    from difffacto_amd import _ffi
+    _close(out, g["new_features"], 2e-4)
+    out.backward(torch.from_numpy(g["gout"]).cuda())
+    worst, at = 0.0, None
+    grads = {k: p.grad for k, p in mod.named_parameters()}
+    grads.update(extra())
+    n = 0
+    for k in g.files:
+        if k.startswith("g.") or k.startswith("d_"):
+            ref = g[k]
+            got = grads[k[2:] if k.startswith("g.") else k].detach().cpu().numpy()
+            assert got.shape == ref.shape, (k, got.shape, ref.shape)
+            e = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+            assert e <= 5e-4, (k, e)
+            if e > worst:
+                worst, at = e, k
+            n += 1
+    sd = mod.state_dict()
+    for k in g.files:
+        if k.startswith("after."):
+            _close(sd[k[6:]], g[k], 2e-4)
+    for name, buf in mod.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(buf) == 1, name
+    return n, worst, at
+
+
+@pytest.mark.parametrize("tag", ["ssg_small", "msg_small", "nobn_groupall"])
+def test_sa_module_train_mode_is_native_and_matches_reference_autograd(tag, monkeypatch):
+    from difffacto_amd.pointnet2_ops import pointnet2_modules as pm
+    g = np.load(os.path.join(GOLDEN, f"satrain_{tag}.npz"))
+    S = int(g["n_scales"])
+    npoint = int(g["npoint"])
+    mod = pm.PointnetSAModuleMSG(npoint=None if npoint < 0 else npoint, radii=[None if npoint < 0 else float(r) for r in g["radii"]],
+                                 nsamples=[None if npoint < 0 else int(n) for n in g["nsamples"]], mlps=[[int(v) for v in g[f"mlp{i}"]] for i in range(S)],
+                                 bn=bool(g["bn"]), use_xyz=bool(g["use_xyz"]))
+    mod = _load_train(mod, g)
+    for seq in mod.mlps:   # the module's torch layers must not run: the native path or nothing
+        for layer in seq:
+            if not isinstance(layer, torch.nn.ReLU):
+                monkeypatch.setattr(layer, "forward", lambda *a, **k: (_ for _ in ()).throw(AssertionError("torch layer used in train mode")))
+    xyz = torch.from_numpy(g["xyz"]).cuda().requires_grad_(True)
+    feats = torch.from_numpy(g["features"]).cuda().requires_grad_(True) if "features" in g.files else None
+    new_xyz, out = mod(xyz, feats)
+    if npoint >= 0:
+        assert np.array_equal(new_xyz.detach().cpu().numpy(), g["new_xyz"])
+    n, worst, at = _check_train(mod, g, out, lambda: {"d_xyz": xyz.grad, **({} if feats is None else {"d_features": feats.grad})})
+    print(f"satrain_{tag}: out {tuple(out.shape)}, {n} gradient tensors vs the reference's autograd, worst {worst:.1e} of max-abs ({at})")
+
+
+def test_fp_module_train_mode_is_native_and_matches_reference_autograd(monkeypatch):
+    from difffacto_amd.pointnet2_ops import pointnet2_modules as pm
+    g = np.load(os.path.join(GOLDEN, "fptrain_small.npz"))
+    mod = _load_train(pm.PointnetFPModule(mlp=[int(v) for v in g["mlp"]]), g)
+    for layer in mod.mlp:
+        if not isinstance(layer, torch.nn.ReLU):
+            monkeypatch.setattr(layer, "forward", lambda *a, **k: (_ for _ in ()).throw(AssertionError("torch layer used in train mode")))
+    c = lambda k: torch.from_numpy(g[k]).cuda()
+    uf, kf = c("unknow_feats").requires_grad_(True), c("known_feats").requires_grad_(True)
+    out = mod(c("unknown"), c("known"), uf, kf)
+    n, worst, at = _check_train(mod, g, out, lambda: {"d_unknow_feats": uf.grad, "d_known_feats": kf.grad})
+    print(f"fptrain_small: out {tuple(out.shape)}, {n} gradient tensors, worst {worst:.1e} of max-abs ({at})")
+
+
+def test_shared_mlp_train_against_torch_layers_at_pointnet2_ssg_sizes():
+    """SA1 of PointNet2SSG (mlp [3 + 3, 64, 64, 128], 512 centres x 32 neighbours, B = 4) and a 1024-wide layer: the native training op against the
+    module's own torch layers (cuDNN-free: Conv2d / BatchNorm2d on the same device) — output, running statistics, every gradient."""
+    from difffacto_amd.pointnet2_ops import pointnet2_modules as pm
+    for spec, B, M, ns, pool in (([6, 64, 64, 128], 4, 512, 32, True), ([259, 256, 512, 1024], 2, 1, 128, True), ([131, 128, 128], 2, 300, 1, False)):
+        ref = _randomize(pm.build_shared_mlp(list(spec), bn=True), 7).train()
+        mine = _randomize(pm.build_shared_mlp(list(spec), bn=True), 7).train()
+        x = torch.randn(B, spec[0], M, ns, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        xr, xm = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        yr = ref(xr).amax(dim=3) if pool else ref(xr)
+        ym = pm.shared_mlp_train(mine, xm, pool=pool)
+        gout = torch.randn_like(yr)
+        yr.backward(gout)
+        ym.backward(gout)
+        _close(ym, yr.detach(), 2e-4)
+        worst = float((xm.grad - xr.grad).abs().max() / xr.grad.abs().max())
+        for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            worst = max(worst, float((p.grad - q.grad).abs().max() / q.grad.abs().max().clamp_min(1e-30)))
+        for (k, b), (_, c) in zip(mine.named_buffers(), ref.named_buffers()):
+            if "running" in k:
+                _close(b, c, 2e-4)
+        print(f"shared MLP train {spec} x (B={B}, M={M}, ns={ns}): worst gradient error {worst:.1e} of max-abs")
+        assert worst <= 1e-3, worst
