@@ -122,8 +122,8 @@ SIGNATURES = {
     "dfx_sa_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfx_fp_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfx_shared_mlp_train_workspace_bytes": (_SZ, [ctypes.POINTER(SharedMlpTrain), _I, _I, _I]),
-    "dfx_shared_mlp_train_forward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "dfx_shared_mlp_train_backward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, ctypes.POINTER(SharedMlpTrain), _P, _I, _I, _I, _I, _P]),
+    "dfx_shared_mlp_train_forward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "dfx_shared_mlp_train_backward": (_I, [ctypes.POINTER(SharedMlpTrain), _P, _SZ, _P, ctypes.POINTER(SharedMlpTrain), _P, _I, _I, _I, _I, _I, _P]),
     "dfx_emd_workspace_bytes": (_SZ, [_I, _I]),
     "dfx_emd_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "dfx_emd_backward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

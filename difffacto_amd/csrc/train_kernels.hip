@@ -1980,13 +1980,16 @@ int bn_fwd(hipStream_t st, const PnWs &w, const float *z, long long R, int Cc, c
   return dfx::check_launch("train: bn_fwd");
 }
 // dz from dy (gradient at the output of [relu] BN); d gamma, d beta written
+// batch_stats = false: BatchNorm in eval() mode under autograd (mean / rstd are the running statistics, constants): dz = g rstd gm — the two
+// correction terms of the batch-statistics form carry the factor 1 / R, which is passed as 0
 int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *be, const float *z, long long R, int Cc, const float *g,
-           const float *mean, const float *rstd, float *dz, float *dgamma, float *dbeta, bool relu) {
+           const float *mean, const float *rstd, float *dz, float *dgamma, float *dbeta, bool relu, bool batch_stats = true) {
+  const float invR = batch_stats ? 1.0f / (float)R : 0.0f;
   const int ns = (int)((R + BN_SLAB - 1) / BN_SLAB);
   const dim3 grid((Cc + 63) / 64, ns);
   if (R <= BN_SLAB && dz != dy && g_bn_fused_stats) {   // few rows: column sums + apply in one launch, the same bits (dz must not alias dy: the sums read all of dy first)
-    if (relu) k_bn_small_bwd<true><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, 1.0f / (float)R);
-    else k_bn_small_bwd<false><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, 1.0f / (float)R);
+    if (relu) k_bn_small_bwd<true><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, invR);
+    else k_bn_small_bwd<false><<<(Cc + 63) / 64, 256, 0, st>>>(dy, z, mean, rstd, g, be, dbeta, dgamma, dz, (int)R, Cc, invR);
     return dfx::check_launch("train: bn_bwd");
   }
   if (relu) k_bn_bwd_part<true><<<grid, 256, 0, st>>>(dy, z, mean, rstd, g, be, w.pb.part, R, Cc);
@@ -1994,8 +1997,8 @@ int bn_bwd(hipStream_t st, const PnWs &w, const float *dy, const float *be, cons
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part, dbeta, ns, Cc, 2 * Cc);
   k_sum_parts<<<(Cc + 31) / 32, 1024, 0, st>>>(w.pb.part + Cc, dgamma, ns, Cc, 2 * Cc);
   const long long total = R * Cc;
-  if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
-  else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, 1.0f / (float)R, total, Cc);
+  if (relu) k_bn_bwd_apply<true><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, invR, total, Cc);
+  else k_bn_bwd_apply<false><<<(int)((total / 4 + 255) / 256), 256, 0, st>>>(dy, be, z, mean, rstd, g, dbeta, dgamma, dz, invR, total, Cc);
   return dfx::check_launch("train: bn_bwd");
 }
 int check_pn(const dfx_pointnet_v2_weights *wt, const void *ws, size_t ws_bytes, int B, int N, const char *what) {
@@ -2145,6 +2148,12 @@ __global__ void k_smt_relu(const float *__restrict__ z, float *__restrict__ y, l
 __global__ void k_smt_relu_bwd(const float *__restrict__ dy, const float *__restrict__ z, float *__restrict__ dz, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dz[i] = z[i] > 0.f ? dy[i] : 0.f;
+}
+// eval() mode under autograd: the layer normalises with its running statistics
+__global__ void k_smt_running_stats(const float *__restrict__ run_mean, const float *__restrict__ run_var, float *__restrict__ mean, float *__restrict__ rstd,
+                                    float eps, int Cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < Cc) mean[c] = run_mean[c], rstd[c] = 1.0f / sqrtf(run_var[c] + eps);
 }
 struct SmtWs {
   float *rows0, *z[DFX_MLP_MAX_LAYERS], *y[DFX_MLP_MAX_LAYERS], *mean[DFX_MLP_MAX_LAYERS], *rstd[DFX_MLP_MAX_LAYERS];
@@ -2830,7 +2839,7 @@ size_t dfx_shared_mlp_train_workspace_bytes(const dfx_shared_mlp_train *t, int B
 }
 
 int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *t, void *workspace, size_t workspace_bytes, const float *x, float *out, int B, int M,
-                                 int ns, int pool, float momentum, dfx_stream_t stream) {
+                                 int ns, int pool, int batch_stats, float momentum, dfx_stream_t stream) {
   int rc = check_smt(t, workspace, workspace_bytes, B, M, ns, "shared_mlp_train_forward");
   if (rc) return rc;
   DFX_REQUIRE(x && out, "shared_mlp_train_forward: null tensor");
@@ -2851,8 +2860,12 @@ int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *t, void *workspace,
       W = w.wpad;
     }
     if ((rc = lin(st, in, K, W, t->conv_b[l], w.z[l], co, R, co, K))) break;
-    if (t->bn_w[l]) {
+    if (t->bn_w[l] && batch_stats) {
       if ((rc = bn_fwd(st, w.pn, w.z[l], R, co, t->bn_w[l], t->bn_b[l], t->bn_mean[l], t->bn_var[l], momentum, t->bn_eps, w.mean[l], w.rstd[l], w.y[l], true))) break;
+    } else if (t->bn_w[l]) {   // eval(): running statistics, nothing updated
+      if (!t->bn_mean[l] || !t->bn_var[l]) { rc = dfx::set_error(DFX_ERR_INVALID_ARG, "shared_mlp_train_forward: layer %d: running statistics required", l); break; }
+      k_smt_running_stats<<<(co + 255) / 256, 256, 0, st>>>(t->bn_mean[l], t->bn_var[l], w.mean[l], w.rstd[l], t->bn_eps, co);
+      k_bn_apply<true><<<(int)((R * co / 4 + 255) / 256), 256, 0, st>>>(w.z[l], w.mean[l], w.rstd[l], t->bn_w[l], t->bn_b[l], w.y[l], R * co, co);
     } else {
       k_smt_relu<<<(int)((R * co + 255) / 256), 256, 0, st>>>(w.z[l], w.y[l], R * co);
     }
@@ -2867,7 +2880,7 @@ int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *t, void *workspace,
 }
 
 int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *t, void *workspace, size_t workspace_bytes, const float *d_out,
-                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, dfx_stream_t stream) {
+                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, int batch_stats, dfx_stream_t stream) {
   int rc = check_smt(t, workspace, workspace_bytes, B, M, ns, "shared_mlp_train_backward");
   if (rc) return rc;
   DFX_REQUIRE(d_out && grads, "shared_mlp_train_backward: null argument");
@@ -2889,7 +2902,7 @@ int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *t, void *workspace
     const float *xin = l == 0 ? w.rows0 : w.y[l - 1];
     float *dz = other;
     if (t->bn_w[l]) {
-      rc = bn_bwd(st, w.pn, dy, t->bn_b[l], w.z[l], R, co, t->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true);
+      rc = bn_bwd(st, w.pn, dy, t->bn_b[l], w.z[l], R, co, t->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true, batch_stats != 0);
     } else {
       k_smt_relu_bwd<<<(int)((R * co + 255) / 256), 256, 0, st>>>(dy, w.z[l], dz, R * co);
     }

@@ -9,8 +9,9 @@ libdfx as well (``dfx_sa_forward_f32`` / ``dfx_fp_forward_f32``: one fused launc
 shapes of PointNet2SSG); the module's torch parameters are only read (so checkpoints load unchanged).
 In ``train()`` mode (round 6) the shared MLP with BATCH-statistics BatchNorm, its running-statistics update, the max
 and their gradients run in libdfx too (``dfx_shared_mlp_train_forward`` / ``_backward`` behind an autograd Function;
-the grouping / interpolation already had native gradient kernels).  Only ``eval()`` with gradients enabled, and stacks
-the training kernels do not serve (an output width that is not a multiple of 4), run the module's own torch layers.
+the grouping / interpolation already had native gradient kernels); ``eval()`` with gradients enabled takes the same kernels
+with the running statistics.  Only stacks the training kernels do not serve (an output width that is not a multiple of 4)
+run the module's own torch layers.
 """
 import ctypes
 from typing import List, Optional, Tuple
@@ -107,8 +108,8 @@ def _inference(module: nn.Module) -> bool:
 
 
 def _train_native_ok(seq: nn.Sequential) -> bool:
-    """The training-mode kernels (dfx_shared_mlp_train_*) serve build_shared_mlp stacks of <= 4 layers whose output widths are multiples of 4, fp32 on
-    the GPU, with BatchNorm in train() mode (batch statistics); anything else stays on the module's torch layers."""
+    """The training kernels (dfx_shared_mlp_train_*) serve build_shared_mlp stacks of <= 4 layers whose output widths are multiples of 4, fp32 on the
+    GPU, BatchNorm in train() mode (batch statistics) or in eval() mode under autograd (running statistics); anything else stays on the torch layers."""
     try:
         layers = _NativeMLP(seq).layers
     except NotImplementedError:
@@ -118,9 +119,10 @@ def _train_native_ok(seq: nn.Sequential) -> bool:
     for conv, bn in layers:
         if conv.out_channels % 4 or conv.out_channels > 1024 or conv.weight.dtype != torch.float32 or not conv.weight.is_cuda:
             return False
-        if bn is not None and (not bn.training or not bn.affine or not bn.track_running_stats or bn.momentum is None):
+        if bn is not None and (not bn.affine or not bn.track_running_stats or bn.momentum is None):
             return False
-    return True
+    modes = {bn.training for _, bn in layers if bn is not None}
+    return len(modes) <= 1   # (all BatchNorm layers in the same mode: batch statistics or running statistics)
 
 
 class _SharedMLPTrainFn(torch.autograd.Function):
@@ -160,6 +162,7 @@ class _SharedMLPTrainFn(torch.autograd.Function):
                 slot["bn"] = conv.out_channels
             slots.append(slot)
         momentum = next((float(bn.momentum) for _, bn in layers if bn is not None), -1.0)
+        batch_stats = int(next((bn.training for _, bn in layers if bn is not None), True))
         lib = _ffi.lib()
         nbytes = lib.dfx_shared_mlp_train_workspace_bytes(ctypes.byref(desc), B, M, ns)
         if nbytes == 0:
@@ -170,12 +173,12 @@ class _SharedMLPTrainFn(torch.autograd.Function):
         out = torch.empty((B, cout, M) if pool else (B, cout, M, ns), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = lib.dfx_shared_mlp_train_forward(ctypes.byref(desc), ctypes.c_void_p(wsp), nbytes, _ffi.ptr(x), _ffi.ptr(out), B, M, ns, int(bool(pool)),
-                                                  momentum, _ffi.current_stream())
+                                                  batch_stats, momentum, _ffi.current_stream())
         _ffi.check(rc, "dfx_shared_mlp_train_forward")
         for _, bn in layers:
-            if bn is not None and bn.num_batches_tracked is not None:
+            if bn is not None and batch_stats and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
-        ctx.desc, ctx.keep, ctx.ws, ctx.wsp, ctx.nbytes, ctx.slots, ctx.dims, ctx.pool = desc, keep, ws, wsp, nbytes, slots, (B, C, M, ns), bool(pool)
+        ctx.desc, ctx.keep, ctx.ws, ctx.wsp, ctx.nbytes, ctx.slots, ctx.dims, ctx.pool, ctx.batch_stats = desc, keep, ws, wsp, nbytes, slots, (B, C, M, ns), bool(pool), batch_stats
         return out
 
     @staticmethod
@@ -202,7 +205,7 @@ class _SharedMLPTrainFn(torch.autograd.Function):
         d_x = torch.empty(B, C, M, ns, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(dev):
             rc = _ffi.lib().dfx_shared_mlp_train_backward(ctypes.byref(ctx.desc), ctypes.c_void_p(ctx.wsp), ctx.nbytes, _ffi.ptr(d_out), ctypes.byref(g), _ffi.ptr(d_x),
-                                                          B, M, ns, int(ctx.pool), _ffi.current_stream())
+                                                          B, M, ns, int(ctx.pool), ctx.batch_stats, _ffi.current_stream())
         _ffi.check(rc, "dfx_shared_mlp_train_backward")
         return (d_x, None, None, *grads)
 
@@ -272,10 +275,10 @@ class _PointnetSAModuleBase(nn.Module):
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if _inference(self):
                 pooled.append(self._forward_native(k, xyz, new_xyz, features))
-            elif self.training and xyz.is_cuda and _train_native_ok(mlp):
-                # train(): grouping (libdfx, with its gradient kernels) -> Conv2d 1x1 + BatchNorm2d (batch statistics) + ReLU -> max, natively (round 6)
+            elif xyz.is_cuda and _train_native_ok(mlp):
+                # train() / eval() under autograd: grouping (libdfx, with its gradient kernels) -> Conv2d 1x1 + BatchNorm2d (batch statistics) + ReLU -> max, natively (round 6)
                 pooled.append(shared_mlp_train(mlp, grouper(xyz, new_xyz, features), pool=True))
-            else:   # eval() with gradients enabled (BatchNorm on its running statistics under autograd), or a stack the training kernels do not serve
+            else:   # a stack the training kernels do not serve (an output width that is not a multiple of 4, mixed BatchNorm modes)
                 nbh = mlp(grouper(xyz, new_xyz, features))   # (B, mlp[-1], npoint, nsample)
                 pooled.append(nbh.amax(dim=3))               # max_pool2d over nsample, squeezed
         return new_xyz, torch.cat(pooled, dim=1)
@@ -345,6 +348,6 @@ class PointnetFPModule(nn.Module):
             weight = inv / inv.sum(dim=2, keepdim=True)
             interp = pu.three_interpolate(known_feats, idx, weight)
         stacked = interp if unknow_feats is None else torch.cat([interp, unknow_feats], dim=1)
-        if self.training and stacked.is_cuda and _train_native_ok(self.mlp):
+        if stacked.is_cuda and _train_native_ok(self.mlp):
             return shared_mlp_train(self.mlp, stacked.unsqueeze(-1), pool=False).squeeze(-1)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

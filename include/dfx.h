@@ -355,7 +355,8 @@ int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *kno
  *   ns = 1); out (B, ch[layers], M) when pool != 0, else (B, ch[layers], M, ns).  ch[l] % 4 == 0 for l >= 1; layers <= DFX_MLP_MAX_LAYERS.
  *   conv_b[l] == NULL when the layer has BatchNorm (bn_w[l] != NULL); bn_mean / bn_var: running statistics, updated IN PLACE by the forward
  *   when momentum >= 0.  grads: the same struct whose conv_w / conv_b / bn_w / bn_b name WRITABLE buffers of the parameters' shapes.
- *   d_x (B, ch[0], M, ns) or NULL.  workspace: dfx_shared_mlp_train_workspace_bytes, 256-byte aligned; the backward reads what the forward of
+ *   batch_stats = 1: BatchNorm of train() mode; 0: eval() mode under autograd (the running statistics normalise, nothing is updated); the same value
+ *   for the forward and its backward.  d_x (B, ch[0], M, ns) or NULL.  workspace: dfx_shared_mlp_train_workspace_bytes, 256-byte aligned; the backward reads what the forward of
  *   the SAME (B, M, ns) call left in it.
  * ------------------------------------------------------------------------------------------ */
 #define DFX_MLP_MAX_LAYERS 4
@@ -369,9 +370,9 @@ typedef struct dfx_shared_mlp_train {
 } dfx_shared_mlp_train;
 size_t dfx_shared_mlp_train_workspace_bytes(const dfx_shared_mlp_train *w, int B, int M, int ns);
 int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *w, void *workspace, size_t workspace_bytes, const float *x, float *out, int B, int M,
-                                 int ns, int pool, float momentum, dfx_stream_t stream);
+                                 int ns, int pool, int batch_stats, float momentum, dfx_stream_t stream);
 int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *w, void *workspace, size_t workspace_bytes, const float *d_out,
-                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, dfx_stream_t stream);
+                                  const dfx_shared_mlp_train *grads, float *d_x, int B, int M, int ns, int pool, int batch_stats, dfx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * PointNetV2 masked max-pool part encoder, eval mode — python/difffacto/models/encoders/pointnet.py:124-213
