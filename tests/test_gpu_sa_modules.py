@@ -199,8 +199,8 @@ def test_fused_set_abstraction_variants_vs_general(B, N, npoint, nsample, mlp):
         assert _ffi.lib().dfx_shared_mlp_is_fused(mod._native(0).handle()) == 1
         out_g = mod._forward_native(0, xyz, new_xyz, feats, force_general=True)
         again = mod._forward_native(0, xyz, new_xyz, feats)
-    with torch.enable_grad():
-        _, out_t = mod(xyz, feats)
+    with torch.no_grad():
+        _, out_t = _torch_layers(mod, xyz, feats)
     assert torch.equal(out_f, again)
     _close(out_f, out_g)
     _close(out_f, out_t.detach())
