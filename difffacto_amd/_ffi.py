@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdfx.so")
 DFX_PREC_F32 = 0
 DFX_PREC_BF16 = 1
 DFX_MAX_DEPTH = 8
-DFX_ABI_VERSION = 4   # include/dfx.h: the argument lists this binding was written against
+DFX_ABI_VERSION = 5   # include/dfx.h: the argument lists this binding was written against
 
 
 class DfxLibraryError(RuntimeError):

@@ -39,10 +39,11 @@ typedef void *dfx_stream_t;
 
 int dfx_version(void);
 /* Bumped whenever an existing entry point changes its argument list (round 2 inserted `shape_offset` into the four sampling
- * calls: 2; round 4 added dfx_last_kernel_variant: 3 — additive, bumped so that a binding written against 3 does not load a library without it).
+ * calls: 2; round 4 added dfx_last_kernel_variant: 3 — additive, bumped so that a binding written against 3 does not load a library without it;
+ * round 5: d_x / d_variances of the denoiser backward: 4; round 6 added dfx_shared_mlp_train_*: 5).
  * Bindings compare dfx_abi_version() with the DFX_ABI_VERSION they were written against at load time (_ffi.py does)
  * instead of shifting arguments silently. */
-#define DFX_ABI_VERSION 4
+#define DFX_ABI_VERSION 5
 int dfx_abi_version(void);
 const char *dfx_last_error(void);
 
