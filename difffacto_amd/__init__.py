@@ -20,7 +20,7 @@ def install(register_in_reference=True, full=False):
       entries are left alone (the reference's own encoder then serves every option it has); accelerate the generation entry point
       of a built model with ``difffacto_amd.encoders.attach(model.encoder)``;
     * ``full=True``: also ``MODELS['AnchorDiffAE']``, ``ENCODERS['PartEncoderForTransformerDecoder' / 'PointNetV2' /
-      'PartAlignerTransformer']`` and ``SAMPLERS['Uniform']`` -> the mirrors of ``networks.py`` / ``encoders.py`` (the shipped
+      'PartAlignerTransformer' / 'PointNet2SSG' / 'PointNet2MSG']`` and ``SAMPLERS['Uniform']`` -> the mirrors of ``networks.py`` / ``encoders.py`` (the shipped
       gen_* / train_*_stage1 configurations run end to end on libdfx; any other option raises NotImplementedError).
     """
     from . import pointnet2_ops
@@ -40,7 +40,7 @@ def install(register_in_reference=True, full=False):
             from . import encoders, networks
             MODELS._modules["AnchorDiffAE"] = networks.AnchorDiffAE
             SAMPLERS._modules["Uniform"] = networks.Uniform
-            for name in ("PartEncoderForTransformerDecoder", "PointNetV2", "PartAlignerTransformer"):
+            for name in ("PartEncoderForTransformerDecoder", "PointNetV2", "PartAlignerTransformer", "PointNet2SSG", "PointNet2MSG"):
                 ENCODERS._modules[name] = getattr(encoders, name)
         return True
     return False

@@ -69,7 +69,7 @@ DFX_MLP_MAX_LAYERS = 4
 class SharedMlpTrain(ctypes.Structure):
     """dfx_shared_mlp_train (include/dfx.h): the PointNet++ shared MLP in training mode."""
     _fields_ = [("layers", ctypes.c_int), ("ch", ctypes.c_int * (DFX_MLP_MAX_LAYERS + 1))] + \
-               [(n, c_fp * DFX_MLP_MAX_LAYERS) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var")] + [("bn_eps", ctypes.c_float)]
+               [(n, c_fp * DFX_MLP_MAX_LAYERS) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var")] + [("bn_eps", ctypes.c_float), ("relu_mask", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/dfx.h declares

@@ -2860,16 +2860,21 @@ int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *t, void *workspace,
       W = w.wpad;
     }
     if ((rc = lin(st, in, K, W, t->conv_b[l], w.z[l], co, R, co, K))) break;
+    const bool relu = (t->relu_mask >> l) & 1u;
+    const float *act = w.y[l];
     if (t->bn_w[l] && batch_stats) {
-      if ((rc = bn_fwd(st, w.pn, w.z[l], R, co, t->bn_w[l], t->bn_b[l], t->bn_mean[l], t->bn_var[l], momentum, t->bn_eps, w.mean[l], w.rstd[l], w.y[l], true))) break;
+      if ((rc = bn_fwd(st, w.pn, w.z[l], R, co, t->bn_w[l], t->bn_b[l], t->bn_mean[l], t->bn_var[l], momentum, t->bn_eps, w.mean[l], w.rstd[l], w.y[l], relu))) break;
     } else if (t->bn_w[l]) {   // eval(): running statistics, nothing updated
       if (!t->bn_mean[l] || !t->bn_var[l]) { rc = dfx::set_error(DFX_ERR_INVALID_ARG, "shared_mlp_train_forward: layer %d: running statistics required", l); break; }
       k_smt_running_stats<<<(co + 255) / 256, 256, 0, st>>>(t->bn_mean[l], t->bn_var[l], w.mean[l], w.rstd[l], t->bn_eps, co);
-      k_bn_apply<true><<<(int)((R * co / 4 + 255) / 256), 256, 0, st>>>(w.z[l], w.mean[l], w.rstd[l], t->bn_w[l], t->bn_b[l], w.y[l], R * co, co);
-    } else {
+      if (relu) k_bn_apply<true><<<(int)((R * co / 4 + 255) / 256), 256, 0, st>>>(w.z[l], w.mean[l], w.rstd[l], t->bn_w[l], t->bn_b[l], w.y[l], R * co, co);
+      else k_bn_apply<false><<<(int)((R * co / 4 + 255) / 256), 256, 0, st>>>(w.z[l], w.mean[l], w.rstd[l], t->bn_w[l], t->bn_b[l], w.y[l], R * co, co);
+    } else if (relu) {
       k_smt_relu<<<(int)((R * co + 255) / 256), 256, 0, st>>>(w.z[l], w.y[l], R * co);
+    } else {
+      act = w.z[l];   // a plain linear layer: its output is what the next layer (or the caller) sees
     }
-    in = w.y[l], K = co;
+    in = act, K = co;
   }
   g_prec = prec_saved;
   if (rc) return rc;
@@ -2899,12 +2904,16 @@ int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *t, void *workspace
   else k_smt_to_rows<<<dim3((unsigned)((L + 31) / 32), (cl + 31) / 32, B), 256, 0, st>>>(d_out, dy, cl, L, cl);
   for (int l = t->layers - 1; l >= 0 && !rc; --l) {
     const int co = t->ch[l + 1], ci = l == 0 ? w.cp0 : t->ch[l], ci_valid = t->ch[l];
-    const float *xin = l == 0 ? w.rows0 : w.y[l - 1];
+    const bool relu = (t->relu_mask >> l) & 1u;
+    const bool plain_below = l > 0 && !t->bn_w[l - 1] && !((t->relu_mask >> (l - 1)) & 1u);   // (the layer below handed its z on: see the forward)
+    const float *xin = l == 0 ? w.rows0 : plain_below ? w.z[l - 1] : w.y[l - 1];
     float *dz = other;
     if (t->bn_w[l]) {
-      rc = bn_bwd(st, w.pn, dy, t->bn_b[l], w.z[l], R, co, t->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), true, batch_stats != 0);
-    } else {
+      rc = bn_bwd(st, w.pn, dy, t->bn_b[l], w.z[l], R, co, t->bn_w[l], w.mean[l], w.rstd[l], dz, mut(grads->bn_w[l]), mut(grads->bn_b[l]), relu, batch_stats != 0);
+    } else if (relu) {
       k_smt_relu_bwd<<<(int)((R * co + 255) / 256), 256, 0, st>>>(dy, w.z[l], dz, R * co);
+    } else {
+      dz = dy;   // plain linear layer
     }
     if (rc) break;
     if ((rc = wgrad(st, w.pn.pb, dz, co, xin, ci, mut(grads->conv_w[l]), t->conv_b[l] ? mut(grads->conv_b[l]) : nullptr, co, ci, ci_valid, R))) break;
@@ -2915,7 +2924,9 @@ int dfx_shared_mlp_train_backward(const dfx_shared_mlp_train *t, void *workspace
         W = w.wpad;
       }
       transpose(st, W, w.wT, co, ci);   // (ci, co)
-      if ((rc = lin(st, dz, co, w.wT, nullptr, dy, ci, R, ci, co))) break;   // (dy's buffer is free: dz has been formed)
+      float *dprev = dz == dy ? other : dy;   // (dy's buffer is free once dz has been formed; a plain layer's dz IS dy: the other buffer then)
+      if ((rc = lin(st, dz, co, w.wT, nullptr, dprev, ci, R, ci, co))) break;
+      if (dprev != dy) std::swap(dy, other);
     }
     // next layer down: its dy is what was just written into `dy`; dz's buffer becomes the scratch
   }

@@ -12,8 +12,8 @@
 All math runs in libdfx (``dfx_sample_latents`` / ``dfx_part_aligner`` / ``dfx_flow_reverse``); the modules only hold
 parameters under the reference's ``state_dict`` keys and draw the random inputs with ``torch.randn`` exactly where
 the reference does.  Option combinations outside the shipped ``configs/gen_*.py`` raise ``NotImplementedError``.
-``PointNetV2`` (the encode-side part encoder) is native in inference as well; the training losses of
-``PartEncoder.forward`` are not part of this path.
+``PointNetV2`` (the encode-side part encoder) is native in inference as well; ``PointNet2SSG`` / ``PointNet2MSG``
+(pointnet2.py, round 6) compose the mirrored set-abstraction layers.
 """
 import ctypes
 import math
@@ -157,6 +157,69 @@ class PointNetV2(nn.Module):
                          "call in torch.no_grad(), or call .train() for the stage-1 training step")
         _unsupported(f"PointNetV2.train() needs batch >= 2 (BatchNorm batch statistics), num_anchors == 4 and zdim % 4 == 0; "
                      f"got B={B}, num_anchors={A}, zdim={self.zdim}")
+
+
+class PointNet2SSG(nn.Module):
+    """``ENCODERS['PointNet2SSG']`` (python/difffacto/models/encoders/pointnet2.py:7-79): three set-abstraction layers (2048 -> 512 centres, r = 0.2, 64
+    neighbours; -> 128, r = 0.4; -> global) and a Linear / BatchNorm1d / ReLU / Dropout head -> (B, num_anchors, zdim).  Same constructor (the reference's
+    spelling ``additioinal_dim`` included), same ``state_dict`` keys (``SA_modules.{i}.mlps.{k}.{j}.*``, ``fc_layer.{0,1,3,4,7}.*``).  Registered by the
+    reference, selected by none of the shipped configs.  Everything runs on libdfx in every mode: FPS / ball query / grouping and the shared MLPs through the
+    mirrored ``PointnetSAModule`` (eval: the fused gather + MLP + max kernels; train() / autograd: ``dfx_shared_mlp_train_*``), the head through the same
+    training kernels (rows = the batch: BatchNorm1d over B); ``nn.Dropout(0.5)`` is torch's elementwise op on torch's generator, as in the reference."""
+
+    def __init__(self, additioinal_dim=4, zdim=256, num_anchors=4):
+        super().__init__()
+        self.additioinal_dim, self.zdim, self.num_anchors = additioinal_dim, zdim, num_anchors
+        self._build_model()
+
+    def _build_model(self):
+        from .pointnet2_ops.pointnet2_modules import PointnetSAModule
+        self.SA_modules = nn.ModuleList([
+            PointnetSAModule(npoint=512, radius=0.2, nsample=64, mlp=[self.additioinal_dim, 64, 64, 128], use_xyz=True),
+            PointnetSAModule(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256], use_xyz=True),
+            PointnetSAModule(mlp=[256, 256, 512, 1024], use_xyz=True)])
+        self.fc_layer = nn.Sequential(nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(True), nn.Linear(512, 256, bias=False),
+                                      nn.BatchNorm1d(256), nn.ReLU(True), nn.Dropout(0.5), nn.Linear(256, self.zdim * self.num_anchors))
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def _head(self, feat):
+        """fc_layer on libdfx: (B, 1024) -> (B, zdim * num_anchors).  The rows of the training kernels are the B shapes (x as (1, C, B, 1))."""
+        from .pointnet2_ops.pointnet2_modules import mlp_train
+        fc = self.fc_layer
+        if fc[1].training != fc[4].training:
+            _unsupported("PointNet2 head with its two BatchNorm1d layers in different modes")
+        x = feat.t().contiguous()[None, :, :, None]
+        h = mlp_train([(fc[0], fc[1]), (fc[3], fc[4])], x, pool=False)                   # Linear + BatchNorm1d + ReLU, twice
+        h = fc[6](h)                                                                       # nn.Dropout(0.5): identity in eval()
+        return mlp_train([(fc[7], None)], h, pool=False, relu_mask=0)[0, :, :, 0].t()      # Linear with bias
+
+    def forward(self, pointcloud):
+        if not pointcloud.is_cuda:
+            raise RuntimeError("PointNet2 encoder: CPU not supported")
+        B = pointcloud.shape[0]
+        xyz, features = self._break_up_pc(pointcloud)
+        for module in self.SA_modules:
+            xyz, features = module(xyz, features)
+        return self._head(features.squeeze(-1)).reshape(B, self.num_anchors, self.zdim)
+
+
+class PointNet2MSG(PointNet2SSG):
+    """``ENCODERS['PointNet2MSG']`` (pointnet2.py:82-115): the multi-scale-grouping variant (three radii per layer, channel concat)."""
+
+    def _build_model(self):
+        super()._build_model()
+        from .pointnet2_ops.pointnet2_modules import PointnetSAModule, PointnetSAModuleMSG
+        a = self.additioinal_dim
+        c1 = 64 + 128 + 128
+        self.SA_modules = nn.ModuleList([
+            PointnetSAModuleMSG(npoint=512, radii=[0.1, 0.2, 0.4], nsamples=[16, 32, 128], mlps=[[a, 32, 32, 64], [a, 64, 64, 128], [a, 64, 96, 128]], use_xyz=True),
+            PointnetSAModuleMSG(npoint=128, radii=[0.2, 0.4, 0.8], nsamples=[32, 64, 128],
+                                mlps=[[c1, 64, 64, 128], [c1, 128, 128, 256], [c1, 128, 128, 256]], use_xyz=True),
+            PointnetSAModule(mlp=[128 + 256 + 256, 256, 512, 1024], use_xyz=True)])
 
 
 class CouplingLayer(nn.Module):

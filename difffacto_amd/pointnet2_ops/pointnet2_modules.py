@@ -126,32 +126,34 @@ def _train_native_ok(seq: nn.Sequential) -> bool:
 
 
 class _SharedMLPTrainFn(torch.autograd.Function):
-    """y = [max over nsample of] mlp(x) for a build_shared_mlp stack in TRAINING mode on libdfx (dfx_shared_mlp_train_forward / _backward): what autograd
-    through nn.Conv2d(1x1) / nn.BatchNorm2d (batch statistics, running-statistics update) / ReLU / F.max_pool2d computes in the reference
-    (pointnet2_modules.py:9-19, :62-70).  x (B, C, M, ns) -> (B, C_out, M) if pool else (B, C_out, M, ns)."""
+    """y = [max over nsample of] mlp(x) for a stack of (1x1 convolution / linear layer [+ BatchNorm] [+ ReLU]) on libdfx (dfx_shared_mlp_train_forward /
+    _backward): what autograd through nn.Conv2d(1x1) / nn.BatchNorm2d / ReLU / F.max_pool2d computes in the reference (pointnet2_modules.py:9-19, :62-70).
+    x (B, C, M, ns) -> (B, C_out, M) if pool else (B, C_out, M, ns).  ``spec``: per layer (c_out, c_in, has_bias, bn module or None); ``params``: the
+    layers' weight [, bias] [, bn.weight, bn.bias] in order; BatchNorm on batch statistics when its module is in train() mode (running statistics
+    updated in place), on the running statistics otherwise."""
 
     @staticmethod
-    def forward(ctx, x, pool, layers, *params):
+    def forward(ctx, x, pool, spec, relu_mask, *params):
         pu._chk(x, "grouped features", torch.float32)
         B, C, M, ns = x.shape
-        L = len(layers)
         desc = _ffi.SharedMlpTrain()
-        desc.layers = L
+        desc.layers = len(spec)
         desc.ch[0] = C
+        desc.relu_mask = int(relu_mask)
         keep, k, slots = [], 0, []
-        for l, (conv, bn) in enumerate(layers):
-            desc.ch[l + 1] = conv.out_channels
-            w = params[k].detach().reshape(conv.out_channels, conv.in_channels).contiguous()
+        for l, (cout, cin, has_bias, bn) in enumerate(spec):
+            desc.ch[l + 1] = cout
+            w = params[k].detach().reshape(cout, cin).contiguous()
+            slot = {"w": (tuple(params[k].shape), w.numel())}
             k += 1
             keep.append(w)
             desc.conv_w[l] = w.data_ptr()
-            slot = {"w": (tuple(params[k - 1].shape), w.numel())}
-            if conv.bias is not None:
+            if has_bias:
                 b = params[k].detach().contiguous()
                 k += 1
                 keep.append(b)
                 desc.conv_b[l] = b.data_ptr()
-                slot["b"] = conv.out_channels
+                slot["b"] = cout
             if bn is not None:
                 g, be = params[k].detach().contiguous(), params[k + 1].detach().contiguous()
                 k += 2
@@ -159,24 +161,25 @@ class _SharedMLPTrainFn(torch.autograd.Function):
                 desc.bn_w[l], desc.bn_b[l] = g.data_ptr(), be.data_ptr()
                 desc.bn_mean[l], desc.bn_var[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
                 desc.bn_eps = float(bn.eps)
-                slot["bn"] = conv.out_channels
+                slot["bn"] = cout
             slots.append(slot)
-        momentum = next((float(bn.momentum) for _, bn in layers if bn is not None), -1.0)
-        batch_stats = int(next((bn.training for _, bn in layers if bn is not None), True))
+        bns = [bn for _, _, _, bn in spec if bn is not None]
+        momentum = float(bns[0].momentum) if bns else -1.0
+        batch_stats = int(bns[0].training) if bns else 1
         lib = _ffi.lib()
         nbytes = lib.dfx_shared_mlp_train_workspace_bytes(ctypes.byref(desc), B, M, ns)
         if nbytes == 0:
             raise RuntimeError("dfx_shared_mlp_train_workspace_bytes: unsupported configuration")
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
         wsp = (ws.data_ptr() + 255) & ~255
-        cout = layers[-1][0].out_channels
+        cout = spec[-1][0]
         out = torch.empty((B, cout, M) if pool else (B, cout, M, ns), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = lib.dfx_shared_mlp_train_forward(ctypes.byref(desc), ctypes.c_void_p(wsp), nbytes, _ffi.ptr(x), _ffi.ptr(out), B, M, ns, int(bool(pool)),
                                                   batch_stats, momentum, _ffi.current_stream())
         _ffi.check(rc, "dfx_shared_mlp_train_forward")
-        for _, bn in layers:
-            if bn is not None and batch_stats and bn.num_batches_tracked is not None:
+        for bn in bns:
+            if batch_stats and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
         ctx.desc, ctx.keep, ctx.ws, ctx.wsp, ctx.nbytes, ctx.slots, ctx.dims, ctx.pool, ctx.batch_stats = desc, keep, ws, wsp, nbytes, slots, (B, C, M, ns), bool(pool), batch_stats
         return out
@@ -207,20 +210,28 @@ class _SharedMLPTrainFn(torch.autograd.Function):
             rc = _ffi.lib().dfx_shared_mlp_train_backward(ctypes.byref(ctx.desc), ctypes.c_void_p(ctx.wsp), ctx.nbytes, _ffi.ptr(d_out), ctypes.byref(g), _ffi.ptr(d_x),
                                                           B, M, ns, int(ctx.pool), ctx.batch_stats, _ffi.current_stream())
         _ffi.check(rc, "dfx_shared_mlp_train_backward")
-        return (d_x, None, None, *grads)
+        return (d_x, None, None, None, *grads)
+
+
+def mlp_train(stack, x: torch.Tensor, pool: bool, relu_mask: Optional[int] = None) -> torch.Tensor:
+    """``stack``: [(layer, bn or None)] with ``layer`` an nn.Conv2d(1x1) or nn.Linear; runs it on libdfx under autograd (``_SharedMLPTrainFn``)."""
+    spec, params = [], []
+    for layer, bn in stack:
+        cout, cin = (layer.out_features, layer.in_features) if isinstance(layer, nn.Linear) else (layer.out_channels, layer.in_channels)
+        spec.append((cout, cin, layer.bias is not None, bn))
+        params.append(layer.weight)
+        if layer.bias is not None:
+            params.append(layer.bias)
+        if bn is not None:
+            params += [bn.weight, bn.bias]
+    if relu_mask is None:
+        relu_mask = (1 << len(spec)) - 1
+    return _SharedMLPTrainFn.apply(x.contiguous(), pool, spec, relu_mask, *params)
 
 
 def shared_mlp_train(seq: nn.Sequential, x: torch.Tensor, pool: bool) -> torch.Tensor:
-    """``mlp(x)`` [+ max over the last axis] of a ``build_shared_mlp`` stack in training mode on libdfx (see ``_SharedMLPTrainFn``)."""
-    layers = _NativeMLP(seq).layers
-    params = []
-    for conv, bn in layers:
-        params.append(conv.weight)
-        if conv.bias is not None:
-            params.append(conv.bias)
-        if bn is not None:
-            params += [bn.weight, bn.bias]
-    return _SharedMLPTrainFn.apply(x.contiguous(), pool, layers, *params)
+    """``mlp(x)`` [+ max over the last axis] of a ``build_shared_mlp`` stack under autograd on libdfx (see ``_SharedMLPTrainFn``)."""
+    return mlp_train(_NativeMLP(seq).layers, x, pool)
 
 
 class _PointnetSAModuleBase(nn.Module):

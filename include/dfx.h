@@ -353,7 +353,7 @@ int dfx_fp_forward_f32(dfx_shared_mlp *h, const float *unknown, const float *kno
  * (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:9-19, :62-70; PointnetFPModule's mlp :170-209 with pool = 0), forward with saved
  * activations and backward — what autograd through nn.Conv2d / nn.BatchNorm2d / F.max_pool2d computes in the reference.  Exact fp32.
  *   x (B, ch[0], M, ns) = the grouper's output (QueryAndGroup / GroupAll through dfx_group_points, or the interpolated + skip features with
- *   ns = 1); out (B, ch[layers], M) when pool != 0, else (B, ch[layers], M, ns).  ch[l] % 4 == 0 for l >= 1; layers <= DFX_MLP_MAX_LAYERS.
+ *   ns = 1; a Linear + BatchNorm1d head over a batch of rows, e.g. PointNet2SSG.fc_layer (models/encoders/pointnet2.py:47-56): B = 1, M = rows, ns = 1); out (B, ch[layers], M) when pool != 0, else (B, ch[layers], M, ns).  ch[l] % 4 == 0 for l >= 1; layers <= DFX_MLP_MAX_LAYERS.
  *   conv_b[l] == NULL when the layer has BatchNorm (bn_w[l] != NULL); bn_mean / bn_var: running statistics, updated IN PLACE by the forward
  *   when momentum >= 0.  grads: the same struct whose conv_w / conv_b / bn_w / bn_b name WRITABLE buffers of the parameters' shapes.
  *   batch_stats = 1: BatchNorm of train() mode; 0: eval() mode under autograd (the running statistics normalise, nothing is updated); the same value
@@ -368,6 +368,7 @@ typedef struct dfx_shared_mlp_train {
   const float *bn_w[DFX_MLP_MAX_LAYERS], *bn_b[DFX_MLP_MAX_LAYERS];
   float *bn_mean[DFX_MLP_MAX_LAYERS], *bn_var[DFX_MLP_MAX_LAYERS];
   float bn_eps;
+  uint32_t relu_mask; /* bit l: ReLU behind layer l (build_shared_mlp: all ones; a Linear head's last layer: 0) */
 } dfx_shared_mlp_train;
 size_t dfx_shared_mlp_train_workspace_bytes(const dfx_shared_mlp_train *w, int B, int M, int ns);
 int dfx_shared_mlp_train_forward(const dfx_shared_mlp_train *w, void *workspace, size_t workspace_bytes, const float *x, float *out, int B, int M,

@@ -412,6 +412,7 @@ def test_install_full_builds_the_mirror_from_the_unmodified_configs(cfg_name):
             base.pop("ret_interval"), base.pop("cimle_sample_num"), base["encoder"]["part_aligner"].pop("noise_scale")
             assert got == base
         assert type(mine.encoder) is encoders.PartEncoderForTransformerDecoder and type(mine.encoder.encoder) is encoders.PointNetV2
+        assert ENCODERS.get("PointNet2SSG") is encoders.PointNet2SSG and ENCODERS.get("PointNet2MSG") is encoders.PointNet2MSG   # (registered, unused by the configs)
         assert type(mine.diffusion) is modules.AnchoredDiffusion and type(mine.diffusion.model) is modules.TransformerNet
         my_sd = mine.state_dict()
         assert list(my_sd) == list(ref_sd) or set(my_sd) == set(ref_sd)
