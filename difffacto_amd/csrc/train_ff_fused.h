@@ -1837,6 +1837,8 @@ template <bool DROP>
 __global__ __launch_bounds__(NW_FWD * 64, 2) void k_ff_fwd_chain(FfChain ch) {
   v16f hc[4];
   int tn = 0;   // (trace builds only)
+  // (Round 6, measured and dropped: the second workgroup of a CU — HW_REG_LDS_ALLOC base != 0 — waiting 16 / 24 / 32 k cycles once at the start, so that the two
+  // co-resident workgroups' VALU-only stretches do not coincide: 661 / 672 / 672 us against 646-651 — they are not in step to begin with, the wait is pure cost)
   if constexpr (FWD_F16) {
     float tv[3];
     for (int b = 0; b < ch.n; ++b) ff_fwd<DROP>(ch.blk[b], ch.blk[b + 1 < ch.n ? b + 1 : b], b + 1 < ch.n, b == 0, b > 0, hc, tv, tn);
