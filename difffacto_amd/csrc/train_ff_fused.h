@@ -1015,9 +1015,12 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
     if (!BWD) {
       if (j + NBUF - 1 < NCHUNK) stage_chunk<BWD>(a.frags, j + NBUF - 1, lds0 + ((j + NBUF - 1) % NBUF) * BUF_BYTES, wave, voff);
     } else {
-      // dropout: this lane's bit word of chunks (j, j + 1), requested IN FRONT of the item's pieces — operations complete in order, so the counted
-      // wait at the item boundary below (at most the newest pieces outstanding) covers it; one register instead of the tile's eight words
-      // (inline asm: hipcc's own wait for a load it knows would be vmcnt(0) at the first use — behind the NEXT item's pieces)
+      // dropout: this lane's bit word of chunks (j, j + 1), requested in front of the item's pieces; one register instead of the tile's eight words
+      // (inline asm: hipcc's own wait for a load it knows would be vmcnt(0) at the first use — behind the NEXT item's pieces).  ROUND 6 FIX: the wait that
+      // covers it is vmcnt(0) at this chunk's item boundary, NOT the counted wait of the other chunks: a load that returns to a register and the LDS-DMA
+      // pieces behind it do not complete in issue order under load — with vmcnt(6) the word was occasionally stale at B = 128 x 2048 (run-to-run
+      // differences of 2e-3 in every gradient below the first block's; tools/soak_train_streams.py with dropout; rounds 5's code had it too).  LDS-DMA
+      // pieces among themselves, and stores against them, keep the counted waits valid (loads of one kind complete in order).
       if (DROP && !(j & 1)) asm volatile("global_load_dword %0, %1, off" : "=v"(dmw) : "v"(dmk + (j >> 1) * 64) : "memory");
       if (!BWD_SPREAD && 2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
     }
@@ -1114,8 +1117,8 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
       FFT(10);
       if (DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(0);
-      if (2 * j + 2 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");
+      if (2 * j + 2 < 2 * NCHUNK && !(DROP && !(j & 1))) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");   // (the last chunk; and with dropout every even chunk: its mask word must have landed)
       FFT(11);
 #ifndef DFX_ABL_BWD_NOBAR   // (ablation builds only: racy, wrong numbers — what do the loop's two barriers cost?)
       __syncthreads();
@@ -1563,10 +1566,9 @@ __device__ __forceinline__ void ff_fwd(const FfArgs &a, const FfArgs &next, cons
   unsigned vmask = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) vmask |= (a.valid[s * 4 + j] != 0.f ? 1u : 0u) << j;
-  // ONE round trip (first block: rows, tables, attention fragments, two records).  Behind a previous block the requests were made in front of its
-  // sixteen row stores, which may stay in flight (operations complete in order: "at most the sixteen newest outstanding" = everything requested landed)
-  if (staged && live) asm volatile("s_waitcnt vmcnt(16)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2])::"memory");
-  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2])::"memory");
+  // ONE round trip (first block: rows, tables, attention fragments, two records; behind a previous block the requests were made in front of its row stores and
+  // have mostly landed).  vmcnt(0), not a count that leaves the sixteen row stores in flight: loads and stores do not complete in order against each other
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2])::"memory");
   {
     float *d0 = lo_half ? gb2 : dump, *d2 = lo_half ? gb2 + 2 * C : b2s;
     d0[tc] = tv[0], d0[C + tc] = tv[1], d2[tc] = tv[2];

@@ -392,6 +392,41 @@ def test_side_stream_training_step_is_bit_identical_to_the_single_stream_one(B, 
         assert np.array_equal(two["d_ctx_code"], one["d_ctx_code"]) and np.array_equal(two["d_ctx_mv"], one["d_ctx_mv"])
 
 
+def test_dropout_training_step_is_bit_reproducible_on_a_full_chip():
+    """Round 6 regression: the backward dX kernel fetches each chunk pair's dropout bit word with an asynchronous load that sits among the
+    LDS-DMA pieces of the weight ring; the counted wait that was meant to cover it (loads complete in order) does not: a load that returns to a
+    register and LDS-DMA loads complete out of order against each other once the chip is busy, and the word was occasionally stale — every
+    gradient below the last block differed by ~2e-3 from run to run at B >= 16 x 2048 (small shapes never showed it: the round-5 tests passed).
+    The word is now waited for with vmcnt(0).  Five runs of one iteration with Dropout(0.2), >= 1024 workgroups, in both stream modes: same bits."""
+    from difffacto_amd import _ffi, synth
+    B, N = 64, 2048
+    rng = np.random.Generator(np.random.PCG64(5))
+    W = synth.make_denoiser_weights(1)
+    pc, mean, logvar, valid = synth.make_latents(B, seed=13, all_valid=False)
+    seg = synth.make_seg_mask(valid, N)
+    var = np.exp(logvar).astype(np.float32)
+    idx = np.broadcast_to(seg.astype(np.int64)[:, None, :], (B, 3, N))
+    anc, vr = np.take_along_axis(mean, idx, axis=2), np.take_along_axis(var, idx, axis=2)
+    c = dict(W=W, x_t=(anc + np.sqrt(vr) * rng.standard_normal((B, 3, N))).astype(np.float32), t=rng.integers(0, 1000, size=(B,)).astype(np.int64),
+             ctx_code=pc, ctx_mv=np.concatenate([mean, var], axis=1).astype(np.float32),
+             anchors_pt=np.ascontiguousarray(anc.transpose(0, 2, 1)), variances_pt=np.ascontiguousarray(vr.transpose(0, 2, 1)),
+             valid=valid, assignment=seg.astype(np.int32), noise=rng.standard_normal((B, 3, N)).astype(np.float32), flags=None)
+    try:
+        for streams in (0, 1):
+            _ffi.lib().dfx_debug_train_streams(streams)
+            runs = [_run(c, False, precision="bf16", dropout=(0.2, 4242)) for _ in range(5)]
+            if streams == 0:
+                one = runs[0]
+            for two in runs:
+                assert two["loss"] == one["loss"]
+                assert np.array_equal(two["eps"], one["eps"])
+                for k in one["grads"]:
+                    assert np.array_equal(two["grads"][k], one["grads"][k]), (streams, k)
+                assert np.array_equal(two["d_ctx_code"], one["d_ctx_code"]) and np.array_equal(two["d_ctx_mv"], one["d_ctx_mv"])
+    finally:
+        _ffi.lib().dfx_debug_train_streams(1)
+
+
 def test_training_step_with_its_side_stream_is_capturable_as_one_hip_graph():
     """The fork / join onto libdfx's side stream inside dfx_denoiser_train_backward uses plain event record / wait pairs, so a stream capture of
     the caller's stream (torch.cuda.graph) takes the side work into the same graph: forward + loss + backward captured once, replayed twice,
