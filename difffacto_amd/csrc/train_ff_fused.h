@@ -22,7 +22,8 @@
 // accumulator-register order of the GELU output), W2^T (rows = hidden units, K = channels) and W1a^T, W1g^T (rows = channels,
 // K = hidden units in register order).  A workgroup (4 wavefronts = 128 points, two workgroups per CU: one's row loads and stores run
 // under the other's chunk loop) streams the chunks L2 -> LDS with LDS-DMA through three buffers — forward: whole chunks (24 KiB), two
-// ahead of the compute, one barrier per chunk; backward: two items per chunk (stage_item), two barriers — with counted s_waitcnt vmcnt.
+// ahead of the compute, one barrier per chunk; backward: the same since round 6 (BWD_TR: one 24 KiB record [W1a | W1g | W2^T] per chunk, the W1a^T / W1g^T
+// operands read out of it with the LDS transpose read; until then two items per chunk, stage_item, and two barriers) — with counted s_waitcnt vmcnt.
 //
 // A workgroup's four tiles belong to ONE shape (its folded attention fragments sit in LDS once); every memory phase issues all of its loads
 // before it consumes any; both kernels are spill-free (a scratch reload behind output stores waits for their acknowledgements); and between two
@@ -56,6 +57,10 @@ constexpr int C = 128, FH = 512, NCHUNK = FH / 32;
 #define DFX_FF_FWD_F16 1
 #endif
 constexpr bool FWD_F16 = DFX_FF_FWD_F16 != 0;
+#ifndef DFX_FF_BWD_TR
+#define DFX_FF_BWD_TR 1   // the backward's second product reads W1a / W1g turned around in LDS instead of transposed tiles of its own (see BWD_SPREAD's neighbour below)
+#endif
+constexpr bool BWD_TR = DFX_FF_BWD_TR != 0;
 constexpr float FWD_A_SCALE = 0.0625f, FWD_G_SCALE = 0.5f;
 constexpr int TILES = FWD_F16 ? 36 : 24;          // tiles per chunk in the pack
 constexpr int TILE_U4 = 128;                      // uint4 per tile (2 units x 64 lanes)
@@ -66,6 +71,12 @@ constexpr int FWD_TILE0 = FWD_F16 ? T_FW1A : 0;   // first tile of the forward's
 constexpr int PACK_RECORDS = FWD_F16 ? NCHUNK + 1 : NCHUNK;   // chunk records in the pack (the forward's skew needs a 17th for the last W2)
 
 __host__ __device__ inline int rho(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+// Round 6: where lane l's 16 bytes of a W1a / W1g fragment (tiles 0 .. 7, unit u) sit inside the unit's 1 KiB: slot l ^ (4 u + 8 (l >> 5)).  Every reader of
+// those tiles indexes with it (k_ff's first product, k_ff_wgrad's operands; ds_read_b128 stays conflict-free: an XOR with a constant inside each 16-lane
+// access group).  It is there for the backward's SECOND product, which reads the same tiles turned around (ds_read_b64_tr_b16, see BWD_TR): the 32 lanes of
+// an access group address rows 4 x (unit, k half) apart, which in the lane-linear image are 1024 / 512 bytes apart = the same banks, four ways; with the two
+// bits folded into the row they are 32 distinct 8-byte slots of a 256-byte bank row (SQ_LDS_BANK_CONFLICT 2.5e7 -> 0 per launch).
+__host__ __device__ inline int w1_slot(int lane, int u) { return lane ^ ((u << 2) | ((lane >> 5) << 3)); }
 // K index (0..31) held by unit u, element e of a lane in half hf
 __host__ __device__ inline int k_nat(int u, int hf, int e) { return 16 * u + 8 * hf + e; }            // operand loaded from memory
 __host__ __device__ inline int k_reg(int u, int hf, int e) { return rho(8 * u + e, hf); }              // operand built from C/D registers
@@ -129,6 +140,7 @@ __global__ void k_ff_pack(PackBatch batch) {
   if (idx >= PACK_RECORDS * TILES * 2 * 64) return;
   const int lane = idx & 63, u = (idx >> 6) & 1, t = (idx >> 7) % TILES, j = idx / (TILES * 128);
   if (j == NCHUNK && t < T_FW2) return;   // the forward's 17th record: only its W2 tiles (hidden chunk 15) are read
+  if (BWD_TR && t >= T_W1AT && t < T_FW1A) return;   // the transposed W1 tiles: nobody reads them (k_ff<true> turns tiles 0 .. 7 around in LDS)
   const int i = lane & 31, hf = lane >> 5;
   __bf16 v[8];
 #pragma unroll
@@ -158,7 +170,7 @@ __global__ void k_ff_pack(PackBatch batch) {
     }
     v[e] = (__bf16)x;
   }
-  a.frags[idx] = *reinterpret_cast<const uint4 *>(v);
+  a.frags[t < T_W2 ? (idx & ~63) | w1_slot(lane, u) : idx] = *reinterpret_cast<const uint4 *>(v);
 }
 
 struct FfArgs {
@@ -652,7 +664,7 @@ constexpr int B1P_FLOATS = NCHUNK * 64, B2P_FLOATS = 128;
 // transposed sets (PK_XNT, PK_DHT: channels on the lanes, points along the registers) in LDS
 enum { PK_XN = 0, PK_DH = 1, PK_XNT = 2, PK_DHT = 3 };
 constexpr int PK_TILE_U4 = 2 * 8 * 64;   // 16 KiB
-constexpr int NW_BWD = 4;   // wavefronts per workgroup, backward: 128 points; the chunk streams in two items through three 24 KiB slots (79 KiB: two workgroups per CU)
+constexpr int NW_BWD = 4;   // wavefronts per workgroup, backward: 128 points; three 24 KiB slots (79 KiB: two workgroups per CU) — one record per chunk (BWD_TR) or two items
 #ifndef DFX_FF_NW_FWD
 #define DFX_FF_NW_FWD 4
 #endif
@@ -681,6 +693,16 @@ constexpr int NBUF = 3;   // LDS chunk buffers: the stream runs two chunks ahead
 #define DFX_WG_CPRIO 0       // k_ff_wgrad: consumer's 24-MFMA stretch
 #endif
 constexpr bool BWD_SPREAD = DFX_FF_BWD_SPREAD != 0;   // backward: ring pieces issued inside the MFMA bursts (see the loop)
+// Round 6: the backward's SECOND product (dxn3 += W1a^T da + W1g^T dg) takes its A operands out of the W1a / W1g tiles of the FIRST product with the LDS
+// transpose read (ds_read_b64_tr_b16: a 16-lane group reads 16 x 4 elements and gets them back turned around — tools/ubench/tr_read_probe.hip pins the lane
+// mapping), instead of from transposed tiles of their own: a chunk is ONE 24 KiB record (not two items, 40 KiB), the ring runs two chunks ahead behind ONE
+// barrier per chunk, and the wave issues six ring pieces per chunk instead of ten.  Same bf16 values, same MFMA operand order: bit-identical gradients.
+static_assert(!(BWD_TR && BWD_SPREAD), "the spread variant belongs to the two-item ring");
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v4s lds_tr16(unsigned lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) v4s *>(lds_addr));
+}
 // (measured, B = 128 x 2048, backward / forward per block: 8 waves x 3 buffers 441 / 161 us; 4 waves x 2 buffers, two workgroups
 // per CU, 513 / 161 us; 8 x 2: 662 / 182 us)
 
@@ -704,7 +726,7 @@ __device__ __forceinline__ void stage_record_fwd(const uint4 *frags, int j, unsi
   for (int k = 0; k < FWD_TILES * 2 / NW_FWD; ++k) dma1k(src + (k * NW_FWD + wave) * 1024, voff, lds_buf + (k * NW_FWD + wave) * 1024);
 }
 
-// Backward: a chunk streams as two items through a ring of three 24 KiB slots — item 2 j = [W1a | W1g | W2^T] of chunk j (tiles 0..7 and
+// Backward (BWD_TR = 0; with BWD_TR only the even items exist: item 2 j IS chunk j's record): a chunk streams as two items through a ring of three 24 KiB slots — item 2 j = [W1a | W1g | W2^T] of chunk j (tiles 0..7 and
 // 12..15: GEMM1 and the d hid product), item 2 j + 1 = [W1a^T | W1g^T] (tiles 16..23: the dxn3 product) — so that a workgroup fits into
 // half a CU's LDS.  Wave w copies pieces w, w + 4, ..: six per even item, four per odd one.
 __device__ __forceinline__ void stage_item(const uint4 *frags, int item, unsigned lds_slot, int wave, unsigned voff) {
@@ -870,9 +892,14 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
   const float *tp2 = lo_half ? (at ? a.bo : a.b1p) : (!BWD ? a.b2p : a.b1p);
   const float tv0 = tp0[tc], tv1 = tp1[tc], tv2 = tp2[tc];
   dma1k(reinterpret_cast<const char *>(a.b1p) + wave * 1024, voff, lds0 + TAB_B1 + wave * 1024);
+  constexpr bool TR = BWD && BWD_TR;
+  // (TR, dropout) the bit word of chunks (0, 1) -> this wave's 256 bytes of the mask buffer: LDS-DMA like the ring's pieces, so that the loop's counted waits
+  // cover it (loads of one kind complete in order; a load that returns to a register does not keep that order against them — HISTORY round 6 #11)
+  const unsigned *dmt = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE : nullptr;   // wave-uniform: this tile's words
+  if (TR && DROP) dma256(dmt, lane * 4, lds0 + TAB_GB3 + wave * 256);
   if (BWD) {
     stage_item(a.frags, 0, lds0, wave, voff);
-    stage_item(a.frags, 1, lds0 + BUF_BYTES, wave, voff);
+    stage_item(a.frags, TR ? 2 : 1, lds0 + BUF_BYTES, wave, voff);
   } else {
     if (at) {   // [A_s | M_s] of this shape -> slot 2
       const char *src = reinterpret_cast<const char *>(a.at_frags + (size_t)s * SHAPE_U4);
@@ -889,7 +916,8 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ONE round trip: rows, tables, attention fragments, the first two chunks / items
   {
-    float *d0 = lo_half ? gb2 : dump, *d2 = lo_half ? gb2 + 2 * C : b2s;   // waves 0, 1: gamma2 | beta2 | b_o; waves 2, 3: b2 (their copies of gamma2 | beta2 go to the dump)
+    // waves 0, 1: gamma2 | beta2 | b_o; waves 2, 3: b2 — their copies of gamma2 | beta2 go to the dump, or (TR: the dump is the mask buffer) on top of waves 0, 1's: the same values
+    float *d0 = lo_half || TR ? gb2 : dump, *d2 = lo_half ? gb2 + 2 * C : b2s;
     d0[tc] = tv0, d0[C + tc] = tv1, d2[tc] = tv2;
   }
   __syncthreads();
@@ -1021,8 +1049,16 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       // pieces behind it do not complete in issue order under load — with vmcnt(6) the word was occasionally stale at B = 128 x 2048 (run-to-run
       // differences of 2e-3 in every gradient below the first block's; tools/soak_train_streams.py with dropout; rounds 5's code had it too).  LDS-DMA
       // pieces among themselves, and stores against them, keep the counted waits valid (loads of one kind complete in order).
-      if (DROP && !(j & 1)) asm volatile("global_load_dword %0, %1, off" : "=v"(dmw) : "v"(dmk + (j >> 1) * 64) : "memory");
-      if (!BWD_SPREAD && 2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
+      if (!TR) {
+        if (DROP && !(j & 1)) asm volatile("global_load_dword %0, %1, off" : "=v"(dmw) : "v"(dmk + (j >> 1) * 64) : "memory");
+        if (!BWD_SPREAD && 2 * j + 2 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 2, lds0 + ((2 * j + 2) % 3) * BUF_BYTES, wave, voff);
+      } else {
+        // one record per chunk, two ahead: chunk j + 2 -> the slot of chunk j - 1 (every wave is past its last read: the barrier below).  Odd chunks first
+        // request the bit word of the NEXT pair (its predecessor was read into a register in chunk j - 1): in front of the pieces, so "at most six
+        // outstanding" at this chunk's end covers it
+        if (DROP && (j & 1) && j + 1 < NCHUNK) dma256(dmt + ((j + 1) >> 1) * 64, lane * 4, lds0 + TAB_GB3 + wave * 256);
+        if (j + 2 < NCHUNK) stage_item(a.frags, 2 * (j + 2), lds0 + ((j + 2) % 3) * BUF_BYTES, wave, voff);
+      }
     }
     // Round 6 (BWD_SPREAD): the wave's pieces of the next chunk's two items are issued from INSIDE the two MFMA bursts, one behind every fourth MFMA (six
     // of item 2 j + 2 in the first burst, four of item 2 j + 3 in the second) instead of back to back in front of them, where each LDS-DMA instruction
@@ -1033,8 +1069,9 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
     const unsigned idst0 = nxt ? lds0 + ((2 * j + 2) % 3) * BUF_BYTES + wave * 1024 : lds0 + TAB_GB3;
     const unsigned idst1 = nxt ? lds0 + ((2 * j + 3) % 3) * BUF_BYTES + wave * 1024 : lds0 + TAB_GB3;
     const unsigned istep = nxt ? 4096u : 0u;
-    const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (BWD ? (2 * j) % 3 : j % NBUF) * BUF_BYTES) + lane;
-    auto frag = [&](int t, int u) -> uint4 { return fr[(lt<BWD>(t) * 2 + u) * 64]; };
+    const uint4 *fr = reinterpret_cast<const uint4 *>(ff_smem + (BWD && !TR ? (2 * j) % 3 : j % NBUF) * BUF_BYTES) + lane;
+    const uint4 *fs0 = fr - lane + w1_slot(lane, 0), *fs1 = fr - lane + w1_slot(lane, 1);
+    auto frag = [&](int t, int u) -> uint4 { return (t < T_W2 ? (u ? fs1 : fs0) : fr)[(lt<BWD>(t) * 2 + u) * 64]; };   // (W1a / W1g: w1_slot)
     // ---- [a | g] = b1 + W1 xn3 ----
     v16f av, gv;
     load16(av, b1s + ((j * 2 + 0) * 2 + hf) * 16);
@@ -1117,6 +1154,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
       // of the GEGLU arithmetic now, so that the second burst's first eight fragments travel while the VALU works ----
       FFT(10);
       if (DFX_FF_MPRIO_BWD) __builtin_amdgcn_s_setprio(0);
+      if (!TR) {
       if (2 * j + 2 < 2 * NCHUNK && !(DROP && !(j & 1))) asm volatile("s_waitcnt vmcnt(6)" : "+v"(dmw)::"memory");   // (dmw: its readers stay behind the wait)
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dmw)::"memory");   // (the last chunk; and with dropout every even chunk: its mask word must have landed)
       FFT(11);
@@ -1125,13 +1163,28 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
 #endif
       FFT(12);
       if (!BWD_SPREAD && 2 * j + 3 < 2 * NCHUNK) stage_item(a.frags, 2 * j + 3, lds0 + ((2 * j + 3) % 3) * BUF_BYTES, wave, voff);
+      }
       const uint4 *fr2 = reinterpret_cast<const uint4 *>(ff_smem + ((2 * j + 1) % 3) * BUF_BYTES) + lane;
+      // TR: the lane's address inside a 2 KiB W1a / W1g tile for the transpose read.  Lane 16 G + s of group G supplies row (hidden unit) 4 (G >> 1) + (s >> 2)
+      // (+ 16 u + 8 r by the immediate), channels 16 (G & 1) + 4 (s & 3) .. + 3 — in the tile's image: unit G & 1, lane slot row + 32 ((s & 3) >> 1), byte
+      // 8 (s & 1) — and receives hidden units 4 (G >> 1) + 0 .. 3 of channel 16 (G & 1) + s: elements 4 r .. 4 r + 3 of the A operand (K in register order)
+      // (the row's slot through w1_slot: bits 2, 3 of the row carry the unit and the k half, so r = 0 / 1 need a base each)
+      const int tu = (lane >> 4) & 1, thf = (lane & 3) >> 1, trow = 4 * (lane >> 5) + ((lane & 15) >> 2) + 32 * thf;
+      const unsigned trb0 = lds0 + (j % 3) * BUF_BYTES + (tu * 64 + w1_slot(trow, tu)) * 16 + 8 * (lane & 1);
+      const unsigned trb1 = lds0 + (j % 3) * BUF_BYTES + (tu * 64 + w1_slot(trow + 8, tu)) * 16 + 8 * (lane & 1);
       // second burst, MFMA m: row tile ct = m & 3, operand q = m >> 2 (W1a^T unit 0, unit 1, W1g^T unit 0, unit 1: the order per accumulator)
-      auto f2 = [&](int m) -> uint4 { return fr2[(lt<BWD>(((m >> 2) < 2 ? T_W1AT : T_W1GT) + (m & 3)) * 2 + ((m >> 2) & 1)) * 64]; };
+      auto f2 = [&](int m) -> uint4 {
+        if (TR) {
+          const unsigned o = ((m >> 3) * 4 + (m & 3)) * 2048 + ((m >> 2) & 1) * 256;
+          return __builtin_bit_cast(uint4, __builtin_shufflevector(lds_tr16(trb0 + o), lds_tr16(trb1 + o), 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        return fr2[(lt<BWD>(((m >> 2) < 2 ? T_W1AT : T_W1GT) + (m & 3)) * 2 + ((m >> 2) & 1)) * 64];
+      };
 #pragma unroll
       for (int i = 0; i < 8; ++i) P[i] = f2(i);
       __builtin_amdgcn_sched_barrier(0);
       if (DROP) {   // d hid in front of the dropout = selected d hid behind it (the scale rides on `a` and on W1a^T)
+        if (TR && !(j & 1)) dmw = reinterpret_cast<const unsigned *>(ff_smem + TAB_GB3)[wave * 64 + lane];   // (landed: the previous chunk's end, or the prologue)
         drop_select(dhid, (j & 1) ? dmw >> 16 : dmw);
       }
       // ---- GEGLU backward on the registers ----
@@ -1172,7 +1225,10 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
     // chunk j + 1 must have landed: loads complete in order, so "at most PIECES outstanding" leaves only chunk j + 2's pieces
     // (whatever the order between loads and the backward's stores); no new pieces in the last two iterations -> drain
     FFT(13);
-    if (BWD) {   // item 2 j + 2 must have landed; the four pieces of item 2 j + 3 may still be out
+    if (TR) {    // chunk j + 1 (and an odd chunk's bit word) must have landed; the six pieces of chunk j + 2 may still be out
+      if (j + 2 < NCHUNK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (BWD) {   // item 2 j + 2 must have landed; the four pieces of item 2 j + 3 may still be out
       if (2 * j + 3 < 2 * NCHUNK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (NBUF > 2 && j + 2 < NCHUNK) {
@@ -1942,8 +1998,8 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          w1a[c][u] = fr[((T_W1A + c) * 2 + u) * 64];
-          w1g[c][u] = fr[((T_W1G + c) * 2 + u) * 64];
+          w1a[c][u] = (fr - lane + w1_slot(lane, u))[((T_W1A + c) * 2 + u) * 64];
+          w1g[c][u] = (fr - lane + w1_slot(lane, u))[((T_W1G + c) * 2 + u) * 64];
           w2t[c][u] = fr[((T_W2T + c) * 2 + u) * 64];
         }
     }
