@@ -1935,8 +1935,18 @@ constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chun
 // LDS: the tiles ([xn3 | dh] fragments, 16 KiB) travel in a ring of three slots, two tiles ahead of the producers (L2 latency under load
 // is longer than one tile's arithmetic); the consumers turn tile k around (two MFMAs with a 0/1 selection matrix per 32 x 32 tile, exact)
 // into one of two 16 KiB slots while they multiply tile k - 1
-constexpr int WG_SLOTS = 3;
-constexpr int WG_RING_A = 0, WG_RING_T = WG_SLOTS * 16384, WG_RING = (WG_SLOTS + 2) * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
+// Round 6 (WG_TR, measured and left OFF): the consumers read the turned operands straight out of the ring's tile with the LDS transpose read (ds_read_b64_tr_b16,
+// as k_ff<true>'s second product does; the tile's 1 KiB fragments land w1_slot-swizzled — the LDS-DMA lanes fetch each other's 16 bytes — so that the reads are
+// conflict-free): no selection MFMAs, no packs and LDS stores of a turned copy, no turned slots; the ring has four slots (tile k - 1 is still being read while
+// tile k + 2 lands).  Bit-identical, 0 bank conflicts — and 2.3 % SLOWER (alternating same-box runs 225.0 / 226.0 against 230.0 / 231.7 us per block,
+// profiles/r06_ab_train_wgrad_tr.txt): the turning is shared by the four consumers (each turns a quarter, all read 16 whole fragments back with ds_read_b128),
+// the transpose read doubles every consumer's read instructions in front of its MFMAs, and the producer, not the consumer, is this kernel's critical wavefront.
+#ifndef DFX_WG_TR
+#define DFX_WG_TR 0
+#endif
+constexpr bool WG_TR = DFX_WG_TR != 0;
+constexpr int WG_SLOTS = WG_TR ? 4 : 3, WG_AHEAD = 2;
+constexpr int WG_RING_A = 0, WG_RING_T = WG_SLOTS * 16384, WG_RING = (WG_SLOTS + (WG_TR ? 0 : 2)) * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
 constexpr int WG_MASK = WG_LDS, WG_LDS_DROP = WG_LDS + WG_SLOTS * 2048;   // dropout: the tiles' bit words (2 KiB each) in a ring of their own, same slots
 template <bool DROP>
 __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
@@ -1959,7 +1969,8 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   const long long per = (a.ntiles + a.nslab - 1) / a.nslab, t0 = (long long)slab * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
   const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
   // iteration k requests tile k + 2: two 1 KiB pieces per wavefront
-  constexpr int AHEAD = WG_SLOTS - 1;
+  constexpr int AHEAD = WG_AHEAD;
+  const unsigned voffq[2] = {WG_TR ? w1_slot(lane, 0) * 16u : voff, WG_TR ? w1_slot(lane, 1) * 16u : voff};   // (piece 2 wave + q is a fragment of unit q)
   auto stage = [&](int k) {
     if (k + AHEAD < nt) {
       // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
@@ -1967,7 +1978,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
                                           : reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + AHEAD) * PK_TILE_U4);
       const unsigned slot = __builtin_amdgcn_readfirstlane((unsigned)((k + AHEAD) % WG_SLOTS));   // (wave-uniform: the LDS address goes through m0)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voff, lds0 + WG_RING_A + slot * 16384 + (wave * 2 + q) * 1024);
+      for (int q = 0; q < 2; ++q) dma1k(src + (wave * 2 + q) * 1024, voffq[q], lds0 + WG_RING_A + slot * 16384 + (wave * 2 + q) * 1024);
       if (DROP)   // + this tile's eight feed-forward bit words: 256 B per wavefront
         dma256(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + AHEAD) * DM_TILE) + wave * 256, lane * 4,
                lds0 + WG_MASK + slot * 2048 + wave * 256);
@@ -2010,17 +2021,18 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     const int dm_off = (j >> 1) * 64 + 32 * ((pj >> 2) & 1) + 4 * (lane >> 5), dm_bit = 16 * (j & 1) + 4 * (pj >> 3) + (pj & 3);
     // 24 MFMAs of tile k: [a | g]^T = xhat3 W1^T + b1, d hid^T = dh W2
     auto mm = [&](int k, v16f &av, v16f &gv, v16f &dv) {
-      const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384) + lane;
+      const uint4 *tb = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384);
+      const uint4 *tlu[2] = {tb + (WG_TR ? w1_slot(lane, 0) : lane), tb + (WG_TR ? w1_slot(lane, 1) : lane)};
 #pragma unroll
       for (int r = 0; r < 16; ++r) av[r] = ba, gv[r] = bg, dv[r] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const uint4 x = tl[(PK_XN * 8 + c * 2 + u) * 64];
+          const uint4 x = tlu[u][(PK_XN * 8 + c * 2 + u) * 64];
           av = mfma(x, w1a[c][u], av);
           gv = mfma(x, w1g[c][u], gv);
-          dv = mfma(tl[(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
+          dv = mfma(tlu[u][(PK_DH * 8 + c * 2 + u) * 64], w2t[c][u], dv);
         }
     };
     // GEGLU forward / backward on tile k's accumulators -> six fragments in LDS
@@ -2104,6 +2116,8 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)(pj == 16 * u + 8 * (lane >> 5) + e ? 1.0f : 0.0f);
     sel[u] = *reinterpret_cast<const uint4 *>(o);
   }
+  const int ctu = (lane >> 4) & 1, ctrow = 4 * (lane >> 5) + ((lane & 15) >> 2) + 32 * ((lane & 3) >> 1);
+  const unsigned ctr0 = (ctu * 64 + w1_slot(ctrow, ctu)) * 16 + 8 * (lane & 1), ctr1 = (ctu * 64 + w1_slot(ctrow + 8, ctu)) * 16 + 8 * (lane & 1);
   for (int k = 0; k <= nt; ++k) {
     if (k < 12) FFT(20);
     arrive(k);
@@ -2112,7 +2126,7 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     // (Round 6, measured and dropped: issuing the selection MFMAs first, then tile k - 1's fragment reads and multiplications one gradient at a time, and the
     // turned tile's four LDS stores last — so that the reads do not queue behind the read -> MFMA -> MFMA -> pack -> store chain — keeps 32 more registers
     // alive beside the 192 accumulators and reads xn3^T twice: 243 against 231 us per block, profiles/r06_ab_train_wgrad_reorder.txt)
-    if (k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
+    if (!WG_TR && k < nt) {   // tile k turned around for the next iteration: consumer cl takes channel tile cl of xn3 and of dh
       const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_A + (k % WG_SLOTS) * 16384) + lane;
       uint4 *to = reinterpret_cast<uint4 *>(fw_smem + WG_RING_T + (k & 1) * 16384) + lane;
       v16f z;
@@ -2129,11 +2143,19 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
     const uint4 *tl = reinterpret_cast<const uint4 *>(fw_smem + WG_RING_T + ((k - 1) & 1) * 16384) - 16 * 64 + lane;   // (index the slot by PK_XNT, PK_DHT)
     const uint4 *pi = packs + (((k - 1) & 1) * WG_CHUNKS + cl) * 6 * 64 + lane;
     const uint4 h0 = pi[0 * 64], h1 = pi[1 * 64], a0 = pi[2 * 64], a1 = pi[3 * 64], g0 = pi[4 * 64], g1 = pi[5 * 64];
+    // WG_TR: operand (kind, channel tile c, K unit uk) = channels on the lanes, points k_reg(uk, hf, e) along the registers, turned out of tile k - 1's own
+    // fragments: lane 16 G + s supplies point row 16 uk + 8 r + 4 (G >> 1) + (s >> 2), channels 16 (G & 1) + 4 (s & 3) .. + 3 (see k_ff<true>'s trb0 / trb1)
+    const unsigned tsb = lds0 + WG_RING_A + ((k - 1) % WG_SLOTS) * 16384;
+    auto turned = [&](int kind, int c, int uk) -> uint4 {
+      if (!WG_TR) return tl[((kind ? PK_DHT : PK_XNT) * 8 + c * 2 + uk) * 64];
+      const unsigned o = tsb + (kind * 8 + c * 2) * 1024 + uk * 256;
+      return __builtin_bit_cast(uint4, __builtin_shufflevector(lds_tr16(o + ctr0), lds_tr16(o + ctr1), 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     if (DFX_WG_CPRIO) __builtin_amdgcn_s_setprio(DFX_WG_CPRIO);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const uint4 x0 = tl[(PK_XNT * 8 + c * 2 + 0) * 64], x1 = tl[(PK_XNT * 8 + c * 2 + 1) * 64];
-      const uint4 d0 = tl[(PK_DHT * 8 + c * 2 + 0) * 64], d1 = tl[(PK_DHT * 8 + c * 2 + 1) * 64];
+      const uint4 x0 = turned(0, c, 0), x1 = turned(0, c, 1);
+      const uint4 d0 = turned(1, c, 0), d1 = turned(1, c, 1);
       dW2[c] = mfma(h1, d1, mfma(h0, d0, dW2[c]));
       dWa[c] = mfma(a1, x1, mfma(a0, x0, dWa[c]));
       dWg[c] = mfma(g1, x1, mfma(g0, x0, dWg[c]));
