@@ -896,7 +896,7 @@ __device__ __forceinline__ void ff_run(const FfArgs &a, const bool first, v16f (
   // (TR, dropout) the bit word of chunks (0, 1) -> this wave's 256 bytes of the mask buffer: LDS-DMA like the ring's pieces, so that the loop's counted waits
   // cover it (loads of one kind complete in order; a load that returns to a register does not keep that order against them — HISTORY round 6 #11)
   const unsigned *dmt = DROP ? a.dmask + (size_t)(rowbase / (32 * C)) * DM_TILE : nullptr;   // wave-uniform: this tile's words
-  if (TR && DROP) dma256(dmt, lane * 4, lds0 + TAB_GB3 + wave * 256);
+  if (TR && DROP) dma256(dmt, lane * 4, lds0 + TAB_GB3 + wave * 256);   // (as sixteen lanes x 16 bytes instead: measured, no difference)
   if (BWD) {
     stage_item(a.frags, 0, lds0, wave, voff);
     stage_item(a.frags, TR ? 2 : 1, lds0 + BUF_BYTES, wave, voff);
@@ -1944,6 +1944,10 @@ constexpr int WG_CHUNKS = 4, WG_NW = 2 * WG_CHUNKS;   // two wavefronts per chun
 #ifndef DFX_WG_TR
 #define DFX_WG_TR 0
 #endif
+#ifndef DFX_WG_CSTAGE
+#define DFX_WG_CSTAGE 1   // the consumers issue the ring's LDS-DMA pieces (see stage)
+#endif
+constexpr bool WG_CSTAGE = DFX_WG_CSTAGE != 0;
 constexpr bool WG_TR = DFX_WG_TR != 0;
 constexpr int WG_SLOTS = WG_TR ? 4 : 3, WG_AHEAD = 2;
 constexpr int WG_RING_A = 0, WG_RING_T = WG_SLOTS * 16384, WG_RING = (WG_SLOTS + (WG_TR ? 0 : 2)) * 16384, WG_PACKS = 2 * WG_CHUNKS * 6 * 1024, WG_LDS = WG_RING + WG_PACKS;
@@ -1972,6 +1976,23 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   constexpr int AHEAD = WG_AHEAD;
   const unsigned voffq[2] = {WG_TR ? w1_slot(lane, 0) * 16u : voff, WG_TR ? w1_slot(lane, 1) * 16u : voff};   // (piece 2 wave + q is a fragment of unit q)
   auto stage = [&](int k) {
+    if (WG_CSTAGE) {
+      // the CONSUMERS request the whole tile (consumer cl: pieces cl, cl + 4, cl + 8, cl + 12; with dropout consumers 0 and 1 one KiB of the bit words each):
+      // the producers are this kernel's critical wavefronts and keep their issue slots for the MFMAs and the GEGLU arithmetic
+      if (consumer && k + AHEAD < nt) {
+        const char *pk = reinterpret_cast<const char *>(a.pk + (size_t)(t0 + k + AHEAD) * PK_TILE_U4);
+        const char *dh = reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + AHEAD) * PK_TILE_U4) - 8192;
+        const unsigned slot = __builtin_amdgcn_readfirstlane((unsigned)((k + AHEAD) % WG_SLOTS));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = cl + 4 * q;
+          dma1k((q < 2 ? pk : dh) + p * 1024, voffq[p & 1], lds0 + WG_RING_A + slot * 16384 + p * 1024);
+        }
+        if (DROP && cl < 2)
+          dma1k(reinterpret_cast<const char *>(a.dmask + (size_t)(t0 + k + AHEAD) * DM_TILE) + cl * 1024, voff, lds0 + WG_MASK + slot * 2048 + cl * 1024);
+      }
+      return;
+    }
     if (k + AHEAD < nt) {
       // pieces 0 .. 7 (waves 0 .. 3): the xhat3 fragments of pk; 8 .. 15: the dh fragments — pk's second set, or the hi half of the gradient tile itself
       const char *src = wave >= WG_NW / 2 ? reinterpret_cast<const char *>(a.dhf + (size_t)(t0 + k + AHEAD) * PK_TILE_U4) - 8192
@@ -1987,6 +2008,15 @@ __global__ __launch_bounds__(WG_NW * 64, 2) void k_ff_wgrad(FwArgs a) {
   // top of iteration k: everything requested before iteration k - 1 has landed, i.e. tiles <= k (loads complete in order; the last iterations
   // request nothing: drain)
   auto arrive = [&](int k) {
+    if (WG_CSTAGE) {   // (only the consumers have pieces in flight: the newest tile's four — five with a KiB of bit words — may stay out)
+      if (consumer) {
+        if (k + AHEAD - 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (DROP && cl < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      __syncthreads();
+      return;
+    }
     if (k + AHEAD - 1 < nt) {
       if (DROP) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
